@@ -1,0 +1,70 @@
+"""Load tests/golden/*.npz (made by tests/golden/make_golden.py from the reference's own code) and
+turn each into (spec, initial unconstrained params, optimiser settings, per-step records)."""
+import glob
+import os
+
+import numpy as np
+
+from oracle import vi_oracle as vo
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def elbo_cases():
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))):
+        tag = os.path.basename(p)[:-4]
+        if tag != "functions":
+            out.append(tag)
+    return out
+
+
+def load(tag):
+    return dict(np.load(os.path.join(GOLDEN, tag + ".npz"), allow_pickle=False))
+
+
+def _lr_irt(item, other):
+    def fn(module, name):
+        return {"lr": item if name in ("a", "b") else other}
+    return fn
+
+
+def _lr_ho(item, other):
+    def fn(module, name):
+        return {"lr": item if name in ("lam0", "lam1", "g", "s") else other}
+    return fn
+
+
+def build(tag, dtype=np.float32):
+    f = load(tag)
+    cls = str(f["cls"])
+    N, J, B = int(f["N"]), int(f["J"]), int(f["B"])
+    enc = {k[len("enc0/"):]: f[k] for k in f if k.startswith("enc0/")}
+    amort = cls.startswith("Vae")
+    if cls in ("VIRT", "VaeIRT"):
+        D = int(f["D"])
+        spec = {"family": "irt", "model": str(f["model"]), "D": D, "Dc": float(f["Dc"]) if "Dc" in f else 1.0,
+                "N": N, "amortized": amort, "share_cov": bool(f["share_cov"]) if "share_cov" in f else False,
+                "a_free": vo.default_a_free(D, J)}
+        params = vo.init_irt_params(spec, J, dtype, encoder=enc if amort else None,
+                                    b0=f["b0"] if "b0" in f else None)
+        lr = _lr_irt(float(f["lr_item"]), float(f["lr_other"])) if "lr_item" in f else float(f["lr"])
+    else:
+        spec = {"family": "hodina", "K": int(f["K"]), "N": N, "amortized": amort, "q": f["q"]}
+        params = vo.init_hodina_params(spec, J, dtype, encoder=enc if amort else None)
+        lr = _lr_ho(float(f["lr_item"]), float(f["lr_other"])) if "lr_item" in f else float(f["lr"])
+    for k in f:
+        if k.startswith("init/"):
+            params[k[5:]] = f[k].astype(dtype)
+    opt = {"lr": lr, "milestones": tuple(int(m) for m in f["milestones"]) if "milestones" in f else (),
+           "gamma": float(f["gamma"]) if "gamma" in f else 0.1}
+    steps = []
+    for t in range(int(f["steps"])):
+        S = int(f["s%d/n_particles" % t])
+        rec = {"loss": float(f["s%d/loss" % t]),
+               "idx": [f["s%d/idx%d" % (t, k)] for k in range(S)],
+               "eps": [f["s%d/eps%d" % (t, k)] for k in range(S)],
+               "grad": {k.split("/grad/")[1]: f[k] for k in f if k.startswith("s%d/grad/" % t)},
+               "param": {k.split("/param/")[1]: f[k] for k in f if k.startswith("s%d/param/" % t)}}
+        steps.append(rec)
+    return spec, params, opt, f["y"], steps, B
