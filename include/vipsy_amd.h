@@ -1,0 +1,140 @@
+/*
+ * vipsy_amd C ABI -- the drop-in boundary for the ELBO-gradient hot path on MI355X (gfx950).
+ *
+ * The reference (inuyasha2012/vipsy) has no native boundary: the op being replaced is
+ *     loss = svi.step(data)                                   vi.py:503-516, called from
+ *     BaseIRT.fit vi.py:634-638 / VCHoDina.fit vi.py:937-942
+ * whose arithmetic lives in pyro-ppl 1.4.0 (Trace_ELBO / TraceEnum_ELBO + pyro.optim.Adam).
+ * This header is what a binding for that op links against: plain C, device pointers and sizes,
+ * no torch types.  Every entry point
+ *   - is asynchronous on the hipStream_t passed as `void* stream`,
+ *   - allocates nothing and never synchronises (graph-capturable),
+ *   - borrows device memory owned by the caller (PyTorch-ROCm in our host code),
+ *   - returns 0 on success, a hipError_t (>0) from the launch, or a VX_E* code (<0) for bad
+ *     arguments.
+ *
+ * One step of the reference loop maps to, in order (vipsy_amd/engine.py drives exactly this):
+ *   guide forward  (encoder / per-person variational rows -> x, entropy)   vi.py:673-723
+ *   model likelihood + gradients                                             vi.py:574-625
+ *   guide backward (encoder weight grads / per-person grads)
+ *   [multi-GPU: one RCCL all-reduce of the flat gradient buffer -- done by the host]
+ *   optimiser on the unconstrained leaves, `free` mask applied               vi.py:508-514
+ *
+ * Data contract: responses are uint8, 1 byte per cell: 0, 1, or 255 = missing (the reference
+ * holds float32 with NaN, vi.py:621).  All parameters / state are float32, unconstrained
+ * (vi.py:510).  Persons are rows; a rank owns the contiguous shard [gid0, gid0 + n_local).
+ */
+#ifndef VIPSY_AMD_H
+#define VIPSY_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VX_OK 0
+#define VX_EINVAL (-1)       /* bad argument / unsupported shape */
+#define VX_EUNIMPL (-2)
+#define VX_ABI_VERSION 1
+
+enum vx_model { VX_IRT_1PL = 1, VX_IRT_2PL = 2, VX_IRT_3PL = 3, VX_IRT_4PL = 4 }; /* vi.py:538-543 */
+
+/* Problem description shared by the IRT entry points (BaseIRT.__init__, vi.py:545-572). */
+typedef struct vx_irt_cfg {
+    int32_t model;       /* enum vx_model */
+    int32_t D;           /* x_feature: latent dimensions */
+    int32_t J;           /* item_size */
+    int32_t H;           /* encoder hidden_dim (amortized guides), else 0 */
+    float   Dc;          /* the scalar `D` of vi.py:549 (1 or 1.702) */
+    float   scale;       /* plate scale N_global / B_global */
+    uint64_t seed;       /* Philox key */
+    uint32_t step;       /* Philox counter word 2: optimisation step */
+    uint32_t stream;     /* Philox counter word 3 high half: particle index */
+} vx_irt_cfg;
+
+int vx_abi_version(void);
+const char* vx_build_info(void);
+
+/* ---- RNG: eps[i, d] = N(0,1) keyed by the GLOBAL person id (Philox4x32-10 + Box-Muller).
+ * gids == NULL means gid = gid0 + i.  Also used by tests to hand the oracle identical eps. */
+int vx_philox_normals(float* eps /*[n][D]*/, const int64_t* gids, int64_t gid0, int64_t n, int32_t D,
+                      uint64_t seed, uint32_t step, uint32_t stream, void* hip_stream);
+/* raw Philox words for bit-exact checks against the oracle: out[i][4] for counter (i, 0, step, stream<<16) */
+int vx_philox_raw(uint32_t* out /*[n][4]*/, int64_t gid0, int64_t n, uint64_t seed, uint32_t step,
+                  uint32_t stream, void* hip_stream);
+
+/* ---- amortized multivariate-normal guide, forward (MvnEncoder.forward + rsample of
+ * MultivariateNormal(loc, scale_tril=LowerCholeskyTransform(M)); vi.py:438-455, 685-693).
+ *   rows   : local row index of each batch member (NULL = 0..nb-1), gids for the RNG = gid0+row
+ *   eps_in : if non-NULL use these draws instead of generating them (parity tests)
+ * Outputs (all [nb][...], float32): h = softplus(fc1), x = loc + L eps, eps, ldT[D][nb] =
+ * exp(diag M) stored dimension-major, ent[i] = 0.5|eps_i|^2 + sum_k M_kk (= log p/q constants
+ * cancelled). */
+int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y /*[n_local][J]*/, const int64_t* rows,
+                       int64_t nb, int64_t gid0,
+                       const float* W1 /*[H][J]*/, const float* b1, const float* W21 /*[D][H]*/,
+                       const float* b21, const float* W22 /*[T][H]*/, const float* b22,
+                       const float* eps_in, float* h /*[nb][H]*/, float* x /*[nb][D]*/,
+                       float* eps /*[nb][D]*/, float* ldT /*[D][nb]*/, float* ent /*[nb]*/,
+                       void* hip_stream);
+
+/* ---- model likelihood + gradients for D >= 2 (irt_2pl..4pl + _get_p_data mask + Bernoulli
+ * log-lik; vi.py:32-66, 596-625).  Consumes x, produces
+ *   gx[nb][D]      d ELBO / d x  = scale * (R A^T - x)          (likelihood + N(0,I) prior)
+ *   ll[nb]         per-person  log p(y_i | x_i) - 0.5 |x_i|^2
+ *   gitem          gradient of the LOSS (= -ELBO), float [D*J + 3*J] laid out
+ *                  [a: D*J | b: J | c_un: J | d_un: J]  (c/d w.r.t. the unconstrained leaves,
+ *                  zero for models without them); summed over this rank's batch only.
+ * `workspace`: vx_irt_lik_workspace_floats(cfg, nb) floats of scratch (partial slabs). */
+int64_t vx_irt_lik_workspace_floats(const vx_irt_cfg* cfg, int64_t nb);
+int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
+                    const float* x /*[nb][D]*/, const float* a /*[D][J]*/, const float* b /*[J]*/,
+                    const float* c_un /*[J] or NULL*/, const float* d_un /*[J] or NULL*/,
+                    float* gx /*[nb][D]*/, float* ll /*[nb]*/, float* gitem /*[D*J + 3*J]*/,
+                    float* workspace, void* hip_stream);
+
+/* ---- amortized MVN guide, backward: encoder weight gradients of the LOSS from gx.
+ * genc = d LOSS / d encoder parameters, flat in the nn.Linear order of vi.py:442-444:
+ *   [W1: H*J | b1: H | W21: D*H | b21: D | W22: T*H | b22: T],  T = D(D+1)/2. */
+int64_t vx_mvn_enc_param_floats(const vx_irt_cfg* cfg);          /* length of genc */
+int64_t vx_mvn_enc_bwd_workspace_floats(const vx_irt_cfg* cfg, int64_t nb);
+int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
+                        const float* W21, const float* W22,
+                        const float* h, const float* eps, const float* ldT, const float* gx,
+                        float* genc, float* workspace, void* hip_stream);
+
+/* ---- D = 1 models (irt_1pl..4pl, Normal guide; vi.py:588-595, 677-684, 701-705), fused:
+ * x = loc + exp(raw) eps, likelihood, prior, entropy, gradients w.r.t. loc/raw and the items.
+ *   loc/raw: [nb] (already gathered for BBVI minibatches, or encoder outputs)
+ *   outputs: gloc[nb], graw[nb] = d LOSS / d loc, d raw;  elbo[nb] = per-person
+ *            log p(y|x) + log p(x) - log q(x) (unscaled);
+ *   gitem:   d LOSS / d [a: J | b: J | c_un: J | d_un: J] for this rank's batch (a = 0 for 1PL).
+ * J <= 1024.  workspace: vx_irt1d_workspace_floats(cfg, nb) floats. */
+int64_t vx_irt1d_workspace_floats(const vx_irt_cfg* cfg, int64_t nb);
+int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, int64_t gid0,
+                  const float* loc, const float* raw, const float* eps_in,
+                  const float* a, const float* b, const float* c_un, const float* d_un,
+                  float* gloc, float* graw, float* elbo, float* gitem, float* workspace,
+                  void* hip_stream);
+
+/* ---- slab reduction: out[i] = alpha * sum_s slabs[s][i]  (fixed order -> deterministic) */
+int vx_reduce_slabs(const float* slabs, int64_t n_slabs, int64_t len, float alpha, float* out,
+                    void* hip_stream);
+/* out[0] = alpha * sum(v) (fixed-order two-stage tree; used for the loss);
+ * workspace: vx_sum_workspace_floats() floats */
+int64_t vx_sum_workspace_floats(void);
+int vx_sum(const float* v, int64_t n, float alpha, float* out, float* workspace, void* hip_stream);
+
+/* ---- optimiser: torch.optim.Adam on a flat float32 buffer split into segments with their own
+ * learning rate (pyro.optim.Adam with callable optim_args; vi.py:514, test.py:345-350), optional
+ * 0/1 `free` mask multiplied into the gradient first (vi.py:511-512). */
+typedef struct vx_adam_seg { int64_t begin, end; float lr; float _pad; } vx_adam_seg;
+int vx_adam_step(float* p, const float* g, float* m, float* v, const float* free_mask /*or NULL*/,
+                 int64_t n, const vx_adam_seg* segs /*host*/, int32_t n_segs, int32_t t,
+                 float beta1, float beta2, float eps, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIPSY_AMD_H */

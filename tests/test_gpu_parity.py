@@ -1,0 +1,191 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle and the golden vectors."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vi_oracle as vo
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _engine_from_fixture(tag):
+    from vipsy_amd.engine import IrtEngine, LrSpec
+    spec, params, opt, y, steps, B = gu.build(tag, np.float64)
+    enc = {k.split("$$$")[1]: v for k, v in params.items() if k.startswith("encoder$$$")}
+    eng = IrtEngine(torch.from_numpy(y).to(_dev()), model=spec["model"], D=spec["D"], Dc=spec["Dc"],
+                    amortized=spec["amortized"], H=(enc["fc1.weight"].shape[0] if enc else 0),
+                    encoder_init=enc if enc else None, b0=params["b"], seed=1)
+    lrs = LrSpec(opt["lr"], milestones=opt["milestones"], gamma=opt["gamma"])
+    return eng, lrs, spec, params, opt, y, steps
+
+
+def test_philox_words_bit_exact():
+    from vipsy_amd import _hip
+    L = _hip.lib()
+    n = 1000
+    out = torch.empty(n, 4, dtype=torch.int32, device=_dev())
+    for seed, step, stream, gid0 in [(1234, 0, 0, 0), (0xDEADBEEFCAFE, 77, 3, (1 << 33) + 5)]:
+        _hip.check(L.vx_philox_raw(_hip.ptr(out), gid0, n, seed, step, stream, _hip.stream_ptr()), "philox_raw")
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(np.uint32)
+        gids = gid0 + np.arange(n, dtype=np.int64)
+        w = vo.philox4x32_10((gids & 0xFFFFFFFF).astype(np.uint32), ((gids >> 32) & 0xFFFFFFFF).astype(np.uint32),
+                             np.uint32(step), np.uint32(stream << 16), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+        np.testing.assert_array_equal(got, np.stack(w, axis=1))
+
+
+@pytest.mark.parametrize("D", [1, 3, 100])
+def test_philox_normals_match_oracle(D):
+    from vipsy_amd import _hip
+    L = _hip.lib()
+    n = 4096
+    out = torch.empty(n, D, dtype=torch.float32, device=_dev())
+    gids = torch.randperm(1 << 20, device=_dev())[:n].to(torch.int64) + (1 << 32)
+    _hip.check(L.vx_philox_normals(_hip.ptr(out), _hip.ptr(gids), 0, n, D, 99, 5, 2, _hip.stream_ptr()), "normals")
+    torch.cuda.synchronize()
+    ref = vo.philox_normals(99, 5, 2, gids.cpu().numpy(), D)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=2e-5, rtol=1e-5)
+    assert abs(float(out.mean())) < 0.05 and abs(float(out.std()) - 1) < 0.05
+
+
+GOLDEN_HIP = ["vaeirt_irt_2pl_d3", "vaeirt_irt_3pl_d2", "vaeirt_irt_4pl_d4",
+              "virt_irt_1pl_d1", "virt_irt_2pl_d1", "virt_irt_3pl_d1", "virt_irt_4pl_d1", "virt_irt_2pl_d1_D1702"]
+
+
+@pytest.mark.parametrize("tag", GOLDEN_HIP)
+def test_hip_replays_reference_steps(tag):
+    """Same y / eps / idx as the reference run -> same loss, gradients and Adam trajectory."""
+    eng, lrs, spec, params, opt, y, steps = _engine_from_fixture(tag)
+    adam = vo.Adam(opt["lr"], milestones=opt["milestones"], gamma=opt["gamma"])
+    for t, rec in enumerate(steps):
+        idx, eps = rec["idx"][0], rec["eps"][0]
+        rows = torch.from_numpy(idx).to(_dev())
+        full = len(idx) == spec["N"] and (idx == np.arange(spec["N"])).all()
+        eng.loss_and_grads(None if full else rows, len(idx), torch.from_numpy(np.ascontiguousarray(eps)).to(_dev()))
+        torch.cuda.synchronize()
+        loss_o, g_o = vo.loss_and_grads(spec, params, y, [idx], [eps])
+        loss_h = float(eng.G[eng.n_params].item())
+        assert loss_h == pytest.approx(loss_o, rel=2e-5), (tag, t)
+        assert loss_h == pytest.approx(rec["loss"], rel=2e-4), (tag, t)
+        for name, go in g_o.items():
+            gh = eng.unconstrained(name, eng.GP if name in ("x_local", "x_scale") else eng.G).cpu().numpy()
+            if name == "a" and spec["a_free"] is not None:
+                gh = gh * spec["a_free"]
+            sc = max(1e-3, float(np.abs(go).max()))
+            np.testing.assert_allclose(gh / sc, go / sc, atol=3e-5, err_msg="%s step %d grad %s" % (tag, t, name))
+            np.testing.assert_allclose(gh / sc, rec["grad"][name] / sc, atol=1e-3, err_msg="golden %s %s" % (tag, name))
+        eng.allreduce()
+        eng.apply_optim(lrs)
+        lrs.scheduler_step()
+        adam.step(params, g_o)
+        adam.scheduler_step()
+        torch.cuda.synchronize()
+        for name, p in rec["param"].items():
+            ph = eng.unconstrained(name).cpu().numpy()
+            np.testing.assert_allclose(ph, params[name], atol=2e-5, rtol=1e-4, err_msg="%s step %d param %s" % (tag, t, name))
+            np.testing.assert_allclose(ph, p, atol=2e-4, rtol=1e-3, err_msg="golden %s step %d param %s" % (tag, t, name))
+
+
+def _random_problem(N, J, D, H, model, miss, seed):
+    rng = np.random.RandomState(seed)
+    y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+    y[rng.rand(N, J) < miss] = 255
+    enc = {"fc1.weight": rng.randn(H, J) / np.sqrt(J), "fc1.bias": 0.1 * rng.randn(H),
+           "fc21.weight": rng.randn(D, H) / np.sqrt(H), "fc21.bias": 0.1 * rng.randn(D),
+           "fc22.weight": 0.3 * rng.randn(D * (D + 1) // 2, H) / np.sqrt(H), "fc22.bias": 0.05 * rng.randn(D * (D + 1) // 2)}
+    return y, enc, rng
+
+
+@pytest.mark.parametrize("N,J,D,H,model,miss,B", [
+    (300, 500, 100, 64, "irt_2pl", 0.0, None),      # headline shape (test_ai_100_dim_2pl, test.py:336)
+    (257, 130, 33, 40, "irt_2pl", 0.3, 101),        # ragged everything, subsample
+    (129, 260, 7, 64, "irt_4pl", 0.2, None),
+    (64, 33, 2, 16, "irt_3pl", 0.5, 17),
+    (1000, 600, 12, 64, "irt_2pl", 0.59, None),     # J > 512: two item groups
+])
+def test_mvn_amortized_step_vs_oracle(N, J, D, H, model, miss, B):
+    from vipsy_amd.engine import IrtEngine, ENC_KEYS
+    y, enc, rng = _random_problem(N, J, D, H, model, miss, seed=N + J + D)
+    eng = IrtEngine(torch.from_numpy(y).to(_dev()), model=model, D=D, amortized=True, H=H,
+                    encoder_init={k: v.astype(np.float32) for k, v in enc.items()}, seed=11)
+    # randomise the item parameters a little so every term is exercised
+    a0 = (eng.unconstrained("a") * torch.from_numpy(1 + 0.3 * rng.randn(D, J)).float().to(_dev()))
+    eng.unconstrained("a").copy_(a0 * eng.unconstrained("a", eng.free))
+    eng.unconstrained("b").copy_(torch.from_numpy(0.5 * rng.randn(1, J)).float())
+    if model in ("irt_3pl", "irt_4pl"):
+        eng.unconstrained("c").add_(torch.from_numpy(0.3 * rng.randn(1, J)).float().to(_dev()))
+    if model == "irt_4pl":
+        eng.unconstrained("d").add_(torch.from_numpy(0.3 * rng.randn(1, J)).float().to(_dev()))
+    idx = np.arange(N) if B is None else np.sort(rng.permutation(N)[:B])
+    rows = None if B is None else torch.from_numpy(idx).to(_dev())
+    eng.loss_and_grads(rows, len(idx))
+    torch.cuda.synchronize()
+    nb = len(idx)
+    fw = eng.last["fw"]
+    eps = fw["eps"][:nb * D].reshape(nb, D).cpu().numpy()
+    # RNG inside the fused kernel == vx_philox_normals == oracle spec, keyed by global person id
+    np.testing.assert_allclose(eps, vo.philox_normals(11, 0, 0, idx, D), atol=2e-5)
+    spec = {"family": "irt", "model": model, "D": D, "Dc": 1.0, "N": N, "amortized": True, "share_cov": False,
+            "a_free": vo.default_a_free(D, J)}
+    params = {n: eng.unconstrained(n).cpu().numpy().astype(np.float64) for n in eng.names()}
+    loss_o, g_o = vo.loss_and_grads(spec, params, y, [idx], [eps])
+    loss_h = float(eng.G[eng.n_params].item())
+    assert loss_h == pytest.approx(loss_o, rel=3e-5)
+    for name, go in g_o.items():
+        gh = eng.unconstrained(name, eng.G).cpu().numpy() * eng.unconstrained(name, eng.free).cpu().numpy()
+        sc = max(1e-6, float(np.abs(go).max()))
+        err = np.abs(gh - go).max() / sc
+        assert err < 2e-4, (name, err)
+
+
+@pytest.mark.parametrize("N,J,model,miss,B", [
+    (1000, 5, "irt_2pl", 0.0, None),                 # config 1 shape (lsat.dat)
+    (5000, 100, "irt_4pl", 0.0, None),               # config 2 shape, scaled down
+    (3000, 500, "irt_2pl", 0.9, None),               # config 4 shape, scaled down, 90 % MCAR
+    (777, 1000, "irt_2pl", 0.59, 100),               # Irt2PLMissing.test_ai shape (test.py:311-319)
+    (100, 65, "irt_1pl", 0.1, 33),
+    (100, 129, "irt_3pl", 0.1, None),
+])
+def test_irt1d_step_vs_oracle(N, J, model, miss, B):
+    from vipsy_amd.engine import IrtEngine
+    rng = np.random.RandomState(N + J)
+    y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+    y[rng.rand(N, J) < miss] = 255
+    eng = IrtEngine(torch.from_numpy(y).to(_dev()), model=model, D=1, seed=5)
+    eng.unconstrained("b").copy_(torch.from_numpy(0.7 * rng.randn(1, J)).float())
+    if model != "irt_1pl":
+        eng.unconstrained("a").copy_(torch.from_numpy(0.5 + 2 * rng.rand(1, J)).float())
+    if model in ("irt_3pl", "irt_4pl"):
+        eng.unconstrained("c").add_(torch.from_numpy(0.3 * rng.randn(1, J)).float().to(_dev()))
+    eng.PP.copy_(torch.from_numpy(np.concatenate([rng.randn(N), 0.3 * rng.randn(N)])).float())
+    idx = np.arange(N) if B is None else np.sort(rng.permutation(N)[:B])
+    rows = None if B is None else torch.from_numpy(idx).to(_dev())
+    eps = vo.philox_normals(5, 0, 0, idx, 1)
+    eng.loss_and_grads(rows, len(idx))
+    torch.cuda.synchronize()
+    spec = {"family": "irt", "model": model, "D": 1, "Dc": 1.0, "N": N, "amortized": False, "share_cov": False,
+            "a_free": None}
+    params = {n: eng.unconstrained(n).cpu().numpy().astype(np.float64) for n in eng.names() + ["x_local", "x_scale"]}
+    loss_o, g_o = vo.loss_and_grads(spec, params, y, [idx], [eps])
+    assert float(eng.G[eng.n_params].item()) == pytest.approx(loss_o, rel=3e-5)
+    for name, go in g_o.items():
+        gh = eng.unconstrained(name, eng.GP if name in ("x_local", "x_scale") else eng.G).cpu().numpy()
+        sc = max(1e-6, float(np.abs(go).max()))
+        assert np.abs(gh - go).max() / sc < 2e-4, name
+
+
+def test_entry_points_reject_bad_arguments():
+    from vipsy_amd import _hip
+    L = _hip.lib()
+    cfg = _hip.IrtCfg(2, 200, 10, 64, 1.0, 1.0, 0, 0, 0)                  # D = 200 > supported 127
+    assert L.vx_irt_lik_workspace_floats(ctypes.byref(cfg), 10) == -1
+    cfg = _hip.IrtCfg(2, 1, 2000, 0, 1.0, 1.0, 0, 0, 0)                   # J > 1024 for the D=1 kernel
+    assert L.vx_irt1d_workspace_floats(ctypes.byref(cfg), 10) == -1
+    assert L.vx_philox_normals(None, None, 0, 10, 1, 0, 0, 0, _hip.stream_ptr()) == -1

@@ -1,0 +1,105 @@
+"""ctypes binding of include/vipsy_amd.h (the C-ABI shared library built from vipsy_amd/csrc).
+
+The product path has NO fallback: if libvipsy_hip.so is missing or an entry point fails, this raises.
+torch is used only as the owner of device memory and streams (plumbing).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libvipsy_hip.so")
+
+
+class VxError(RuntimeError):
+    pass
+
+
+class IrtCfg(ctypes.Structure):
+    """struct vx_irt_cfg (include/vipsy_amd.h)."""
+    _fields_ = [("model", ctypes.c_int32), ("D", ctypes.c_int32), ("J", ctypes.c_int32), ("H", ctypes.c_int32),
+                ("Dc", ctypes.c_float), ("scale", ctypes.c_float), ("seed", ctypes.c_uint64),
+                ("step", ctypes.c_uint32), ("stream", ctypes.c_uint32)]
+
+
+class AdamSeg(ctypes.Structure):
+    _fields_ = [("begin", ctypes.c_int64), ("end", ctypes.c_int64), ("lr", ctypes.c_float), ("_pad", ctypes.c_float)]
+
+
+class HoDinaCfg(ctypes.Structure):
+    """struct vx_hodina_cfg (include/vipsy_amd.h)."""
+    _fields_ = [("K", ctypes.c_int32), ("J", ctypes.c_int32), ("H", ctypes.c_int32), ("_pad", ctypes.c_int32),
+                ("scale", ctypes.c_float), ("_pad2", ctypes.c_float), ("seed", ctypes.c_uint64),
+                ("step", ctypes.c_uint32), ("stream", ctypes.c_uint32)]
+
+
+_P = ctypes.c_void_p
+_I64 = ctypes.c_int64
+_I32 = ctypes.c_int32
+_U32 = ctypes.c_uint32
+_U64 = ctypes.c_uint64
+_F = ctypes.c_float
+_CFG = ctypes.POINTER(IrtCfg)
+
+# name -> (restype, argtypes); every symbol the header declares must be listed here
+SIGNATURES = {
+    "vx_abi_version": (ctypes.c_int, []),
+    "vx_build_info": (ctypes.c_char_p, []),
+    "vx_philox_normals": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _U64, _U32, _U32, _P]),
+    "vx_philox_raw": (ctypes.c_int, [_P, _I64, _I64, _U64, _U32, _U32, _P]),
+    "vx_mvn_enc_forward": (ctypes.c_int, [_CFG, _P, _P, _I64, _I64] + [_P] * 6 + [_P] + [_P] * 5 + [_P]),
+    "vx_irt_lik_workspace_floats": (_I64, [_CFG, _I64]),
+    "vx_irt_lik_grad": (ctypes.c_int, [_CFG, _P, _P, _I64] + [_P] * 5 + [_P] * 3 + [_P, _P]),
+    "vx_mvn_enc_param_floats": (_I64, [_CFG]),
+    "vx_mvn_enc_bwd_workspace_floats": (_I64, [_CFG, _I64]),
+    "vx_mvn_enc_backward": (ctypes.c_int, [_CFG, _P, _P, _I64] + [_P] * 6 + [_P, _P, _P]),
+    "vx_irt1d_workspace_floats": (_I64, [_CFG, _I64]),
+    "vx_irt1d_grad": (ctypes.c_int, [_CFG, _P, _P, _I64, _I64] + [_P] * 3 + [_P] * 4 + [_P] * 4 + [_P, _P]),
+    "vx_reduce_slabs": (ctypes.c_int, [_P, _I64, _I64, _F, _P, _P]),
+    "vx_sum_workspace_floats": (_I64, []),
+    "vx_sum": (ctypes.c_int, [_P, _I64, _F, _P, _P, _P]),
+    "vx_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, ctypes.POINTER(AdamSeg), _I32, _I32, _F, _F, _F, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (once).  Raises VxError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VxError("HIP extension missing: %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback in the product path)" % LIB_PATH)
+        try:
+            handle = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise VxError("cannot load %s: %s" % (LIB_PATH, e))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise VxError("%s failed with code %d" % (what, rc))
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_contiguous(), "device buffers handed to the C ABI must be contiguous"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise VxError("vipsy_amd needs an MI355X (HIP device); none is visible and there is no CPU fallback")

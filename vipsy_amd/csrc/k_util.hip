@@ -1,0 +1,93 @@
+// Utility kernels: Philox fill, fixed-order reductions, segmented Adam.
+#pragma once
+#include "vx_common.h"
+
+__global__ void k_philox_normals(float* __restrict__ eps, const int64_t* __restrict__ gids, int64_t gid0,
+                                 int64_t n, int D, uint64_t seed, uint32_t step, uint32_t stream) {
+    const int nblk = (D + 3) >> 2;
+    const int64_t total = n * nblk;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / nblk;
+        const int blk = (int)(e - i * nblk);
+        const int64_t gid = gids ? gids[i] : gid0 + i;
+        f32x4 z = philox_normal4(seed, step, stream, gid, (uint32_t)blk);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (4 * blk + q < D) eps[i * D + 4 * blk + q] = z[q];
+    }
+}
+
+__global__ void k_philox_raw(uint32_t* __restrict__ out, int64_t gid0, int64_t n, uint64_t seed, uint32_t step,
+                             uint32_t stream) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t gid = gid0 + i;
+        u32x4 w = philox4x32_10((uint32_t)gid, (uint32_t)((uint64_t)gid >> 32), step, stream << 16,
+                                (uint32_t)seed, (uint32_t)(seed >> 32));
+        out[4 * i + 0] = w.x; out[4 * i + 1] = w.y; out[4 * i + 2] = w.z; out[4 * i + 3] = w.w;
+    }
+}
+
+// out[i] = alpha * sum_s slabs[s * stride + i]   (s ascending -> deterministic)
+__global__ void k_reduce_slabs(const float* __restrict__ slabs, int64_t n_slabs, int64_t stride, int64_t len,
+                               float alpha, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        for (int64_t s = 0; s < n_slabs; ++s) acc += slabs[s * stride + i];
+        out[i] = alpha * acc;
+    }
+}
+
+// two-stage fixed-order sum: stage 1 -> partial[blockIdx], stage 2 (1 block) -> out[0]
+__global__ void k_sum_stage1(const float* __restrict__ v, int64_t n, float* __restrict__ partial) {
+    __shared__ float red[256 / VX_WAVE];
+    float acc = 0.f;
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per;
+    const int64_t hi = lo + per < n ? lo + per : n;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) acc += v[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+        partial[blockIdx.x] = t;
+    }
+}
+__global__ void k_sum_stage2(const float* __restrict__ partial, int n, float alpha, float* __restrict__ out) {
+    __shared__ float red[256 / VX_WAVE];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += partial[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+        out[0] = alpha * t;
+    }
+}
+
+#define VX_MAX_SEGS 16
+struct AdamSegs { int64_t begin[VX_MAX_SEGS]; int64_t end[VX_MAX_SEGS]; float lr[VX_MAX_SEGS]; int n; };
+
+// torch.optim.Adam: p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                       float* __restrict__ v, const float* __restrict__ free_mask, int64_t n, AdamSegs segs,
+                       float beta1, float beta2, float eps, float bc1, float bc2_sqrt) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float lr = 0.f;
+        bool found = false;
+        for (int s = 0; s < segs.n; ++s)
+            if (i >= segs.begin[s] && i < segs.end[s]) { lr = segs.lr[s]; found = true; }
+        if (!found) continue;
+        float gi = g[i];
+        if (free_mask) gi *= free_mask[i];
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - (lr / bc1) * (mi / denom);
+    }
+}

@@ -1,0 +1,371 @@
+// C-ABI entry points (include/vipsy_amd.h).  Host-side launch logic only; one translation unit.
+#include "vx_common.h"
+#include "k_util.hip"
+#include "k_mvn_enc.hip"
+#include "k_mvn_enc_bwd.hip"
+#include "k_irt_lik.hip"
+#include "k_irt1d.hip"
+
+#include <mutex>
+
+namespace {
+
+int g_num_cu = 0;
+int num_cu() {
+    if (g_num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            g_num_cu = prop.multiProcessorCount;
+        if (g_num_cu <= 0) g_num_cu = 256;
+    }
+    return g_num_cu;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    if (bytes > 160 * 1024) return VX_EINVAL;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return e == hipSuccess ? VX_OK : (int)e;
+}
+
+inline int grid_1d(int64_t n, int block) {
+    int64_t g = (n + block - 1) / block;
+    const int64_t cap = (int64_t)num_cu() * 8;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+inline int tril_len(int D) { return D * (D + 1) / 2; }
+
+EncDims make_enc_dims(const vx_irt_cfg* cfg, int64_t nb) {
+    EncDims dm;
+    dm.D = cfg->D; dm.J = cfg->J; dm.H = cfg->H;
+    dm.Hp = (cfg->H + 31) / 32 * 32;
+    dm.DS = enc_ds(cfg->D);
+    dm.T = tril_len(cfg->D);
+    dm.nb = nb;
+    return dm;
+}
+
+bool enc_cfg_ok(const vx_irt_cfg* cfg) {
+    return cfg && cfg->D >= 2 && cfg->D <= 127 && cfg->H >= 1 && cfg->H <= 64 && cfg->J >= 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vx_abi_version(void) { return VX_ABI_VERSION; }
+const char* vx_build_info(void) { return "vipsy_amd gfx950 fp32-mfma " __DATE__ " " __TIME__; }
+
+int vx_philox_normals(float* eps, const int64_t* gids, int64_t gid0, int64_t n, int32_t D, uint64_t seed,
+                      uint32_t step, uint32_t stream, void* hs) {
+    if (!eps || n < 0 || D < 1) return VX_EINVAL;
+    if (n == 0) return VX_OK;
+    const int64_t total = n * ((D + 3) / 4);
+    hipLaunchKernelGGL(k_philox_normals, dim3(grid_1d(total, 256)), dim3(256), 0, (hipStream_t)hs, eps, gids,
+                       gid0, n, (int)D, seed, step, stream);
+    VX_CHECK_LAUNCH();
+    return VX_OK;
+}
+
+int vx_philox_raw(uint32_t* out, int64_t gid0, int64_t n, uint64_t seed, uint32_t step, uint32_t stream,
+                  void* hs) {
+    if (!out || n < 0) return VX_EINVAL;
+    if (n == 0) return VX_OK;
+    hipLaunchKernelGGL(k_philox_raw, dim3(grid_1d(n, 256)), dim3(256), 0, (hipStream_t)hs, out, gid0, n, seed,
+                       step, stream);
+    VX_CHECK_LAUNCH();
+    return VX_OK;
+}
+
+int vx_reduce_slabs(const float* slabs, int64_t n_slabs, int64_t len, float alpha, float* out, void* hs) {
+    if (!slabs || !out || n_slabs < 1 || len < 0) return VX_EINVAL;
+    if (len == 0) return VX_OK;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(grid_1d(len, 256)), dim3(256), 0, (hipStream_t)hs, slabs, n_slabs,
+                       len, len, alpha, out);
+    VX_CHECK_LAUNCH();
+    return VX_OK;
+}
+
+int64_t vx_sum_workspace_floats(void) { return 1024; }
+
+int vx_sum(const float* v, int64_t n, float alpha, float* out, float* workspace, void* hs) {
+    if (!v || !out || !workspace || n < 0) return VX_EINVAL;
+    int nblk = (int)((n + 4095) / 4096);
+    if (nblk < 1) nblk = 1;
+    if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL(k_sum_stage1, dim3(nblk), dim3(256), 0, (hipStream_t)hs, v, n, workspace);
+    VX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_sum_stage2, dim3(1), dim3(256), 0, (hipStream_t)hs, workspace, nblk, alpha, out);
+    VX_CHECK_LAUNCH();
+    return VX_OK;
+}
+
+int vx_adam_step(float* p, const float* g, float* m, float* v, const float* free_mask, int64_t n,
+                 const vx_adam_seg* segs, int32_t n_segs, int32_t t, float beta1, float beta2, float eps,
+                 void* hs) {
+    if (!p || !g || !m || !v || !segs || n_segs < 1 || n_segs > VX_MAX_SEGS || t < 1) return VX_EINVAL;
+    AdamSegs s;
+    s.n = n_segs;
+    for (int i = 0; i < n_segs; ++i) {
+        if (segs[i].begin < 0 || segs[i].end > n || segs[i].begin > segs[i].end) return VX_EINVAL;
+        s.begin[i] = segs[i].begin; s.end[i] = segs[i].end; s.lr[i] = segs[i].lr;
+    }
+    const double bc1 = 1.0 - pow((double)beta1, (double)t);
+    const double bc2 = 1.0 - pow((double)beta2, (double)t);
+    hipLaunchKernelGGL(k_adam, dim3(grid_1d(n, 256)), dim3(256), 0, (hipStream_t)hs, p, g, m, v, free_mask, n, s,
+                       beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+    VX_CHECK_LAUNCH();
+    return VX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, int64_t gid0,
+                       const float* W1, const float* b1, const float* W21, const float* b21, const float* W22,
+                       const float* b22, const float* eps_in, float* h, float* x, float* eps, float* ldT,
+                       float* ent, void* hs) {
+    if (!enc_cfg_ok(cfg) || !y || !W1 || !b1 || !W21 || !b21 || !W22 || !b22 || !h || !x || !eps || !ldT || !ent ||
+        nb < 0)
+        return VX_EINVAL;
+    if (nb == 0) return VX_OK;
+    EncDims dm = make_enc_dims(cfg, nb);
+    const size_t lds = enc_fwd_lds_floats(dm.D, dm.Hp) * sizeof(float);
+    const dim3 grid((unsigned)((nb + ENC_P - 1) / ENC_P));
+    int rc;
+#define LAUNCH_FWD(HT)                                                                                       \
+    rc = set_lds(k_mvn_enc_fwd<HT>, lds);                                                                    \
+    if (rc) return rc;                                                                                       \
+    hipLaunchKernelGGL(k_mvn_enc_fwd<HT>, grid, dim3(ENC_THREADS), lds, (hipStream_t)hs, dm, y, rows, gid0, W1, \
+                       b1, W21, b21, W22, b22, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent)
+    if (dm.Hp == 32) { LAUNCH_FWD(1); } else { LAUNCH_FWD(2); }
+#undef LAUNCH_FWD
+    VX_CHECK_LAUNCH();
+    return VX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+static void lik_plan(const vx_irt_cfg* cfg, int64_t nb, int& kt, int& nch, int& groups, int& n_pr) {
+    const int dk = cfg->D + 1;
+    kt = dk <= 32 ? 1 : (dk <= 64 ? 2 : 4);
+    nch = cfg->J <= LIK_JC ? 1 : (cfg->J <= 2 * LIK_JC ? 2 : 4);
+    groups = (cfg->J + nch * LIK_JC - 1) / (nch * LIK_JC);
+    const int64_t n_ptiles = (nb + LIK_P - 1) / LIK_P;
+    int64_t want = num_cu() / groups;
+    if (want < 1) want = 1;
+    n_pr = (int)(n_ptiles < want ? n_ptiles : want);
+    if (n_pr < 1) n_pr = 1;
+}
+
+static bool lik_cfg_ok(const vx_irt_cfg* cfg) {
+    return cfg && cfg->D >= 2 && cfg->D <= 127 && cfg->J >= 1 && cfg->model >= VX_IRT_2PL &&
+           cfg->model <= VX_IRT_4PL;
+}
+
+int64_t vx_irt_lik_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
+    if (!lik_cfg_ok(cfg) || nb < 0) return VX_EINVAL;
+    int kt, nch, groups, n_pr;
+    lik_plan(cfg, nb, kt, nch, groups, n_pr);
+    const int64_t slab_len = (int64_t)cfg->D * cfg->J + 3 * (int64_t)cfg->J;
+    int64_t w = (int64_t)n_pr * slab_len;
+    if (groups > 1) w += (int64_t)groups * nb * (cfg->D + 1);
+    return w;
+}
+
+int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* x,
+                    const float* a, const float* b, const float* c_un, const float* d_un, float* gx, float* ll,
+                    float* gitem, float* workspace, void* hs) {
+    if (!lik_cfg_ok(cfg) || !y || !x || !a || !b || !gx || !ll || !gitem || !workspace || nb < 0) return VX_EINVAL;
+    if (cfg->model >= VX_IRT_3PL && !c_un) return VX_EINVAL;
+    if (cfg->model == VX_IRT_4PL && !d_un) return VX_EINVAL;
+    int kt, nch, groups, n_pr;
+    lik_plan(cfg, nb, kt, nch, groups, n_pr);
+    LikDims dm;
+    dm.D = cfg->D; dm.J = cfg->J; dm.DS = lik_ds(cfg->D); dm.Dk2 = (cfg->D + 2) & ~1; dm.model = cfg->model;
+    dm.Dc = cfg->Dc; dm.scale = cfg->scale; dm.nb = nb;
+    dm.slab_len = (int64_t)cfg->D * cfg->J + 3 * (int64_t)cfg->J;
+    const int gen = cfg->model >= VX_IRT_3PL ? 1 : 0;
+    float* slabs = workspace;
+    float* gx_part = groups > 1 ? workspace + (int64_t)n_pr * dm.slab_len : gx;
+    float* ll_part = groups > 1 ? gx_part + (int64_t)groups * nb * cfg->D : ll;
+    hipStream_t st = (hipStream_t)hs;
+    // slabs are only partially written when a model has no c/d segment: clear them first
+    hipError_t he = hipMemsetAsync(slabs, 0, sizeof(float) * (size_t)n_pr * dm.slab_len, st);
+    if (he != hipSuccess) return (int)he;
+    if (nb > 0) {
+        const size_t lds = lik_lds_floats(cfg->D, nch, gen) * sizeof(float);
+        const dim3 grid((unsigned)groups, (unsigned)n_pr);
+        int rc = VX_EINVAL;
+#define LAUNCH_LIK(KT, NCH, GEN)                                                                             \
+    rc = set_lds(k_irt_lik<KT, NCH, GEN>, lds);                                                              \
+    if (rc) return rc;                                                                                       \
+    hipLaunchKernelGGL((k_irt_lik<KT, NCH, GEN>), grid, dim3(LIK_THREADS), lds, st, dm, y, rows, x, a, b, c_un, \
+                       d_un, gx_part, ll_part, slabs)
+#define DISPATCH_NCH(KT, GEN)                                     \
+    if (nch == 1) { LAUNCH_LIK(KT, 1, GEN); }                     \
+    else if (nch == 2) { LAUNCH_LIK(KT, 2, GEN); }                \
+    else { LAUNCH_LIK(KT, 4, GEN); }
+#define DISPATCH_KT(GEN)                                          \
+    if (kt == 1) { DISPATCH_NCH(1, GEN) }                         \
+    else if (kt == 2) { DISPATCH_NCH(2, GEN) }                    \
+    else { DISPATCH_NCH(4, GEN) }
+        if (gen) { DISPATCH_KT(1) } else { DISPATCH_KT(0) }
+#undef DISPATCH_KT
+#undef DISPATCH_NCH
+#undef LAUNCH_LIK
+        VX_CHECK_LAUNCH();
+        if (groups > 1) {
+            int r2 = vx_reduce_slabs(gx_part, groups, nb * cfg->D, 1.0f, gx, hs);
+            if (r2) return r2;
+            r2 = vx_reduce_slabs(ll_part, groups, nb, 1.0f, ll, hs);
+            if (r2) return r2;
+        }
+    }
+    // loss gradients = -(d ELBO / d .)
+    return vx_reduce_slabs(slabs, n_pr, dm.slab_len, -1.0f, gitem, hs);
+}
+
+// ------------------------------------------------------------------------------------------------
+static void encb_plan(const vx_irt_cfg* cfg, int64_t nb, int& n_rowslabs, int& n_prw, int& n_jg, int& n_prf) {
+    const int64_t RT = (int64_t)tril_len(cfg->D) + cfg->D;
+    n_rowslabs = (int)((RT + BW_ROWS - 1) / BW_ROWS);
+    n_jg = (cfg->J + FC1_JG - 1) / FC1_JG;
+    const int64_t n_ptiles = (nb + ENC_P - 1) / ENC_P;
+    int64_t w = num_cu() / n_rowslabs; if (w < 1) w = 1;
+    n_prw = (int)(n_ptiles < w ? n_ptiles : w); if (n_prw < 1) n_prw = 1;
+    int64_t f = num_cu() / n_jg; if (f < 1) f = 1;
+    n_prf = (int)(n_ptiles < f ? n_ptiles : f); if (n_prf < 1) n_prf = 1;
+}
+
+int64_t vx_mvn_enc_param_floats(const vx_irt_cfg* cfg) {
+    if (!enc_cfg_ok(cfg)) return VX_EINVAL;
+    const int64_t D = cfg->D, J = cfg->J, H = cfg->H, T = tril_len(cfg->D);
+    return H * J + H + D * H + D + T * H + T;
+}
+
+int64_t vx_mvn_enc_bwd_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
+    if (!enc_cfg_ok(cfg) || nb < 0) return VX_EINVAL;
+    int n_rowslabs, n_prw, n_jg, n_prf;
+    encb_plan(cfg, nb, n_rowslabs, n_prw, n_jg, n_prf);
+    const int64_t D = cfg->D, J = cfg->J, H = cfg->H, T = tril_len(cfg->D);
+    return nb * H + (int64_t)n_prw * (D * H + D + T * H + T) + (int64_t)n_prf * (H * J + H);
+}
+
+int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
+                        const float* W21, const float* W22, const float* h, const float* eps, const float* ldT,
+                        const float* gx, float* genc, float* workspace, void* hs) {
+    if (!enc_cfg_ok(cfg) || !y || !W21 || !W22 || !h || !eps || !ldT || !gx || !genc || !workspace || nb < 0)
+        return VX_EINVAL;
+    int n_rowslabs, n_prw, n_jg, n_prf;
+    encb_plan(cfg, nb, n_rowslabs, n_prw, n_jg, n_prf);
+    EncDims dm = make_enc_dims(cfg, nb);
+    const int64_t D = cfg->D, J = cfg->J, H = cfg->H, T = dm.T;
+    const int64_t lenw = D * H + D + T * H + T, lenf = H * J + H;
+    float* ghpre = workspace;
+    float* slabs_w = ghpre + nb * H;
+    float* slabs_f = slabs_w + (int64_t)n_prw * lenw;
+    hipStream_t st = (hipStream_t)hs;
+    int rc;
+    if (nb > 0) {
+        {
+            const size_t lds = enc_bwdh_lds_floats(dm.D, dm.Hp) * sizeof(float);
+            const dim3 grid((unsigned)((nb + ENC_P - 1) / ENC_P));
+#define LAUNCH_BH(HT)                                                                                        \
+    rc = set_lds(k_mvn_enc_bwd_h<HT>, lds);                                                                  \
+    if (rc) return rc;                                                                                       \
+    hipLaunchKernelGGL(k_mvn_enc_bwd_h<HT>, grid, dim3(ENC_THREADS), lds, st, dm, cfg->scale, W21, W22, h, eps, \
+                       ldT, gx, ghpre)
+            if (dm.Hp == 32) { LAUNCH_BH(1); } else { LAUNCH_BH(2); }
+#undef LAUNCH_BH
+            VX_CHECK_LAUNCH();
+        }
+        {
+            const size_t lds = enc_bwdw_lds_floats(dm.D, dm.Hp) * sizeof(float);
+            const dim3 grid((unsigned)n_rowslabs, (unsigned)n_prw);
+#define LAUNCH_BW(HT)                                                                                        \
+    rc = set_lds(k_mvn_enc_bwd_w<HT>, lds);                                                                  \
+    if (rc) return rc;                                                                                       \
+    hipLaunchKernelGGL(k_mvn_enc_bwd_w<HT>, grid, dim3(ENC_THREADS), lds, st, dm, cfg->scale, h, eps, ldT, gx,  \
+                       slabs_w, lenw)
+            if (dm.Hp == 32) { LAUNCH_BW(1); } else { LAUNCH_BW(2); }
+#undef LAUNCH_BW
+            VX_CHECK_LAUNCH();
+        }
+        {
+            const size_t lds = fc1_bwd_lds_floats(dm.Hp) * sizeof(float);
+            const dim3 grid((unsigned)n_jg, (unsigned)n_prf);
+#define LAUNCH_F1(HT)                                                                                        \
+    rc = set_lds(k_fc1_bwd<HT>, lds);                                                                        \
+    if (rc) return rc;                                                                                       \
+    hipLaunchKernelGGL(k_fc1_bwd<HT>, grid, dim3(ENC_THREADS), lds, st, dm, y, rows, ghpre, slabs_f, lenf)
+            if (dm.Hp == 32) { LAUNCH_F1(1); } else { LAUNCH_F1(2); }
+#undef LAUNCH_F1
+            VX_CHECK_LAUNCH();
+        }
+    } else {
+        hipError_t he = hipMemsetAsync(slabs_w, 0, sizeof(float) * (size_t)(n_prw * lenw + n_prf * lenf), st);
+        if (he != hipSuccess) return (int)he;
+    }
+    // flat encoder-gradient layout = nn.Linear order: [W1 | b1 | W21 | b21 | W22 | b22]; loss grads = -dELBO
+    rc = vx_reduce_slabs(slabs_f, n_prf, lenf, -1.0f, genc, hs);
+    if (rc) return rc;
+    return vx_reduce_slabs(slabs_w, n_prw, lenw, -1.0f, genc + lenf, hs);
+}
+
+// ------------------------------------------------------------------------------------------------
+static int irt1d_blocks(int64_t nb) {
+    const int64_t n_groups = (nb + 63) / 64;
+    int64_t blocks = (n_groups + 3) / 4;
+    const int64_t cap = (int64_t)num_cu() * 4;
+    if (blocks > cap) blocks = cap;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+static bool irt1d_cfg_ok(const vx_irt_cfg* cfg) {
+    return cfg && cfg->D == 1 && cfg->J >= 1 && cfg->J <= 1024 && cfg->model >= VX_IRT_1PL &&
+           cfg->model <= VX_IRT_4PL;
+}
+
+int64_t vx_irt1d_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
+    if (!irt1d_cfg_ok(cfg) || nb < 0) return VX_EINVAL;
+    return (int64_t)irt1d_blocks(nb) * 4 * cfg->J;
+}
+
+int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, int64_t gid0,
+                  const float* loc, const float* raw, const float* eps_in, const float* a, const float* b,
+                  const float* c_un, const float* d_un, float* gloc, float* graw, float* elbo, float* gitem,
+                  float* workspace, void* hs) {
+    if (!irt1d_cfg_ok(cfg) || !y || !loc || !raw || !b || !gloc || !graw || !elbo || !gitem || !workspace || nb < 0)
+        return VX_EINVAL;
+    if (cfg->model >= VX_IRT_2PL && !a) return VX_EINVAL;
+    if (cfg->model >= VX_IRT_3PL && !c_un) return VX_EINVAL;
+    if (cfg->model == VX_IRT_4PL && !d_un) return VX_EINVAL;
+    const int blocks = irt1d_blocks(nb);
+    Irt1dDims dm;
+    dm.J = cfg->J; dm.model = cfg->model; dm.Dc = cfg->Dc; dm.scale = cfg->scale; dm.nb = nb;
+    const size_t lds = sizeof(float) * 4 * (size_t)cfg->J;
+    hipStream_t st = (hipStream_t)hs;
+    const int ipl_need = (cfg->J + 63) / 64;
+#define LAUNCH_1D(MODEL, IPL)                                                                                \
+    hipLaunchKernelGGL((k_irt1d<MODEL, IPL>), dim3(blocks), dim3(I1_THREADS), lds, st, dm, y, rows, gid0, loc, raw, \
+                       eps_in, cfg->seed, cfg->step, cfg->stream, a, b, c_un, d_un, gloc, graw, elbo, workspace)
+#define DISPATCH_IPL(MODEL)                                        \
+    if (ipl_need <= 1) { LAUNCH_1D(MODEL, 1); }                    \
+    else if (ipl_need <= 2) { LAUNCH_1D(MODEL, 2); }               \
+    else if (ipl_need <= 4) { LAUNCH_1D(MODEL, 4); }               \
+    else if (ipl_need <= 8) { LAUNCH_1D(MODEL, 8); }               \
+    else { LAUNCH_1D(MODEL, 16); }
+    switch (cfg->model) {
+        case VX_IRT_1PL: DISPATCH_IPL(1) break;
+        case VX_IRT_2PL: DISPATCH_IPL(2) break;
+        case VX_IRT_3PL: DISPATCH_IPL(3) break;
+        default: DISPATCH_IPL(4) break;
+    }
+#undef DISPATCH_IPL
+#undef LAUNCH_1D
+    VX_CHECK_LAUNCH();
+    return vx_reduce_slabs(workspace, blocks, 4 * (int64_t)cfg->J, -1.0f, gitem, hs);
+}
+
+}  // extern "C"

@@ -1,0 +1,121 @@
+// Common device helpers for the vipsy_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vipsy_amd.h"
+
+#define VX_WAVE 64
+#define VX_EPS32 1.1920928955078125e-07f          // torch clamp_probs epsilon (float32)
+#define VX_LOGP_MISSING (-1.1920928244535389e-07f) // log Bern(0 | clamp(0)) = -log1p(eps) (vi.py:621-624)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// fp32 MFMA 32x32x2 (v_mfma_f32_32x32x2_f32): exact fp32 fma chain, 64 cycles / SIMD.
+//   A: lane l holds A[m = l & 31][k = l >> 5]
+//   B: lane l holds B[k = l >> 5][n = l & 31]
+//   C: lane l, reg r holds C[m = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][n = l & 31]
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int crow32(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (same spec as oracle/vi_oracle.py::philox4x32_10)
+// ---------------------------------------------------------------------------------------------
+struct u32x4 { uint32_t x, y, z, w; };
+
+__host__ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                        uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        uint64_t p0 = (uint64_t)c0 * 0xD2511F53u;
+        uint64_t p1 = (uint64_t)c2 * 0xCD9E8D57u;
+        uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * 5.9604644775390625e-08f; }
+
+// four standard normals for (person gid, block) -- dims 4*block .. 4*block+3
+__device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint32_t step, uint32_t stream, int64_t gid,
+                                                uint32_t block) {
+    u32x4 w = philox4x32_10((uint32_t)gid, (uint32_t)((uint64_t)gid >> 32), step, (stream << 16) | block,
+                            (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float two_pi = 6.283185307179586f;
+    float r0 = sqrtf(-2.0f * logf(u01(w.x))), t0 = two_pi * u01(w.y);
+    float r1 = sqrtf(-2.0f * logf(u01(w.z))), t1 = two_pi * u01(w.w);
+    float s0, c0, s1, c1;
+    sincosf(t0, &s0, &c0);
+    sincosf(t1, &s1, &c1);
+    f32x4 o;
+    o[0] = r0 * c0; o[1] = r0 * s0; o[2] = r1 * c1; o[3] = r1 * s1;
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scalar math
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float softplusf_(float x) { return fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x))); }
+
+// One response cell: given z = Dc*(x.a + b) returns log-lik term `lp`
+// and dlp/dz; for 3PL/4PL also dlp/dc_un, dlp/dd_un via out params.  y: 0/1/255(missing).
+// 2PL fast path: P = sigmoid(z) clamped to [eps, 1-eps] == z clamped to +-logit(1-eps).
+template <int MODEL>
+__device__ __forceinline__ void irt_cell(float z, unsigned y, float c, float d, float& lp, float& dz,
+                                         float& dc, float& dd) {
+    if (y == 255u) { lp = VX_LOGP_MISSING; dz = 0.f; dc = 0.f; dd = 0.f; return; }
+    const float yf = (float)y;
+    if (MODEL <= 2) {
+        const float ZL = 15.942384719848633f;       // logit(1 - eps32)
+        const bool inside = fabsf(z) <= ZL;
+        const float zc = fminf(fmaxf(z, -ZL), ZL);
+        const float e = __expf(-fabsf(zc));
+        const float sp = fmaxf(zc, 0.f) + log1pf(e);          // softplus(zc)
+        lp = yf * zc - sp;
+        const float sg = (zc >= 0.f) ? 1.0f / (1.0f + e) : e / (1.0f + e);
+        dz = inside ? (yf - sg) : 0.f;
+        dc = 0.f; dd = 0.f;
+    } else {
+        const float e = __expf(-fabsf(z));
+        const float sg = (z >= 0.f) ? 1.0f / (1.0f + e) : e / (1.0f + e);
+        const float P = c + (d - c) * sg;
+        const bool inside = (P >= VX_EPS32) && (P <= 1.0f - VX_EPS32);
+        const float Pc = fminf(fmaxf(P, VX_EPS32), 1.0f - VX_EPS32);
+        lp = (y != 0u) ? __logf(Pc) : log1pf(-Pc);
+        const float dP = inside ? (yf - Pc) / (Pc * (1.0f - Pc)) : 0.f;
+        dz = dP * (d - c) * sg * (1.0f - sg);
+        dc = dP * (1.0f - sg) * c * (1.0f - c);      // w.r.t. unconstrained c (sigmoid transform)
+        dd = (MODEL == 4) ? dP * sg * d * (1.0f - d) : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave / block reductions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+#define VX_CHECK_LAUNCH()                                  \
+    do {                                                   \
+        hipError_t e__ = hipGetLastError();                \
+        if (e__ != hipSuccess) return (int)e__;            \
+    } while (0)
