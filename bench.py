@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""ELBO-gradient steps/sec on the BASELINE.json headline workload:
+2PL IRT, 1M persons x 500 items x 100 latent dims, amortized MvnEncoder guide (hidden 64),
+full batch, one particle (reference: IrtMultiDimTestCase.test_ai_100_dim_2pl, test.py:336-361, scaled
+to 1M persons).  One "step" = one svi.step: guide forward, likelihood + gradients, guide backward,
+[all-reduce of the flat gradient buffer], Adam.  Persons are sharded over the ranks (strong scaling:
+the 1M-person problem is fixed, every rank owns N / world persons).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see the field notes in DESIGN.md section "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (model, N, J, D, H, amortized, missing)
+    "irt2pl_100d_amortized_1Mx500": ("irt_2pl", 1000000, 500, 100, 64, True, 0.0),
+    "irt4pl_1d_bbvi_100kx100": ("irt_4pl", 100000, 100, 1, 0, False, 0.0),
+    "irt2pl_1d_bbvi_missing90_1Mx500": ("irt_2pl", 1000000, 500, 1, 0, False, 0.9),
+}
+
+
+def enc_fwd_flops_per_person(J, D, H):
+    """Algorithmic flops of the guide-forward kernel per person:
+    fc1 J*H + fc21 H*D + fc22 H*T + L.eps T multiply-adds, 2 flops each."""
+    T = D * (D + 1) // 2
+    return 2.0 * (J * H + H * D + H * T + T)
+
+
+def cpu_baseline(J, D, H, n_sample, min_seconds=10.0):
+    """The CPU restatement of the reference step (oracle/vi_oracle.py, numpy float32, all host
+    threads numpy's BLAS uses) on a bounded sample of the same workload: n_sample persons, full
+    step (loss, all gradients, Adam).  Reported, never the thing measured by `value`."""
+    from oracle import vi_oracle as vo
+    rng = np.random.RandomState(0)
+    y = rng.randint(0, 2, size=(n_sample, J)).astype(np.uint8)
+    spec = {"family": "irt", "model": "irt_2pl", "D": D, "Dc": 1.0, "N": n_sample, "amortized": True,
+            "share_cov": False, "a_free": vo.default_a_free(D, J)}
+    enc = {"fc1.weight": rng.randn(H, J) / np.sqrt(J), "fc1.bias": np.zeros(H),
+           "fc21.weight": rng.randn(D, H) / 8, "fc21.bias": np.zeros(D),
+           "fc22.weight": 0.1 * rng.randn(D * (D + 1) // 2, H) / 8, "fc22.bias": np.zeros(D * (D + 1) // 2)}
+    params = vo.init_irt_params(spec, J, np.float32, encoder=enc)
+    adam = vo.Adam(1e-3)
+    idx = np.arange(n_sample)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        eps = rng.randn(n_sample, D).astype(np.float32)
+        _, g = vo.loss_and_grads(spec, params, y, [idx], [eps])
+        adam.step(params, g)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= min_seconds and reps >= 1:
+            break
+    return el / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="irt2pl_100d_amortized_1Mx500", choices=sorted(WORKLOADS))
+    ap.add_argument("--persons", type=int, default=None, help="override N (debug only; makes the line non-headline)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+
+    from vipsy_amd import synth
+    from vipsy_amd.engine import IrtEngine, LrSpec
+
+    model, N, J, D, H, amortized, missing = WORKLOADS[args.workload]
+    if args.persons:
+        N = args.persons
+    # contiguous person shards
+    per = (N + world - 1) // world
+    gid0 = rank * per
+    n_local = max(0, min(N, gid0 + per) - gid0)
+
+    if D > 1:
+        a, b = synth.mirt_item_params(J, D, seed=20243)
+        items = {"a": a, "b": b}
+    else:
+        items = synth.irt_item_params(J, model, seed=20242)
+    y = synth.simulate_responses(n_local, gid0, items, model, dev, seed=20240, missing=missing)
+
+    def lr_fn(module_name, param_name):                     # test.py:345-350
+        return {"lr": 1e-2 if param_name in ("a", "b") else 1e-3}
+    lrs = LrSpec(lr_fn, milestones=(), gamma=0.1)
+    eng = IrtEngine(y, model=model, D=D, n_global=N, gid0=gid0, amortized=amortized, H=H, seed=1234)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.step(lrs)
+        lrs.scheduler_step()
+    # per-phase HIP events on the launch stream (torch's current stream == the stream handed to the C ABI)
+    ev = []
+    eng.events = ev
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = eng.step(lrs)
+        lrs.scheduler_step()
+    sync()
+    dt = time.perf_counter() - t0
+    eng.events = None
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    loss_v = float(loss.item())
+
+    phases = {}
+    for name, e0, e1 in ev:
+        phases.setdefault(name, []).append(e0.elapsed_time(e1))
+    phase_ms = {k: float(np.mean(v)) for k, v in phases.items()}
+
+    if rank == 0:
+        out = {
+            "metric": "ELBO-grad steps/sec, 1M persons x 500 items x 100-dim 2PL IRT",
+            "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "persons": N, "items": J, "dims": D, "hidden": H,
+                       "guide": "amortized MvnEncoder" if amortized else "BBVI per-person", "batch": "full (B=N)",
+                       "particles": 1, "missing_rate": missing, "persons_per_rank": per,
+                       "parallelism": "persons sharded x%d, 1 all-reduce/step" % world},
+            "person_rows_per_s": N * args.steps / dt,
+            "loss_last": loss_v, "phase_ms": phase_ms,
+        }
+        if D > 1 and "guide_forward" in phase_ms:
+            fl = enc_fwd_flops_per_person(J, D, H) * n_local
+            ach = fl / (phase_ms["guide_forward"] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "k_mvn_enc_fwd", "bound": "mfma", "achieved": ach,
+                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                               "traffic": None,
+                               "algorithmic_flops_per_launch": fl, "avg_launch_ms": phase_ms["guide_forward"]}
+        elif "irt1d" in phase_ms:
+            by = (J + 48.0) * n_local                       # y row + 6 fp32 r/w per person
+            ach = by / (phase_ms["irt1d"] * 1e-3) / 1e9
+            out["roofline"] = {"kernel": "k_irt1d", "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS,
+                               "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None,
+                               "algorithmic_bytes_per_launch": by, "avg_launch_ms": phase_ms["irt1d"]}
+        if world == 1 and not args.no_cpu_baseline and D > 1:
+            n_s = 4000
+            sec = cpu_baseline(J, D, H, n_s)
+            out["cpu_baseline"] = {"value": 1.0 / (sec * N / n_s), "unit": "steps/s", "cores": os.cpu_count(),
+                                   "kind": "port",
+                                   "sample": "%d of %d persons, full step (loss + all grads + Adam) with the numpy "
+                                             "oracle in float32, time scaled linearly to %d persons" % (n_s, N, N),
+                                   "sample_seconds_per_step": sec}
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(I1_THREADS) void k_irt1d(
     const int64_t wg = (int64_t)blockIdx.x * (I1_THREADS / 64) + wave;
     // persons are handed out in groups of 64 so that lane l owns person g*64 + l of each group
     const int64_t n_groups = (dm.nb + 63) / 64;
-    float aq[IPL], bq[IPL], cq[IPL], dq[IPL], ga[IPL], gb[IPL], gc[IPL], gd[IPL];
+    float aq[IPL], bq[IPL], cq[IPL], dq[IPL], oq[IPL], ga[IPL], gb[IPL], gc[IPL], gd[IPL];
 #pragma unroll
     for (int q = 0; q < IPL; ++q) {
         const int j = lane + 64 * q;
@@ -37,6 +37,7 @@ __global__ __launch_bounds__(I1_THREADS) void k_irt1d(
         bq[q] = ok ? b[j] : 0.f;
         cq[q] = (MODEL >= 3 && ok) ? fminf(sigmoidf_(c_un[j]), 1.0f - VX_EPS32) : 0.f;
         dq[q] = (MODEL >= 4 && ok) ? fminf(sigmoidf_(d_un[j]), 1.0f - VX_EPS32) : 1.0f;
+        oq[q] = (MODEL >= 4 && ok) ? fmaxf(sigmoidf_(-d_un[j]), VX_EPS32) : 0.f;
         ga[q] = gb[q] = gc[q] = gd[q] = 0.f;
     }
     for (int64_t grp = wg; grp < n_groups; grp += n_waves) {
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(I1_THREADS) void k_irt1d(
                     const unsigned yy = yr[j];
                     const float z = dm.Dc * (x * aq[q] + bq[q]);
                     float lp, dz, dc, dd;
-                    irt_cell<MODEL>(z, yy, cq[q], dq[q], lp, dz, dc, dd);
+                    irt_cell<MODEL>(z, yy, cq[q], dq[q], oq[q], lp, dz, dc, dd);
                     const float t = dm.Dc * dz;
                     llp += lp;
                     gxp += t * aq[q];

@@ -23,7 +23,7 @@ __host__ __device__ inline int lik_ds(int D) { return (D + 2) | 1; }
 __host__ __device__ inline size_t lik_lds_floats(int D, int nch, int gen) {
     const size_t DS = lik_ds(D), Dk2 = (D + 2) & ~1;
     return (size_t)LIK_P * DS + Dk2 * (LIK_JC + 1) + (size_t)LIK_JC * (LIK_P + 1) + LIK_P * 33 + LIK_P +
-           (gen ? (size_t)(2 * LIK_JC + 2 * nch * LIK_JC) : 0);
+           (gen ? (size_t)(3 * LIK_JC + 2 * nch * LIK_JC) : 0);
 }
 
 template <int KT, int NCH, int GEN>
@@ -42,7 +42,8 @@ __global__ __launch_bounds__(LIK_THREADS) void k_irt_lik(
     float* ll_lds = R_lds + LIK_JC * RS + LIK_P * 33; // [P]
     float* cs = ll_lds + LIK_P;                       // GEN: c[JC], d[JC], gc[NCH*JC], gd[NCH*JC]
     float* dsv = cs + LIK_JC;
-    float* gc_acc = dsv + LIK_JC;
+    float* omds = dsv + LIK_JC;
+    float* gc_acc = omds + LIK_JC;
     float* gd_acc = gc_acc + NCH * LIK_JC;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int g = blockIdx.x;
@@ -98,7 +99,9 @@ __global__ __launch_bounds__(LIK_THREADS) void k_irt_lik(
                 if (GEN && tid < LIK_JC) {
                     const int j = jc + tid;
                     cs[tid] = (j < J) ? fminf(sigmoidf_(c_un[j]), 1.0f - VX_EPS32) : 0.f;
-                    dsv[tid] = (dm.model == 4 && j < J) ? fminf(sigmoidf_(d_un[j]), 1.0f - VX_EPS32) : 1.0f;
+                    const bool has_d = (dm.model == 4 && j < J);
+                    dsv[tid] = has_d ? fminf(sigmoidf_(d_un[j]), 1.0f - VX_EPS32) : 1.0f;
+                    omds[tid] = has_d ? fmaxf(sigmoidf_(-d_un[j]), VX_EPS32) : 0.f;
                 }
                 __syncthreads();
                 // ---- Z^T tile: rows = items of this wave, cols = persons
@@ -126,10 +129,10 @@ __global__ __launch_bounds__(LIK_THREADS) void k_irt_lik(
                         float lp = 0.f, dz = 0.f, dc = 0.f, dd = 0.f;
                         if (yy != 254u) {
                             if (GEN) {
-                                if (dm.model == 4) irt_cell<4>(z, yy, cs[jj], dsv[jj], lp, dz, dc, dd);
-                                else irt_cell<3>(z, yy, cs[jj], 1.0f, lp, dz, dc, dd);
+                                if (dm.model == 4) irt_cell<4>(z, yy, cs[jj], dsv[jj], omds[jj], lp, dz, dc, dd);
+                                else irt_cell<3>(z, yy, cs[jj], 1.0f, 0.f, lp, dz, dc, dd);
                             } else {
-                                irt_cell<2>(z, yy, 0.f, 1.f, lp, dz, dc, dd);
+                                irt_cell<2>(z, yy, 0.f, 1.f, 0.f, lp, dz, dc, dd);
                             }
                         }
                         llp += lp;
@@ -240,6 +243,6 @@ __global__ __launch_bounds__(LIK_THREADS) void k_irt_lik(
             }
         }
     } else if (tid < 0) {
-        (void)cs; (void)dsv;
+        (void)cs; (void)dsv; (void)omds;
     }
 }

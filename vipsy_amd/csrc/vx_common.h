@@ -73,15 +73,18 @@ __device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint32_t step, ui
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float softplusf_(float x) { return fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x))); }
 
-// One response cell: given z = Dc*(x.a + b) returns log-lik term `lp`
-// and dlp/dz; for 3PL/4PL also dlp/dc_un, dlp/dd_un via out params.  y: 0/1/255(missing).
-// 2PL fast path: P = sigmoid(z) clamped to [eps, 1-eps] == z clamped to +-logit(1-eps).
+// One response cell: given z = Dc*(x.a + b) returns the log-lik term `lp`
+// and dlp/dz; for 3PL/4PL also dlp/dc_un, dlp/dd_un.  y: 0/1/255(missing).
+// 2PL: P = sigmoid(z) clamped to [eps, 1-eps]  ==  z clamped to +-logit(1-eps), zero gradient outside.
+// 3PL/4PL: P = c + (d-c) s(z) and Q = 1-P = (1-d) + (d-c) s(-z) are both formed from positive terms
+// (omd = 1-d = sigmoid(-d_un) comes from the leaf), so (y-P)/(P(1-P)) = y ? 1/P : -1/Q keeps full
+// float32 accuracy where the reference's own float32 chain (sigmoid -> clamp -> log / log1p) loses it.
 template <int MODEL>
-__device__ __forceinline__ void irt_cell(float z, unsigned y, float c, float d, float& lp, float& dz,
+__device__ __forceinline__ void irt_cell(float z, unsigned y, float c, float d, float omd, float& lp, float& dz,
                                          float& dc, float& dd) {
     if (y == 255u) { lp = VX_LOGP_MISSING; dz = 0.f; dc = 0.f; dd = 0.f; return; }
-    const float yf = (float)y;
     if (MODEL <= 2) {
+        const float yf = (float)y;
         const float ZL = 15.942384719848633f;       // logit(1 - eps32)
         const bool inside = fabsf(z) <= ZL;
         const float zc = fminf(fmaxf(z, -ZL), ZL);
@@ -93,15 +96,20 @@ __device__ __forceinline__ void irt_cell(float z, unsigned y, float c, float d, 
         dc = 0.f; dd = 0.f;
     } else {
         const float e = __expf(-fabsf(z));
-        const float sg = (z >= 0.f) ? 1.0f / (1.0f + e) : e / (1.0f + e);
-        const float P = c + (d - c) * sg;
-        const bool inside = (P >= VX_EPS32) && (P <= 1.0f - VX_EPS32);
+        const float r = 1.0f / (1.0f + e);
+        const float sg = (z >= 0.f) ? r : e * r;             // sigmoid(z)
+        const float sn = (z >= 0.f) ? e * r : r;             // sigmoid(-z) = 1 - sg, no cancellation
+        const float dmc = d - c;
+        const float P = c + dmc * sg;
+        const float Q = omd + dmc * sn;
+        const bool inside = (P >= VX_EPS32) && (Q >= VX_EPS32);
         const float Pc = fminf(fmaxf(P, VX_EPS32), 1.0f - VX_EPS32);
-        lp = (y != 0u) ? __logf(Pc) : log1pf(-Pc);
-        const float dP = inside ? (yf - Pc) / (Pc * (1.0f - Pc)) : 0.f;
-        dz = dP * (d - c) * sg * (1.0f - sg);
-        dc = dP * (1.0f - sg) * c * (1.0f - c);      // w.r.t. unconstrained c (sigmoid transform)
-        dd = (MODEL == 4) ? dP * sg * d * (1.0f - d) : 0.f;
+        const float Qc = fminf(fmaxf(Q, VX_EPS32), 1.0f - VX_EPS32);
+        lp = (y != 0u) ? logf(Pc) : logf(Qc);
+        const float dP = inside ? ((y != 0u) ? 1.0f / Pc : -1.0f / Qc) : 0.f;
+        dz = dP * dmc * sg * sn;
+        dc = dP * sn * c * (1.0f - c);               // w.r.t. unconstrained c (sigmoid transform)
+        dd = (MODEL == 4) ? dP * sg * d * omd : 0.f;
     }
 }
 

@@ -180,7 +180,7 @@ class IrtEngine(object):
                 a_init = a_init * af
             a_free = af
         if model != "irt_1pl":
-            self.view("a").copy_(a_init)
+            self.view("a").copy_(a_init.reshape(-1))
             if a_free is not None:
                 self.free[self.off["a"]:self.off["a"] + Dd * J] = torch.as_tensor(a_free, dtype=torch.float32).reshape(-1)
         if b0 is not None:
@@ -208,6 +208,7 @@ class IrtEngine(object):
         self._ws = {}
         self.sum_ws = torch.empty(1024, **f32)
         self.last = {}
+        self.events = None               # bench.py: list collecting (phase, start_event, end_event)
 
     # -- parameter access (constrained values as pyro.param(name) returns them) -----------------
     def names(self):
@@ -261,6 +262,9 @@ class IrtEngine(object):
             self._ws[key] = t
         return t
 
+    def _phase(self, name):
+        return _Phase(self.events, name)
+
     # -- one ELBO-gradient step ------------------------------------------------------------------
     def loss_and_grads(self, rows=None, b_global=None, eps=None, stream_id=0):
         """Fills self.G (flat grads + loss slot) and per-person grads for ONE particle.
@@ -281,11 +285,14 @@ class IrtEngine(object):
                   "ldT": self._buf("ldT", nb * D), "ent": self._buf("ent", nb)}
             gx, ll = self._buf("gx", nb * D), self._buf("ll", nb)
             enc = self._enc()
-            be.mvn_enc_forward(cfg, self.y, rows, nb, self.gid0, enc, eps, fw)
-            be.lik_grad(cfg, self.y, rows, nb, fw["x"], a, self.view("b"), c_un, d_un, gx, ll, gitem,
-                        self._buf("lik_ws", be.lik_workspace(cfg, nb)))
-            be.mvn_enc_backward(cfg, self.y, rows, nb, enc, fw, gx, self.G[self.n_item:self.n_params],
-                                self._buf("encb_ws", be.mvn_enc_bwd_workspace(cfg, nb)))
+            lik_ws = self._buf("lik_ws", be.lik_workspace(cfg, nb))
+            encb_ws = self._buf("encb_ws", be.mvn_enc_bwd_workspace(cfg, nb))
+            with self._phase("guide_forward"):
+                be.mvn_enc_forward(cfg, self.y, rows, nb, self.gid0, enc, eps, fw)
+            with self._phase("likelihood"):
+                be.lik_grad(cfg, self.y, rows, nb, fw["x"], a, self.view("b"), c_un, d_un, gx, ll, gitem, lik_ws)
+            with self._phase("guide_backward"):
+                be.mvn_enc_backward(cfg, self.y, rows, nb, enc, fw, gx, self.G[self.n_item:self.n_params], encb_ws)
             # loss = -scale * sum_i (ll_i + ent_i)
             tmp = self._buf("loss2", 2)
             be.sum_into(ll, nb, -scale, tmp[0:1], self.sum_ws)
@@ -301,9 +308,10 @@ class IrtEngine(object):
                 loc, raw = self.PP[:n][rows].contiguous(), self.PP[n:][rows].contiguous()
                 gloc, graw = self._buf("gloc", nb), self._buf("graw", nb)
             elbo = self._buf("elbo", nb)
-            be.irt1d_grad(cfg, self.y, rows, nb, self.gid0, loc, raw, eps, a, self.view("b"), c_un, d_un,
-                          gloc, graw, elbo, self._buf("g1d", 4 * self.J),
-                          self._buf("i1d_ws", be.irt1d_workspace(cfg, nb)))
+            g1d, i1d_ws = self._buf("g1d", 4 * self.J), self._buf("i1d_ws", be.irt1d_workspace(cfg, nb))
+            with self._phase("irt1d"):
+                be.irt1d_grad(cfg, self.y, rows, nb, self.gid0, loc, raw, eps, a, self.view("b"), c_un, d_un,
+                              gloc, graw, elbo, g1d, i1d_ws)
             g1 = self._ws["g1d"]
             J = self.J
             gitem.zero_()
@@ -344,10 +352,32 @@ class IrtEngine(object):
             self.loss_and_grads(rows, b_global, eps, 0)
         else:
             raise NotImplementedError("num_particles > 1 is handled by vipsy_amd.svi")
-        self.allreduce()
+        with self._phase("allreduce"):
+            self.allreduce()
         loss = self.G[self.n_params].clone()
-        self.apply_optim(lrs)
+        with self._phase("optimizer"):
+            self.apply_optim(lrs)
         return loss
+
+
+class _Phase(object):
+    """Brackets a phase with HIP events on the current stream when bench.py asks for it."""
+
+    def __init__(self, sink, name):
+        self.sink, self.name = sink, name
+
+    def __enter__(self):
+        if self.sink is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.sink is not None:
+            self.e1.record()
+            self.sink.append((self.name, self.e0, self.e1))
+        return False
 
 
 def _merge_segments(segs):

@@ -1,0 +1,125 @@
+"""Synthetic response data with the distributions of the reference's Random* generators
+(vi.py:120-412), produced on the device in uint8 (0 / 1 / 255 = missing).
+
+Benchmark / test INPUT only; torch ops are used as plumbing for setup work that
+is never inside a timed region.  Item-side draws (J or D x J values) are made on the host exactly as
+the reference does; the N x J Bernoulli draws are made on the device in row chunks so 1M x 500 never
+needs an fp32 N x J host matrix.
+"""
+import math
+import random
+
+import numpy as np
+import torch
+
+
+def _gen_omega(n, rnd):
+    """Angles in [0, pi/2] summing to (n-1) pi/2 (vi.py:344-364): direction cosines of an item."""
+    lo = [0.0] * n
+    up = [math.pi / 2] * n
+    total = math.pi / 2 * (n - 1)
+    out = []
+    while len(lo) > 1:
+        a = max(total - sum(up[1:]), lo[0])
+        b = min(total - sum(lo[1:]), up[0])
+        t = rnd.uniform(a, b)
+        out.append(t)
+        lo, up, total = lo[1:], up[1:], total - t
+    out.append(total)
+    return out
+
+
+def mirt_item_params(J, D, seed, mdisc_log_scale=0.5, mdiff_loc=0.5, mdiff_scale=1.0):
+    """RandomMilIrt2PL item side (vi.py:325-329, 366-380): a (D,J) with the identification zero
+    pattern a[i, J-i:] = 0 and floor 0.01; b = -mdiff * mdisc."""
+    g = torch.Generator().manual_seed(seed)
+    rnd = random.Random(seed)
+    mdisc = torch.exp(torch.randn(J, generator=g) * mdisc_log_scale)
+    mdiff = torch.randn(J, generator=g) * mdiff_scale + mdiff_loc
+    a = torch.zeros(D, J)
+    for j in range(J):
+        n = D if j < J - D + 1 else J - j
+        om = torch.tensor(_gen_omega(n, rnd), dtype=torch.float32)
+        a[:n, j] = mdisc[j] * torch.cos(om)
+    a.clamp_(min=0.01)                                   # vi.py:372
+    for i in range(D):
+        a[i, J - i:] = 0                                 # vi.py:378-379
+    b = (-mdiff * mdisc).reshape(1, J)
+    return a, b
+
+
+def irt_item_params(J, model, seed, D=1):
+    """RandomIrt1PL..4PL item side (vi.py:229, 256-258, 279, 299)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {"b": torch.randn(1, J, generator=g)}
+    if model != "irt_1pl":
+        a = torch.rand(D, J, generator=g) * 2.5 + 0.5
+        for i in range(D):
+            a[i, J - i:] = 0
+        out["a"] = a
+    if model in ("irt_3pl", "irt_4pl"):
+        out["c"] = torch.rand(1, J, generator=g) * 0.15 + 0.05
+    if model == "irt_4pl":
+        out["d"] = torch.rand(1, J, generator=g) * 0.15 + 0.8
+    return out
+
+
+def simulate_responses(n, gid0, items, model, device, seed, missing=0.0, chunk=65536, Dc=1.0):
+    """y[i, j] ~ Bernoulli(P_ij) for persons gid0 .. gid0+n-1 with x_i ~ N(0, I) (vi.py:228, 335);
+    MCAR missingness at rate `missing`.  Deterministic per (seed, global person id chunk)."""
+    J = items["b"].shape[1]
+    D = items["a"].shape[0] if "a" in items else 1
+    a = items["a"].to(device) if "a" in items else torch.ones(1, J, device=device)
+    b = items["b"].to(device)
+    c = items["c"].to(device) if "c" in items else None
+    d = items["d"].to(device) if "d" in items else None
+    y = torch.empty(n, J, dtype=torch.uint8, device=device)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        g = torch.Generator(device=device).manual_seed(seed * 1000003 + (gid0 + s))
+        x = torch.randn(e - s, D, generator=g, device=device)
+        p = torch.sigmoid(Dc * (x @ a + b))
+        if c is not None:
+            p = c + ((d if d is not None else 1.0) - c) * p
+        yy = (torch.rand(e - s, J, generator=g, device=device) < p).to(torch.uint8)
+        if missing > 0:
+            yy[torch.rand(e - s, J, generator=g, device=device) < missing] = 255
+        y[s:e] = yy
+    return y
+
+
+def hodina_params(J, K, seed):
+    """RandomHoDina item side (vi.py:148-156, 193-194): q with the zero-column fix-up, g, s, lam0, lam1."""
+    g = torch.Generator().manual_seed(seed)
+    q = (torch.rand(K, J, generator=g) < 0.5).float()
+    empty = q.sum(0) == 0
+    if bool(empty.any()):
+        idx = torch.randint(0, K, (int(empty.sum()),), generator=g)
+        q[:, empty] = torch.eye(K)[idx].T
+    return {"q": q, "g": torch.rand(1, J, generator=g) * 0.3, "s": torch.rand(1, J, generator=g) * 0.3,
+            "lam0": torch.randn(1, K, generator=g), "lam1": torch.rand(1, K, generator=g) * 2.5 + 0.5}
+
+
+def simulate_hodina(n, gid0, prm, device, seed, missing=0.0, chunk=262144):
+    """theta ~ N(0,1); attr_k ~ Bern(sigmoid(theta lam1_k + lam0_k)); DINA response (vi.py:69-83, 103-116)."""
+    q = prm["q"].to(device)
+    K, J = q.shape
+    need = (q ** 2).sum(0)
+    y = torch.empty(n, J, dtype=torch.uint8, device=device)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        g = torch.Generator(device=device).manual_seed(seed * 1000003 + (gid0 + s))
+        th = torch.randn(e - s, 1, generator=g, device=device)
+        ap = torch.sigmoid(th @ prm["lam1"].to(device) + prm["lam0"].to(device))
+        attr = (torch.rand(e - s, K, generator=g, device=device) < ap).float()
+        eta = ((attr @ q) == need).float()
+        p = eta * (1 - prm["s"].to(device)) + (1 - eta) * prm["g"].to(device)
+        yy = (torch.rand(e - s, J, generator=g, device=device) < p).to(torch.uint8)
+        if missing > 0:
+            yy[torch.rand(e - s, J, generator=g, device=device) < missing] = 255
+        y[s:e] = yy
+    return y
+
+
+def np_u8(y):
+    return y.detach().cpu().numpy().astype(np.uint8)
