@@ -189,3 +189,39 @@ def test_entry_points_reject_bad_arguments():
     cfg = _hip.IrtCfg(2, 1, 2000, 0, 1.0, 1.0, 0, 0, 0)                   # J > 1024 for the D=1 kernel
     assert L.vx_irt1d_workspace_floats(ctypes.byref(cfg), 10) == -1
     assert L.vx_philox_normals(None, None, 0, 10, 1, 0, 0, 0, _hip.stream_ptr()) == -1
+
+
+def test_generic_and_fast_kernels_agree():
+    """The specialised fast kernels (hidden 64, J % 4 == 0) against the shape-generic ones
+    (VX_FORCE_GENERIC=1 in a child process) on the headline shape."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import json, os, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from vipsy_amd.engine import IrtEngine
+rng = np.random.RandomState(5)
+N, J, D, H = 500, 500, 100, 64
+y = rng.randint(0, 2, size=(N, J)).astype(np.uint8); y[rng.rand(N, J) < 0.2] = 255
+eng = IrtEngine(torch.from_numpy(y).cuda(), model="irt_2pl", D=D, amortized=True, H=H, seed=21)
+eng.unconstrained("b").copy_(torch.from_numpy(0.5 * rng.randn(1, J)).float())
+eng.loss_and_grads()
+torch.cuda.synchronize()
+out = {"loss": float(eng.G[eng.n_params].item()), "g": eng.G[:eng.n_params].double().cpu().numpy().tolist(),
+       "x": eng.last["fw"]["x"][:N * D].double().cpu().numpy().tolist()}
+print("RESULT" + json.dumps(out))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("0", "1"):
+        env = dict(os.environ, VX_FORCE_GENERIC=mode)
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][0]
+        res[mode] = json.loads(line[6:])
+    assert res["0"]["loss"] == pytest.approx(res["1"]["loss"], rel=1e-6)
+    x0, x1 = np.array(res["0"]["x"]), np.array(res["1"]["x"])
+    np.testing.assert_allclose(x0, x1, atol=2e-5, rtol=1e-5)
+    g0, g1 = np.array(res["0"]["g"]), np.array(res["1"]["g"])
+    assert np.abs(g0 - g1).max() <= 2e-5 * max(1.0, np.abs(g1).max())

@@ -2,11 +2,12 @@
 #include "vx_common.h"
 #include "k_util.hip"
 #include "k_mvn_enc.hip"
+#include "k_mvn_enc_fast.hip"
 #include "k_mvn_enc_bwd.hip"
 #include "k_irt_lik.hip"
 #include "k_irt1d.hip"
 
-#include <mutex>
+#include <cstdlib>
 
 namespace {
 
@@ -46,6 +47,16 @@ EncDims make_enc_dims(const vx_irt_cfg* cfg, int64_t nb) {
     dm.T = tril_len(cfg->D);
     dm.nb = nb;
     return dm;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// VX_FORCE_GENERIC=1 routes everything through the shape-generic kernels (used by the tests to
+// cross-check the specialised fast paths against them).
+bool force_generic() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VX_FORCE_GENERIC"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
 }
 
 bool enc_cfg_ok(const vx_irt_cfg* cfg) {
@@ -131,9 +142,21 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
         return VX_EINVAL;
     if (nb == 0) return VX_OK;
     EncDims dm = make_enc_dims(cfg, nb);
-    const size_t lds = enc_fwd_lds_floats(dm.D, dm.Hp) * sizeof(float);
     const dim3 grid((unsigned)((nb + ENC_P - 1) / ENC_P));
     int rc;
+    if (!force_generic() && cfg->H == 64 && cfg->J % 4 == 0 && aligned16(y) && aligned16(W1) && aligned16(b1) &&
+        aligned16(W21) && aligned16(W22) && aligned16(h)) {
+        const size_t ldsf = enc_fwd_fast_lds_floats(dm.D, dm.J) * sizeof(float);
+        if (ldsf <= 160 * 1024) {
+            rc = set_lds(k_mvn_enc_fwd_fast, ldsf);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_mvn_enc_fwd_fast, grid, dim3(ENC_THREADS), ldsf, (hipStream_t)hs, dm, y, rows, gid0, W1,
+                               b1, W21, b21, W22, b22, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent);
+            VX_CHECK_LAUNCH();
+            return VX_OK;
+        }
+    }
+    const size_t lds = enc_fwd_lds_floats(dm.D, dm.Hp) * sizeof(float);
 #define LAUNCH_FWD(HT)                                                                                       \
     rc = set_lds(k_mvn_enc_fwd<HT>, lds);                                                                    \
     if (rc) return rc;                                                                                       \
