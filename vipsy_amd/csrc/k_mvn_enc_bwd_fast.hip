@@ -1,0 +1,254 @@
+// Fast paths of the amortized MVN guide backward for hidden_dim == 64 and D % 4 == 0 (same mathematics
+// and outputs as k_mvn_enc_bwd_h / k_mvn_enc_bwd_w in k_mvn_enc_bwd.hip).  What changes is the staging:
+// every global -> LDS copy is a batch of independent 16-byte loads held in registers across the previous
+// MFMA phase (issue early, write late), tiles are exact linear images of the global rows, and bwd_h is
+// sized for two workgroups per CU.
+#pragma once
+#include "k_mvn_enc_bwd.hip"
+
+#define BH_ROWS 64                      // head rows per LDS tile in bwd_h_fast
+
+__host__ __device__ inline size_t enc_bwdh_fast_lds_floats(int D) {
+    return 2 * (size_t)ENC_P * D + (size_t)BH_ROWS * 64 + BH_ROWS;
+}
+
+__global__ __launch_bounds__(ENC_THREADS, 2) void k_mvn_enc_bwd_h_fast(
+    EncDims dm, float scale, const float* __restrict__ W21, const float* __restrict__ W22,
+    const float* __restrict__ h_in, const float* __restrict__ eps_in, const float* __restrict__ ldT,
+    const float* __restrict__ gx_in, float* __restrict__ ghpre_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int H = 64;
+    const int D = dm.D, T = dm.T;
+    float* gx_lds = smem;                              // [P][D]  linear image of gx rows
+    float* eps_lds = gx_lds + ENC_P * D;               // [P][D]
+    float* Wt = eps_lds + ENC_P * D;                   // [BH_ROWS][64]
+    uint32_t* rowtab = (uint32_t*)(Wt + BH_ROWS * H);  // [BH_ROWS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int64_t i0 = (int64_t)blockIdx.x * ENC_P;
+    const int64_t RT = (int64_t)T + D;
+    const int n_tiles = (int)((RT + BH_ROWS - 1) / BH_ROWS);
+    const int pvalid = (int)((dm.nb - i0) < ENC_P ? (dm.nb - i0) : ENC_P);
+
+    // gx / eps tiles: contiguous [pvalid * D] floats in global memory
+    {
+        const int n4 = ENC_P * D / 4, v4 = pvalid * D / 4;
+        const float4* g4 = (const float4*)(gx_in + i0 * D);
+        const float4* e4 = (const float4*)(eps_in + i0 * D);
+        for (int base = 0; base < n4; base += ENC_THREADS * 4) {
+            float4 a[4], b[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = base + q * ENC_THREADS + tid;
+                const bool ok = idx < v4;
+                a[q] = ok ? g4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+                b[q] = ok ? e4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = base + q * ENC_THREADS + tid;
+                if (idx < n4) { ((float4*)gx_lds)[idx] = a[q]; ((float4*)eps_lds)[idx] = b[q]; }
+            }
+        }
+    }
+    const int u = wave & 1, ht = wave >> 1;
+    const int p = 32 * u + l31;
+    const int64_t i = i0 + p;
+    f32x16 acc = zero16();
+    // W tile prefetch: 64 rows x 64 floats = 1024 float4, 4 per thread
+    float4 wp[4];
+    auto prefetch = [&](int tile) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f = tid + ENC_THREADS * q;
+            const int64_t r = (int64_t)tile * BH_ROWS + (f >> 4);
+            const float* src = (r < T) ? W22 + r * H : (r < RT ? W21 + (r - T) * H : nullptr);
+            wp[q] = src ? *(const float4*)(src + 4 * (f & 15)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    prefetch(0);
+    const float* gx_p = gx_lds + p * D;
+    const float* eps_p = eps_lds + p * D;
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        __syncthreads();                                // previous MFMA phase done with Wt / rowtab
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ((float4*)Wt)[tid + ENC_THREADS * q] = wp[q];
+        if (tid < BH_ROWS) rowtab[tid] = enc_row_code((int64_t)tile * BH_ROWS + tid, T, D);
+        __syncthreads();
+        if (tile + 1 < n_tiles) prefetch(tile + 1);     // in flight during the MFMA phase
+        const float* ap = Wt + (half * 32) * H + 32 * ht + l31;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint4 cd = *(const uint4*)(rowtab + half * 32 + 4 * q);
+            const uint32_t cdv[4] = {cd.x, cd.y, cd.z, cd.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t cc = cdv[e];
+                float v = 0.f;
+                if (cc != ROW_NONE) {
+                    if (cc & ROW_LOC) {
+                        v = gx_p[cc & 0xFFFFu];
+                    } else {
+                        const int k = (int)(cc >> 16), l = (int)(cc & 0xFFFFu);
+                        v = gx_p[k] * eps_p[l];
+                        if (l == k) v = (i < dm.nb) ? v * ldT[(int64_t)k * dm.nb + i] + scale : 0.f;
+                    }
+                }
+                acc = mfma32(ap[(4 * q + e) * H], v, acc);
+            }
+        }
+    }
+    // gh -> ghpre = gh * sigmoid(pre), sigmoid(pre) = 1 - exp(-h)
+    if (i < dm.nb) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int hh0 = 32 * ht + 8 * g + 4 * half;
+            const float4 hv = *(const float4*)(h_in + i * H + hh0);
+            float4 o;
+            o.x = acc[4 * g + 0] * (1.0f - __expf(-hv.x));
+            o.y = acc[4 * g + 1] * (1.0f - __expf(-hv.y));
+            o.z = acc[4 * g + 2] * (1.0f - __expf(-hv.z));
+            o.w = acc[4 * g + 3] * (1.0f - __expf(-hv.w));
+            *(float4*)(ghpre_out + i * H + hh0) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+#define BWF_RT 6                        // row tiles (of 32) per wave -> 768 head rows per workgroup
+#define BWF_ROWS (4 * BWF_RT * 32)
+
+__host__ __device__ inline size_t enc_bwdw_fast_lds_floats(int D) { return 3 * (size_t)ENC_P * D + ENC_P * 64; }
+
+// slab layout (one per person range): [W21: D*H | b21: D | W22: T*H | b22: T]
+__global__ __launch_bounds__(ENC_THREADS, 1) void k_mvn_enc_bwd_w_fast(
+    EncDims dm, float scale, const float* __restrict__ h_in, const float* __restrict__ eps_in,
+    const float* __restrict__ ldT, const float* __restrict__ gx_in, float* __restrict__ slabs,
+    int64_t slab_len) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int H = 64;
+    const int D = dm.D, T = dm.T;
+    float* gx_lds = smem;                   // [P][D]
+    float* eps_lds = gx_lds + ENC_P * D;    // [P][D]
+    float* ld_lds = eps_lds + ENC_P * D;    // [D][P]  (dimension-major, as ldT)
+    float* h_lds = ld_lds + ENC_P * D;      // [P][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int64_t RT = (int64_t)T + D;
+    const int64_t rbase = (int64_t)blockIdx.x * BWF_ROWS + (int64_t)wave * BWF_RT * 32;
+    int koff[BWF_RT], loff[BWF_RT];         // per-lane row description: V = gx[k] * eps[l] (or variants)
+    int kind[BWF_RT];                       // 0 none, 1 tril off-diagonal, 2 diagonal, 3 loc
+#pragma unroll
+    for (int t = 0; t < BWF_RT; ++t) {
+        const uint32_t cc = enc_row_code(rbase + 32 * t + l31, T, D);
+        koff[t] = 0; loff[t] = 0; kind[t] = 0;
+        if (cc != ROW_NONE) {
+            if (cc & ROW_LOC) { kind[t] = 3; koff[t] = (int)(cc & 0xFFFFu); }
+            else {
+                koff[t] = (int)(cc >> 16); loff[t] = (int)(cc & 0xFFFFu);
+                kind[t] = (koff[t] == loff[t]) ? 2 : 1;
+            }
+        }
+    }
+    f32x16 acc[BWF_RT][2];
+    float bsum[BWF_RT];
+#pragma unroll
+    for (int t = 0; t < BWF_RT; ++t) { bsum[t] = 0.f; acc[t][0] = zero16(); acc[t][1] = zero16(); }
+
+    const int n4d = ENC_P * D / 4;          // float4 count of one [P][D] tile
+    constexpr int NQ = 7;                   // ceil(64*127/4 / 256) = 8 would be the bound for D = 127; D%4==0 -> <= 124
+    float4 pg[NQ + 1], pe[NQ + 1], pl[NQ + 1], ph[4];
+    const int64_t n_ptiles = (dm.nb + ENC_P - 1) / ENC_P;
+    auto prefetch = [&](int64_t tile) {
+        const int64_t i0 = tile * ENC_P;
+        const int pv = (int)((dm.nb - i0) < ENC_P ? (dm.nb - i0) : ENC_P);
+        const float4* g4 = (const float4*)(gx_in + i0 * D);
+        const float4* e4 = (const float4*)(eps_in + i0 * D);
+#pragma unroll
+        for (int q = 0; q <= NQ; ++q) {
+            const int idx = tid + ENC_THREADS * q;
+            const bool ok = idx < pv * D / 4;
+            pg[q] = ok ? g4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+            pe[q] = ok ? e4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+            // ld tile [D][P]: float4 idx -> k = idx / 16, persons 4*(idx%16)..+3
+            const int k = idx >> 4, p4 = 4 * (idx & 15);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < n4d) {
+                const float* src = ldT + (int64_t)k * dm.nb + i0 + p4;
+                if (p4 + 3 < pv && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0)) v = *(const float4*)src;
+                else {
+                    if (p4 + 0 < pv) v.x = src[0];
+                    if (p4 + 1 < pv) v.y = src[1];
+                    if (p4 + 2 < pv) v.z = src[2];
+                    if (p4 + 3 < pv) v.w = src[3];
+                }
+            }
+            pl[q] = v;
+        }
+        const float4* h4 = (const float4*)(h_in + i0 * H);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + ENC_THREADS * q;
+            ph[q] = (idx < pv * H / 4) ? h4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    int64_t tile = blockIdx.y;
+    if (tile < n_ptiles) prefetch(tile);
+    for (; tile < n_ptiles; tile += gridDim.y) {
+        const int64_t i0 = tile * ENC_P;
+        const int pvalid = (int)((dm.nb - i0) < ENC_P ? (dm.nb - i0) : ENC_P);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q <= NQ; ++q) {
+            const int idx = tid + ENC_THREADS * q;
+            if (idx < n4d) {
+                ((float4*)gx_lds)[idx] = pg[q];
+                ((float4*)eps_lds)[idx] = pe[q];
+                ((float4*)ld_lds)[idx] = pl[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ((float4*)h_lds)[tid + ENC_THREADS * q] = ph[q];
+        __syncthreads();
+        if (tile + gridDim.y < n_ptiles) prefetch(tile + gridDim.y);
+#pragma unroll 2
+        for (int s = 0; s < ENC_P / 2; ++s) {
+            const int p = 2 * s + half;
+            const float* gx_p = gx_lds + p * D;
+            const float* eps_p = eps_lds + p * D;
+            const float b0 = h_lds[p * H + l31], b1 = h_lds[p * H + 32 + l31];
+#pragma unroll
+            for (int t = 0; t < BWF_RT; ++t) {
+                float v = 0.f;
+                if (kind[t] == 1) v = gx_p[koff[t]] * eps_p[loff[t]];
+                else if (kind[t] == 2) v = (p < pvalid) ? gx_p[koff[t]] * eps_p[loff[t]] * ld_lds[koff[t] * ENC_P + p] + scale : 0.f;
+                else if (kind[t] == 3) v = gx_p[koff[t]];
+                bsum[t] += v;
+                acc[t][0] = mfma32(v, b0, acc[t][0]);
+                acc[t][1] = mfma32(v, b1, acc[t][1]);
+            }
+        }
+    }
+    float* slab = slabs + (int64_t)blockIdx.y * slab_len;
+    float* sW21 = slab;
+    float* sb21 = sW21 + (int64_t)D * H;
+    float* sW22 = sb21 + D;
+    float* sb22 = sW22 + (int64_t)T * H;
+#pragma unroll
+    for (int t = 0; t < BWF_RT; ++t) {
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+            const int hh = 32 * ht + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = rbase + 32 * t + crow32(r, half);
+                if (row < T) sW22[row * H + hh] = acc[t][ht][r];
+                else if (row < RT) sW21[(row - T) * H + hh] = acc[t][ht][r];
+            }
+        }
+        const float bt = bsum[t] + __shfl_xor(bsum[t], 32, 64);
+        const int64_t row = rbase + 32 * t + l31;
+        if (half == 0) {
+            if (row < T) sb22[row] = bt;
+            else if (row < RT) sb21[row - T] = bt;
+        }
+    }
+}

@@ -4,6 +4,7 @@
 #include "k_mvn_enc.hip"
 #include "k_mvn_enc_fast.hip"
 #include "k_mvn_enc_bwd.hip"
+#include "k_mvn_enc_bwd_fast.hip"
 #include "k_irt_lik.hip"
 #include "k_irt1d.hip"
 
@@ -250,9 +251,15 @@ int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows
 }
 
 // ------------------------------------------------------------------------------------------------
+static bool encb_fast_shape(const vx_irt_cfg* cfg) {
+    return !force_generic() && cfg->H == 64 && cfg->D % 4 == 0 &&
+           enc_bwdw_fast_lds_floats(cfg->D) * sizeof(float) <= 160 * 1024;
+}
+
 static void encb_plan(const vx_irt_cfg* cfg, int64_t nb, int& n_rowslabs, int& n_prw, int& n_jg, int& n_prf) {
     const int64_t RT = (int64_t)tril_len(cfg->D) + cfg->D;
-    n_rowslabs = (int)((RT + BW_ROWS - 1) / BW_ROWS);
+    const int rows_per_wg = encb_fast_shape(cfg) ? BWF_ROWS : BW_ROWS;
+    n_rowslabs = (int)((RT + rows_per_wg - 1) / rows_per_wg);
     n_jg = (cfg->J + FC1_JG - 1) / FC1_JG;
     const int64_t n_ptiles = (nb + ENC_P - 1) / ENC_P;
     int64_t w = num_cu() / n_rowslabs; if (w < 1) w = 1;
@@ -290,7 +297,28 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     float* slabs_f = slabs_w + (int64_t)n_prw * lenw;
     hipStream_t st = (hipStream_t)hs;
     int rc;
-    if (nb > 0) {
+    const bool fast = encb_fast_shape(cfg) && aligned16(W21) && aligned16(W22) && aligned16(h) && aligned16(eps) &&
+                      aligned16(gx) && aligned16(ghpre);
+    if (nb > 0 && fast) {
+        {
+            const size_t lds = enc_bwdh_fast_lds_floats(dm.D) * sizeof(float);
+            rc = set_lds(k_mvn_enc_bwd_h_fast, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_mvn_enc_bwd_h_fast, dim3((unsigned)((nb + ENC_P - 1) / ENC_P)), dim3(ENC_THREADS), lds,
+                               st, dm, cfg->scale, W21, W22, h, eps, ldT, gx, ghpre);
+            VX_CHECK_LAUNCH();
+        }
+        {
+            const size_t lds = enc_bwdw_fast_lds_floats(dm.D) * sizeof(float);
+            rc = set_lds(k_mvn_enc_bwd_w_fast, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_mvn_enc_bwd_w_fast, dim3((unsigned)n_rowslabs, (unsigned)n_prw), dim3(ENC_THREADS), lds,
+                               st, dm, cfg->scale, h, eps, ldT, gx, slabs_w, lenw);
+            VX_CHECK_LAUNCH();
+        }
+    } else if (nb > 0) {
+        // the plan may have assumed the fast row-slab size (misaligned buffers): re-derive for this kernel
+        n_rowslabs = (int)(((int64_t)dm.T + dm.D + BW_ROWS - 1) / BW_ROWS);
         {
             const size_t lds = enc_bwdh_lds_floats(dm.D, dm.Hp) * sizeof(float);
             const dim3 grid((unsigned)((nb + ENC_P - 1) / ENC_P));
@@ -315,6 +343,8 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
 #undef LAUNCH_BW
             VX_CHECK_LAUNCH();
         }
+    }
+    if (nb > 0) {
         {
             const size_t lds = fc1_bwd_lds_floats(dm.Hp) * sizeof(float);
             const dim3 grid((unsigned)n_jg, (unsigned)n_prf);
