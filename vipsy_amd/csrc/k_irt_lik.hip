@@ -14,6 +14,7 @@
 
 struct LikDims {
     int D, J, DS, Dk2, model;   // DS: odd LDS stride >= D + 2;  Dk2 = (D + 1) rounded up to even
+    int fast;                   // D % 4 == 0, J % 4 == 0, 16-byte aligned x / a / b / y: batched 16-byte staging
     float Dc, scale;
     int64_t nb;
     int64_t slab_len;           // D*J + 3*J
@@ -62,12 +63,40 @@ __global__ __launch_bounds__(LIK_THREADS) void k_irt_lik(
 
     for (int64_t tile = blockIdx.y; tile < n_ptiles; tile += gridDim.y) {
         const int64_t i0 = tile * LIK_P;
-        for (int e = tid; e < LIK_P * DS; e += LIK_THREADS) {
-            const int p = e / DS, k = e - p * DS;
-            const int64_t i = i0 + p;
-            float v = 0.f;
-            if (i < dm.nb) v = (k < D) ? x[i * D + k] : (k == D ? 1.0f : 0.f);
-            x_lds[e] = v;
+        if (dm.fast) {
+            // [P][D] contiguous floats -> [P][DS]; all loads of a batch are in flight before the first store
+            const int c4 = D / 4, n4 = LIK_P * c4;
+            const int pv = (int)((dm.nb - i0) < LIK_P ? (dm.nb - i0) : LIK_P);
+            const float4* src = (const float4*)(x + i0 * D);
+            for (int base = 0; base < n4; base += LIK_THREADS * 4) {
+                float4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int idx = base + q * LIK_THREADS + tid;
+                    v[q] = (idx < pv * c4) ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int idx = base + q * LIK_THREADS + tid;
+                    if (idx < n4) {
+                        const int p = idx / c4, c = idx - p * c4;
+                        float* dst = x_lds + p * DS + 4 * c;
+                        dst[0] = v[q].x; dst[1] = v[q].y; dst[2] = v[q].z; dst[3] = v[q].w;
+                    }
+                }
+            }
+            for (int e = tid; e < LIK_P * (DS - D); e += LIK_THREADS) {
+                const int p = e / (DS - D), k = D + (e - p * (DS - D));
+                x_lds[p * DS + k] = (k == D && p < pv) ? 1.0f : 0.f;
+            }
+        } else {
+            for (int e = tid; e < LIK_P * DS; e += LIK_THREADS) {
+                const int p = e / DS, k = e - p * DS;
+                const int64_t i = i0 + p;
+                float v = 0.f;
+                if (i < dm.nb) v = (k < D) ? x[i * D + k] : (k == D ? 1.0f : 0.f);
+                x_lds[e] = v;
+            }
         }
         if (tid < LIK_P) ll_lds[tid] = 0.f;
         f32x16 gxa[GXT];
@@ -79,22 +108,65 @@ __global__ __launch_bounds__(LIK_THREADS) void k_irt_lik(
             constexpr int c = decltype(cc)::value;
             const int jc = jbase + c * LIK_JC;
             if (jc < J) {                                                   // block-uniform
-                for (int e = tid; e < Dk2 * LIK_JC; e += LIK_THREADS) {
-                    const int k = e / LIK_JC, jj = e - k * LIK_JC;
-                    const int j = jc + jj;
-                    float v = 0.f;
-                    if (j < J) v = (k < D) ? a[(int64_t)k * J + j] : (k == D ? b[j] : 0.f);
-                    a_lds[k * AS + jj] = v;
-                }
-                for (int e = tid; e < LIK_P * LIK_JC; e += LIK_THREADS) {
-                    const int p = e / LIK_JC, jj = e - p * LIK_JC;
-                    const int64_t i = i0 + p;
-                    uint8_t yy = 254;                                        // 254 = outside the problem
-                    if (i < dm.nb && jc + jj < J) {
-                        const int64_t row = rows ? rows[i] : i;
-                        yy = y[row * J + jc + jj];
+                if (dm.fast) {
+                    // a_aug chunk: (D+1) rows x 32 float4; response chunk: P rows x 32 words
+                    const int n4 = Dk2 * (LIK_JC / 4);
+                    for (int base = 0; base < n4; base += LIK_THREADS * 4) {
+                        float4 v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int idx = base + q * LIK_THREADS + tid;
+                            const int k = idx >> 5, j = jc + 4 * (idx & 31);
+                            v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (idx < n4 && j < J) {
+                                if (k < D) v[q] = *(const float4*)(a + (int64_t)k * J + j);
+                                else if (k == D) v[q] = *(const float4*)(b + j);
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int idx = base + q * LIK_THREADS + tid;
+                            if (idx < n4) {
+                                float* dst = a_lds + (idx >> 5) * AS + 4 * (idx & 31);
+                                dst[0] = v[q].x; dst[1] = v[q].y; dst[2] = v[q].z; dst[3] = v[q].w;
+                            }
+                        }
                     }
-                    Yb[p * YS + jj] = yy;
+                    uint32_t w[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int idx = q * LIK_THREADS + tid;                  // P * 32 words = 8 per thread
+                        const int p = idx >> 5, jw = jc + 4 * (idx & 31);
+                        const int64_t i = i0 + p;
+                        w[q] = 0xFEFEFEFEu;                                     // 254 = outside the problem
+                        if (i < dm.nb && jw < J) {
+                            const int64_t row = rows ? rows[i] : i;
+                            w[q] = *(const uint32_t*)(y + row * J + jw);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int idx = q * LIK_THREADS + tid;
+                        ((uint32_t*)Yb)[(idx >> 5) * (YS / 4) + (idx & 31)] = w[q];
+                    }
+                } else {
+                    for (int e = tid; e < Dk2 * LIK_JC; e += LIK_THREADS) {
+                        const int k = e / LIK_JC, jj = e - k * LIK_JC;
+                        const int j = jc + jj;
+                        float v = 0.f;
+                        if (j < J) v = (k < D) ? a[(int64_t)k * J + j] : (k == D ? b[j] : 0.f);
+                        a_lds[k * AS + jj] = v;
+                    }
+                    for (int e = tid; e < LIK_P * LIK_JC; e += LIK_THREADS) {
+                        const int p = e / LIK_JC, jj = e - p * LIK_JC;
+                        const int64_t i = i0 + p;
+                        uint8_t yy = 254;                                        // 254 = outside the problem
+                        if (i < dm.nb && jc + jj < J) {
+                            const int64_t row = rows ? rows[i] : i;
+                            yy = y[row * J + jc + jj];
+                        }
+                        Yb[p * YS + jj] = yy;
+                    }
                 }
                 if (GEN && tid < LIK_JC) {
                     const int j = jc + tid;
@@ -211,10 +283,21 @@ __global__ __launch_bounds__(LIK_THREADS) void k_irt_lik(
             }
         }
         __syncthreads();
-        for (int e = tid; e < LIK_P * D; e += LIK_THREADS) {
-            const int p = e / D, k = e - p * D;
-            const int64_t i = i0 + p;
-            if (i < dm.nb) gx_part[((int64_t)g * dm.nb + i) * D + k] = x_lds[p * DS + k];
+        if (dm.fast) {
+            const int c4 = D / 4;
+            float4* dst = (float4*)(gx_part + ((int64_t)g * dm.nb + i0) * D);
+            const int pv = (int)((dm.nb - i0) < LIK_P ? (dm.nb - i0) : LIK_P);
+            for (int idx = tid; idx < pv * c4; idx += LIK_THREADS) {
+                const int p = idx / c4, c = idx - p * c4;
+                const float* sp = x_lds + p * DS + 4 * c;
+                dst[idx] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+            }
+        } else {
+            for (int e = tid; e < LIK_P * D; e += LIK_THREADS) {
+                const int p = e / D, k = e - p * D;
+                const int64_t i = i0 + p;
+                if (i < dm.nb) gx_part[((int64_t)g * dm.nb + i) * D + k] = x_lds[p * DS + k];
+            }
         }
         __syncthreads();
     }

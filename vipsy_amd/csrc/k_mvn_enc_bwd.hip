@@ -236,15 +236,17 @@ __host__ __device__ inline size_t fc1_bwd_lds_floats(int Hp) {
 }
 
 // slab layout: [W1: H*J | b1: H]
+// fast != 0 (H == 64, J % 4 == 0, aligned ghpre / y): tiles are fetched as batches of independent 16-byte /
+// 4-byte loads one person tile ahead (issue before the MFMA phase, write to LDS after it).
 template <int HT>
 __global__ __launch_bounds__(ENC_THREADS) void k_fc1_bwd(
     EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows,
-    const float* __restrict__ ghpre, float* __restrict__ slabs, int64_t slab_len) {
+    const float* __restrict__ ghpre, float* __restrict__ slabs, int64_t slab_len, int fast) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int J = dm.J, H = dm.H, Hp = dm.Hp;
-    const int HS = Hp + 1;
+    const int HS = fast ? 64 : Hp + 1;
     float* g_lds = smem;                                   // [P][HS]
-    int8_t* Yi = (int8_t*)(g_lds + ENC_P * HS);            // [P][FC1_YS] encoder input as int8 (-1,0,1)
+    int8_t* Yi = (int8_t*)(g_lds + ENC_P * (Hp + 1));      // [P][FC1_YS] encoder input as int8 (-1,0,1)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int jg0 = blockIdx.x * FC1_JG;
     f32x16 acc[FC1_IT][HT];
@@ -256,26 +258,61 @@ __global__ __launch_bounds__(ENC_THREADS) void k_fc1_bwd(
 #pragma unroll
         for (int ht = 0; ht < HT; ++ht) acc[t][ht] = zero16();
     const int64_t n_ptiles = (dm.nb + ENC_P - 1) / ENC_P;
-    for (int64_t tile = blockIdx.y; tile < n_ptiles; tile += gridDim.y) {
+    float4 pg[4];
+    uint32_t pw[32];
+    auto prefetch = [&](int64_t tile) {
+        const int64_t i0 = tile * ENC_P;
+        const int pv = (int)((dm.nb - i0) < ENC_P ? (dm.nb - i0) : ENC_P);
+        const float4* g4 = (const float4*)(ghpre + i0 * 64);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + ENC_THREADS * q;
+            pg[q] = (idx < pv * 16) ? g4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const int idx = tid + ENC_THREADS * q;                  // P x 128 words
+            const int p = idx >> 7, jw = jg0 + 4 * (idx & 127);
+            pw[q] = 0u;
+            if (p < pv && jw < J) {
+                const int64_t row = rows ? rows[i0 + p] : i0 + p;
+                pw[q] = *(const uint32_t*)(y + row * J + jw);       // bytes 0/1/255 == int8 0/1/-1 (vi.py:689-691)
+            }
+        }
+    };
+    int64_t tile = blockIdx.y;
+    if (fast && tile < n_ptiles) prefetch(tile);
+    for (; tile < n_ptiles; tile += gridDim.y) {
         const int64_t i0 = tile * ENC_P;
         __syncthreads();
-        for (int e = tid; e < ENC_P * Hp; e += ENC_THREADS) {
-            const int p = e / Hp, hh = e - p * Hp;
-            const int64_t i = i0 + p;
-            g_lds[p * HS + hh] = (i < dm.nb && hh < H) ? ghpre[i * H + hh] : 0.f;
-        }
-        for (int e = tid; e < ENC_P * FC1_JG; e += ENC_THREADS) {
-            const int p = e / FC1_JG, jj = e - p * FC1_JG;
-            const int64_t i = i0 + p;
-            int8_t v = 0;
-            if (i < dm.nb && jg0 + jj < J) {
-                const int64_t row = rows ? rows[i] : i;
-                const unsigned yy = y[row * J + jg0 + jj];
-                v = (yy == 255u) ? (int8_t)-1 : (int8_t)yy;
+        if (fast) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ((float4*)g_lds)[tid + ENC_THREADS * q] = pg[q];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                const int idx = tid + ENC_THREADS * q;
+                ((uint32_t*)Yi)[(idx >> 7) * (FC1_YS / 4) + (idx & 127)] = pw[q];
             }
-            Yi[p * FC1_YS + jj] = v;
+        } else {
+            for (int e = tid; e < ENC_P * Hp; e += ENC_THREADS) {
+                const int p = e / Hp, hh = e - p * Hp;
+                const int64_t i = i0 + p;
+                g_lds[p * HS + hh] = (i < dm.nb && hh < H) ? ghpre[i * H + hh] : 0.f;
+            }
+            for (int e = tid; e < ENC_P * FC1_JG; e += ENC_THREADS) {
+                const int p = e / FC1_JG, jj = e - p * FC1_JG;
+                const int64_t i = i0 + p;
+                int8_t v = 0;
+                if (i < dm.nb && jg0 + jj < J) {
+                    const int64_t row = rows ? rows[i] : i;
+                    const unsigned yy = y[row * J + jg0 + jj];
+                    v = (yy == 255u) ? (int8_t)-1 : (int8_t)yy;
+                }
+                Yi[p * FC1_YS + jj] = v;
+            }
         }
         __syncthreads();
+        if (fast && tile + gridDim.y < n_ptiles) prefetch(tile + gridDim.y);
 #pragma unroll 2
         for (int s = 0; s < ENC_P / 2; ++s) {
             const int p = 2 * s + half;

@@ -5,11 +5,34 @@
 // sized for two workgroups per CU.
 #pragma once
 #include "k_mvn_enc_bwd.hip"
+#include "k_mvn_enc_fast.hip"
 
 #define BH_ROWS 64                      // head rows per LDS tile in bwd_h_fast
 
+// gx / eps tiles are [P][D + 4]: slots D..D+3 hold {0,..} for gx and {1,0,0,0} for eps, so that with the row
+// code of enc_row_code_fast every non-diagonal row is  V = gx[p][kx] * eps[p][lx]  with no branch.
 __host__ __device__ inline size_t enc_bwdh_fast_lds_floats(int D) {
-    return 2 * (size_t)ENC_P * D + (size_t)BH_ROWS * 64 + BH_ROWS;
+    return 2 * (size_t)ENC_P * (D + 4) + (size_t)BH_ROWS * 64 + BH_ROWS;
+}
+
+// stage a [P][D] tile of contiguous global rows into a [P][D+4] LDS image (pad = padv,0,0,0)
+__device__ __forceinline__ void stage_rows_padded(float* lds, const float* g, int D, int pvalid, float padv,
+                                                  int tid) {
+    const int c4 = D / 4, n4 = ENC_P * c4;
+    for (int base = 0; base < n4; base += ENC_THREADS * 4) {
+        float4 a[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = base + q * ENC_THREADS + tid;
+            a[q] = (idx < pvalid * c4) ? ((const float4*)g)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = base + q * ENC_THREADS + tid;
+            if (idx < n4) { const int p = idx / c4, c = idx - p * c4; ((float4*)lds)[p * (c4 + 1) + c] = a[q]; }
+        }
+    }
+    if (tid < ENC_P) ((float4*)lds)[tid * (c4 + 1) + c4] = make_float4(padv, 0.f, 0.f, 0.f);
 }
 
 __global__ __launch_bounds__(ENC_THREADS, 2) void k_mvn_enc_bwd_h_fast(
@@ -19,9 +42,10 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_mvn_enc_bwd_h_fast(
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int H = 64;
     const int D = dm.D, T = dm.T;
-    float* gx_lds = smem;                              // [P][D]  linear image of gx rows
-    float* eps_lds = gx_lds + ENC_P * D;               // [P][D]
-    float* Wt = eps_lds + ENC_P * D;                   // [BH_ROWS][64]
+    const int DP = D + 4;
+    float* gx_lds = smem;                              // [P][D+4]
+    float* eps_lds = gx_lds + ENC_P * DP;              // [P][D+4]
+    float* Wt = eps_lds + ENC_P * DP;                  // [BH_ROWS][64]
     uint32_t* rowtab = (uint32_t*)(Wt + BH_ROWS * H);  // [BH_ROWS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int64_t i0 = (int64_t)blockIdx.x * ENC_P;
@@ -29,27 +53,8 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_mvn_enc_bwd_h_fast(
     const int n_tiles = (int)((RT + BH_ROWS - 1) / BH_ROWS);
     const int pvalid = (int)((dm.nb - i0) < ENC_P ? (dm.nb - i0) : ENC_P);
 
-    // gx / eps tiles: contiguous [pvalid * D] floats in global memory
-    {
-        const int n4 = ENC_P * D / 4, v4 = pvalid * D / 4;
-        const float4* g4 = (const float4*)(gx_in + i0 * D);
-        const float4* e4 = (const float4*)(eps_in + i0 * D);
-        for (int base = 0; base < n4; base += ENC_THREADS * 4) {
-            float4 a[4], b[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int idx = base + q * ENC_THREADS + tid;
-                const bool ok = idx < v4;
-                a[q] = ok ? g4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-                b[q] = ok ? e4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int idx = base + q * ENC_THREADS + tid;
-                if (idx < n4) { ((float4*)gx_lds)[idx] = a[q]; ((float4*)eps_lds)[idx] = b[q]; }
-            }
-        }
-    }
+    stage_rows_padded(gx_lds, gx_in + i0 * D, D, pvalid, 0.f, tid);
+    stage_rows_padded(eps_lds, eps_in + i0 * D, D, pvalid, 1.f, tid);
     const int u = wave & 1, ht = wave >> 1;
     const int p = 32 * u + l31;
     const int64_t i = i0 + p;
@@ -66,13 +71,13 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_mvn_enc_bwd_h_fast(
         }
     };
     prefetch(0);
-    const float* gx_p = gx_lds + p * D;
-    const float* eps_p = eps_lds + p * D;
+    const float* gx_p = gx_lds + p * DP;
+    const float* eps_p = eps_lds + p * DP;
     for (int tile = 0; tile < n_tiles; ++tile) {
         __syncthreads();                                // previous MFMA phase done with Wt / rowtab
 #pragma unroll
         for (int q = 0; q < 4; ++q) ((float4*)Wt)[tid + ENC_THREADS * q] = wp[q];
-        if (tid < BH_ROWS) rowtab[tid] = enc_row_code((int64_t)tile * BH_ROWS + tid, T, D);
+        if (tid < BH_ROWS) rowtab[tid] = enc_row_code_fast((int64_t)tile * BH_ROWS + tid, T, D);
         __syncthreads();
         if (tile + 1 < n_tiles) prefetch(tile + 1);     // in flight during the MFMA phase
         const float* ap = Wt + (half * 32) * H + 32 * ht + l31;
@@ -80,21 +85,19 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_mvn_enc_bwd_h_fast(
         for (int q = 0; q < 8; ++q) {
             const uint4 cd = *(const uint4*)(rowtab + half * 32 + 4 * q);
             const uint32_t cdv[4] = {cd.x, cd.y, cd.z, cd.w};
+            float vv[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t cc = cdv[e];
-                float v = 0.f;
-                if (cc != ROW_NONE) {
-                    if (cc & ROW_LOC) {
-                        v = gx_p[cc & 0xFFFFu];
-                    } else {
-                        const int k = (int)(cc >> 16), l = (int)(cc & 0xFFFFu);
-                        v = gx_p[k] * eps_p[l];
-                        if (l == k) v = (i < dm.nb) ? v * ldT[(int64_t)k * dm.nb + i] + scale : 0.f;
+            for (int e = 0; e < 4; ++e) vv[e] = gx_p[(cdv[e] >> 16) & 0x7FFFu] * eps_p[cdv[e] & 0xFFFFu];
+            if ((cd.x | cd.y | cd.z | cd.w) & FC_DIAG) {                          // half-wave uniform, rare
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (cdv[e] & FC_DIAG) {
+                        const int k = (int)(cdv[e] & 0xFFFFu);
+                        vv[e] = (i < dm.nb) ? vv[e] * ldT[(int64_t)k * dm.nb + i] + scale : 0.f;
                     }
-                }
-                acc = mfma32(ap[(4 * q + e) * H], v, acc);
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma32(ap[(4 * q + e) * H], vv[e], acc);
         }
     }
     // gh -> ghpre = gh * sigmoid(pre), sigmoid(pre) = 1 - exp(-h)
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_mvn_enc_bwd_h_fast(
 #define BWF_RT 6                        // row tiles (of 32) per wave -> 768 head rows per workgroup
 #define BWF_ROWS (4 * BWF_RT * 32)
 
-__host__ __device__ inline size_t enc_bwdw_fast_lds_floats(int D) { return 3 * (size_t)ENC_P * D + ENC_P * 64; }
+__host__ __device__ inline size_t enc_bwdw_fast_lds_floats(int D) { return 2 * (size_t)ENC_P * (D + 4) + (size_t)ENC_P * D + ENC_P * 64; }
 
 // slab layout (one per person range): [W21: D*H | b21: D | W22: T*H | b22: T]
 __global__ __launch_bounds__(ENC_THREADS, 1) void k_mvn_enc_bwd_w_fast(
@@ -127,26 +130,23 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_mvn_enc_bwd_w_fast(
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int H = 64;
     const int D = dm.D, T = dm.T;
-    float* gx_lds = smem;                   // [P][D]
-    float* eps_lds = gx_lds + ENC_P * D;    // [P][D]
-    float* ld_lds = eps_lds + ENC_P * D;    // [D][P]  (dimension-major, as ldT)
+    const int DP = D + 4, C4 = D / 4;
+    float* gx_lds = smem;                   // [P][D+4]  slot D = 0
+    float* eps_lds = gx_lds + ENC_P * DP;   // [P][D+4]  slot D = 1
+    float* ld_lds = eps_lds + ENC_P * DP;   // [D][P]  (dimension-major, as ldT)
     float* h_lds = ld_lds + ENC_P * D;      // [P][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int64_t RT = (int64_t)T + D;
     const int64_t rbase = (int64_t)blockIdx.x * BWF_ROWS + (int64_t)wave * BWF_RT * 32;
-    int koff[BWF_RT], loff[BWF_RT];         // per-lane row description: V = gx[k] * eps[l] (or variants)
-    int kind[BWF_RT];                       // 0 none, 1 tril off-diagonal, 2 diagonal, 3 loc
+    int koff[BWF_RT], loff[BWF_RT];         // per-lane row description: V = gx[kx] * eps[lx] (enc_row_code_fast)
+    bool isd[BWF_RT], anyd[BWF_RT];
 #pragma unroll
     for (int t = 0; t < BWF_RT; ++t) {
-        const uint32_t cc = enc_row_code(rbase + 32 * t + l31, T, D);
-        koff[t] = 0; loff[t] = 0; kind[t] = 0;
-        if (cc != ROW_NONE) {
-            if (cc & ROW_LOC) { kind[t] = 3; koff[t] = (int)(cc & 0xFFFFu); }
-            else {
-                koff[t] = (int)(cc >> 16); loff[t] = (int)(cc & 0xFFFFu);
-                kind[t] = (koff[t] == loff[t]) ? 2 : 1;
-            }
-        }
+        const uint32_t cc = enc_row_code_fast(rbase + 32 * t + l31, T, D);
+        koff[t] = (int)((cc >> 16) & 0x7FFFu);
+        loff[t] = (int)(cc & 0xFFFFu);
+        isd[t] = (cc & FC_DIAG) != 0;
+        anyd[t] = __any(isd[t]);
     }
     f32x16 acc[BWF_RT][2];
     float bsum[BWF_RT];
@@ -200,10 +200,15 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_mvn_enc_bwd_w_fast(
         for (int q = 0; q <= NQ; ++q) {
             const int idx = tid + ENC_THREADS * q;
             if (idx < n4d) {
-                ((float4*)gx_lds)[idx] = pg[q];
-                ((float4*)eps_lds)[idx] = pe[q];
+                const int pp = idx / C4, c = idx - pp * C4;
+                ((float4*)gx_lds)[pp * (C4 + 1) + c] = pg[q];
+                ((float4*)eps_lds)[pp * (C4 + 1) + c] = pe[q];
                 ((float4*)ld_lds)[idx] = pl[q];
             }
+        }
+        if (tid < ENC_P) {
+            ((float4*)gx_lds)[tid * (C4 + 1) + C4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ((float4*)eps_lds)[tid * (C4 + 1) + C4] = make_float4(1.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) ((float4*)h_lds)[tid + ENC_THREADS * q] = ph[q];
@@ -212,15 +217,16 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_mvn_enc_bwd_w_fast(
 #pragma unroll 2
         for (int s = 0; s < ENC_P / 2; ++s) {
             const int p = 2 * s + half;
-            const float* gx_p = gx_lds + p * D;
-            const float* eps_p = eps_lds + p * D;
+            const float* gx_p = gx_lds + p * DP;
+            const float* eps_p = eps_lds + p * DP;
             const float b0 = h_lds[p * H + l31], b1 = h_lds[p * H + 32 + l31];
 #pragma unroll
             for (int t = 0; t < BWF_RT; ++t) {
-                float v = 0.f;
-                if (kind[t] == 1) v = gx_p[koff[t]] * eps_p[loff[t]];
-                else if (kind[t] == 2) v = (p < pvalid) ? gx_p[koff[t]] * eps_p[loff[t]] * ld_lds[koff[t] * ENC_P + p] + scale : 0.f;
-                else if (kind[t] == 3) v = gx_p[koff[t]];
+                float v = gx_p[koff[t]] * eps_p[loff[t]];
+                if (anyd[t]) {                                                   // wave-uniform, rare
+                    const float ldv = ld_lds[(isd[t] ? loff[t] : 0) * ENC_P + p];
+                    if (isd[t]) v = (p < pvalid) ? v * ldv + scale : 0.f;
+                }
                 bsum[t] += v;
                 acc[t][0] = mfma32(v, b0, acc[t][0]);
                 acc[t][1] = mfma32(v, b1, acc[t][1]);

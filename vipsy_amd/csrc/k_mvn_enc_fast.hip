@@ -12,6 +12,20 @@
 #include "k_mvn_enc.hip"
 
 #define EF_HS 65                       // h_lds stride (odd: conflict-free person-major reads)
+#define FC_DIAG 0x80000000u
+
+// Row code of the fast kernels: (kx << 16) | lx such that for every non-diagonal row the contribution
+// is simply  x[p][kx] += v * eps[p][lx]  with no branch:
+//   tril off-diagonal (k,l): kx = k, lx = l;   loc row k: kx = k, lx = D (slot D of every eps row holds 1);
+//   padding row: kx = D (a dump slot never read back), lx = D.   Diagonal rows carry FC_DIAG | (k<<16) | k
+//   and take the (rare, half-wave-uniform) exp() path.
+__device__ __forceinline__ uint32_t enc_row_code_fast(int64_t r, int T, int D) {
+    const uint32_t cc = enc_row_code(r, T, D);
+    if (cc == ROW_NONE) return ((uint32_t)D << 16) | (uint32_t)D;
+    if (cc & ROW_LOC) return ((cc & 0xFFFFu) << 16) | (uint32_t)D;
+    if ((cc >> 16) == (cc & 0xFFFFu)) return FC_DIAG | cc;
+    return cc;
+}
 
 __host__ __device__ inline int ef_ys(int J) { return ((J + 63) / 64) * 64 + 4; }     // bytes per person row
 __host__ __device__ inline size_t enc_fwd_fast_lds_floats(int D, int J) {
@@ -146,7 +160,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_mvn_enc_fwd_fast(
                 }
         }
         for (int e = tid; e < ENC_P * DS; e += ENC_THREADS) x_lds[e] = 0.f;
-        if (tid < ENC_P) ent_lds[tid] = 0.f;
+        if (tid < ENC_P) { ent_lds[tid] = 0.f; eps_lds[tid * DS + D] = 1.0f; }     // slot D: the "times one" of loc rows
     }
     __syncthreads();
     // ---------------------------------------------------------------- phase B: head rows, per wave
@@ -158,7 +172,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_mvn_enc_fwd_fast(
         auto prefetch = [&](float4 (&A)[8], uint32_t& code, float& bias, int tt) {
             const int64_t r = (int64_t)tt * 32 + l31;
             const float* src = (r < T) ? W22 + r * H : (r < RT ? W21 + (r - T) * H : nullptr);
-            code = enc_row_code(r, T, D);
+            code = enc_row_code_fast(r, T, D);
             bias = (r < T) ? b22[r] : (r < RT ? b21[r - T] : 0.f);
 #pragma unroll
             for (int q = 0; q < 8; ++q)
@@ -190,29 +204,23 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_mvn_enc_fwd_fast(
                     const float4 bs = *(const float4*)(biasw + rl);
                     const uint32_t cdv[4] = {cd.x, cd.y, cd.z, cd.w};
                     const float bsv[4] = {bs.x, bs.y, bs.z, bs.w};
+                    // LDS float atomics are expensive (~100+ cycles each): merge the rows of a group that
+                    // share kx (the common case: four consecutive entries of one tril row) into one add
                     int curk = -1;
                     float part = 0.f;
 #pragma unroll
                     for (int jx = 0; jx < 4; ++jx) {
                         const uint32_t cc = cdv[jx];
-                        if (cc == ROW_NONE) continue;
                         const float v = (uu == 0 ? a0[4 * g + jx] : a1[4 * g + jx]) + bsv[jx];
-                        int k;
+                        const int k = (int)((cc >> 16) & 0x7FFFu);
                         float contrib;
-                        if (cc & ROW_LOC) {
-                            k = (int)(cc & 0xFFFFu);
-                            contrib = v;                                              // loc head (vi.py:450)
+                        if (cc & FC_DIAG) {                                           // half-wave uniform, rare
+                            const float ld = expf(v);                                 // exp(diag M): vi.py:686
+                            contrib = ld * ep[k];
+                            atomicAdd(&ent_lds[p], v);
+                            if (i < dm.nb) ldT[(int64_t)k * dm.nb + i] = ld;
                         } else {
-                            k = (int)(cc >> 16);
-                            const int l = (int)(cc & 0xFFFFu);
-                            if (l < k) {
-                                contrib = v * ep[l];                                  // tril(M,-1) eps
-                            } else {
-                                const float ld = expf(v);                             // exp(diag M): vi.py:686
-                                contrib = ld * ep[k];
-                                atomicAdd(&ent_lds[p], v);
-                                if (i < dm.nb) ldT[(int64_t)k * dm.nb + i] = ld;
-                            }
+                            contrib = v * ep[cc & 0xFFFFu];
                         }
                         if (k != curk) {
                             if (curk >= 0) atomicAdd(&xp[curk], part);
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_mvn_enc_fwd_fast(
                             part += contrib;
                         }
                     }
-                    if (curk >= 0) atomicAdd(&xp[curk], part);
+                    atomicAdd(&xp[curk], part);
                 }
             }
             __builtin_amdgcn_wave_barrier();

@@ -173,7 +173,7 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
 static void lik_plan(const vx_irt_cfg* cfg, int64_t nb, int& kt, int& nch, int& groups, int& n_pr) {
     const int dk = cfg->D + 1;
     kt = dk <= 32 ? 1 : (dk <= 64 ? 2 : 4);
-    nch = cfg->J <= LIK_JC ? 1 : (cfg->J <= 2 * LIK_JC ? 2 : 4);
+    nch = cfg->J <= LIK_JC ? 1 : 2;      // 4 chunks of register-resident GA tiles spill; 2 do not
     groups = (cfg->J + nch * LIK_JC - 1) / (nch * LIK_JC);
     const int64_t n_ptiles = (nb + LIK_P - 1) / LIK_P;
     int64_t want = num_cu() / groups;
@@ -209,6 +209,8 @@ int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows
     dm.D = cfg->D; dm.J = cfg->J; dm.DS = lik_ds(cfg->D); dm.Dk2 = (cfg->D + 2) & ~1; dm.model = cfg->model;
     dm.Dc = cfg->Dc; dm.scale = cfg->scale; dm.nb = nb;
     dm.slab_len = (int64_t)cfg->D * cfg->J + 3 * (int64_t)cfg->J;
+    dm.fast = (!force_generic() && cfg->D % 4 == 0 && cfg->J % 4 == 0 && aligned16(x) && aligned16(a) && aligned16(b) &&
+               aligned16(y) && aligned16(gx) && (nb * cfg->D) % 4 == 0) ? 1 : 0;
     const int gen = cfg->model >= VX_IRT_3PL ? 1 : 0;
     float* slabs = workspace;
     float* gx_part = groups > 1 ? workspace + (int64_t)n_pr * dm.slab_len : gx;
@@ -228,8 +230,7 @@ int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows
                        d_un, gx_part, ll_part, slabs)
 #define DISPATCH_NCH(KT, GEN)                                     \
     if (nch == 1) { LAUNCH_LIK(KT, 1, GEN); }                     \
-    else if (nch == 2) { LAUNCH_LIK(KT, 2, GEN); }                \
-    else { LAUNCH_LIK(KT, 4, GEN); }
+    else { LAUNCH_LIK(KT, 2, GEN); }
 #define DISPATCH_KT(GEN)                                          \
     if (kt == 1) { DISPATCH_NCH(1, GEN) }                         \
     else if (kt == 2) { DISPATCH_NCH(2, GEN) }                    \
@@ -348,10 +349,11 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
         {
             const size_t lds = fc1_bwd_lds_floats(dm.Hp) * sizeof(float);
             const dim3 grid((unsigned)n_jg, (unsigned)n_prf);
+            const int f1fast = (!force_generic() && cfg->H == 64 && cfg->J % 4 == 0 && aligned16(ghpre) && aligned16(y)) ? 1 : 0;
 #define LAUNCH_F1(HT)                                                                                        \
     rc = set_lds(k_fc1_bwd<HT>, lds);                                                                        \
     if (rc) return rc;                                                                                       \
-    hipLaunchKernelGGL(k_fc1_bwd<HT>, grid, dim3(ENC_THREADS), lds, st, dm, y, rows, ghpre, slabs_f, lenf)
+    hipLaunchKernelGGL(k_fc1_bwd<HT>, grid, dim3(ENC_THREADS), lds, st, dm, y, rows, ghpre, slabs_f, lenf, f1fast)
             if (dm.Hp == 32) { LAUNCH_F1(1); } else { LAUNCH_F1(2); }
 #undef LAUNCH_F1
             VX_CHECK_LAUNCH();
