@@ -12,7 +12,32 @@
 // gx / eps tiles are [P][D + 4]: slots D..D+3 hold {0,..} for gx and {1,0,0,0} for eps, so that with the row
 // code of enc_row_code_fast every non-diagonal row is  V = gx[p][kx] * eps[p][lx]  with no branch.
 __host__ __device__ inline size_t enc_bwdh_fast_lds_floats(int D) {
-    return 2 * (size_t)ENC_P * (D + 4) + (size_t)BH_ROWS * 64 + BH_ROWS;
+    return 2 * (size_t)ENC_P * enc_ds(D) + (size_t)BH_ROWS * 64 + BH_ROWS + 8;
+}
+
+// stage a [P][D] tile of contiguous global rows into a [P][DS] LDS image with ODD stride DS >= D + 1
+// (lanes index persons in bwd_h, so an even stride would be an 8-way bank conflict); slot D := padv
+__device__ __forceinline__ void stage_rows_odd(float* lds, const float* g, int D, int DS, int pvalid, float padv,
+                                               int tid) {
+    const int c4 = D / 4, n4 = ENC_P * c4;
+    for (int base = 0; base < n4; base += ENC_THREADS * 4) {
+        float4 a[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = base + q * ENC_THREADS + tid;
+            a[q] = (idx < pvalid * c4) ? ((const float4*)g)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = base + q * ENC_THREADS + tid;
+            if (idx < n4) {
+                const int p = idx / c4, c = idx - p * c4;
+                float* dst = lds + p * DS + 4 * c;
+                dst[0] = a[q].x; dst[1] = a[q].y; dst[2] = a[q].z; dst[3] = a[q].w;
+            }
+        }
+    }
+    if (tid < ENC_P) lds[tid * DS + D] = padv;
 }
 
 // stage a [P][D] tile of contiguous global rows into a [P][D+4] LDS image (pad = padv,0,0,0)
@@ -42,10 +67,12 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_mvn_enc_bwd_h_fast(
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int H = 64;
     const int D = dm.D, T = dm.T;
-    const int DP = D + 4;
-    float* gx_lds = smem;                              // [P][D+4]
-    float* eps_lds = gx_lds + ENC_P * DP;              // [P][D+4]
-    float* Wt = eps_lds + ENC_P * DP;                  // [BH_ROWS][64]
+    const int DP = dm.DS;                              // odd stride >= D + 1
+    float* gx_lds = smem;                              // [P][DS]
+    float* eps_lds = gx_lds + ENC_P * DP;              // [P][DS]
+    // [BH_ROWS][64]; offset rounded up to a multiple of 4 floats by INDEX arithmetic (a uintptr_t cast would
+    // make the pointer generic and turn every LDS access below into a slow flat_load / flat_store)
+    float* Wt = smem + ((2 * ENC_P * DP + 3) & ~3);
     uint32_t* rowtab = (uint32_t*)(Wt + BH_ROWS * H);  // [BH_ROWS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int64_t i0 = (int64_t)blockIdx.x * ENC_P;
@@ -53,8 +80,8 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_mvn_enc_bwd_h_fast(
     const int n_tiles = (int)((RT + BH_ROWS - 1) / BH_ROWS);
     const int pvalid = (int)((dm.nb - i0) < ENC_P ? (dm.nb - i0) : ENC_P);
 
-    stage_rows_padded(gx_lds, gx_in + i0 * D, D, pvalid, 0.f, tid);
-    stage_rows_padded(eps_lds, eps_in + i0 * D, D, pvalid, 1.f, tid);
+    stage_rows_odd(gx_lds, gx_in + i0 * D, D, DP, pvalid, 0.f, tid);
+    stage_rows_odd(eps_lds, eps_in + i0 * D, D, DP, pvalid, 1.f, tid);
     const int u = wave & 1, ht = wave >> 1;
     const int p = 32 * u + l31;
     const int64_t i = i0 + p;
@@ -117,10 +144,10 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_mvn_enc_bwd_h_fast(
 }
 
 // ---------------------------------------------------------------------------------------------
-#define BWF_RT 6                        // row tiles (of 32) per wave -> 768 head rows per workgroup
+#define BWF_RT 5                        // row tiles (of 32) per wave -> 768 head rows per workgroup
 #define BWF_ROWS (4 * BWF_RT * 32)
 
-__host__ __device__ inline size_t enc_bwdw_fast_lds_floats(int D) { return 2 * (size_t)ENC_P * (D + 4) + (size_t)ENC_P * D + ENC_P * 64; }
+__host__ __device__ inline size_t enc_bwdw_fast_lds_floats(int D) { return 2 * (size_t)ENC_P * (D + 4) + (size_t)ENC_P * (D + 1) + ENC_P * 64; }
 
 // slab layout (one per person range): [W21: D*H | b21: D | W22: T*H | b22: T]
 __global__ __launch_bounds__(ENC_THREADS, 1) void k_mvn_enc_bwd_w_fast(
@@ -133,20 +160,23 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_mvn_enc_bwd_w_fast(
     const int DP = D + 4, C4 = D / 4;
     float* gx_lds = smem;                   // [P][D+4]  slot D = 0
     float* eps_lds = gx_lds + ENC_P * DP;   // [P][D+4]  slot D = 1
-    float* ld_lds = eps_lds + ENC_P * DP;   // [D][P]  (dimension-major, as ldT)
-    float* h_lds = ld_lds + ENC_P * D;      // [P][64]
+    float* ld_lds = eps_lds + ENC_P * DP;   // [D + 1][P]  (dimension-major, as ldT); row D holds ones
+    float* h_lds = ld_lds + ENC_P * (D + 1);   // [P][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int64_t RT = (int64_t)T + D;
     const int64_t rbase = (int64_t)blockIdx.x * BWF_ROWS + (int64_t)wave * BWF_RT * 32;
-    int koff[BWF_RT], loff[BWF_RT];         // per-lane row description: V = gx[kx] * eps[lx] (enc_row_code_fast)
-    bool isd[BWF_RT], anyd[BWF_RT];
+    // per-lane row description (enc_row_code_fast):  V = gx[kx] * eps[lx] * ld[ldrow] + addv * valid
+    // (ldrow = D, the row of ones, and addv = 0 for every non-diagonal row) -- no branch in the hot loop
+    int koff[BWF_RT], loff[BWF_RT], ldoff[BWF_RT];
+    float addv[BWF_RT];
 #pragma unroll
     for (int t = 0; t < BWF_RT; ++t) {
         const uint32_t cc = enc_row_code_fast(rbase + 32 * t + l31, T, D);
         koff[t] = (int)((cc >> 16) & 0x7FFFu);
         loff[t] = (int)(cc & 0xFFFFu);
-        isd[t] = (cc & FC_DIAG) != 0;
-        anyd[t] = __any(isd[t]);
+        const bool isd = (cc & FC_DIAG) != 0;
+        ldoff[t] = (isd ? loff[t] : D) * ENC_P;
+        addv[t] = isd ? scale : 0.f;
     }
     f32x16 acc[BWF_RT][2];
     float bsum[BWF_RT];
@@ -207,30 +237,45 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_mvn_enc_bwd_w_fast(
             }
         }
         if (tid < ENC_P) {
-            ((float4*)gx_lds)[tid * (C4 + 1) + C4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            // gx slot D = 0 (padding rows), slot D+1 = 1 for persons inside the batch (gates the "+ scale")
+            ((float4*)gx_lds)[tid * (C4 + 1) + C4] = make_float4(0.f, tid < pvalid ? 1.f : 0.f, 0.f, 0.f);
             ((float4*)eps_lds)[tid * (C4 + 1) + C4] = make_float4(1.f, 0.f, 0.f, 0.f);
+            ld_lds[D * ENC_P + tid] = 1.0f;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) ((float4*)h_lds)[tid + ENC_THREADS * q] = ph[q];
         __syncthreads();
         if (tile + gridDim.y < n_ptiles) prefetch(tile + gridDim.y);
-#pragma unroll 2
-        for (int s = 0; s < ENC_P / 2; ++s) {
+        // operands of k-step s+1 are read from LDS while the MFMAs of step s run (one step of software
+        // pipelining: with one wave per SIMD nothing else hides the LDS latency)
+        float g0[BWF_RT], e0[BWF_RT], d0[BWF_RT], g1[BWF_RT], e1[BWF_RT], d1[BWF_RT];
+        float hb0[2], hb1[2], vf0, vf1;
+        auto fetch = [&](float (&g)[BWF_RT], float (&e)[BWF_RT], float (&d)[BWF_RT], float (&hb)[2], float& vf, int s) {
             const int p = 2 * s + half;
             const float* gx_p = gx_lds + p * DP;
             const float* eps_p = eps_lds + p * DP;
-            const float b0 = h_lds[p * H + l31], b1 = h_lds[p * H + 32 + l31];
+            hb[0] = h_lds[p * H + l31];
+            hb[1] = h_lds[p * H + 32 + l31];
+            vf = gx_p[D + 1];
+#pragma unroll
+            for (int t = 0; t < BWF_RT; ++t) { g[t] = gx_p[koff[t]]; e[t] = eps_p[loff[t]]; d[t] = ld_lds[ldoff[t] + p]; }
+        };
+        auto mma = [&](const float (&g)[BWF_RT], const float (&e)[BWF_RT], const float (&d)[BWF_RT],
+                       const float (&hb)[2], float vf) {
 #pragma unroll
             for (int t = 0; t < BWF_RT; ++t) {
-                float v = gx_p[koff[t]] * eps_p[loff[t]];
-                if (anyd[t]) {                                                   // wave-uniform, rare
-                    const float ldv = ld_lds[(isd[t] ? loff[t] : 0) * ENC_P + p];
-                    if (isd[t]) v = (p < pvalid) ? v * ldv + scale : 0.f;
-                }
+                const float v = fmaf(g[t] * e[t], d[t], addv[t] * vf);
                 bsum[t] += v;
-                acc[t][0] = mfma32(v, b0, acc[t][0]);
-                acc[t][1] = mfma32(v, b1, acc[t][1]);
+                acc[t][0] = mfma32(v, hb[0], acc[t][0]);
+                acc[t][1] = mfma32(v, hb[1], acc[t][1]);
             }
+        };
+        fetch(g0, e0, d0, hb0, vf0, 0);
+        for (int s = 0; s < ENC_P / 2; s += 2) {
+            fetch(g1, e1, d1, hb1, vf1, s + 1);
+            mma(g0, e0, d0, hb0, vf0);
+            if (s + 2 < ENC_P / 2) fetch(g0, e0, d0, hb0, vf0, s + 2);
+            mma(g1, e1, d1, hb1, vf1);
         }
     }
     float* slab = slabs + (int64_t)blockIdx.y * slab_len;
