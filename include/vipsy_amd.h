@@ -118,6 +118,39 @@ int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, 
                   float* gloc, float* graw, float* elbo, float* gitem, float* workspace,
                   void* hip_stream);
 
+/* ---- amortized Normal guide for ONE latent dimension (NormEncoder, vi.py:417-435; VaeIRT with
+ * x_feature == 1, vi.py:677-684, and VaeCHoDina, vi.py:968-981).  cfg->J, cfg->H are used.
+ *   forward : h[nb][H] = softplus(fc1 yin), loc[nb] = fc21 h, raw[nb] = fc22 h  (scale = exp(raw))
+ *   backward: genc = d LOSS / d [W1: H*J | b1: H | W21: H | b21: 1 | W22: H | b22: 1] from
+ *             gloc / graw = d LOSS / d loc, raw (as produced by vx_irt1d_grad / vx_hodina_grad). */
+int64_t vx_norm_enc_param_floats(const vx_irt_cfg* cfg);
+int vx_norm_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
+                        const float* W1, const float* b1, const float* W21, const float* b21,
+                        const float* W22, const float* b22, float* h, float* loc, float* raw,
+                        void* hip_stream);
+int64_t vx_norm_enc_bwd_workspace_floats(const vx_irt_cfg* cfg, int64_t nb);
+int vx_norm_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
+                         const float* W21, const float* W22, const float* h, const float* gloc,
+                         const float* graw, float* genc, float* workspace, void* hip_stream);
+
+/* ---- HO-DINA with exact enumeration of the 2^K attribute patterns (VCHoDina / VaeCHoDina model,
+ * vi.py:897-923, under TraceEnum_ELBO; guide theta ~ Normal(loc, exp(raw)), vi.py:925-934 / 968-981).
+ *   q: [K][J] float 0/1 Q-matrix (vi.py:741);  lam0 [K], lam1_un [K] (positive -> exp), g_un / s_un [J]
+ *   (interval(0,1) -> sigmoid).  K <= 10, J <= 1024.
+ * Outputs: gloc / graw [nb] = d LOSS / d loc, raw;  elbo[nb] per-person ELBO terms (unscaled);
+ *   gitem = d LOSS / d [g_un: J | s_un: J | lam0: K | lam1_un: K] for this rank's batch. */
+typedef struct vx_hodina_cfg {
+    int32_t K, J, H, _pad;
+    float scale, _pad2;
+    uint64_t seed;
+    uint32_t step, stream;
+} vx_hodina_cfg;
+int64_t vx_hodina_workspace_floats(const vx_hodina_cfg* cfg, int64_t nb);
+int vx_hodina_grad(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, int64_t gid0,
+                   const float* loc, const float* raw, const float* eps_in, const float* q,
+                   const float* lam0, const float* lam1_un, const float* g_un, const float* s_un,
+                   float* gloc, float* graw, float* elbo, float* gitem, float* workspace, void* hip_stream);
+
 /* ---- slab reduction: out[i] = alpha * sum_s slabs[s][i]  (fixed order -> deterministic) */
 int vx_reduce_slabs(const float* slabs, int64_t n_slabs, int64_t len, float alpha, float* out,
                     void* hip_stream);

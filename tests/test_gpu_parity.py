@@ -16,12 +16,20 @@ def _dev():
 
 
 def _engine_from_fixture(tag):
-    from vipsy_amd.engine import IrtEngine, LrSpec
+    from vipsy_amd.engine import IrtEngine, HoDinaEngine, LrSpec
     spec, params, opt, y, steps, B = gu.build(tag, np.float64)
     enc = {k.split("$$$")[1]: v for k, v in params.items() if k.startswith("encoder$$$")}
-    eng = IrtEngine(torch.from_numpy(y).to(_dev()), model=spec["model"], D=spec["D"], Dc=spec["Dc"],
-                    amortized=spec["amortized"], H=(enc["fc1.weight"].shape[0] if enc else 0),
-                    encoder_init=enc if enc else None, b0=params["b"], seed=1)
+    yt = torch.from_numpy(y).to(_dev())
+    if spec["family"] == "hodina":
+        eng = HoDinaEngine(yt, spec["q"], amortized=spec["amortized"], H=(enc["fc1.weight"].shape[0] if enc else 0),
+                           encoder_init=enc if enc else None, seed=1)
+    else:
+        eng = IrtEngine(yt, model=spec["model"], D=spec["D"], Dc=spec["Dc"], amortized=spec["amortized"],
+                        H=(enc["fc1.weight"].shape[0] if enc else 0), encoder_init=enc if enc else None,
+                        b0=params["b"], seed=1)
+    for name in eng.all_names():                      # fixture-specific initial values (e.g. pre-seeded lam1)
+        eng.unconstrained(name).copy_(torch.from_numpy(np.asarray(params[name], np.float32)).reshape(
+            eng.unconstrained(name).shape))
     lrs = LrSpec(opt["lr"], milestones=opt["milestones"], gamma=opt["gamma"])
     return eng, lrs, spec, params, opt, y, steps
 
@@ -56,7 +64,9 @@ def test_philox_normals_match_oracle(D):
 
 
 GOLDEN_HIP = ["vaeirt_irt_2pl_d3", "vaeirt_irt_3pl_d2", "vaeirt_irt_4pl_d4",
-              "virt_irt_1pl_d1", "virt_irt_2pl_d1", "virt_irt_3pl_d1", "virt_irt_4pl_d1", "virt_irt_2pl_d1_D1702"]
+              "virt_irt_1pl_d1", "virt_irt_2pl_d1", "virt_irt_3pl_d1", "virt_irt_4pl_d1", "virt_irt_2pl_d1_D1702",
+              "vaeirt_irt_2pl_d1", "vaeirt_irt_4pl_d1",
+              "vchodina_k3", "vchodina_k4_sub", "vchodina_k4_clamp", "vaechodina_k3"]
 
 
 @pytest.mark.parametrize("tag", GOLDEN_HIP)
@@ -68,15 +78,16 @@ def test_hip_replays_reference_steps(tag):
         idx, eps = rec["idx"][0], rec["eps"][0]
         rows = torch.from_numpy(idx).to(_dev())
         full = len(idx) == spec["N"] and (idx == np.arange(spec["N"])).all()
-        eng.loss_and_grads(None if full else rows, len(idx), torch.from_numpy(np.ascontiguousarray(eps)).to(_dev()))
+        eng.loss_and_grads(None if full else rows, len(idx),
+                           torch.from_numpy(np.ascontiguousarray(eps, dtype=np.float32)).to(_dev()))
         torch.cuda.synchronize()
         loss_o, g_o = vo.loss_and_grads(spec, params, y, [idx], [eps])
         loss_h = float(eng.G[eng.n_params].item())
         assert loss_h == pytest.approx(loss_o, rel=2e-5), (tag, t)
         assert loss_h == pytest.approx(rec["loss"], rel=2e-4), (tag, t)
         for name, go in g_o.items():
-            gh = eng.unconstrained(name, eng.GP if name in ("x_local", "x_scale") else eng.G).cpu().numpy()
-            if name == "a" and spec["a_free"] is not None:
+            gh = eng.unconstrained(name, eng.GP if name in eng.pp_names else eng.G).cpu().numpy()
+            if name == "a" and spec.get("a_free") is not None:
                 gh = gh * spec["a_free"]
             sc = max(1e-3, float(np.abs(go).max()))
             np.testing.assert_allclose(gh / sc, go / sc, atol=3e-5, err_msg="%s step %d grad %s" % (tag, t, name))
@@ -225,3 +236,69 @@ print("RESULT" + json.dumps(out))
     np.testing.assert_allclose(x0, x1, atol=2e-5, rtol=1e-5)
     g0, g1 = np.array(res["0"]["g"]), np.array(res["1"]["g"])
     assert np.abs(g0 - g1).max() <= 2e-5 * max(1.0, np.abs(g1).max())
+
+
+@pytest.mark.parametrize("N,J,K,miss,B,amort", [
+    (500, 30, 8, 0.0, None, False),                  # config 5 shape (PaHoDina), scaled down
+    (333, 100, 5, 0.2, 77, False),                   # reference defaults q_size=5, item_size=100 (vi.py:125,138)
+    (200, 70, 9, 0.1, None, False),                  # 512 patterns: 8 per lane
+    (150, 40, 10, 0.0, 50, True),                    # 1024 patterns, amortized guide
+    (100, 9, 1, 0.3, None, True),
+])
+def test_hodina_step_vs_oracle(N, J, K, miss, B, amort):
+    from vipsy_amd.engine import HoDinaEngine, ENC_KEYS
+    rng = np.random.RandomState(N + J + K)
+    q = (rng.rand(K, J) < 0.4).astype(np.float32)
+    q[rng.randint(0, K, size=J), np.arange(J)] = 1.0
+    y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+    y[rng.rand(N, J) < miss] = 255
+    eng = HoDinaEngine(torch.from_numpy(y).to(_dev()), q, amortized=amort, H=64, seed=9)
+    eng.unconstrained("lam0").copy_(torch.from_numpy(0.5 * rng.randn(1, K)).float())
+    eng.unconstrained("lam1").copy_(torch.from_numpy(0.4 * rng.randn(1, K)).float())
+    eng.unconstrained("g").add_(torch.from_numpy(0.5 * rng.randn(1, J)).float().to(_dev()))
+    eng.unconstrained("s").add_(torch.from_numpy(0.5 * rng.randn(1, J)).float().to(_dev()))
+    if not amort:
+        eng.PP.copy_(torch.from_numpy(np.concatenate([rng.randn(N), 0.3 * rng.randn(N)])).float())
+    idx = np.arange(N) if B is None else np.sort(rng.permutation(N)[:B])
+    rows = None if B is None else torch.from_numpy(idx).to(_dev())
+    eps = vo.philox_normals(9, 0, 0, idx, 1)
+    eng.loss_and_grads(rows, len(idx))
+    torch.cuda.synchronize()
+    spec = {"family": "hodina", "K": K, "N": N, "amortized": amort, "q": q}
+    params = {n: eng.unconstrained(n).cpu().numpy().astype(np.float64) for n in eng.all_names()}
+    loss_o, g_o = vo.loss_and_grads(spec, params, y, [idx], [eps])
+    assert float(eng.G[eng.n_params].item()) == pytest.approx(loss_o, rel=5e-5)
+    for name, go in g_o.items():
+        gh = eng.unconstrained(name, eng.GP if name in eng.pp_names else eng.G).cpu().numpy()
+        sc = max(1e-6, float(np.abs(go).max()))
+        assert np.abs(gh - go).max() / sc < 5e-4, (name, np.abs(gh - go).max() / sc)
+
+
+@pytest.mark.parametrize("N,J,model,miss,B", [
+    (700, 500, "irt_2pl", 0.59, 100),                # Irt2PLMissing.test_ai (test.py:311-327), J scaled
+    (300, 100, "irt_4pl", 0.0, None),                # Irt4PL.test_ai
+    (129, 37, "irt_1pl", 0.2, 64),
+])
+def test_irt1d_amortized_step_vs_oracle(N, J, model, miss, B):
+    from vipsy_amd.engine import IrtEngine
+    rng = np.random.RandomState(N + J)
+    y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+    y[rng.rand(N, J) < miss] = 255
+    eng = IrtEngine(torch.from_numpy(y).to(_dev()), model=model, D=1, amortized=True, H=64, seed=5)
+    eng.unconstrained("b").copy_(torch.from_numpy(0.7 * rng.randn(1, J)).float())
+    if model != "irt_1pl":
+        eng.unconstrained("a").copy_(torch.from_numpy(0.5 + 2 * rng.rand(1, J)).float())
+    idx = np.arange(N) if B is None else np.sort(rng.permutation(N)[:B])
+    rows = None if B is None else torch.from_numpy(idx).to(_dev())
+    eps = vo.philox_normals(5, 0, 0, idx, 1)
+    eng.loss_and_grads(rows, len(idx))
+    torch.cuda.synchronize()
+    spec = {"family": "irt", "model": model, "D": 1, "Dc": 1.0, "N": N, "amortized": True, "share_cov": False,
+            "a_free": None}
+    params = {n: eng.unconstrained(n).cpu().numpy().astype(np.float64) for n in eng.names()}
+    loss_o, g_o = vo.loss_and_grads(spec, params, y, [idx], [eps])
+    assert float(eng.G[eng.n_params].item()) == pytest.approx(loss_o, rel=3e-5)
+    for name, go in g_o.items():
+        gh = eng.unconstrained(name, eng.G).cpu().numpy()
+        sc = max(1e-6, float(np.abs(go).max()))
+        assert np.abs(gh - go).max() / sc < 3e-4, (name, np.abs(gh - go).max() / sc)

@@ -7,6 +7,8 @@
 #include "k_mvn_enc_bwd_fast.hip"
 #include "k_irt_lik.hip"
 #include "k_irt1d.hip"
+#include "k_hodina.hip"
+#include "k_norm_enc.hip"
 
 #include <cstdlib>
 
@@ -421,6 +423,146 @@ int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, 
 #undef LAUNCH_1D
     VX_CHECK_LAUNCH();
     return vx_reduce_slabs(workspace, blocks, 4 * (int64_t)cfg->J, -1.0f, gitem, hs);
+}
+
+// ------------------------------------------------------------------------------------------------
+static bool nenc_cfg_ok(const vx_irt_cfg* cfg) { return cfg && cfg->H >= 1 && cfg->H <= 64 && cfg->J >= 1; }
+
+static void nenc_plan(const vx_irt_cfg* cfg, int64_t nb, int& nblk, int& n_jg, int& n_prf) {
+    int hp = 1;
+    while (hp < cfg->H) hp <<= 1;
+    const int ppb = 256 / hp;
+    int64_t b = (nb + ppb - 1) / ppb;
+    if (b > 1024) b = 1024;
+    nblk = (int)(b < 1 ? 1 : b);
+    n_jg = (cfg->J + FC1_JG - 1) / FC1_JG;
+    const int64_t n_ptiles = (nb + ENC_P - 1) / ENC_P;
+    int64_t f = num_cu() / n_jg; if (f < 1) f = 1;
+    n_prf = (int)(n_ptiles < f ? n_ptiles : f); if (n_prf < 1) n_prf = 1;
+}
+
+int64_t vx_norm_enc_param_floats(const vx_irt_cfg* cfg) {
+    if (!nenc_cfg_ok(cfg)) return VX_EINVAL;
+    return (int64_t)cfg->H * cfg->J + 3 * (int64_t)cfg->H + 2;
+}
+
+int vx_norm_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* W1,
+                        const float* b1, const float* W21, const float* b21, const float* W22, const float* b22,
+                        float* h, float* loc, float* raw, void* hs) {
+    if (!nenc_cfg_ok(cfg) || !y || !W1 || !b1 || !W21 || !b21 || !W22 || !b22 || !h || !loc || !raw || nb < 0)
+        return VX_EINVAL;
+    if (nb == 0) return VX_OK;
+    EncDims dm;
+    dm.D = 1; dm.J = cfg->J; dm.H = cfg->H; dm.Hp = (cfg->H + 31) / 32 * 32; dm.DS = 3; dm.T = 1; dm.nb = nb;
+    const size_t lds = norm_enc_fwd_lds_floats(dm.Hp) * sizeof(float);
+    const dim3 grid((unsigned)((nb + ENC_P - 1) / ENC_P));
+    int rc;
+#define LAUNCH_NF(HT)                                                                                        \
+    rc = set_lds(k_norm_enc_fwd<HT>, lds);                                                                   \
+    if (rc) return rc;                                                                                       \
+    hipLaunchKernelGGL(k_norm_enc_fwd<HT>, grid, dim3(ENC_THREADS), lds, (hipStream_t)hs, dm, y, rows, W1, b1, W21,  \
+                       b21, W22, b22, h, loc, raw)
+    if (dm.Hp == 32) { LAUNCH_NF(1); } else { LAUNCH_NF(2); }
+#undef LAUNCH_NF
+    VX_CHECK_LAUNCH();
+    return VX_OK;
+}
+
+int64_t vx_norm_enc_bwd_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
+    if (!nenc_cfg_ok(cfg) || nb < 0) return VX_EINVAL;
+    int nblk, n_jg, n_prf;
+    nenc_plan(cfg, nb, nblk, n_jg, n_prf);
+    const int64_t H = cfg->H, J = cfg->J;
+    return nb * H + (int64_t)nblk * (2 * H + 2) + (int64_t)n_prf * (H * J + H);
+}
+
+int vx_norm_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* W21,
+                         const float* W22, const float* h, const float* gloc, const float* graw, float* genc,
+                         float* workspace, void* hs) {
+    if (!nenc_cfg_ok(cfg) || !y || !W21 || !W22 || !h || !gloc || !graw || !genc || !workspace || nb < 0)
+        return VX_EINVAL;
+    int nblk, n_jg, n_prf;
+    nenc_plan(cfg, nb, nblk, n_jg, n_prf);
+    const int64_t H = cfg->H, J = cfg->J;
+    const int64_t lenh = 2 * H + 2, lenf = H * J + H;
+    float* ghpre = workspace;
+    float* slabs_h = ghpre + nb * H;
+    float* slabs_f = slabs_h + (int64_t)nblk * lenh;
+    hipStream_t st = (hipStream_t)hs;
+    hipError_t he = hipMemsetAsync(slabs_h, 0, sizeof(float) * (size_t)(nblk * lenh + (nb == 0 ? n_prf * lenf : 0)), st);
+    if (he != hipSuccess) return (int)he;
+    int rc;
+    if (nb > 0) {
+        hipLaunchKernelGGL(k_norm_enc_bwd_small, dim3(nblk), dim3(256), 2 * 256 * sizeof(float), st, (int)H, nb, W21, W22,
+                           h, gloc, graw, ghpre, slabs_h);
+        VX_CHECK_LAUNCH();
+        EncDims dm;
+        dm.D = 1; dm.J = cfg->J; dm.H = cfg->H; dm.Hp = (cfg->H + 31) / 32 * 32; dm.DS = 3; dm.T = 1; dm.nb = nb;
+        const size_t lds = fc1_bwd_lds_floats(dm.Hp) * sizeof(float);
+        const dim3 grid((unsigned)n_jg, (unsigned)n_prf);
+        const int f1fast = (!force_generic() && cfg->H == 64 && cfg->J % 4 == 0 && aligned16(ghpre) && aligned16(y)) ? 1 : 0;
+#define LAUNCH_F1(HT)                                                                                        \
+    rc = set_lds(k_fc1_bwd<HT>, lds);                                                                        \
+    if (rc) return rc;                                                                                       \
+    hipLaunchKernelGGL(k_fc1_bwd<HT>, grid, dim3(ENC_THREADS), lds, st, dm, y, rows, ghpre, slabs_f, lenf, f1fast)
+        if (dm.Hp == 32) { LAUNCH_F1(1); } else { LAUNCH_F1(2); }
+#undef LAUNCH_F1
+        VX_CHECK_LAUNCH();
+    }
+    rc = vx_reduce_slabs(slabs_f, n_prf, lenf, -1.0f, genc, hs);
+    if (rc) return rc;
+    return vx_reduce_slabs(slabs_h, nblk, lenh, -1.0f, genc + lenf, hs);
+}
+
+// ------------------------------------------------------------------------------------------------
+static bool hodina_cfg_ok(const vx_hodina_cfg* cfg) {
+    return cfg && cfg->K >= 1 && cfg->K <= 10 && cfg->J >= 1 && cfg->J <= 1024;
+}
+
+static int hodina_blocks(int64_t nb) {
+    const int64_t n_groups = (nb + 63) / 64;
+    int64_t blocks = (n_groups + HD_WAVES - 1) / HD_WAVES;
+    const int64_t cap = (int64_t)num_cu() * 4;
+    if (blocks > cap) blocks = cap;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+int64_t vx_hodina_workspace_floats(const vx_hodina_cfg* cfg, int64_t nb) {
+    if (!hodina_cfg_ok(cfg) || nb < 0) return VX_EINVAL;
+    return (int64_t)hodina_blocks(nb) * (2 * cfg->J + 2 * cfg->K);
+}
+
+int vx_hodina_grad(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, int64_t gid0,
+                   const float* loc, const float* raw, const float* eps_in, const float* q, const float* lam0,
+                   const float* lam1_un, const float* g_un, const float* s_un, float* gloc, float* graw,
+                   float* elbo, float* gitem, float* workspace, void* hs) {
+    if (!hodina_cfg_ok(cfg) || !y || !loc || !raw || !q || !lam0 || !lam1_un || !g_un || !s_un || !gloc || !graw ||
+        !elbo || !gitem || !workspace || nb < 0)
+        return VX_EINVAL;
+    const int blocks = hodina_blocks(nb);
+    HoDinaDims dm;
+    dm.K = cfg->K; dm.J = cfg->J; dm.C = 1 << cfg->K; dm.scale = cfg->scale; dm.nb = nb;
+    const int len = 2 * cfg->J + 2 * cfg->K;
+    const int tabf = HD_WAVES * dm.C;
+    const size_t lds = sizeof(float) * (size_t)(tabf > len ? tabf : len);
+    hipStream_t st = (hipStream_t)hs;
+    const int logcpl = cfg->K <= 8 ? 2 : (cfg->K == 9 ? 3 : 4);
+    const int jpl = (cfg->J + 63) / 64;
+#define LAUNCH_HD(L, JP)                                                                                      \
+    hipLaunchKernelGGL((k_hodina<L, JP>), dim3(blocks), dim3(HD_THREADS), lds, st, dm, y, rows, gid0, loc, raw,   \
+                       eps_in, cfg->seed, cfg->step, cfg->stream, q, lam0, lam1_un, g_un, s_un, gloc, graw, elbo, \
+                       workspace)
+#define DISPATCH_JPL(L)                              \
+    if (jpl <= 1) { LAUNCH_HD(L, 1); }               \
+    else if (jpl <= 2) { LAUNCH_HD(L, 2); }          \
+    else if (jpl <= 4) { LAUNCH_HD(L, 4); }          \
+    else if (jpl <= 8) { LAUNCH_HD(L, 8); }          \
+    else { LAUNCH_HD(L, 16); }
+    if (logcpl == 2) { DISPATCH_JPL(2) } else if (logcpl == 3) { DISPATCH_JPL(3) } else { DISPATCH_JPL(4) }
+#undef DISPATCH_JPL
+#undef LAUNCH_HD
+    VX_CHECK_LAUNCH();
+    return vx_reduce_slabs(workspace, blocks, len, -1.0f, gitem, hs);
 }
 
 }  // extern "C"

@@ -85,6 +85,45 @@ class HipBackend(object):
                                   _hip.ptr(ws), _hip.stream_ptr())
         _hip.check(rc, "vx_irt1d_grad")
 
+    def norm_enc_forward(self, cfg, y, rows, nb, enc, out):
+        rc = self.L.vx_norm_enc_forward(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb,
+                                        _hip.ptr(enc["fc1.weight"]), _hip.ptr(enc["fc1.bias"]),
+                                        _hip.ptr(enc["fc21.weight"]), _hip.ptr(enc["fc21.bias"]),
+                                        _hip.ptr(enc["fc22.weight"]), _hip.ptr(enc["fc22.bias"]),
+                                        _hip.ptr(out["h"]), _hip.ptr(out["loc"]), _hip.ptr(out["raw"]),
+                                        _hip.stream_ptr())
+        _hip.check(rc, "vx_norm_enc_forward")
+
+    def norm_enc_bwd_workspace(self, cfg, nb):
+        n = self.L.vx_norm_enc_bwd_workspace_floats(ctypes.byref(cfg), nb)
+        if n < 0:
+            raise _hip.VxError("vx_norm_enc_bwd_workspace_floats: unsupported configuration (code %d)" % n)
+        return n
+
+    def norm_enc_backward(self, cfg, y, rows, nb, enc, h, gloc, graw, genc, ws):
+        rc = self.L.vx_norm_enc_backward(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb,
+                                         _hip.ptr(enc["fc21.weight"]), _hip.ptr(enc["fc22.weight"]), _hip.ptr(h),
+                                         _hip.ptr(gloc), _hip.ptr(graw), _hip.ptr(genc), _hip.ptr(ws),
+                                         _hip.stream_ptr())
+        _hip.check(rc, "vx_norm_enc_backward")
+
+    @staticmethod
+    def hodina_cfg(K, J, H, scale, seed, step, stream):
+        return _hip.HoDinaCfg(K, J, H, 0, scale, 0.0, seed, step, stream)
+
+    def hodina_workspace(self, cfg, nb):
+        n = self.L.vx_hodina_workspace_floats(ctypes.byref(cfg), nb)
+        if n < 0:
+            raise _hip.VxError("vx_hodina_workspace_floats: unsupported configuration (code %d)" % n)
+        return n
+
+    def hodina_grad(self, cfg, y, rows, nb, gid0, loc, raw, eps_in, q, lam0, lam1, g, s_, gloc, graw, elbo, gitem, ws):
+        rc = self.L.vx_hodina_grad(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb, gid0, _hip.ptr(loc),
+                                   _hip.ptr(raw), _hip.ptr(eps_in), _hip.ptr(q), _hip.ptr(lam0), _hip.ptr(lam1),
+                                   _hip.ptr(g), _hip.ptr(s_), _hip.ptr(gloc), _hip.ptr(graw), _hip.ptr(elbo),
+                                   _hip.ptr(gitem), _hip.ptr(ws), _hip.stream_ptr())
+        _hip.check(rc, "vx_hodina_grad")
+
     def sum_into(self, v, n, alpha, out, ws):
         rc = self.L.vx_sum(_hip.ptr(v), n, alpha, _hip.ptr(out), _hip.ptr(ws), _hip.stream_ptr())
         _hip.check(rc, "vx_sum")
@@ -125,14 +164,131 @@ class LrSpec(object):
         self.epoch += 1
 
 
-class IrtEngine(object):
+class _EngineBase(object):
+    """State and optimiser plumbing shared by the IRT and HO-DINA engines.
+
+    Replicated parameters live in ONE flat float32 buffer `P` (subclasses define the segments in
+    `self.off` / `self.shape`); the gradient buffer `G` has one extra trailing slot for the loss so a
+    single all-reduce carries everything.  Per-person variational rows (BBVI
+    guides) live in `PP` = [loc: n | raw: n], sharded with the persons, never reduced across ranks."""
+
+    pp_names = ("x_local", "x_scale")
+
+    def _alloc(self, n_params, n_local, per_person):
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.n_params = n_params
+        self.P = torch.zeros(n_params, **f32)
+        self.G = torch.zeros(n_params + 1, **f32)
+        self.M = torch.zeros(n_params, **f32)
+        self.V = torch.zeros(n_params, **f32)
+        self.free = torch.ones(n_params, **f32)
+        self.per_person = per_person
+        if per_person:
+            self.pp_len = 2 * n_local
+            self.PP = torch.zeros(self.pp_len, **f32)
+            self.GP = torch.zeros(self.pp_len, **f32)
+            self.MP = torch.zeros(self.pp_len, **f32)
+            self.VP = torch.zeros(self.pp_len, **f32)
+        self._ws = {}
+        self.sum_ws = torch.empty(1024, **f32)
+        self.last = {}
+        self.events = None               # bench.py: list collecting (phase, start_event, end_event)
+        self.t = 0                       # optimiser step counter (Adam bias correction, Philox step)
+
+    def view(self, name, buf=None):
+        buf = self.P if buf is None else buf
+        o = self.off[name]
+        return buf[o:o + int(np.prod(self.shape[name]))]
+
+    def unconstrained(self, name, buf=None):
+        if name in self.pp_names:
+            b = self.PP if buf is None else buf
+            n = self.n_local
+            return (b[:n] if name == self.pp_names[0] else b[n:]).reshape(n, 1)
+        return self.view(name, buf).reshape(self.shape[name])
+
+    def _enc(self):
+        return {k: self.view("encoder$$$" + k) for k in ENC_KEYS}
+
+    def _buf(self, key, n):
+        t = self._ws.get(key)
+        if t is None or t.numel() < n:
+            t = torch.empty(max(int(n), 1), dtype=torch.float32, device=self.dev)
+            self._ws[key] = t
+        return t
+
+    def _phase(self, name):
+        return _Phase(self.events, name)
+
+    def _gather_pp(self, rows, nb):
+        """loc/raw (and their gradient targets) of the batch rows of a per-person guide."""
+        n = self.n_local
+        if rows is None:
+            return self.PP[:n], self.PP[n:], self.GP[:n], self.GP[n:]
+        return (self.PP[:n][rows].contiguous(), self.PP[n:][rows].contiguous(),
+                self._buf("gloc", nb), self._buf("graw", nb))
+
+    def _scatter_pp(self, rows, nb, gloc, graw):
+        """Dense per-person gradients: zero off the batch, exactly what autograd hands the per-tensor
+        Adam of the reference."""
+        if rows is not None:
+            n = self.n_local
+            self.GP.zero_()
+            self.GP[:n].index_add_(0, rows, gloc[:nb])
+            self.GP[n:].index_add_(0, rows, graw[:nb])
+
+    def allreduce(self):
+        if self.group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            torch.distributed.all_reduce(self.G, group=self.group)
+
+    def apply_optim(self, lrs):
+        """Adam on the unconstrained leaves with the `free` mask (vi.py:508-514)."""
+        self.t += 1
+        segs = []
+        for name in self.names():
+            o = self.off[name]
+            segs.append((o, o + int(np.prod(self.shape[name])), float(lrs.lr_of(name))))
+        segs = _merge_segments(segs)
+        self.be.adam(self.P, self.G, self.M, self.V, self.free, self.n_params, segs, self.t, lrs.betas, lrs.eps)
+        if self.per_person:
+            n = self.n_local
+            segs = _merge_segments([(0, n, float(lrs.lr_of(self.pp_names[0]))),
+                                    (n, 2 * n, float(lrs.lr_of(self.pp_names[1])))])
+            self.be.adam(self.PP, self.GP, self.MP, self.VP, None, self.pp_len, segs, self.t, lrs.betas, lrs.eps)
+
+    def step(self, lrs, rows=None, b_global=None, eps=None, num_particles=1):
+        """loss_and_grads + optimiser, the body of SVI.step (vi.py:505-516).  `rows` (and `eps`) may be
+        lists with one entry per particle: every particle draws its own subsample.
+        Returns the loss as a 0-d device tensor (no host sync)."""
+        S = int(num_particles)
+        if S == 1:
+            self.loss_and_grads(rows[0] if isinstance(rows, (list, tuple)) else rows, b_global,
+                                eps[0] if isinstance(eps, (list, tuple)) else eps, 0)
+        else:
+            accG = torch.zeros_like(self.G)
+            accP = torch.zeros_like(self.GP) if self.per_person else None
+            for sidx in range(S):
+                r = rows[sidx] if isinstance(rows, (list, tuple)) else rows
+                e = eps[sidx] if isinstance(eps, (list, tuple)) else eps
+                self.loss_and_grads(r, b_global, e, sidx)
+                accG.add_(self.G, alpha=1.0 / S)                 # surrogate / num_particles (App. B.2)
+                if accP is not None:
+                    accP.add_(self.GP, alpha=1.0 / S)
+            self.G.copy_(accG)
+            if accP is not None:
+                self.GP.copy_(accP)
+        with self._phase("allreduce"):
+            self.allreduce()
+        loss = self.G[self.n_params].clone()
+        with self._phase("optimizer"):
+            self.apply_optim(lrs)
+        return loss
+
+
+class IrtEngine(_EngineBase):
     """IRT ELBO-gradient step (VIRT / VaeIRT of the reference, vi.py:536-723) on one rank.
 
-    Parameters live in ONE flat float32 buffer, replicated on every rank:
-        [a: D*J | b: J | c_un: J | d_un: J | encoder (nn.Linear order, amortized only)]
-    followed in the gradient buffer by one extra slot holding the loss, so a single all-reduce
-    carries everything.  Per-person variational rows (BBVI) are sharded and never leave the rank.
-    """
+    Flat parameter buffer: [a: D*J | b: J | c_un: J | d_un: J | encoder (nn.Linear order, amortized only)]."""
 
     def __init__(self, y_u8, model="irt_2pl", D=1, Dc=1.0, n_global=None, gid0=0, amortized=False, H=64,
                  share_cov=False, a_free=None, a0=None, b0=None, encoder_init=None, seed=1234, group=None,
@@ -147,29 +303,26 @@ class IrtEngine(object):
         self.model, self.D, self.Dc = model, int(D), float(Dc)
         self.amortized, self.H, self.share_cov = bool(amortized), int(H) if amortized else 0, bool(share_cov)
         self.seed, self.group = int(seed), group
-        self.t = 0                       # optimiser step counter (Adam bias correction, Philox step)
         J, Dd = self.J, self.D
-        f32 = dict(dtype=torch.float32, device=self.dev)
-        # ---- flat parameter buffer ------------------------------------------------------------
+        if not self.amortized and Dd > 1:
+            raise NotImplementedError("BBVI with x_feature > 1 (per-person Cholesky rows) is not on the HIP path yet")
         self.off = {"a": 0, "b": Dd * J, "c": Dd * J + J, "d": Dd * J + 2 * J}
+        self.shape = {"a": (Dd, J), "b": (1, J), "c": (1, J), "d": (1, J)}
         self.n_item = Dd * J + 3 * J
-        self.n_enc = 0
+        o = (self.n_item + 63) // 64 * 64                         # encoder tensors start on 256-byte boundaries
         if self.amortized:
             T = Dd * (Dd + 1) // 2 if Dd > 1 else 1
-            nloc = Dd
-            self.enc_shapes = {"fc1.weight": (self.H, J), "fc1.bias": (self.H,), "fc21.weight": (nloc, self.H),
-                               "fc21.bias": (nloc,), "fc22.weight": (T, self.H), "fc22.bias": (T,)}
-            o = self.n_item
+            self.enc_shapes = {"fc1.weight": (self.H, J), "fc1.bias": (self.H,), "fc21.weight": (Dd, self.H),
+                               "fc21.bias": (Dd,), "fc22.weight": (T, self.H), "fc22.bias": (T,)}
+            self.enc_off0 = o
             for k in ENC_KEYS:
                 self.off["encoder$$$" + k] = o
+                self.shape["encoder$$$" + k] = self.enc_shapes[k]
                 o += int(np.prod(self.enc_shapes[k]))
-            self.n_enc = o - self.n_item
-        self.n_params = self.n_item + self.n_enc
-        self.P = torch.zeros(self.n_params, **f32)
-        self.G = torch.zeros(self.n_params + 1, **f32)          # + loss slot
-        self.M = torch.zeros(self.n_params, **f32)
-        self.V = torch.zeros(self.n_params, **f32)
-        self.free = torch.ones(self.n_params, **f32)
+            self.n_enc = o - self.enc_off0
+        else:
+            o = self.n_item
+        self._alloc(o, self.n_local, per_person=not self.amortized)
         # reference initial values (vi.py:567-587)
         a_init = torch.ones(Dd, J) if a0 is None else torch.as_tensor(a0, dtype=torch.float32).reshape(Dd, J).clone()
         if a_free is None and Dd > 1:
@@ -194,21 +347,6 @@ class IrtEngine(object):
                 encoder_init = default_encoder_init(J, Dd, self.H, seed)
             for k in ENC_KEYS:
                 self.view("encoder$$$" + k).copy_(torch.as_tensor(encoder_init[k], dtype=torch.float32).reshape(-1))
-        else:
-            # per-person variational rows (vi.py:702-703, 707, 717-721), sharded with the persons
-            n = self.n_local
-            if Dd == 1:
-                self.pp_len = 2 * n                                 # [x_local: n | log x_scale: n]
-            else:
-                raise NotImplementedError("BBVI with x_feature > 1 is not on the HIP path yet")
-            self.PP = torch.zeros(self.pp_len, **f32)
-            self.GP = torch.zeros(self.pp_len, **f32)
-            self.MP = torch.zeros(self.pp_len, **f32)
-            self.VP = torch.zeros(self.pp_len, **f32)
-        self._ws = {}
-        self.sum_ws = torch.empty(1024, **f32)
-        self.last = {}
-        self.events = None               # bench.py: list collecting (phase, start_event, end_event)
 
     # -- parameter access (constrained values as pyro.param(name) returns them) -----------------
     def names(self):
@@ -223,26 +361,8 @@ class IrtEngine(object):
             out += ["encoder$$$" + k for k in ENC_KEYS]
         return out
 
-    def view(self, name, buf=None):
-        buf = self.P if buf is None else buf
-        o = self.off[name]
-        if name == "a":
-            return buf[o:o + self.D * self.J]
-        if name in ("b", "c", "d"):
-            return buf[o:o + self.J]
-        k = name.split("$$$")[1]
-        return buf[o:o + int(np.prod(self.enc_shapes[k]))]
-
-    def unconstrained(self, name, buf=None):
-        if name == "a":
-            return self.view(name, buf).reshape(self.D, self.J)
-        if name in ("b", "c", "d"):
-            return self.view(name, buf).reshape(1, self.J)
-        if name == "x_local":
-            return (self.PP if buf is None else buf)[:self.n_local].reshape(self.n_local, 1)
-        if name == "x_scale":
-            return (self.PP if buf is None else buf)[self.n_local:].reshape(self.n_local, 1)
-        return self.view(name, buf).reshape(self.enc_shapes[name.split("$$$")[1]])
+    def all_names(self):
+        return self.names() + (list(self.pp_names) if self.per_person else [])
 
     def param(self, name):
         u = self.unconstrained(name)
@@ -251,19 +371,6 @@ class IrtEngine(object):
         if name == "x_scale":
             return torch.exp(u)
         return u.clone()
-
-    def _enc(self):
-        return {k: self.view("encoder$$$" + k) for k in ENC_KEYS}
-
-    def _buf(self, key, n):
-        t = self._ws.get(key)
-        if t is None or t.numel() < n:
-            t = torch.empty(max(int(n), 1), dtype=torch.float32, device=self.dev)
-            self._ws[key] = t
-        return t
-
-    def _phase(self, name):
-        return _Phase(self.events, name)
 
     # -- one ELBO-gradient step ------------------------------------------------------------------
     def loss_and_grads(self, rows=None, b_global=None, eps=None, stream_id=0):
@@ -279,7 +386,7 @@ class IrtEngine(object):
         a = self.view("a") if self.model != "irt_1pl" else None
         gitem = self.G[:self.n_item]
         lossslot = self.G[self.n_params:self.n_params + 1]
-        if self.D > 1 and self.amortized:
+        if self.D > 1:
             D, H = self.D, self.H
             fw = {"h": self._buf("h", nb * H), "x": self._buf("x", nb * D), "eps": self._buf("eps", nb * D),
                   "ldT": self._buf("ldT", nb * D), "ent": self._buf("ent", nb)}
@@ -292,72 +399,144 @@ class IrtEngine(object):
             with self._phase("likelihood"):
                 be.lik_grad(cfg, self.y, rows, nb, fw["x"], a, self.view("b"), c_un, d_un, gx, ll, gitem, lik_ws)
             with self._phase("guide_backward"):
-                be.mvn_enc_backward(cfg, self.y, rows, nb, enc, fw, gx, self.G[self.n_item:self.n_params], encb_ws)
+                be.mvn_enc_backward(cfg, self.y, rows, nb, enc, fw, gx,
+                                    self.G[self.enc_off0:self.enc_off0 + self.n_enc], encb_ws)
             # loss = -scale * sum_i (ll_i + ent_i)
             tmp = self._buf("loss2", 2)
             be.sum_into(ll, nb, -scale, tmp[0:1], self.sum_ws)
             be.sum_into(fw["ent"], nb, -scale, tmp[1:2], self.sum_ws)
             torch.add(tmp[0:1], tmp[1:2], out=lossslot)
             self.last = {"fw": fw, "gx": gx, "ll": ll, "nb": nb}
-        elif self.D == 1 and not self.amortized:
-            n = self.n_local
-            if rows is None:
-                loc, raw = self.PP[:n], self.PP[n:]
-                gloc, graw = self.GP[:n], self.GP[n:]
-            else:
-                loc, raw = self.PP[:n][rows].contiguous(), self.PP[n:][rows].contiguous()
-                gloc, graw = self._buf("gloc", nb), self._buf("graw", nb)
-            elbo = self._buf("elbo", nb)
+        else:
             g1d, i1d_ws = self._buf("g1d", 4 * self.J), self._buf("i1d_ws", be.irt1d_workspace(cfg, nb))
+            elbo = self._buf("elbo", nb)
+            if self.amortized:
+                H = self.H
+                enc = self._enc()
+                fw = {"h": self._buf("h", nb * H), "loc": self._buf("loc", nb), "raw": self._buf("raw", nb)}
+                gloc, graw = self._buf("gloc", nb), self._buf("graw", nb)
+                nb_ws = self._buf("nencb_ws", be.norm_enc_bwd_workspace(cfg, nb))
+                with self._phase("guide_forward"):
+                    be.norm_enc_forward(cfg, self.y, rows, nb, enc, fw)
+                loc, raw = fw["loc"], fw["raw"]
+            else:
+                loc, raw, gloc, graw = self._gather_pp(rows, nb)
             with self._phase("irt1d"):
                 be.irt1d_grad(cfg, self.y, rows, nb, self.gid0, loc, raw, eps, a, self.view("b"), c_un, d_un,
                               gloc, graw, elbo, g1d, i1d_ws)
-            g1 = self._ws["g1d"]
             J = self.J
             gitem.zero_()
-            gitem[self.off["a"]:self.off["a"] + J].copy_(g1[0:J])
-            gitem[self.off["b"]:self.off["b"] + 3 * J].copy_(g1[J:4 * J])
-            if rows is not None:                                  # dense grads over all local rows (App. A.2)
-                self.GP.zero_()
-                self.GP[:n].index_add_(0, rows, gloc[:nb])
-                self.GP[n:].index_add_(0, rows, graw[:nb])
+            gitem[self.off["a"]:self.off["a"] + J].copy_(g1d[0:J])
+            gitem[self.off["b"]:self.off["b"] + 3 * J].copy_(g1d[J:4 * J])
+            if self.amortized:
+                with self._phase("guide_backward"):
+                    be.norm_enc_backward(cfg, self.y, rows, nb, enc, fw["h"], gloc, graw,
+                                         self.G[self.enc_off0:self.enc_off0 + self.n_enc], nb_ws)
+            else:
+                self._scatter_pp(rows, nb, gloc, graw)
             be.sum_into(elbo, nb, -scale, lossslot, self.sum_ws)
             self.last = {"elbo": elbo, "nb": nb}
+
+
+class HoDinaEngine(_EngineBase):
+    """HO-DINA ELBO-gradient step with exact enumeration (VCHoDina / VaeCHoDina, vi.py:894-981).
+
+    Flat parameter buffer: [g_un: J | s_un: J | lam0: K | lam1_un: K | encoder (amortized only)];
+    per-person rows theta_local / log theta_scale for the BBVI guide (vi.py:928-929)."""
+
+    pp_names = ("theta_local", "theta_scale")
+
+    def __init__(self, y_u8, q, n_global=None, gid0=0, amortized=False, H=64, encoder_init=None, seed=1234,
+                 group=None, backend=None):
+        self.be = backend if backend is not None else HipBackend()
+        self.y = y_u8.contiguous()
+        assert self.y.dtype == torch.uint8 and self.y.dim() == 2
+        self.dev = self.y.device
+        self.n_local, self.J = self.y.shape
+        self.N = int(n_global) if n_global is not None else self.n_local
+        self.gid0 = int(gid0)
+        q = torch.as_tensor(q, dtype=torch.float32)
+        assert q.dim() == 2 and q.shape[1] == self.J
+        if not bool(((q == 0) | (q == 1)).all()):
+            raise ValueError("the Q-matrix must be binary (the subset test of vi.py:78-81 assumes it)")
+        self.K = int(q.shape[0])
+        self.q = q.to(self.dev).contiguous()
+        self.amortized, self.H = bool(amortized), int(H) if amortized else 0
+        self.seed, self.group = int(seed), group
+        J, K = self.J, self.K
+        self.off = {"g": 0, "s": J, "lam0": 2 * J, "lam1": 2 * J + K}
+        self.shape = {"g": (1, J), "s": (1, J), "lam0": (1, K), "lam1": (1, K)}
+        self.n_item = 2 * J + 2 * K
+        o = self.n_item
+        if self.amortized:
+            o = (self.n_item + 63) // 64 * 64
+            self.enc_shapes = {"fc1.weight": (self.H, J), "fc1.bias": (self.H,), "fc21.weight": (1, self.H),
+                               "fc21.bias": (1,), "fc22.weight": (1, self.H), "fc22.bias": (1,)}
+            self.enc_off0 = o
+            for k in ENC_KEYS:
+                self.off["encoder$$$" + k] = o
+                self.shape["encoder$$$" + k] = self.enc_shapes[k]
+                o += int(np.prod(self.enc_shapes[k]))
+            self.n_enc = o - self.enc_off0
+        self._alloc(o, self.n_local, per_person=not self.amortized)
+        # vi.py:901-904: lam0 = 0, lam1 = 1 (positive -> log 1 = 0), g = s = 0.1 (interval(0,1) -> logit)
+        self.view("g").fill_(float(np.float32(_logit(np.float32(0.1)))))
+        self.view("s").fill_(float(np.float32(_logit(np.float32(0.1)))))
+        if self.amortized:
+            if encoder_init is None:
+                encoder_init = default_encoder_init(J, 1, self.H, seed)
+            for k in ENC_KEYS:
+                self.view("encoder$$$" + k).copy_(torch.as_tensor(encoder_init[k], dtype=torch.float32).reshape(-1))
+
+    def names(self):
+        out = ["g", "s", "lam0", "lam1"]
+        if self.amortized:
+            out += ["encoder$$$" + k for k in ENC_KEYS]
+        return out
+
+    def all_names(self):
+        return self.names() + (list(self.pp_names) if self.per_person else [])
+
+    def param(self, name):
+        u = self.unconstrained(name)
+        if name in ("g", "s"):
+            return torch.sigmoid(u)
+        if name in ("lam1", "theta_scale"):
+            return torch.exp(u)
+        return u.clone()
+
+    def loss_and_grads(self, rows=None, b_global=None, eps=None, stream_id=0):
+        be = self.be
+        nb = self.n_local if rows is None else int(rows.numel())
+        Bg = int(b_global) if b_global is not None else (self.N if rows is None else nb)
+        scale = float(self.N) / float(Bg)
+        cfg = be.hodina_cfg(self.K, self.J, self.H, scale, self.seed, self.t, stream_id)
+        elbo = self._buf("elbo", nb)
+        ws = self._buf("hd_ws", be.hodina_workspace(cfg, nb))
+        lossslot = self.G[self.n_params:self.n_params + 1]
+        if self.amortized:
+            icfg = be.cfg("irt_2pl", 1, self.J, self.H, 1.0, scale, self.seed, self.t, stream_id)
+            enc = self._enc()
+            fw = {"h": self._buf("h", nb * self.H), "loc": self._buf("loc", nb), "raw": self._buf("raw", nb)}
+            gloc, graw = self._buf("gloc", nb), self._buf("graw", nb)
+            nb_ws = self._buf("nencb_ws", be.norm_enc_bwd_workspace(icfg, nb))
+            with self._phase("guide_forward"):
+                be.norm_enc_forward(icfg, self.y, rows, nb, enc, fw)
+            loc, raw = fw["loc"], fw["raw"]
         else:
-            raise NotImplementedError("guide/model combination not on the HIP path yet")
-
-    def allreduce(self):
-        if self.group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
-            torch.distributed.all_reduce(self.G, group=self.group)
-
-    def apply_optim(self, lrs):
-        """Adam on the unconstrained leaves with the `free` mask (vi.py:508-514)."""
-        self.t += 1
-        segs = []
-        for name in self.names():
-            v = self.view(name)
-            o = self.off[name]
-            segs.append((o, o + v.numel(), float(lrs.lr_of(name))))
-        segs = _merge_segments(segs)
-        self.be.adam(self.P, self.G, self.M, self.V, self.free, self.n_params, segs, self.t, lrs.betas, lrs.eps)
-        if not self.amortized:
-            n = self.n_local
-            segs = _merge_segments([(0, n, float(lrs.lr_of("x_local"))), (n, 2 * n, float(lrs.lr_of("x_scale")))])
-            self.be.adam(self.PP, self.GP, self.MP, self.VP, None, self.pp_len, segs, self.t, lrs.betas, lrs.eps)
-
-    def step(self, lrs, rows=None, b_global=None, eps=None, num_particles=1):
-        """loss_and_grads + optimiser, the body of SVI.step (vi.py:505-516).  Returns the loss as a
-        0-d device tensor (no host sync)."""
-        if num_particles == 1:
-            self.loss_and_grads(rows, b_global, eps, 0)
+            loc, raw, gloc, graw = self._gather_pp(rows, nb)
+        with self._phase("hodina"):
+            be.hodina_grad(cfg, self.y, rows, nb, self.gid0, loc, raw, eps, self.q, self.view("lam0"),
+                           self.view("lam1"), self.view("g"), self.view("s"), gloc, graw, elbo,
+                           self.G[:self.n_item], ws)
+        if self.amortized:
+            with self._phase("guide_backward"):
+                be.norm_enc_backward(icfg, self.y, rows, nb, enc, fw["h"], gloc, graw,
+                                     self.G[self.enc_off0:self.enc_off0 + self.n_enc], nb_ws)
         else:
-            raise NotImplementedError("num_particles > 1 is handled by vipsy_amd.svi")
-        with self._phase("allreduce"):
-            self.allreduce()
-        loss = self.G[self.n_params].clone()
-        with self._phase("optimizer"):
-            self.apply_optim(lrs)
-        return loss
+            self._scatter_pp(rows, nb, gloc, graw)
+        be.sum_into(elbo, nb, -scale, lossslot, self.sum_ws)
+        self.last = {"elbo": elbo, "nb": nb}
 
 
 class _Phase(object):
