@@ -1,0 +1,100 @@
+"""The vi.py-compatible class surface (vipsy_amd/vi.py): constructor / fit signatures of the reference's
+demos (test.py:265-662), parameter recovery with the reference's own error metric (test.py:70-91)."""
+import numpy as np
+import pytest
+import torch
+
+
+def test_surface_matches_reference_names():
+    from vipsy_amd import vi
+    for n in ("VIRT", "VaeIRT", "VCHoDina", "VaeCHoDina", "VCDM", "VaeCDM", "VCCDM", "VaeCCDM", "Adam", "MultiStepLR",
+              "Trace_ELBO", "TraceEnum_ELBO", "param", "clear_param_store", "rmse_", "Irt2PL", "Irt4PL", "IrtMultiDim",
+              "HoDina"):
+        assert hasattr(vi, n), n
+    with pytest.raises(NotImplementedError):
+        vi.VCCDM(q=None, data=None)
+    spec = vi.MultiStepLR({"optimizer": torch.optim.Adam, "optim_args": lambda m, n: {"lr": 1e-2 if n == "a" else 1e-3},
+                           "milestones": [2], "gamma": 0.1}).spec()
+    assert spec.lr_of("a") == 1e-2 and spec.lr_of("encoder$$$fc1.weight") == 1e-3
+    spec.scheduler_step(); spec.scheduler_step()
+    assert spec.lr_of("a") == pytest.approx(1e-3)
+
+
+def test_nan_float_input_is_converted_to_u8():
+    from vipsy_amd.vi import to_u8
+    y = torch.tensor([[0., 1., float("nan")], [1., float("nan"), 0.]])
+    out = to_u8(y, torch.device("cpu"))
+    assert out.dtype == torch.uint8 and out.tolist() == [[0, 1, 255], [1, 255, 0]]
+    with pytest.raises(ValueError):
+        to_u8(torch.tensor([[0.5]]), torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_virt_2pl_recovers_item_parameters():
+    """Irt2PLTestCase.test_bbvi (test.py:281-284), shortened: N=4000, J=20, full batch."""
+    from vipsy_amd import vi, synth
+    vi.clear_param_store()
+    dev = torch.device("cuda:0")
+    items = synth.irt_item_params(20, "irt_2pl", seed=3)
+    y = synth.simulate_responses(4000, 0, items, "irt_2pl", dev, seed=4)
+
+    class RI(object):
+        a, b = items["a"], items["b"]
+    m = vi.VIRT(data=y, model="irt_2pl")
+    l0 = m.fit(optim=vi.Adam({"lr": 5e-2}), max_iter=1, progress=False)
+    l1 = m.fit(optim=vi.Adam({"lr": 5e-2}), max_iter=600, random_instance=RI, progress=False)
+    assert l1 < l0
+    err = vi.rmse_(20, "irt_2pl", RI, 1)
+    assert err["b"] < 0.12 and err["a"] < 0.25, err
+
+
+@pytest.mark.gpu
+def test_vaeirt_multidim_runs_reference_call_pattern():
+    """IrtMultiDimTestCase.test_ai_100_dim_2pl call pattern (test.py:336-361) at D=4, J=40."""
+    from vipsy_amd import vi, synth
+    vi.clear_param_store()
+    dev = torch.device("cuda:0")
+    a, b = synth.mirt_item_params(40, 4, seed=5)
+    y = synth.simulate_responses(3000, 0, {"a": a, "b": b}, "irt_2pl", dev, seed=6)
+
+    def optim(_, param_name):
+        return {"lr": 1e-2} if param_name in ("a", "b") else {"lr": 1e-3}
+    sched = vi.MultiStepLR({"optimizer": torch.optim.Adam, "optim_args": optim, "milestones": [250], "gamma": 0.1})
+    m = vi.VaeIRT(data=y, model="irt_2pl", subsample_size=500, x_feature=4)
+    first = m.fit(optim=sched, max_iter=1, loss=vi.Trace_ELBO(num_particles=1), progress=False)
+    last = m.fit(optim=sched, max_iter=300, loss=vi.Trace_ELBO(num_particles=1), progress=False)
+    assert np.isfinite(last) and last < first
+    ahat = vi.param("a")
+    assert ahat.shape == (4, 40)
+    assert float(ahat[1, -1]) == 0.0 and float(ahat[3, -3:].abs().sum()) == 0.0     # identification zeros stay frozen
+    err = float((vi.param("b").cpu() - b).abs().mean())
+    assert err < 0.6
+
+
+@pytest.mark.gpu
+def test_vchodina_recovers_guess_and_slip():
+    """PaHoDinaTestCase.test_bbvi (test.py:638-641) at N=3000, J=30, K=3."""
+    from vipsy_amd import vi, synth
+    vi.clear_param_store()
+    dev = torch.device("cuda:0")
+    prm = synth.hodina_params(30, 3, seed=8)
+    y = synth.simulate_hodina(3000, 0, prm, dev, seed=9)
+    m = vi.VCHoDina(data=y, q=prm["q"], subsample_size=3000)
+    m.fit(optim=vi.Adam({"lr": 1e-1}), max_iter=300, progress=False)
+    g_err = float((vi.param("g").cpu() - prm["g"]).abs().mean())
+    s_err = float((vi.param("s").cpu() - prm["s"]).abs().mean())
+    assert g_err < 0.06 and s_err < 0.08, (g_err, s_err)
+
+
+@pytest.mark.gpu
+def test_two_particles_and_amortized_1d():
+    from vipsy_amd import vi, synth
+    vi.clear_param_store()
+    dev = torch.device("cuda:0")
+    items = synth.irt_item_params(24, "irt_4pl", seed=10)
+    y = synth.simulate_responses(2000, 0, items, "irt_4pl", dev, seed=11, missing=0.3)
+    m = vi.VaeIRT(data=y, model="irt_4pl", subsample_size=200)
+    l = m.fit(optim=vi.Adam({"lr": 1e-2}), loss=vi.Trace_ELBO(num_particles=2), max_iter=50, progress=False)
+    assert np.isfinite(l)
+    c = vi.param("c")
+    assert ((c > 0) & (c < 1)).all()

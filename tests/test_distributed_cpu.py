@@ -1,0 +1,41 @@
+"""world_size-2 gloo runs of the engine's host logic (oracle-backed compute, CPU): the sharded run must
+reproduce the single-process run -- same losses, same replicated parameters, same per-person rows."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "_dist_worker.py")
+
+
+def _run(case, world, tmp_path, port):
+    out = str(tmp_path / ("%s_w%d" % (case, world)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    if world == 1:
+        cmd = [sys.executable, WORKER, case, out]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER, case, out]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return [json.load(open(out + ".%d" % r)) for r in range(world)]
+
+
+@pytest.mark.parametrize("case,port", [("irt1d", 29611), ("mvn", 29613)])
+def test_two_ranks_match_one_rank(case, port, tmp_path):
+    one = _run(case, 1, tmp_path, port)[0]
+    two = _run(case, 2, tmp_path, port + 1)
+    for r in two:
+        np.testing.assert_allclose(r["loss"], one["loss"], rtol=1e-5)
+        np.testing.assert_allclose(r["P"], one["P"], rtol=1e-4, atol=1e-6)      # replicated params identical
+    np.testing.assert_allclose(two[0]["P"], two[1]["P"], rtol=0, atol=0)         # bit-identical across ranks
+    if "PP" in one:
+        n = len(one["PP"]) // 2
+        loc = np.concatenate([np.array(r["PP"])[:len(r["PP"]) // 2] for r in two])
+        raw = np.concatenate([np.array(r["PP"])[len(r["PP"]) // 2:] for r in two])
+        np.testing.assert_allclose(loc, np.array(one["PP"])[:n], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(raw, np.array(one["PP"])[n:], rtol=1e-4, atol=1e-6)
