@@ -98,3 +98,19 @@ def test_two_particles_and_amortized_1d():
     assert np.isfinite(l)
     c = vi.param("c")
     assert ((c > 0) & (c < 1)).all()
+
+
+@pytest.mark.gpu
+def test_config1_lsat6_bbvi_lands_near_the_known_answer():
+    """BASELINE config 1: VIRT('irt_2pl') on the reference's lsat.dat with the fit() defaults (vi.py:627);
+    known answer = exact marginal ML, VI lands within the Gaussian-q bias."""
+    import os
+    from vipsy_amd import vi
+    vi.clear_param_store()
+    y = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lsat6.npz"))["y"]
+    m = vi.VIRT(data=torch.from_numpy(y), model="irt_2pl")
+    m.fit(max_iter=1500, progress=False)
+    a = vi.param("a").cpu().numpy()[0]
+    b = vi.param("b").cpu().numpy()[0]
+    assert np.abs(a - np.array([0.8257, 0.7227, 0.8909, 0.6884, 0.6569])).max() < 0.15, a
+    assert np.abs(b - np.array([2.7732, 0.9902, 0.2491, 1.2848, 2.0533])).max() < 0.15, b
