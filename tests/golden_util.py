@@ -14,7 +14,7 @@ def elbo_cases():
     out = []
     for p in sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))):
         tag = os.path.basename(p)[:-4]
-        if tag != "functions":
+        if tag not in ("functions", "lsat6"):
             out.append(tag)
     return out
 
