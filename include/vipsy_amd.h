@@ -77,7 +77,10 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y /*[n_local][J]*/,
                        const float* b21, const float* W22 /*[T][H]*/, const float* b22,
                        const float* eps_in, float* h /*[nb][H]*/, float* x /*[nb][D]*/,
                        float* eps /*[nb][D]*/, float* ldT /*[D][nb]*/, float* ent /*[nb]*/,
-                       void* hip_stream);
+                       float* packws /*vx_mvn_pack_floats(cfg) floats or NULL*/, void* hip_stream);
+/* `packws` holds this step's packed copy of the head weights (a re-ordering of fc22 | fc21 rows that the
+ * fast kernels use, see vipsy_amd/csrc/k_pack.hip); forward fills it, the matching backward call reads it. */
+int64_t vx_mvn_pack_floats(const vx_irt_cfg* cfg);
 
 /* ---- model likelihood + gradients for D >= 2 (irt_2pl..4pl + _get_p_data mask + Bernoulli
  * log-lik; vi.py:32-66, 596-625).  Consumes x, produces
@@ -102,7 +105,7 @@ int64_t vx_mvn_enc_bwd_workspace_floats(const vx_irt_cfg* cfg, int64_t nb);
 int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
                         const float* W21, const float* W22,
                         const float* h, const float* eps, const float* ldT, const float* gx,
-                        float* genc, float* workspace, void* hip_stream);
+                        float* genc, float* workspace, const float* packws, void* hip_stream);
 
 /* ---- D = 1 models (irt_1pl..4pl, Normal guide; vi.py:588-595, 677-684, 701-705), fused:
  * x = loc + exp(raw) eps, likelihood, prior, entropy, gradients w.r.t. loc/raw and the items.

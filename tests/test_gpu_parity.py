@@ -225,17 +225,18 @@ out = {"loss": float(eng.G[eng.n_params].item()), "g": eng.G[:eng.n_params].doub
 print("RESULT" + json.dumps(out))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for mode in ("0", "1"):
-        env = dict(os.environ, VX_FORCE_GENERIC=mode)
+    for mode in ("0", "1", "fast"):
+        env = dict(os.environ, VX_FORCE_GENERIC="1" if mode == "1" else "0", VX_MVN="fast" if mode == "fast" else "packed")
         p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][0]
         res[mode] = json.loads(line[6:])
-    assert res["0"]["loss"] == pytest.approx(res["1"]["loss"], rel=1e-6)
-    x0, x1 = np.array(res["0"]["x"]), np.array(res["1"]["x"])
-    np.testing.assert_allclose(x0, x1, atol=2e-5, rtol=1e-5)
-    g0, g1 = np.array(res["0"]["g"]), np.array(res["1"]["g"])
-    assert np.abs(g0 - g1).max() <= 2e-5 * max(1.0, np.abs(g1).max())
+    for m in ("0", "fast"):                            # packed-layout kernels, reference-order fast kernels
+        assert res[m]["loss"] == pytest.approx(res["1"]["loss"], rel=1e-6)
+        x0, x1 = np.array(res[m]["x"]), np.array(res["1"]["x"])
+        np.testing.assert_allclose(x0, x1, atol=2e-5, rtol=1e-5)
+        g0, g1 = np.array(res[m]["g"]), np.array(res["1"]["g"])
+        assert np.abs(g0 - g1).max() <= 2e-5 * max(1.0, np.abs(g1).max())
 
 
 @pytest.mark.parametrize("N,J,K,miss,B,amort", [

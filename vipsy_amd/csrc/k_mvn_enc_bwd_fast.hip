@@ -6,6 +6,7 @@
 #pragma once
 #include "k_mvn_enc_bwd.hip"
 #include "k_mvn_enc_fast.hip"
+#include "k_pack.hip"
 
 #define BH_ROWS 64                      // head rows per LDS tile in bwd_h_fast
 
@@ -149,11 +150,13 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_mvn_enc_bwd_h_fast(
 
 __host__ __device__ inline size_t enc_bwdw_fast_lds_floats(int D) { return 2 * (size_t)ENC_P * (D + 4) + (size_t)ENC_P * (D + 1) + ENC_P * 64; }
 
-// slab layout (one per person range): [W21: D*H | b21: D | W22: T*H | b22: T]
+// slab layout (one per person range): PACKED = false: [W21: D*H | b21: D | W22: T*H | b22: T] (reference rows);
+//                                       PACKED = true : [Wp-grad: Rp*H | bp-grad: Rp] (packed rows, k_pack.hip)
+template <bool PACKED>
 __global__ __launch_bounds__(ENC_THREADS, 1) void k_mvn_enc_bwd_w_fast(
     EncDims dm, float scale, const float* __restrict__ h_in, const float* __restrict__ eps_in,
-    const float* __restrict__ ldT, const float* __restrict__ gx_in, float* __restrict__ slabs,
-    int64_t slab_len) {
+    const float* __restrict__ ldT, const float* __restrict__ gx_in, const uint32_t* __restrict__ gtab,
+    float* __restrict__ slabs, int64_t slab_len) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int H = 64;
     const int D = dm.D, T = dm.T;
@@ -171,7 +174,21 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_mvn_enc_bwd_w_fast(
     float addv[BWF_RT];
 #pragma unroll
     for (int t = 0; t < BWF_RT; ++t) {
-        const uint32_t cc = enc_row_code_fast(rbase + 32 * t + l31, T, D);
+        uint32_t cc;
+        if (PACKED) {
+            const int64_t pr = rbase + 32 * t + l31;
+            cc = ((uint32_t)D << 16) | (uint32_t)D;                              // padding: gx slot D = 0
+            if (pr < pk_rows(D)) {
+                const uint32_t code = gtab[pr >> 3];
+                const uint32_t type = code >> 28, k = (code >> 12) & 0xFFFFu, l0 = code & 0xFFFu;
+                const uint32_t jx = (uint32_t)(pr & 7);
+                if (type == PK_OFF) { if (l0 + jx < k) cc = (k << 16) | (l0 + jx); }
+                else if (type == PK_DIAG) { if (k + jx < (uint32_t)D) cc = FC_DIAG | ((k + jx) << 16) | (k + jx); }
+                else if (type == PK_LOC) { if (k + jx < (uint32_t)D) cc = ((k + jx) << 16) | (uint32_t)D; }
+            }
+        } else {
+            cc = enc_row_code_fast(rbase + 32 * t + l31, T, D);
+        }
         koff[t] = (int)((cc >> 16) & 0x7FFFu);
         loff[t] = (int)(cc & 0xFFFFu);
         const bool isd = (cc & FC_DIAG) != 0;
@@ -283,6 +300,7 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_mvn_enc_bwd_w_fast(
     float* sb21 = sW21 + (int64_t)D * H;
     float* sW22 = sb21 + D;
     float* sb22 = sW22 + (int64_t)T * H;
+    const int64_t Rp = pk_rows(D);
 #pragma unroll
     for (int t = 0; t < BWF_RT; ++t) {
 #pragma unroll
@@ -291,15 +309,23 @@ __global__ __launch_bounds__(ENC_THREADS, 1) void k_mvn_enc_bwd_w_fast(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = rbase + 32 * t + crow32(r, half);
-                if (row < T) sW22[row * H + hh] = acc[t][ht][r];
-                else if (row < RT) sW21[(row - T) * H + hh] = acc[t][ht][r];
+                if (PACKED) {
+                    if (row < Rp) slab[row * H + hh] = acc[t][ht][r];
+                } else {
+                    if (row < T) sW22[row * H + hh] = acc[t][ht][r];
+                    else if (row < RT) sW21[(row - T) * H + hh] = acc[t][ht][r];
+                }
             }
         }
         const float bt = bsum[t] + __shfl_xor(bsum[t], 32, 64);
         const int64_t row = rbase + 32 * t + l31;
         if (half == 0) {
-            if (row < T) sb22[row] = bt;
-            else if (row < RT) sb21[row - T] = bt;
+            if (PACKED) {
+                if (row < Rp) slab[Rp * H + row] = bt;
+            } else {
+                if (row < T) sb22[row] = bt;
+                else if (row < RT) sb21[row - T] = bt;
+            }
         }
     }
 }

@@ -1,0 +1,377 @@
+// Amortized MVN guide on the PACKED head layout (k_pack.hip): hidden_dim == 64, J % 4 == 0, D % 4 == 0.
+// Same mathematics and outputs as the generic kernels (k_mvn_enc.hip / k_mvn_enc_bwd.hip).
+//
+// Because every aligned group of 8 packed rows has one type and one k with l0 % 8 == 0, nothing is decoded
+// per element:
+//   forward : per 4 accumulator rows one 16-byte eps read + 4 FMAs; the partial x[p][k] lives in a REGISTER
+//             and is flushed to LDS (plain read-modify-write by the lower half-wave, fixed order, no atomics)
+//             only when k changes -- about 2 D flushes per person instead of T scatter-adds;
+//   backward: V[r,p] = gx[p][k] * eps[p][l0 + ..] -- one 16-byte eps read per 4 MFMA B operands.
+// The bias of a head row enters as one extra k-step (A = bias, B = 1), so the epilogue has no bias lookup.
+#pragma once
+#include "k_pack.hip"
+#include "k_mvn_enc_fast.hip"
+#include "k_mvn_enc_bwd.hip"
+
+// LDS stride (floats) for arrays read with ds_read_b128 by lanes = persons: multiple of 4 with an ODD
+// multiple-of-4 count (conflict-free 16-lane groups), covering index roundup8(D) + 3
+__host__ __device__ inline int pk_dse(int D) {
+    int s = ((D + 7) / 8 * 8 + 4) / 4;
+    if ((s & 1) == 0) ++s;
+    return 4 * s;
+}
+
+#define EP_THREADS 128
+#define EP_WAVES 2
+#define EP_WP 32
+
+__host__ __device__ inline size_t enc_p_wave_floats(int D, int J) {
+    const size_t a = (size_t)EP_WP * ef_ys(J) / 4;
+    const size_t b = (size_t)EP_WP * pk_dse(D) + (size_t)EP_WP * enc_ds(D);     // eps (16-B reads) | x (4-B reads)
+    return ((a > b ? a : b) + 3) & ~(size_t)3;
+}
+__host__ __device__ inline size_t enc_p_lds_floats(int D, int J) { return EP_WAVES * enc_p_wave_floats(D, J); }
+
+__global__ __launch_bounds__(EP_THREADS, 2) void k_mvn_enc_fwd_p(
+    EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, int64_t gid0,
+    const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ Wp,
+    const float* __restrict__ bp, const uint32_t* __restrict__ gtab, const float* __restrict__ eps_in,
+    uint64_t seed, uint32_t step, uint32_t stream, float* __restrict__ h_out, float* __restrict__ x_out,
+    float* __restrict__ eps_out, float* __restrict__ ldT, float* __restrict__ ent_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int H = 64;
+    const int D = dm.D, J = dm.J;
+    const int DS = pk_dse(D), DX = dm.DS;
+    const int YS = ef_ys(J);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    float* R1 = smem + wave * enc_p_wave_floats(D, J);
+    int8_t* Yi = (int8_t*)R1;                                 // phase A
+    float* eps_lds = R1;                                      // phase B  [32][DS]
+    float* x_lds = R1 + EP_WP * DS;                           //          [32][DX]
+    const int64_t i0 = ((int64_t)blockIdx.x * EP_WAVES + wave) * EP_WP;
+    const int p = l31;
+    const int64_t i = i0 + p;
+    if (i0 >= dm.nb) return;                                  // waves share nothing: no workgroup barrier below
+
+    // ---------------------------------------------------------------- stage this wave's response rows (bytes)
+    {
+        const int YW = YS / 4, JW = J / 4;
+        uint32_t* Yw = (uint32_t*)R1;
+        for (int base = 0; base < EP_WP * YW; base += 64 * 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int idx = base + q * 64 + lane;
+                v[q] = 0u;
+                if (idx < EP_WP * YW) {
+                    const int pp = idx / YW, wq = idx - pp * YW;
+                    const int64_t ii = i0 + pp;
+                    if (wq < JW && ii < dm.nb) {
+                        const int64_t row = rows ? rows[ii] : ii;
+                        v[q] = *(const uint32_t*)(y + row * J + 4 * wq);    // bytes 0/1/255 == int8 0/1/-1 (vi.py:689-691)
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int idx = base + q * 64 + lane;
+                if (idx < EP_WP * YW) Yw[idx] = v[q];
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---------------------------------------------------------------- phase A: fc1 (+ softplus), both hidden tiles
+    f32x16 hreg[2];
+    {
+        f32x16 acc0 = zero16(), acc1 = zero16();
+        const int nchunk = (J + 31) / 32;
+        auto loadA = [&](float4 (&A)[2][4], int c) {
+            const int j0 = c * 32 + half * 16;
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht) {
+                const float* src = W1 + (int64_t)(32 * ht + l31) * J + j0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    A[ht][q] = (j0 + 4 * q + 4 <= J) ? *(const float4*)(src + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto compute = [&](const float4 (&A)[2][4], int c) {
+            const int8_t* yp = Yi + p * YS + c * 32 + half * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int w = *(const int*)(yp + 4 * q);
+                const float y0 = (float)((w << 24) >> 24), y1 = (float)((w << 16) >> 24);
+                const float y2 = (float)((w << 8) >> 24), y3 = (float)(w >> 24);
+                acc0 = mfma32(A[0][q].x, y0, acc0); acc1 = mfma32(A[1][q].x, y0, acc1);
+                acc0 = mfma32(A[0][q].y, y1, acc0); acc1 = mfma32(A[1][q].y, y1, acc1);
+                acc0 = mfma32(A[0][q].z, y2, acc0); acc1 = mfma32(A[1][q].z, y2, acc1);
+                acc0 = mfma32(A[0][q].w, y3, acc0); acc1 = mfma32(A[1][q].w, y3, acc1);
+            }
+        };
+        float4 A0[2][4], A1[2][4];
+        loadA(A0, 0);
+        for (int c = 0; c < nchunk; c += 2) {
+            if (c + 1 < nchunk) loadA(A1, c + 1);
+            compute(A0, c);
+            if (c + 2 < nchunk) loadA(A0, c + 2);
+            if (c + 1 < nchunk) compute(A1, c + 1);
+        }
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int hh0 = 32 * ht + 8 * g + 4 * half;
+                const float4 bb = *(const float4*)(b1 + hh0);
+                float4 hv;
+                hv.x = softplusf_((ht ? acc1 : acc0)[4 * g + 0] + bb.x);            // vi.py:449
+                hv.y = softplusf_((ht ? acc1 : acc0)[4 * g + 1] + bb.y);
+                hv.z = softplusf_((ht ? acc1 : acc0)[4 * g + 2] + bb.z);
+                hv.w = softplusf_((ht ? acc1 : acc0)[4 * g + 3] + bb.w);
+                hreg[ht][4 * g + 0] = hv.x; hreg[ht][4 * g + 1] = hv.y;
+                hreg[ht][4 * g + 2] = hv.z; hreg[ht][4 * g + 3] = hv.w;
+                if (i < dm.nb) *(float4*)(h_out + i * H + hh0) = hv;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();                          // response bytes no longer needed
+    // ---------------------------------------------------------------- eps (zero padded to DS), x := 0
+    {
+        for (int e = lane; e < EP_WP * (DS + DX); e += 64) R1[e] = 0.f;
+        __builtin_amdgcn_wave_barrier();
+        const int nblk = (D + 3) >> 2;
+        for (int e = lane; e < EP_WP * nblk; e += 64) {
+            const int pp = e / nblk, blk = e - pp * nblk;
+            const int64_t ii = i0 + pp;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            if (ii < dm.nb) {
+                if (eps_in) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (4 * blk + q < D) z[q] = eps_in[ii * D + 4 * blk + q];
+                } else {
+                    const int64_t row = rows ? rows[ii] : ii;
+                    z = philox_normal4(seed, step, stream, gid0 + row, (uint32_t)blk);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (4 * blk + q < D) {
+                    eps_lds[pp * DS + 4 * blk + q] = z[q];
+                    if (ii < dm.nb) eps_out[ii * D + 4 * blk + q] = z[q];
+                }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---------------------------------------------------------------- phase B: packed head rows, 32 per tile
+    float ent_acc = 0.f;
+    {
+        const int n_rt = pk_rows(D) / 32;
+        const float* ep = eps_lds + p * DS;
+        float* xp = x_lds + p * DX;
+        uint32_t cur_k = 0xFFFFFFFFu;                          // k whose partial sum is held in cur_part
+        float cur_part = 0.f;
+        auto flush = [&]() {
+            if (cur_k != 0xFFFFFFFFu) {                        // wave-uniform
+                const float tot = cur_part + __shfl_xor(cur_part, 32, 64);
+                if (half == 0) xp[cur_k] += tot;
+            }
+        };
+        // A[ht][g] = Wp[row][32ht + 8g + 4half .. +3]: the hidden units this lane's hreg[ht][4g..4g+3] hold
+        auto prefetch = [&](float4 (&A)[2][4], float& biasA, uint4& gc, int tt) {
+            const float* src = Wp + ((int64_t)tt * 32 + l31) * H;
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) A[ht][g] = *(const float4*)(src + 32 * ht + 8 * g + 4 * half);
+            biasA = (half == 0) ? bp[tt * 32 + l31] : 0.f;
+            gc = *(const uint4*)(gtab + 4 * tt);               // uniform address: 4 group codes of this tile
+        };
+        auto tile = [&](const float4 (&A)[2][4], float biasA, uint4 gc) {
+            f32x16 a = zero16();
+            a = mfma32(biasA, (half == 0) ? 1.0f : 0.f, a);    // + bias[row] as a 65th k-step
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    a = mfma32(A[ht][g].x, hreg[ht][4 * g + 0], a);
+                    a = mfma32(A[ht][g].y, hreg[ht][4 * g + 1], a);
+                    a = mfma32(A[ht][g].z, hreg[ht][4 * g + 2], a);
+                    a = mfma32(A[ht][g].w, hreg[ht][4 * g + 3], a);
+                }
+            const uint32_t gcv[4] = {gc.x, gc.y, gc.z, gc.w};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint32_t code = __builtin_amdgcn_readfirstlane(gcv[g]);
+                const uint32_t type = code >> 28, k = (code >> 12) & 0xFFFFu, l0 = code & 0xFFFu;
+                if (type == PK_OFF) {                          // rows (k, l0 + 4half + j) live in a[4g + j]
+                    const float4 e4 = *(const float4*)(ep + l0 + 4 * half);
+                    const float part = a[4 * g + 0] * e4.x + a[4 * g + 1] * e4.y + a[4 * g + 2] * e4.z + a[4 * g + 3] * e4.w;
+                    if (k != cur_k) { flush(); cur_k = k; cur_part = part; }
+                    else cur_part += part;
+                } else if (type == PK_DIAG || type == PK_LOC) { // rows k0 + 4half + j: every element its own k
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx) {
+                        const int kk = (int)k + 4 * half + jx;
+                        if (kk < D) {
+                            const float v = a[4 * g + jx];
+                            if (type == PK_DIAG) {
+                                const float ld = expf(v);                          // exp(diag M): vi.py:686
+                                xp[kk] += ld * ep[kk];
+                                ent_acc += v;
+                                if (i < dm.nb) ldT[(int64_t)kk * dm.nb + i] = ld;
+                            } else {
+                                xp[kk] += v;                                       // loc head (vi.py:450)
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        float4 A0[2][4], A1[2][4];
+        float bA0 = 0.f, bA1 = 0.f;
+        uint4 g0 = make_uint4(0, 0, 0, 0), g1 = make_uint4(0, 0, 0, 0);
+        prefetch(A0, bA0, g0, 0);
+        for (int tt = 0; tt < n_rt; tt += 2) {
+            if (tt + 1 < n_rt) prefetch(A1, bA1, g1, tt + 1);
+            tile(A0, bA0, g0);
+            if (tt + 2 < n_rt) prefetch(A0, bA0, g0, tt + 2);
+            if (tt + 1 < n_rt) tile(A1, bA1, g1);
+        }
+        flush();
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---------------------------------------------------------------- write x, entropy part
+    {
+        const int pv = (int)((dm.nb - i0) < EP_WP ? (dm.nb - i0) : EP_WP);
+        for (int e = lane; e < pv * D; e += 64) {
+            const int pp = e / D, k = e - pp * D;
+            x_out[i0 * D + e] = x_lds[pp * DX + k];
+        }
+        ent_acc += __shfl_xor(ent_acc, 32, 64);
+        if (half == 0 && i < dm.nb) {
+            float s = 0.f;
+            for (int k = 0; k < D; ++k) { const float e = eps_lds[p * DS + k]; s += e * e; }
+            ent_out[i] = 0.5f * s + ent_acc;                  // -log q + const = 0.5|eps|^2 + sum_k M_kk
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward, person-parallel: gh^T[hh,p] = sum_r Wp[r,hh] V[r,p];  ghpre = gh * sigmoid(pre)
+#define BHP_ROWS 64
+
+__host__ __device__ inline size_t enc_bwdh_p_lds_floats(int D) {
+    return (((size_t)ENC_P * enc_ds(D) + 3) & ~(size_t)3) + (size_t)ENC_P * pk_dse(D) + (size_t)BHP_ROWS * 64;
+}
+
+__global__ __launch_bounds__(ENC_THREADS, 2) void k_mvn_enc_bwd_h_p(
+    EncDims dm, float scale, const float* __restrict__ Wp, const uint32_t* __restrict__ gtab,
+    const float* __restrict__ h_in, const float* __restrict__ eps_in, const float* __restrict__ ldT,
+    const float* __restrict__ gx_in, float* __restrict__ ghpre_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int H = 64;
+    const int D = dm.D;
+    const int DG = dm.DS;                               // odd stride: gx is read one float per lane (lane = person)
+    const int DE = pk_dse(D);                           // 16-byte friendly stride: eps is read four floats per lane
+    float* gx_lds = smem;                                                    // [P][DG]
+    float* eps_lds = smem + (((size_t)ENC_P * DG + 3) & ~(size_t)3);         // [P][DE]
+    float* Wt = eps_lds + ENC_P * DE;                                        // [BHP_ROWS][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int64_t i0 = (int64_t)blockIdx.x * ENC_P;
+    const int n_tiles = pk_rows(D) / BHP_ROWS + ((pk_rows(D) % BHP_ROWS) ? 1 : 0);
+    const int Rp = pk_rows(D);
+    const int pvalid = (int)((dm.nb - i0) < ENC_P ? (dm.nb - i0) : ENC_P);
+
+    for (int e = tid; e < ENC_P * DE; e += ENC_THREADS) eps_lds[e] = 0.f;
+    __syncthreads();
+    {
+        const int c4 = D / 4, n4 = ENC_P * c4;
+        const float4* g4 = (const float4*)(gx_in + i0 * D);
+        const float4* e4 = (const float4*)(eps_in + i0 * D);
+        for (int base = 0; base < n4; base += ENC_THREADS * 4) {
+            float4 a[4], b[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = base + q * ENC_THREADS + tid;
+                const bool ok = idx < pvalid * c4;
+                a[q] = ok ? g4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+                b[q] = ok ? e4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = base + q * ENC_THREADS + tid;
+                if (idx < n4) {
+                    const int pp = idx / c4, c = idx - pp * c4;
+                    float* dg = gx_lds + pp * DG + 4 * c;
+                    dg[0] = a[q].x; dg[1] = a[q].y; dg[2] = a[q].z; dg[3] = a[q].w;
+                    *(float4*)(eps_lds + pp * DE + 4 * c) = b[q];
+                }
+            }
+        }
+    }
+    const int u = wave & 1, ht = wave >> 1;
+    const int p = 32 * u + l31;
+    const int64_t i = i0 + p;
+    f32x16 acc = zero16();
+    float4 wp[4];
+    auto prefetch = [&](int tile) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f = tid + ENC_THREADS * q;                        // 1024 float4 per 64-row tile
+            const int r = tile * BHP_ROWS + (f >> 4);
+            wp[q] = (r < Rp) ? *(const float4*)(Wp + (int64_t)r * H + 4 * (f & 15)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    prefetch(0);
+    const float* gx_p = gx_lds + p * DG;
+    const float* eps_p = eps_lds + p * DE;
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        __syncthreads();                                                // previous MFMA phase done with Wt
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ((float4*)Wt)[tid + ENC_THREADS * q] = wp[q];
+        __syncthreads();
+        if (tile + 1 < n_tiles) prefetch(tile + 1);
+        // K order: lane-half `half` walks packed rows 32*half + 0..31 of the tile = 4 groups of 8 rows
+        const float* ap = Wt + (half * 32) * H + 32 * ht + l31;
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            const int grp = tile * (BHP_ROWS / 8) + half * 4 + gg;
+            const uint32_t code = (8 * grp < Rp) ? gtab[grp] : 0u;      // uniform per half-wave
+            const uint32_t type = code >> 28, k = (code >> 12) & 0xFFFFu, l0 = code & 0xFFFu;
+            float v[8];
+            if (type == PK_OFF) {
+                const float gk = gx_p[k];
+                const float4 ea = *(const float4*)(eps_p + l0), eb = *(const float4*)(eps_p + l0 + 4);
+                v[0] = gk * ea.x; v[1] = gk * ea.y; v[2] = gk * ea.z; v[3] = gk * ea.w;
+                v[4] = gk * eb.x; v[5] = gk * eb.y; v[6] = gk * eb.z; v[7] = gk * eb.w;
+            } else if (type == PK_LOC) {
+#pragma unroll
+                for (int jx = 0; jx < 8; ++jx) v[jx] = ((int)k + jx < D) ? gx_p[k + jx] : 0.f;
+            } else if (type == PK_DIAG) {
+#pragma unroll
+                for (int jx = 0; jx < 8; ++jx) {
+                    const int kk = (int)k + jx;
+                    v[jx] = (kk < D && i < dm.nb) ? gx_p[kk] * eps_p[kk] * ldT[(int64_t)kk * dm.nb + i] + scale : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int jx = 0; jx < 8; ++jx) v[jx] = 0.f;
+            }
+#pragma unroll
+            for (int jx = 0; jx < 8; ++jx) acc = mfma32(ap[(8 * gg + jx) * H], v[jx], acc);
+        }
+    }
+    if (i < dm.nb) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int hh0 = 32 * ht + 8 * g + 4 * half;
+            const float4 hv = *(const float4*)(h_in + i * H + hh0);
+            float4 o;
+            o.x = acc[4 * g + 0] * (1.0f - __expf(-hv.x));
+            o.y = acc[4 * g + 1] * (1.0f - __expf(-hv.y));
+            o.z = acc[4 * g + 2] * (1.0f - __expf(-hv.z));
+            o.w = acc[4 * g + 3] * (1.0f - __expf(-hv.w));
+            *(float4*)(ghpre_out + i * H + hh0) = o;
+        }
+    }
+}

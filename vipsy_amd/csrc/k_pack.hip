@@ -1,0 +1,87 @@
+// Packed head layout of the amortized MVN guide.
+//
+// The reference stores fc22's rows in torch.tril_indices order (vi.py:453): (0,0),(1,0),(1,1),(2,0),...  For the
+// MFMA kernels a 32-row tile of that order mixes several (k, l) runs and forces a per-element decode.  The packed
+// order (rebuilt from the flat parameters by k_pack_heads every step, 1.4 MB, a few microseconds) is
+//   section OFF : for k = 1..D-1 the entries (k, 0..k-1), each k padded with zero rows to a multiple of 8
+//   section DIAG: (k,k) for k = 0..D-1, padded to a multiple of 8
+//   section LOC : fc21 rows k = 0..D-1, padded to a multiple of 8
+//   tail        : zero rows up to a multiple of 32
+// so every aligned group of 8 packed rows has ONE type and ONE k (OFF) and its l0 is a multiple of 8.
+// gtab[group] = type << 28 | k << 12 | l0   (DIAG / LOC groups: k = first k of the group).
+#pragma once
+#include "vx_common.h"
+
+#define PK_NONE 0u
+#define PK_OFF 1u
+#define PK_DIAG 2u
+#define PK_LOC 3u
+
+__host__ __device__ inline int pk_off_rows(int k) {          // packed rows before the entries of row k (k >= 1)
+    const int m = k - 1, q = m / 8, rem = m % 8;
+    return 8 * (8 * (q * (q + 1) / 2) + rem * (q + 1));
+}
+__host__ __device__ inline int pk_sec(int D) { return (D + 7) / 8 * 8; }
+__host__ __device__ inline int pk_off_total(int D) { return pk_off_rows(D); }
+__host__ __device__ inline int pk_rows(int D) { return (pk_off_total(D) + 2 * pk_sec(D) + 31) / 32 * 32; }
+
+// packed row -> (source row in the concatenated [W22 rows 0..T-1 | W21 rows T..T+D-1] space, or -1), group code
+__device__ __forceinline__ void pk_decode(int pr, int D, int T, int& src, uint32_t& gcode) {
+    const int offT = pk_off_total(D), sec = pk_sec(D);
+    src = -1;
+    gcode = PK_NONE << 28;
+    if (pr < offT) {
+        int k = 1;
+        while (k + 1 <= D - 1 && pk_off_rows(k + 1) <= pr) ++k;       // D <= 127: a short search
+        const int l = pr - pk_off_rows(k);
+        if (l < k) src = k * (k + 1) / 2 + l;
+        gcode = (PK_OFF << 28) | ((uint32_t)k << 12) | (uint32_t)(l & ~7);
+    } else if (pr < offT + sec) {
+        const int k = pr - offT;
+        if (k < D) src = k * (k + 1) / 2 + k;
+        gcode = (PK_DIAG << 28) | ((uint32_t)(k & ~7) << 12);
+    } else if (pr < offT + 2 * sec) {
+        const int k = pr - offT - sec;
+        if (k < D) src = T + k;
+        gcode = (PK_LOC << 28) | ((uint32_t)(k & ~7) << 12);
+    }
+}
+
+// Wp[Rp][H] (H floats per row), bp[Rp], gtab[Rp/8]
+__global__ void k_pack_heads(int D, int H, const float* __restrict__ W21, const float* __restrict__ b21,
+                             const float* __restrict__ W22, const float* __restrict__ b22, float* __restrict__ Wp,
+                             float* __restrict__ bp, uint32_t* __restrict__ gtab) {
+    const int T = D * (D + 1) / 2, Rp = pk_rows(D);
+    const int pr = blockIdx.x;
+    if (pr >= Rp) return;
+    int src;
+    uint32_t gcode;
+    pk_decode(pr, D, T, src, gcode);
+    const float* w = (src < 0) ? nullptr : (src < T ? W22 + (int64_t)src * H : W21 + (int64_t)(src - T) * H);
+    for (int hh = threadIdx.x; hh < H; hh += blockDim.x) Wp[(int64_t)pr * H + hh] = w ? w[hh] : 0.f;
+    if (threadIdx.x == 0) {
+        bp[pr] = (src < 0) ? 0.f : (src < T ? b22[src] : b21[src - T]);
+        if ((pr & 7) == 0) gtab[pr >> 3] = gcode;
+    }
+}
+
+// out = alpha * sum_s slabs[s] gathered from packed rows back to the reference layout
+//   slab: [Wp-grad: Rp*H | bp-grad: Rp];  out: [W21: D*H | b21: D | W22: T*H | b22: T]
+__global__ void k_unpack_head_grads(int D, int H, const float* __restrict__ slabs, int n_slabs, int64_t slab_len,
+                                    float alpha, float* __restrict__ out) {
+    const int T = D * (D + 1) / 2, Rp = pk_rows(D);
+    const int pr = blockIdx.x;
+    if (pr >= Rp) return;
+    int src;
+    uint32_t gcode;
+    pk_decode(pr, D, T, src, gcode);
+    if (src < 0) return;
+    float* oW = (src < T) ? out + (int64_t)D * H + D + (int64_t)src * H : out + (int64_t)(src - T) * H;
+    float* ob = (src < T) ? out + (int64_t)D * H + D + (int64_t)T * H + src : out + (int64_t)D * H + (src - T);
+    for (int hh = threadIdx.x; hh <= H; hh += blockDim.x) {
+        float acc = 0.f;
+        const int64_t off = (hh < H) ? (int64_t)pr * H + hh : (int64_t)Rp * H + pr;
+        for (int s = 0; s < n_slabs; ++s) acc += slabs[(int64_t)s * slab_len + off];
+        if (hh < H) oW[hh] = alpha * acc; else *ob = alpha * acc;
+    }
+}

@@ -3,6 +3,8 @@
 #include "k_util.hip"
 #include "k_mvn_enc.hip"
 #include "k_mvn_enc_fast.hip"
+#include "k_mvn_enc_r.hip"
+#include "k_mvn_packed.hip"
 #include "k_mvn_enc_bwd.hip"
 #include "k_mvn_enc_bwd_fast.hip"
 #include "k_irt_lik.hip"
@@ -60,6 +62,15 @@ bool force_generic() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("VX_FORCE_GENERIC"); v = (e && e[0] == '1') ? 1 : 0; }
     return v == 1;
+}
+
+// VX_MVN=fast keeps the reference row order (the pre-packing kernels); default is the packed head layout
+bool packed_ok(const vx_irt_cfg* cfg) {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VX_MVN"); v = (e && e[0] == 'f') ? 0 : 1; }
+    return v == 1 && !force_generic() && cfg->H == 64 && cfg->J % 4 == 0 && cfg->D % 4 == 0 &&
+           enc_p_lds_floats(cfg->D, cfg->J) * sizeof(float) <= 160 * 1024 &&
+           enc_bwdw_fast_lds_floats(cfg->D) * sizeof(float) <= 160 * 1024;
 }
 
 bool enc_cfg_ok(const vx_irt_cfg* cfg) {
@@ -139,7 +150,7 @@ int vx_adam_step(float* p, const float* g, float* m, float* v, const float* free
 int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, int64_t gid0,
                        const float* W1, const float* b1, const float* W21, const float* b21, const float* W22,
                        const float* b22, const float* eps_in, float* h, float* x, float* eps, float* ldT,
-                       float* ent, void* hs) {
+                       float* ent, float* packws, void* hs) {
     if (!enc_cfg_ok(cfg) || !y || !W1 || !b1 || !W21 || !b21 || !W22 || !b22 || !h || !x || !eps || !ldT || !ent ||
         nb < 0)
         return VX_EINVAL;
@@ -147,8 +158,38 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
     EncDims dm = make_enc_dims(cfg, nb);
     const dim3 grid((unsigned)((nb + ENC_P - 1) / ENC_P));
     int rc;
+    if (packed_ok(cfg) && packws && aligned16(packws) && aligned16(y) && aligned16(W1) && aligned16(b1) &&
+        aligned16(W21) && aligned16(W22) && aligned16(h)) {
+        const int Rp = pk_rows(cfg->D);
+        float* Wp = packws;
+        float* bp = Wp + (int64_t)Rp * 64;
+        uint32_t* gtab = (uint32_t*)(bp + Rp);
+        hipLaunchKernelGGL(k_pack_heads, dim3(Rp), dim3(64), 0, (hipStream_t)hs, (int)cfg->D, 64, W21, b21, W22, b22, Wp,
+                           bp, gtab);
+        VX_CHECK_LAUNCH();
+        const size_t ldsp = enc_p_lds_floats(dm.D, dm.J) * sizeof(float);
+        rc = set_lds(k_mvn_enc_fwd_p, ldsp);
+        if (rc) return rc;
+        const dim3 gridp((unsigned)((nb + EP_WAVES * EP_WP - 1) / (EP_WAVES * EP_WP)));
+        hipLaunchKernelGGL(k_mvn_enc_fwd_p, gridp, dim3(EP_THREADS), ldsp, (hipStream_t)hs, dm, y, rows, gid0, W1, b1, Wp,
+                           bp, gtab, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent);
+        VX_CHECK_LAUNCH();
+        return VX_OK;
+    }
     if (!force_generic() && cfg->H == 64 && cfg->J % 4 == 0 && aligned16(y) && aligned16(W1) && aligned16(b1) &&
         aligned16(W21) && aligned16(W22) && aligned16(h)) {
+        static int variant = -1;                          // VX_ENC_FWD=atomic selects the previous (LDS-atomic) form
+        if (variant < 0) { const char* e = getenv("VX_ENC_FWD"); variant = (e && e[0] == 'a') ? 1 : 0; }
+        const size_t ldsr = enc_r_lds_floats(dm.D, dm.J) * sizeof(float);
+        if (variant == 0 && ldsr <= 160 * 1024) {
+            rc = set_lds(k_mvn_enc_fwd_r, ldsr);
+            if (rc) return rc;
+            const dim3 gridr((unsigned)((nb + ER_WAVES * ER_WP - 1) / (ER_WAVES * ER_WP)));
+            hipLaunchKernelGGL(k_mvn_enc_fwd_r, gridr, dim3(ER_THREADS), ldsr, (hipStream_t)hs, dm, y, rows, gid0, W1, b1,
+                               W21, b21, W22, b22, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent);
+            VX_CHECK_LAUNCH();
+            return VX_OK;
+        }
         const size_t ldsf = enc_fwd_fast_lds_floats(dm.D, dm.J) * sizeof(float);
         if (ldsf <= 160 * 1024) {
             rc = set_lds(k_mvn_enc_fwd_fast, ldsf);
@@ -260,7 +301,7 @@ static bool encb_fast_shape(const vx_irt_cfg* cfg) {
 }
 
 static void encb_plan(const vx_irt_cfg* cfg, int64_t nb, int& n_rowslabs, int& n_prw, int& n_jg, int& n_prf) {
-    const int64_t RT = (int64_t)tril_len(cfg->D) + cfg->D;
+    const int64_t RT = packed_ok(cfg) ? (int64_t)pk_rows(cfg->D) : (int64_t)tril_len(cfg->D) + cfg->D;
     const int rows_per_wg = encb_fast_shape(cfg) ? BWF_ROWS : BW_ROWS;
     n_rowslabs = (int)((RT + rows_per_wg - 1) / rows_per_wg);
     n_jg = (cfg->J + FC1_JG - 1) / FC1_JG;
@@ -269,6 +310,12 @@ static void encb_plan(const vx_irt_cfg* cfg, int64_t nb, int& n_rowslabs, int& n
     n_prw = (int)(n_ptiles < w ? n_ptiles : w); if (n_prw < 1) n_prw = 1;
     int64_t f = num_cu() / n_jg; if (f < 1) f = 1;
     n_prf = (int)(n_ptiles < f ? n_ptiles : f); if (n_prf < 1) n_prf = 1;
+}
+
+int64_t vx_mvn_pack_floats(const vx_irt_cfg* cfg) {
+    if (!enc_cfg_ok(cfg)) return VX_EINVAL;
+    const int64_t Rp = pk_rows(cfg->D);
+    return Rp * 64 + Rp + Rp / 8 + 8;
 }
 
 int64_t vx_mvn_enc_param_floats(const vx_irt_cfg* cfg) {
@@ -282,25 +329,52 @@ int64_t vx_mvn_enc_bwd_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
     int n_rowslabs, n_prw, n_jg, n_prf;
     encb_plan(cfg, nb, n_rowslabs, n_prw, n_jg, n_prf);
     const int64_t D = cfg->D, J = cfg->J, H = cfg->H, T = tril_len(cfg->D);
-    return nb * H + (int64_t)n_prw * (D * H + D + T * H + T) + (int64_t)n_prf * (H * J + H);
+    int64_t lenw = D * H + D + T * H + T;
+    if (packed_ok(cfg) && (int64_t)pk_rows(cfg->D) * (H + 1) > lenw) lenw = (int64_t)pk_rows(cfg->D) * (H + 1);
+    return nb * H + (int64_t)n_prw * lenw + (int64_t)n_prf * (H * J + H);
 }
 
 int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
                         const float* W21, const float* W22, const float* h, const float* eps, const float* ldT,
-                        const float* gx, float* genc, float* workspace, void* hs) {
+                        const float* gx, float* genc, float* workspace, const float* packws, void* hs) {
     if (!enc_cfg_ok(cfg) || !y || !W21 || !W22 || !h || !eps || !ldT || !gx || !genc || !workspace || nb < 0)
         return VX_EINVAL;
     int n_rowslabs, n_prw, n_jg, n_prf;
     encb_plan(cfg, nb, n_rowslabs, n_prw, n_jg, n_prf);
     EncDims dm = make_enc_dims(cfg, nb);
     const int64_t D = cfg->D, J = cfg->J, H = cfg->H, T = dm.T;
-    const int64_t lenw = D * H + D + T * H + T, lenf = H * J + H;
+    const int64_t lenw_ref = D * H + D + T * H + T, lenf = H * J + H;
+    const int64_t Rp = pk_rows(cfg->D);
+    const bool packed = packed_ok(cfg) && packws && aligned16(packws) && aligned16(h) && aligned16(eps) &&
+                        aligned16(gx) && aligned16(workspace) && nb > 0;
+    if (packed_ok(cfg) && !packed && nb > 0) return VX_EINVAL;      // the plan assumed the packed row space
+    const int64_t lenw = (packed_ok(cfg) && Rp * (H + 1) > lenw_ref) ? Rp * (H + 1) : lenw_ref;
     float* ghpre = workspace;
     float* slabs_w = ghpre + nb * H;
     float* slabs_f = slabs_w + (int64_t)n_prw * lenw;
     hipStream_t st = (hipStream_t)hs;
     int rc;
-    const bool fast = encb_fast_shape(cfg) && aligned16(W21) && aligned16(W22) && aligned16(h) && aligned16(eps) &&
+    if (packed) {
+        const float* Wp = packws;
+        const uint32_t* gtab = (const uint32_t*)(packws + Rp * 64 + Rp);
+        {
+            const size_t lds = enc_bwdh_p_lds_floats(dm.D) * sizeof(float);
+            rc = set_lds(k_mvn_enc_bwd_h_p, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_mvn_enc_bwd_h_p, dim3((unsigned)((nb + ENC_P - 1) / ENC_P)), dim3(ENC_THREADS), lds, st,
+                               dm, cfg->scale, Wp, gtab, h, eps, ldT, gx, ghpre);
+            VX_CHECK_LAUNCH();
+        }
+        {
+            const size_t lds = enc_bwdw_fast_lds_floats(dm.D) * sizeof(float);
+            rc = set_lds(k_mvn_enc_bwd_w_fast<true>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_mvn_enc_bwd_w_fast<true>, dim3((unsigned)n_rowslabs, (unsigned)n_prw), dim3(ENC_THREADS),
+                               lds, st, dm, cfg->scale, h, eps, ldT, gx, gtab, slabs_w, Rp * (H + 1));
+            VX_CHECK_LAUNCH();
+        }
+    }
+    const bool fast = !packed && encb_fast_shape(cfg) && aligned16(W21) && aligned16(W22) && aligned16(h) && aligned16(eps) &&
                       aligned16(gx) && aligned16(ghpre);
     if (nb > 0 && fast) {
         {
@@ -313,13 +387,13 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
         }
         {
             const size_t lds = enc_bwdw_fast_lds_floats(dm.D) * sizeof(float);
-            rc = set_lds(k_mvn_enc_bwd_w_fast, lds);
+            rc = set_lds(k_mvn_enc_bwd_w_fast<false>, lds);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_mvn_enc_bwd_w_fast, dim3((unsigned)n_rowslabs, (unsigned)n_prw), dim3(ENC_THREADS), lds,
-                               st, dm, cfg->scale, h, eps, ldT, gx, slabs_w, lenw);
+            hipLaunchKernelGGL(k_mvn_enc_bwd_w_fast<false>, dim3((unsigned)n_rowslabs, (unsigned)n_prw), dim3(ENC_THREADS),
+                               lds, st, dm, cfg->scale, h, eps, ldT, gx, (const uint32_t*)nullptr, slabs_w, lenw);
             VX_CHECK_LAUNCH();
         }
-    } else if (nb > 0) {
+    } else if (nb > 0 && !packed) {
         // the plan may have assumed the fast row-slab size (misaligned buffers): re-derive for this kernel
         n_rowslabs = (int)(((int64_t)dm.T + dm.D + BW_ROWS - 1) / BW_ROWS);
         {
@@ -367,7 +441,13 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     // flat encoder-gradient layout = nn.Linear order: [W1 | b1 | W21 | b21 | W22 | b22]; loss grads = -dELBO
     rc = vx_reduce_slabs(slabs_f, n_prf, lenf, -1.0f, genc, hs);
     if (rc) return rc;
-    return vx_reduce_slabs(slabs_w, n_prw, lenw, -1.0f, genc + lenf, hs);
+    if (packed) {
+        hipLaunchKernelGGL(k_unpack_head_grads, dim3((unsigned)Rp), dim3(128), 0, st, (int)D, (int)H, slabs_w, n_prw,
+                           Rp * (H + 1), -1.0f, genc + lenf);
+        VX_CHECK_LAUNCH();
+        return VX_OK;
+    }
+    return vx_reduce_slabs(slabs_w, n_prw, lenw_ref, -1.0f, genc + lenf, hs);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -44,8 +44,14 @@ class HipBackend(object):
                                        _hip.ptr(enc["fc22.weight"]), _hip.ptr(enc["fc22.bias"]),
                                        _hip.ptr(eps_in), _hip.ptr(out["h"]), _hip.ptr(out["x"]),
                                        _hip.ptr(out["eps"]), _hip.ptr(out["ldT"]), _hip.ptr(out["ent"]),
-                                       _hip.stream_ptr())
+                                       _hip.ptr(out.get("packws")), _hip.stream_ptr())
         _hip.check(rc, "vx_mvn_enc_forward")
+
+    def mvn_pack_floats(self, cfg):
+        n = self.L.vx_mvn_pack_floats(ctypes.byref(cfg))
+        if n < 0:
+            raise _hip.VxError("vx_mvn_pack_floats: unsupported configuration (code %d)" % n)
+        return n
 
     def lik_workspace(self, cfg, nb):
         n = self.L.vx_irt_lik_workspace_floats(ctypes.byref(cfg), nb)
@@ -69,7 +75,7 @@ class HipBackend(object):
         rc = self.L.vx_mvn_enc_backward(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb,
                                         _hip.ptr(enc["fc21.weight"]), _hip.ptr(enc["fc22.weight"]),
                                         _hip.ptr(fw["h"]), _hip.ptr(fw["eps"]), _hip.ptr(fw["ldT"]), _hip.ptr(gx),
-                                        _hip.ptr(genc), _hip.ptr(ws), _hip.stream_ptr())
+                                        _hip.ptr(genc), _hip.ptr(ws), _hip.ptr(fw.get("packws")), _hip.stream_ptr())
         _hip.check(rc, "vx_mvn_enc_backward")
 
     def irt1d_workspace(self, cfg, nb):
@@ -390,6 +396,8 @@ class IrtEngine(_EngineBase):
             D, H = self.D, self.H
             fw = {"h": self._buf("h", nb * H), "x": self._buf("x", nb * D), "eps": self._buf("eps", nb * D),
                   "ldT": self._buf("ldT", nb * D), "ent": self._buf("ent", nb)}
+            if hasattr(be, "mvn_pack_floats"):
+                fw["packws"] = self._buf("packws", be.mvn_pack_floats(cfg))
             gx, ll = self._buf("gx", nb * D), self._buf("ll", nb)
             enc = self._enc()
             lik_ws = self._buf("lik_ws", be.lik_workspace(cfg, nb))
