@@ -227,15 +227,20 @@ __global__ __launch_bounds__(EP_THREADS, 2) void k_mvn_enc_fwd_p(
                 }
             }
         };
-        float4 A0[2][4], A1[2][4];
-        float bA0 = 0.f, bA1 = 0.f;
-        uint4 g0 = make_uint4(0, 0, 0, 0), g1 = make_uint4(0, 0, 0, 0);
+        // three register sets: the weights of tile t+2 are requested while tile t computes (L2 latency under
+        // load exceeds one 33-MFMA tile)
+        float4 A0[2][4], A1[2][4], A2[2][4];
+        float bA0 = 0.f, bA1 = 0.f, bA2 = 0.f;
+        uint4 g0 = make_uint4(0, 0, 0, 0), g1 = make_uint4(0, 0, 0, 0), g2 = make_uint4(0, 0, 0, 0);
         prefetch(A0, bA0, g0, 0);
-        for (int tt = 0; tt < n_rt; tt += 2) {
-            if (tt + 1 < n_rt) prefetch(A1, bA1, g1, tt + 1);
+        if (1 < n_rt) prefetch(A1, bA1, g1, 1);
+        for (int tt = 0; tt < n_rt; tt += 3) {
+            if (tt + 2 < n_rt) prefetch(A2, bA2, g2, tt + 2);
             tile(A0, bA0, g0);
-            if (tt + 2 < n_rt) prefetch(A0, bA0, g0, tt + 2);
+            if (tt + 3 < n_rt) prefetch(A0, bA0, g0, tt + 3);
             if (tt + 1 < n_rt) tile(A1, bA1, g1);
+            if (tt + 4 < n_rt) prefetch(A1, bA1, g1, tt + 4);
+            if (tt + 2 < n_rt) tile(A2, bA2, g2);
         }
         flush();
     }
@@ -314,6 +319,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_mvn_enc_bwd_h_p(
     const int64_t i = i0 + p;
     f32x16 acc = zero16();
     float4 wp[4];
+    uint4 gcn = make_uint4(0, 0, 0, 0);                                 // group codes of the prefetched tile (this half)
     auto prefetch = [&](int tile) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -321,6 +327,8 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_mvn_enc_bwd_h_p(
             const int r = tile * BHP_ROWS + (f >> 4);
             wp[q] = (r < Rp) ? *(const float4*)(Wp + (int64_t)r * H + 4 * (f & 15)) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        const int g0i = tile * (BHP_ROWS / 8) + half * 4;               // gtab is padded by 8 entries past Rp / 8
+        gcn = (8 * g0i < Rp) ? *(const uint4*)(gtab + g0i) : make_uint4(0, 0, 0, 0);
     };
     prefetch(0);
     const float* gx_p = gx_lds + p * DG;
@@ -330,13 +338,13 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_mvn_enc_bwd_h_p(
 #pragma unroll
         for (int q = 0; q < 4; ++q) ((float4*)Wt)[tid + ENC_THREADS * q] = wp[q];
         __syncthreads();
+        const uint32_t gcur[4] = {gcn.x, gcn.y, gcn.z, gcn.w};
         if (tile + 1 < n_tiles) prefetch(tile + 1);
         // K order: lane-half `half` walks packed rows 32*half + 0..31 of the tile = 4 groups of 8 rows
         const float* ap = Wt + (half * 32) * H + 32 * ht + l31;
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg) {
-            const int grp = tile * (BHP_ROWS / 8) + half * 4 + gg;
-            const uint32_t code = (8 * grp < Rp) ? gtab[grp] : 0u;      // uniform per half-wave
+            const uint32_t code = gcur[gg];                             // uniform per half-wave
             const uint32_t type = code >> 28, k = (code >> 12) & 0xFFFFu, l0 = code & 0xFFFu;
             float v[8];
             if (type == PK_OFF) {
