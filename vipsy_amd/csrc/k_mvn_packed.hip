@@ -165,30 +165,27 @@ __global__ __launch_bounds__(EP_THREADS, 2) void k_mvn_enc_fwd_p(
     // ---------------------------------------------------------------- phase B: packed head rows, 32 per tile
     float ent_acc = 0.f;
     {
-        const int n_rt = pk_rows(D) / 32;
+        const int n_off = pk_off_total(D) / 32;                // multiple of 3
+        const int n_sec = pk_sec(D) / 32;
         const float* ep = eps_lds + p * DS;
         float* xp = x_lds + p * DX;
-        uint32_t cur_k = 0xFFFFFFFFu;                          // k whose partial sum is held in cur_part
-        float cur_part = 0.f;
-        auto flush = [&]() {
-            if (cur_k != 0xFFFFFFFFu) {                        // wave-uniform
-                const float tot = cur_part + __shfl_xor(cur_part, 32, 64);
-                if (half == 0) xp[cur_k] += tot;
-            }
-        };
-        // A[ht][g] = Wp[row][32ht + 8g + 4half .. +3]: the hidden units this lane's hreg[ht][4g..4g+3] hold
+        const float one = (half == 0) ? 1.0f : 0.f;
+        // A[ht][g] = Wp[row][32ht + 8g + 4half .. +3]: the hidden units this lane's hreg[ht][4g..4g+3] hold.
+        // NOTE: nothing in the OFF loop is conditional -- with loads issued under a condition hipcc falls back to
+        // s_waitcnt vmcnt(0) at every use and the whole L2 latency is exposed each tile.
         auto prefetch = [&](float4 (&A)[2][4], float& biasA, uint4& gc, int tt) {
             const float* src = Wp + ((int64_t)tt * 32 + l31) * H;
 #pragma unroll
             for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) A[ht][g] = *(const float4*)(src + 32 * ht + 8 * g + 4 * half);
-            biasA = (half == 0) ? bp[tt * 32 + l31] : 0.f;
+            const float bv = bp[tt * 32 + l31];
+            biasA = (half == 0) ? bv : 0.f;
             gc = *(const uint4*)(gtab + 4 * tt);               // uniform address: 4 group codes of this tile
         };
-        auto tile = [&](const float4 (&A)[2][4], float biasA, uint4 gc) {
+        auto mma = [&](const float4 (&A)[2][4], float biasA) {
             f32x16 a = zero16();
-            a = mfma32(biasA, (half == 0) ? 1.0f : 0.f, a);    // + bias[row] as a 65th k-step
+            a = mfma32(biasA, one, a);                         // + bias[row] as a 65th k-step
 #pragma unroll
             for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
@@ -198,51 +195,76 @@ __global__ __launch_bounds__(EP_THREADS, 2) void k_mvn_enc_fwd_p(
                     a = mfma32(A[ht][g].z, hreg[ht][4 * g + 2], a);
                     a = mfma32(A[ht][g].w, hreg[ht][4 * g + 3], a);
                 }
+            return a;
+        };
+        // ---- OFF section: x[p][k] += sum_l M[p,(k,l)] eps[p,l]; the partial sum of the current k stays in a register
+        uint32_t cur_k = 1;                                    // the first packed group belongs to k = 1
+        float cur_part = 0.f;
+        auto flush = [&]() {
+            const float tot = cur_part + __shfl_xor(cur_part, 32, 64);
+            if (half == 0) xp[cur_k] += tot;
+        };
+        auto tile_off = [&](const float4 (&A)[2][4], float biasA, uint4 gc) {
+            // eps reads are issued BEFORE the MFMA chain: an LDS read in the dependent path costs 20-45 % of the
+            // matrix pipe (tools/mfma_ubench.hip)
             const uint32_t gcv[4] = {gc.x, gc.y, gc.z, gc.w};
+            uint32_t kq[4];
+            float4 e4[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const uint32_t code = __builtin_amdgcn_readfirstlane(gcv[g]);
-                const uint32_t type = code >> 28, k = (code >> 12) & 0xFFFFu, l0 = code & 0xFFFu;
-                if (type == PK_OFF) {                          // rows (k, l0 + 4half + j) live in a[4g + j]
-                    const float4 e4 = *(const float4*)(ep + l0 + 4 * half);
-                    const float part = a[4 * g + 0] * e4.x + a[4 * g + 1] * e4.y + a[4 * g + 2] * e4.z + a[4 * g + 3] * e4.w;
-                    if (k != cur_k) { flush(); cur_k = k; cur_part = part; }
-                    else cur_part += part;
-                } else if (type == PK_DIAG || type == PK_LOC) { // rows k0 + 4half + j: every element its own k
+                kq[g] = (code >> 12) & 0xFFFFu;
+                e4[g] = *(const float4*)(ep + (code & 0xFFFu) + 4 * half);
+            }
+            const f32x16 a = mma(A, biasA);
 #pragma unroll
-                    for (int jx = 0; jx < 4; ++jx) {
-                        const int kk = (int)k + 4 * half + jx;
-                        if (kk < D) {
-                            const float v = a[4 * g + jx];
-                            if (type == PK_DIAG) {
-                                const float ld = expf(v);                          // exp(diag M): vi.py:686
-                                xp[kk] += ld * ep[kk];
-                                ent_acc += v;
-                                if (i < dm.nb) ldT[(int64_t)kk * dm.nb + i] = ld;
-                            } else {
-                                xp[kk] += v;                                       // loc head (vi.py:450)
-                            }
-                        }
+            for (int g = 0; g < 4; ++g) {                      // rows (k, l0 + 4half + j) live in a[4g + j]
+                const float part = a[4 * g + 0] * e4[g].x + a[4 * g + 1] * e4[g].y + a[4 * g + 2] * e4[g].z +
+                                   a[4 * g + 3] * e4[g].w;
+                if (kq[g] != cur_k) { flush(); cur_k = kq[g]; cur_part = part; }      // wave-uniform
+                else cur_part += part;
+            }
+        };
+        {
+            float4 A0[2][4], A1[2][4], A2[2][4];
+            float bA0, bA1, bA2;
+            uint4 g0, g1, g2;
+            prefetch(A0, bA0, g0, 0);
+            prefetch(A1, bA1, g1, 1);
+            for (int tt = 0; tt < n_off; tt += 3) {            // straight-line body; tiles n_off, n_off+1 exist (DIAG)
+                prefetch(A2, bA2, g2, tt + 2);
+                tile_off(A0, bA0, g0);
+                prefetch(A0, bA0, g0, tt + 3);
+                tile_off(A1, bA1, g1);
+                prefetch(A1, bA1, g1, tt + 4);
+                tile_off(A2, bA2, g2);
+            }
+            flush();
+        }
+        // ---- DIAG section (exp(M_kk) eps_k, entropy, ldT) and LOC section (the loc head): 2 * n_sec small tiles
+        for (int tt = n_off; tt < n_off + 2 * n_sec; ++tt) {
+            float4 A[2][4];
+            float bA;
+            uint4 gc;
+            prefetch(A, bA, gc, tt);
+            const f32x16 a = mma(A, bA);
+            const bool is_diag = tt < n_off + n_sec;
+            const int k0 = 32 * (tt - (is_diag ? n_off : n_off + n_sec));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = k0 + crow32(r, half);
+                if (kk < D) {
+                    if (is_diag) {
+                        const float ld = expf(a[r]);                               // exp(diag M): vi.py:686
+                        xp[kk] += ld * ep[kk];
+                        ent_acc += a[r];
+                        if (i < dm.nb) ldT[(int64_t)kk * dm.nb + i] = ld;
+                    } else {
+                        xp[kk] += a[r];                                            // loc head (vi.py:450)
                     }
                 }
             }
-        };
-        // three register sets: the weights of tile t+2 are requested while tile t computes (L2 latency under
-        // load exceeds one 33-MFMA tile)
-        float4 A0[2][4], A1[2][4], A2[2][4];
-        float bA0 = 0.f, bA1 = 0.f, bA2 = 0.f;
-        uint4 g0 = make_uint4(0, 0, 0, 0), g1 = make_uint4(0, 0, 0, 0), g2 = make_uint4(0, 0, 0, 0);
-        prefetch(A0, bA0, g0, 0);
-        if (1 < n_rt) prefetch(A1, bA1, g1, 1);
-        for (int tt = 0; tt < n_rt; tt += 3) {
-            if (tt + 2 < n_rt) prefetch(A2, bA2, g2, tt + 2);
-            tile(A0, bA0, g0);
-            if (tt + 3 < n_rt) prefetch(A0, bA0, g0, tt + 3);
-            if (tt + 1 < n_rt) tile(A1, bA1, g1);
-            if (tt + 4 < n_rt) prefetch(A1, bA1, g1, tt + 4);
-            if (tt + 2 < n_rt) tile(A2, bA2, g2);
         }
-        flush();
     }
     __builtin_amdgcn_wave_barrier();
     // ---------------------------------------------------------------- write x, entropy part

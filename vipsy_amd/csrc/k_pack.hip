@@ -3,10 +3,12 @@
 // The reference stores fc22's rows in torch.tril_indices order (vi.py:453): (0,0),(1,0),(1,1),(2,0),...  For the
 // MFMA kernels a 32-row tile of that order mixes several (k, l) runs and forces a per-element decode.  The packed
 // order (rebuilt from the flat parameters by k_pack_heads every step, 1.4 MB, a few microseconds) is
-//   section OFF : for k = 1..D-1 the entries (k, 0..k-1), each k padded with zero rows to a multiple of 8
-//   section DIAG: (k,k) for k = 0..D-1, padded to a multiple of 8
-//   section LOC : fc21 rows k = 0..D-1, padded to a multiple of 8
-//   tail        : zero rows up to a multiple of 32
+//   section OFF : for k = 1..D-1 the entries (k, 0..k-1), each k padded with zero rows to a multiple of 8;
+//                 the section itself padded to a multiple of 96 rows (the forward kernel walks it 3 tiles at a time)
+//   section DIAG: (k,k) for k = 0..D-1, padded to a multiple of 32
+//   section LOC : fc21 rows k = 0..D-1, padded to a multiple of 32
+//   tail        : zero rows up to a multiple of 64
+// so a 32-row tile never mixes sections (the kernels run one branch-free loop per section),
 // so every aligned group of 8 packed rows has ONE type and ONE k (OFF) and its l0 is a multiple of 8.
 // gtab[group] = type << 28 | k << 12 | l0   (DIAG / LOC groups: k = first k of the group).
 #pragma once
@@ -21,9 +23,9 @@ __host__ __device__ inline int pk_off_rows(int k) {          // packed rows befo
     const int m = k - 1, q = m / 8, rem = m % 8;
     return 8 * (8 * (q * (q + 1) / 2) + rem * (q + 1));
 }
-__host__ __device__ inline int pk_sec(int D) { return (D + 7) / 8 * 8; }
-__host__ __device__ inline int pk_off_total(int D) { return pk_off_rows(D); }
-__host__ __device__ inline int pk_rows(int D) { return (pk_off_total(D) + 2 * pk_sec(D) + 31) / 32 * 32; }
+__host__ __device__ inline int pk_sec(int D) { return (D + 31) / 32 * 32; }
+__host__ __device__ inline int pk_off_total(int D) { return (pk_off_rows(D) + 95) / 96 * 96; }   // whole groups of 3 tiles
+__host__ __device__ inline int pk_rows(int D) { return (pk_off_total(D) + 2 * pk_sec(D) + 63) / 64 * 64; }
 
 // packed row -> (source row in the concatenated [W22 rows 0..T-1 | W21 rows T..T+D-1] space, or -1), group code
 __device__ __forceinline__ void pk_decode(int pr, int D, int T, int& src, uint32_t& gcode) {
@@ -31,11 +33,15 @@ __device__ __forceinline__ void pk_decode(int pr, int D, int T, int& src, uint32
     src = -1;
     gcode = PK_NONE << 28;
     if (pr < offT) {
-        int k = 1;
-        while (k + 1 <= D - 1 && pk_off_rows(k + 1) <= pr) ++k;       // D <= 127: a short search
-        const int l = pr - pk_off_rows(k);
-        if (l < k) src = k * (k + 1) / 2 + l;
-        gcode = (PK_OFF << 28) | ((uint32_t)k << 12) | (uint32_t)(l & ~7);
+        if (pr < pk_off_rows(D)) {
+            int k = 1;
+            while (k + 1 <= D - 1 && pk_off_rows(k + 1) <= pr) ++k;   // D <= 127: a short search
+            const int l = pr - pk_off_rows(k);
+            if (l < k) src = k * (k + 1) / 2 + l;
+            gcode = (PK_OFF << 28) | ((uint32_t)k << 12) | (uint32_t)(l & ~7);
+        } else {
+            gcode = (PK_OFF << 28) | ((uint32_t)(D - 1) << 12);       // section padding: zero rows of the last k
+        }
     } else if (pr < offT + sec) {
         const int k = pr - offT;
         if (k < D) src = k * (k + 1) / 2 + k;
