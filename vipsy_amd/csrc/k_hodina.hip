@@ -113,7 +113,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
         float my_elbo = 0.f, my_gth = 0.f;
         const int cnt = (int)((dm.nb - grp * 64) < 64 ? (dm.nb - grp * 64) : 64);
         for (int pp = 0; pp < cnt; ++pp) {
-            const float th = __shfl(thv, pp, 64);
+            const float th = lane_bcast(thv, pp);
             const int64_t prow = __shfl(row, pp, 64);
             const uint8_t* yr = y + prow * J;
             // -- item side: lp0 = log Bern(y; g), lp1 = log Bern(y; 1 - s)   (p_cj in {g_j, 1 - s_j}, vi.py:82)
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
                     atomicAdd(&tab[qpat[u]], lp1 - lp0);               // f(S) = sum of delta_j over items with q_j = S
                 }
             }
-            base = wave_sum(base);
+            base = wave_sum_dpp(base);
             __builtin_amdgcn_wave_barrier();
             float Bc[CPL];
 #pragma unroll
@@ -144,12 +144,12 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
             const float tk = th * l1 + l0;
             const float pik = sigmoidf_(tk);
             float S0 = (lane < K) ? -softplusf_(tk) : 0.f;                 // log(1 - pi_k)
-            S0 = wave_sum(S0);
+            S0 = wave_sum_dpp(S0);
             float Ac[CPL];
 #pragma unroll
             for (int ii = 0; ii < CPL; ++ii) Ac[ii] = S0;
             for (int k = 0; k < K; ++k) {
-                const float t = __shfl(tk, k, 64);
+                const float t = lane_bcast(tk, k);
 #pragma unroll
                 for (int ii = 0; ii < CPL; ++ii)
                     if ((CPL * lane + ii) & (1 << k)) Ac[ii] += t;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
             bool ins[CPL];
 #pragma unroll
             for (int ii = 0; ii < CPL; ++ii) { const int c = CPL * lane + ii; pr[ii] = (c < C) ? __expf(Ac[ii]) : 0.f; psum += pr[ii]; }
-            psum = wave_sum(psum);
+            psum = wave_sum_dpp(psum);
             float fmx = -3.0e38f;
 #pragma unroll
             for (int ii = 0; ii < CPL; ++ii) {
@@ -170,17 +170,17 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
                 fc[ii] = (c < C) ? lg + base + Bc[ii] : -3.0e38f;
                 fmx = fmaxf(fmx, fc[ii]);
             }
-            fmx = wave_max(fmx);
+            fmx = wave_max_dpp(fmx);
             float rs = 0.f, rc[CPL];
 #pragma unroll
             for (int ii = 0; ii < CPL; ++ii) { rc[ii] = (CPL * lane + ii < C) ? __expf(fc[ii] - fmx) : 0.f; rs += rc[ii]; }
-            rs = wave_sum(rs);
+            rs = wave_sum_dpp(rs);
             const float lse = fmx + logf(rs);
             const float rinv = 1.0f / rs;
             float rins = 0.f;
 #pragma unroll
             for (int ii = 0; ii < CPL; ++ii) { rc[ii] *= rinv; rins += ins[ii] ? rc[ii] : 0.f; }
-            rins = wave_sum(rins);
+            rins = wave_sum_dpp(rins);
             float rho[CPL];
 #pragma unroll
             for (int ii = 0; ii < CPL; ++ii) rho[ii] = (ins[ii] ? rc[ii] : 0.f) - pr[ii] * rins;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
             if (lane < K) tau = tab[1 << lane] - pik * tab[0];
             gl0 += tau;
             gl1 += tau * th;
-            float gth = wave_sum(tau * l1);
+            float gth = wave_sum_dpp(tau * l1);
             gth -= th;                                                    // prior N(0,1)
             if (lane == pp) {
                 my_gth = gth;

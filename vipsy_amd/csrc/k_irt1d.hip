@@ -1,8 +1,11 @@
 // D = 1 IRT (irt_1pl..4pl with a Normal guide; vi.py:22-66, 588-595, 617-625, 684/705), one fused pass:
 // x = loc + exp(raw) eps -> masked Bernoulli log-lik -> prior/entropy -> gradients.
-// Layout: item-per-lane.  Each lane keeps the parameters and gradient accumulators of items
-// lane, lane+64, ... in registers; a wave walks its persons, the response row is read coalesced
-// (one byte per lane per 64-item slice), and only two values per person cross lanes.
+//
+// Layout: item-per-lane.  Lane l keeps the parameters and gradient accumulators of items 4l..4l+3 (+256, ...)
+// in registers; a wave walks its persons in groups of 64 (lane l also owns the per-person scalars of person
+// 64 g + l), the response row is read as one coalesced 4-byte word per lane per 256-item slice, the next
+// person's words are requested before the current one is evaluated, and the only cross-lane traffic is two
+// DPP wave reductions (log-lik, d/dx) per person -- no LDS in the person loop.
 #pragma once
 #include "vx_common.h"
 
@@ -14,7 +17,8 @@ struct Irt1dDims {
     int64_t nb;
 };
 
-template <int MODEL, int IPL>
+// WPL = 4-item words per lane (items 256 w + 4 lane + 0..3); J <= 1024 -> WPL <= 4
+template <int MODEL, int WPL, bool WORDS>
 __global__ __launch_bounds__(I1_THREADS) void k_irt1d(
     Irt1dDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, int64_t gid0,
     const float* __restrict__ loc, const float* __restrict__ raw, const float* __restrict__ eps_in,
@@ -22,16 +26,16 @@ __global__ __launch_bounds__(I1_THREADS) void k_irt1d(
     const float* __restrict__ c_un, const float* __restrict__ d_un, float* __restrict__ gloc,
     float* __restrict__ graw, float* __restrict__ elbo, float* __restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [4*J] block-level item-grad reduction
+    constexpr int IPL = 4 * WPL;
     const int J = dm.J;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t n_waves = (int64_t)gridDim.x * (I1_THREADS / 64);
     const int64_t wg = (int64_t)blockIdx.x * (I1_THREADS / 64) + wave;
-    // persons are handed out in groups of 64 so that lane l owns person g*64 + l of each group
     const int64_t n_groups = (dm.nb + 63) / 64;
     float aq[IPL], bq[IPL], cq[IPL], dq[IPL], oq[IPL], ga[IPL], gb[IPL], gc[IPL], gd[IPL];
 #pragma unroll
     for (int q = 0; q < IPL; ++q) {
-        const int j = lane + 64 * q;
+        const int j = 256 * (q >> 2) + 4 * lane + (q & 3);
         const bool ok = j < J;
         aq[q] = (MODEL >= 2) ? (ok ? a[j] : 0.f) : 1.0f;
         bq[q] = ok ? b[j] : 0.f;
@@ -40,6 +44,24 @@ __global__ __launch_bounds__(I1_THREADS) void k_irt1d(
         oq[q] = (MODEL >= 4 && ok) ? fmaxf(sigmoidf_(-d_un[j]), VX_EPS32) : 0.f;
         ga[q] = gb[q] = gc[q] = gd[q] = 0.f;
     }
+    // one person's response words for this lane; 254 = outside the problem (j >= J)
+    auto load_words = [&](uint32_t (&w)[WPL], int64_t prow) {
+        const uint8_t* yr = y + prow * J;
+#pragma unroll
+        for (int u = 0; u < WPL; ++u) {
+            const int j0 = 256 * u + 4 * lane;
+            if (WORDS) {                                   // J % 4 == 0: a word is entirely inside or outside
+                uint32_t v = 0xFEFEFEFEu;
+                if (j0 < J) v = *(const uint32_t*)(yr + j0);
+                w[u] = v;
+            } else {
+                uint32_t v = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v |= (uint32_t)((j0 + e < J) ? yr[j0 + e] : 254u) << (8 * e);
+                w[u] = v;
+            }
+        }
+    };
     for (int64_t grp = wg; grp < n_groups; grp += n_waves) {
         const int64_t i = grp * 64 + lane;
         const bool valid = i < dm.nb;
@@ -52,33 +74,43 @@ __global__ __launch_bounds__(I1_THREADS) void k_irt1d(
         }
         const float sig = __expf(r);
         const float xv = l + sig * e;
+        const int row_lo = (int)(uint32_t)row, row_hi = (int)(uint32_t)((uint64_t)row >> 32);
         float my_ll = 0.f, my_gx = 0.f;
         const int cnt = (int)((dm.nb - grp * 64) < 64 ? (dm.nb - grp * 64) : 64);
+        uint32_t wcur[WPL], wnext[WPL];
+        {
+            const int64_t prow = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(row_hi, 0) << 32) |
+                                           (uint32_t)__builtin_amdgcn_readlane(row_lo, 0));
+            load_words(wcur, prow);
+        }
         for (int pp = 0; pp < cnt; ++pp) {
-            const float x = __shfl(xv, pp, 64);
-            const int64_t prow = __shfl(row, pp, 64);
-            const uint8_t* yr = y + prow * J;
+            const int pn = (pp + 1 < cnt) ? pp + 1 : pp;                    // prefetch the next person's words
+            {
+                const int64_t prow = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(row_hi, pn) << 32) |
+                                               (uint32_t)__builtin_amdgcn_readlane(row_lo, pn));
+                load_words(wnext, prow);
+            }
+            const float x = lane_bcast(xv, pp);
             float llp = 0.f, gxp = 0.f;
 #pragma unroll
             for (int q = 0; q < IPL; ++q) {
-                const int j = lane + 64 * q;
-                if (j < J) {
-                    const unsigned yy = yr[j];
-                    const float z = dm.Dc * (x * aq[q] + bq[q]);
-                    float lp, dz, dc, dd;
-                    irt_cell<MODEL>(z, yy, cq[q], dq[q], oq[q], lp, dz, dc, dd);
-                    const float t = dm.Dc * dz;
-                    llp += lp;
-                    gxp += t * aq[q];
-                    gb[q] += t;
-                    if (MODEL >= 2) ga[q] += t * x;
-                    if (MODEL >= 3) gc[q] += dc;
-                    if (MODEL >= 4) gd[q] += dd;
-                }
+                const unsigned yy = (wcur[q >> 2] >> (8 * (q & 3))) & 0xFFu;
+                const float z = dm.Dc * fmaf(x, aq[q], bq[q]);
+                float lp, dz, dc, dd;
+                irt_cell<MODEL>(z, yy, cq[q], dq[q], oq[q], lp, dz, dc, dd);    // branch-free; y >= 254 -> no gradient
+                const float t = dm.Dc * dz;
+                llp += lp;
+                gxp = fmaf(t, aq[q], gxp);
+                gb[q] += t;
+                if (MODEL >= 2) ga[q] = fmaf(t, x, ga[q]);
+                if (MODEL >= 3) gc[q] += dc;
+                if (MODEL >= 4) gd[q] += dd;
             }
-            llp = wave_sum(llp);
-            gxp = wave_sum(gxp);
+            llp = wave_sum_dpp(llp);
+            gxp = wave_sum_dpp(gxp);
             if (lane == pp) { my_ll = llp; my_gx = gxp; }
+#pragma unroll
+            for (int u = 0; u < WPL; ++u) wcur[u] = wnext[u];
         }
         if (valid) {
             const float gxt = dm.scale * (my_gx - xv);                 // d ELBO / d x (likelihood + prior)
@@ -92,7 +124,7 @@ __global__ __launch_bounds__(I1_THREADS) void k_irt1d(
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < IPL; ++q) {
-        const int j = lane + 64 * q;
+        const int j = 256 * (q >> 2) + 4 * lane + (q & 3);
         if (j < J) {
             if (MODEL >= 2) atomicAdd(&smem[j], ga[q]);
             atomicAdd(&smem[J + j], gb[q]);

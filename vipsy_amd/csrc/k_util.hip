@@ -28,13 +28,24 @@ __global__ void k_philox_raw(uint32_t* __restrict__ out, int64_t gid0, int64_t n
     }
 }
 
-// out[i] = alpha * sum_s slabs[s * stride + i]   (s ascending -> deterministic)
-__global__ void k_reduce_slabs(const float* __restrict__ slabs, int64_t n_slabs, int64_t stride, int64_t len,
-                               float alpha, float* __restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
+// out[i] = alpha * sum_s slabs[s * stride + i].  Block = 64 columns x 4 slab groups (slab s goes to group s % 4,
+// summed in ascending s; the four group sums are added in fixed order) -> deterministic, and parallel enough
+// when there are many slabs but few columns (the D = 1 kernels: ~1000 slabs x 2000 columns).
+__global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ slabs, int64_t n_slabs, int64_t stride,
+                                                      int64_t len, float alpha, float* __restrict__ out) {
+    __shared__ float part[4][64];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    for (int64_t c0 = (int64_t)blockIdx.x * 64; c0 < len; c0 += (int64_t)gridDim.x * 64) {
+        const int64_t i = c0 + col;
         float acc = 0.f;
-        for (int64_t s = 0; s < n_slabs; ++s) acc += slabs[s * stride + i];
-        out[i] = alpha * acc;
+        if (i < len) {
+#pragma unroll 8
+            for (int64_t s = grp; s < n_slabs; s += 4) acc += slabs[s * stride + i];
+        }
+        part[grp][col] = acc;
+        __syncthreads();
+        if (grp == 0 && i < len) out[i] = alpha * ((part[0][col] + part[1][col]) + (part[2][col] + part[3][col]));
+        __syncthreads();
     }
 }
 

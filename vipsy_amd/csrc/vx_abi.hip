@@ -108,7 +108,7 @@ int vx_philox_raw(uint32_t* out, int64_t gid0, int64_t n, uint64_t seed, uint32_
 int vx_reduce_slabs(const float* slabs, int64_t n_slabs, int64_t len, float alpha, float* out, void* hs) {
     if (!slabs || !out || n_slabs < 1 || len < 0) return VX_EINVAL;
     if (len == 0) return VX_OK;
-    hipLaunchKernelGGL(k_reduce_slabs, dim3(grid_1d(len, 256)), dim3(256), 0, (hipStream_t)hs, slabs, n_slabs,
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(grid_1d(len, 64)), dim3(256), 0, (hipStream_t)hs, slabs, n_slabs,
                        len, len, alpha, out);
     VX_CHECK_LAUNCH();
     return VX_OK;
@@ -483,16 +483,17 @@ int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, 
     dm.J = cfg->J; dm.model = cfg->model; dm.Dc = cfg->Dc; dm.scale = cfg->scale; dm.nb = nb;
     const size_t lds = sizeof(float) * 4 * (size_t)cfg->J;
     hipStream_t st = (hipStream_t)hs;
-    const int ipl_need = (cfg->J + 63) / 64;
-#define LAUNCH_1D(MODEL, IPL)                                                                                \
-    hipLaunchKernelGGL((k_irt1d<MODEL, IPL>), dim3(blocks), dim3(I1_THREADS), lds, st, dm, y, rows, gid0, loc, raw, \
-                       eps_in, cfg->seed, cfg->step, cfg->stream, a, b, c_un, d_un, gloc, graw, elbo, workspace)
+    const int wpl_need = (cfg->J + 255) / 256;
+    const int words_ok = (cfg->J % 4 == 0 && aligned16(y)) ? 1 : 0;     // 4-byte response loads need aligned rows
+#define LAUNCH_1DW(MODEL, WPL, WORDS)                                                                         \
+    hipLaunchKernelGGL((k_irt1d<MODEL, WPL, WORDS>), dim3(blocks), dim3(I1_THREADS), lds, st, dm, y, rows, gid0, loc, \
+                       raw, eps_in, cfg->seed, cfg->step, cfg->stream, a, b, c_un, d_un, gloc, graw, elbo, workspace)
+#define LAUNCH_1D(MODEL, WPL)                                      \
+    if (words_ok) { LAUNCH_1DW(MODEL, WPL, true); } else { LAUNCH_1DW(MODEL, WPL, false); }
 #define DISPATCH_IPL(MODEL)                                        \
-    if (ipl_need <= 1) { LAUNCH_1D(MODEL, 1); }                    \
-    else if (ipl_need <= 2) { LAUNCH_1D(MODEL, 2); }               \
-    else if (ipl_need <= 4) { LAUNCH_1D(MODEL, 4); }               \
-    else if (ipl_need <= 8) { LAUNCH_1D(MODEL, 8); }               \
-    else { LAUNCH_1D(MODEL, 16); }
+    if (wpl_need <= 1) { LAUNCH_1D(MODEL, 1); }                    \
+    else if (wpl_need <= 2) { LAUNCH_1D(MODEL, 2); }               \
+    else { LAUNCH_1D(MODEL, 4); }
     switch (cfg->model) {
         case VX_IRT_1PL: DISPATCH_IPL(1) break;
         case VX_IRT_2PL: DISPATCH_IPL(2) break;
@@ -501,6 +502,7 @@ int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, 
     }
 #undef DISPATCH_IPL
 #undef LAUNCH_1D
+#undef LAUNCH_1DW
     VX_CHECK_LAUNCH();
     return vx_reduce_slabs(workspace, blocks, 4 * (int64_t)cfg->J, -1.0f, gitem, hs);
 }

@@ -79,34 +79,40 @@ __device__ __forceinline__ float softplusf_(float x) { return fmaxf(x, 0.f) + lo
 // 3PL/4PL: P = c + (d-c) s(z) and Q = 1-P = (1-d) + (d-c) s(-z) are both formed from positive terms
 // (omd = 1-d = sigmoid(-d_un) comes from the leaf), so (y-P)/(P(1-P)) = y ? 1/P : -1/Q keeps full
 // float32 accuracy where the reference's own float32 chain (sigmoid -> clamp -> log / log1p) loses it.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 template <int MODEL>
 __device__ __forceinline__ void irt_cell(float z, unsigned y, float c, float d, float omd, float& lp, float& dz,
                                          float& dc, float& dd) {
-    if (y == 255u) { lp = VX_LOGP_MISSING; dz = 0.f; dc = 0.f; dd = 0.f; return; }
+    // y >= 254: missing cell (255) or a cell outside the problem (254): no gradient; only 255 carries the
+    // reference's constant log Bern(0 | clamp(0))
+    const bool obs = y < 2u;
     if (MODEL <= 2) {
         const float yf = (float)y;
         const float ZL = 15.942384719848633f;       // logit(1 - eps32)
-        const bool inside = fabsf(z) <= ZL;
         const float zc = fminf(fmaxf(z, -ZL), ZL);
         const float e = __expf(-fabsf(zc));
-        const float sp = fmaxf(zc, 0.f) + log1pf(e);          // softplus(zc)
-        lp = yf * zc - sp;
-        const float sg = (zc >= 0.f) ? 1.0f / (1.0f + e) : e / (1.0f + e);
-        dz = inside ? (yf - sg) : 0.f;
+        const float r = fast_rcp(1.0f + e);
+        const float sp = fmaxf(zc, 0.f) + __logf(1.0f + e);   // softplus(zc); abs. error <= 6e-8
+        const float sg = (zc >= 0.f) ? r : e * r;
+        lp = obs ? fmaf(yf, zc, -sp) : (y == 255u ? VX_LOGP_MISSING : 0.f);
+        dz = (obs && zc == z) ? (yf - sg) : 0.f;              // zero gradient where the clamp is active
         dc = 0.f; dd = 0.f;
     } else {
         const float e = __expf(-fabsf(z));
-        const float r = 1.0f / (1.0f + e);
+        const float r = fast_rcp(1.0f + e);
         const float sg = (z >= 0.f) ? r : e * r;             // sigmoid(z)
         const float sn = (z >= 0.f) ? e * r : r;             // sigmoid(-z) = 1 - sg, no cancellation
         const float dmc = d - c;
         const float P = c + dmc * sg;
         const float Q = omd + dmc * sn;
-        const bool inside = (P >= VX_EPS32) && (Q >= VX_EPS32);
+        const bool inside = obs && (P >= VX_EPS32) && (Q >= VX_EPS32);
         const float Pc = fminf(fmaxf(P, VX_EPS32), 1.0f - VX_EPS32);
         const float Qc = fminf(fmaxf(Q, VX_EPS32), 1.0f - VX_EPS32);
-        lp = (y != 0u) ? logf(Pc) : logf(Qc);
-        const float dP = inside ? ((y != 0u) ? 1.0f / Pc : -1.0f / Qc) : 0.f;
+        const float sel = (y == 1u) ? Pc : Qc;
+        lp = obs ? __logf(sel) : (y == 255u ? VX_LOGP_MISSING : 0.f);
+        const float inv = fast_rcp(sel);
+        const float dP = inside ? ((y == 1u) ? inv : -inv) : 0.f;
         dz = dP * dmc * sg * sn;
         dc = dP * sn * c * (1.0f - c);               // w.r.t. unconstrained c (sigmoid transform)
         dd = (MODEL == 4) ? dP * sg * d * omd : 0.f;
@@ -120,6 +126,39 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// DPP wave reductions (VALU speed; __shfl_xor lowers to ds_bpermute, an LDS-pipe round trip per step).
+// After the six steps lane 63 holds the wave total; v_readlane broadcasts it through an SGPR.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov0(float v) {           // lanes not written (or reading out of range) get 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, true));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_movv(float v, float old) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_mov0<0xB1, 0xF>(v);          // quad_perm [1,0,3,2]
+    v += dpp_mov0<0x4E, 0xF>(v);          // quad_perm [2,3,0,1]
+    v += dpp_mov0<0x141, 0xF>(v);         // row_half_mirror
+    v += dpp_mov0<0x140, 0xF>(v);         // row_mirror          -> every lane holds its 16-lane row sum
+    v += dpp_mov0<0x142, 0xA>(v);         // row_bcast:15 into rows 1 and 3
+    v += dpp_mov0<0x143, 0xC>(v);         // row_bcast:31 into rows 2 and 3 -> lane 63 = wave sum
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = fmaxf(v, dpp_movv<0xB1, 0xF>(v, v));
+    v = fmaxf(v, dpp_movv<0x4E, 0xF>(v, v));
+    v = fmaxf(v, dpp_movv<0x141, 0xF>(v, v));
+    v = fmaxf(v, dpp_movv<0x140, 0xF>(v, v));
+    v = fmaxf(v, dpp_movv<0x142, 0xA>(v, v));
+    v = fmaxf(v, dpp_movv<0x143, 0xC>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane_uniform) {      // lane index must be wave-uniform
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane_uniform));
 }
 
 #define VX_CHECK_LAUNCH()                                  \
