@@ -121,6 +121,17 @@ int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, 
                   float* gloc, float* graw, float* elbo, float* gitem, float* workspace,
                   void* hip_stream);
 
+/* ---- black-box MVN guide with per-person or shared Cholesky rows (VIRT.guide, x_feature > 1, vi.py:706-723).
+ *   loc: [n_local][D];  M: [n_local][D][D] unconstrained (shared == 0) or [D][D] (shared == 1, share_cov=True)
+ *   forward : x[nb][D] = loc[row] + L eps, eps[nb][D], ent[nb] = 0.5|eps|^2 + sum_k M_kk
+ *   backward: gloc[n_local][D], gM (same shape as M) = d LOSS / d loc, M for the batch rows; the caller zeroes
+ *             both buffers first (dense per-person gradients, zero off the batch; shared M accumulates). */
+int vx_mvn_bbvi_forward(const vx_irt_cfg* cfg, int64_t nb, const int64_t* rows, int64_t gid0, const float* loc,
+                        const float* M, int32_t shared, const float* eps_in, float* x, float* eps, float* ent,
+                        void* hip_stream);
+int vx_mvn_bbvi_backward(const vx_irt_cfg* cfg, int64_t nb, const int64_t* rows, const float* M, int32_t shared,
+                         const float* gx, const float* eps, float* gloc, float* gM, void* hip_stream);
+
 /* ---- amortized Normal guide for ONE latent dimension (NormEncoder, vi.py:417-435; VaeIRT with
  * x_feature == 1, vi.py:677-684, and VaeCHoDina, vi.py:968-981).  cfg->J, cfg->H are used.
  *   forward : h[nb][H] = softplus(fc1 yin), loc[nb] = fc21 h, raw[nb] = fc22 h  (scale = exp(raw))

@@ -26,7 +26,7 @@ def _engine_from_fixture(tag):
     else:
         eng = IrtEngine(yt, model=spec["model"], D=spec["D"], Dc=spec["Dc"], amortized=spec["amortized"],
                         H=(enc["fc1.weight"].shape[0] if enc else 0), encoder_init=enc if enc else None,
-                        b0=params["b"], seed=1)
+                        b0=params["b"], share_cov=spec["share_cov"], seed=1)
     for name in eng.all_names():                      # fixture-specific initial values (e.g. pre-seeded lam1)
         eng.unconstrained(name).copy_(torch.from_numpy(np.asarray(params[name], np.float32)).reshape(
             eng.unconstrained(name).shape))
@@ -66,7 +66,8 @@ def test_philox_normals_match_oracle(D):
 GOLDEN_HIP = ["vaeirt_irt_2pl_d3", "vaeirt_irt_3pl_d2", "vaeirt_irt_4pl_d4",
               "virt_irt_1pl_d1", "virt_irt_2pl_d1", "virt_irt_3pl_d1", "virt_irt_4pl_d1", "virt_irt_2pl_d1_D1702",
               "vaeirt_irt_2pl_d1", "vaeirt_irt_4pl_d1",
-              "vchodina_k3", "vchodina_k4_sub", "vchodina_k4_clamp", "vaechodina_k3"]
+              "vchodina_k3", "vchodina_k4_sub", "vchodina_k4_clamp", "vaechodina_k3",
+              "virt_irt_2pl_d3_perperson", "virt_irt_2pl_d3_share"]
 
 
 @pytest.mark.parametrize("tag", GOLDEN_HIP)
@@ -86,7 +87,7 @@ def test_hip_replays_reference_steps(tag):
         assert loss_h == pytest.approx(loss_o, rel=2e-5), (tag, t)
         assert loss_h == pytest.approx(rec["loss"], rel=2e-4), (tag, t)
         for name, go in g_o.items():
-            gh = eng.unconstrained(name, eng.GP if name in eng.pp_names else eng.G).cpu().numpy()
+            gh = eng.unconstrained(name, eng.GP if (eng.per_person and name in eng.pp_off) else eng.G).cpu().numpy()
             if name == "a" and spec.get("a_free") is not None:
                 gh = gh * spec["a_free"]
             sc = max(1e-3, float(np.abs(go).max()))
@@ -187,7 +188,7 @@ def test_irt1d_step_vs_oracle(N, J, model, miss, B):
     loss_o, g_o = vo.loss_and_grads(spec, params, y, [idx], [eps])
     assert float(eng.G[eng.n_params].item()) == pytest.approx(loss_o, rel=3e-5)
     for name, go in g_o.items():
-        gh = eng.unconstrained(name, eng.GP if name in ("x_local", "x_scale") else eng.G).cpu().numpy()
+        gh = eng.unconstrained(name, eng.GP if (eng.per_person and name in eng.pp_off) else eng.G).cpu().numpy()
         sc = max(1e-6, float(np.abs(go).max()))
         assert np.abs(gh - go).max() / sc < 2e-4, name
 
@@ -270,7 +271,7 @@ def test_hodina_step_vs_oracle(N, J, K, miss, B, amort):
     loss_o, g_o = vo.loss_and_grads(spec, params, y, [idx], [eps])
     assert float(eng.G[eng.n_params].item()) == pytest.approx(loss_o, rel=5e-5)
     for name, go in g_o.items():
-        gh = eng.unconstrained(name, eng.GP if name in eng.pp_names else eng.G).cpu().numpy()
+        gh = eng.unconstrained(name, eng.GP if (eng.per_person and name in eng.pp_off) else eng.G).cpu().numpy()
         sc = max(1e-6, float(np.abs(go).max()))
         assert np.abs(gh - go).max() / sc < 5e-4, (name, np.abs(gh - go).max() / sc)
 
@@ -301,5 +302,35 @@ def test_irt1d_amortized_step_vs_oracle(N, J, model, miss, B):
     assert float(eng.G[eng.n_params].item()) == pytest.approx(loss_o, rel=3e-5)
     for name, go in g_o.items():
         gh = eng.unconstrained(name, eng.G).cpu().numpy()
+        sc = max(1e-6, float(np.abs(go).max()))
+        assert np.abs(gh - go).max() / sc < 3e-4, (name, np.abs(gh - go).max() / sc)
+
+
+@pytest.mark.parametrize("N,J,D,share,B", [(300, 64, 20, False, None), (257, 40, 100, False, 50), (200, 33, 9, True, 64)])
+def test_mvn_bbvi_step_vs_oracle(N, J, D, share, B):
+    """VIRT with x_feature > 1: per-person / shared Cholesky rows (vi.py:706-723)."""
+    from vipsy_amd.engine import IrtEngine
+    rng = np.random.RandomState(N + D)
+    y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+    y[rng.rand(N, J) < 0.15] = 255
+    eng = IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_2pl", D=D, share_cov=share, seed=13)
+    eng.unconstrained("b").copy_(torch.from_numpy(0.5 * rng.randn(1, J)).float())
+    eng.unconstrained("x_local").copy_(torch.from_numpy(0.5 * rng.randn(N, D)).float())
+    eng.unconstrained("x_scale").copy_(torch.from_numpy(0.2 * rng.randn(*eng.unconstrained("x_scale").shape)).float())
+    idx = np.arange(N) if B is None else np.sort(rng.permutation(N)[:B])
+    rows = None if B is None else torch.from_numpy(idx).to(_dev())
+    eng.loss_and_grads(rows, len(idx))
+    torch.cuda.synchronize()
+    eps = eng.last["fw"]["eps"][:len(idx) * D].reshape(len(idx), D).cpu().numpy()
+    np.testing.assert_allclose(eps, vo.philox_normals(13, 0, 0, idx, D), atol=2e-5)
+    spec = {"family": "irt", "model": "irt_2pl", "D": D, "Dc": 1.0, "N": N, "amortized": False, "share_cov": share,
+            "a_free": vo.default_a_free(D, J)}
+    params = {n: eng.unconstrained(n).cpu().numpy().astype(np.float64) for n in eng.all_names()}
+    loss_o, g_o = vo.loss_and_grads(spec, params, y, [idx], [eps])
+    assert float(eng.G[eng.n_params].item()) == pytest.approx(loss_o, rel=3e-5)
+    for name, go in g_o.items():
+        gh = eng.unconstrained(name, eng.GP if (eng.per_person and name in eng.pp_off) else eng.G).cpu().numpy()
+        if name == "a":
+            gh = gh * spec["a_free"]
         sc = max(1e-6, float(np.abs(go).max()))
         assert np.abs(gh - go).max() / sc < 3e-4, (name, np.abs(gh - go).max() / sc)

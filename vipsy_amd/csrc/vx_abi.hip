@@ -11,6 +11,7 @@
 #include "k_irt1d.hip"
 #include "k_hodina.hip"
 #include "k_norm_enc.hip"
+#include "k_mvn_bbvi.hip"
 
 #include <cstdlib>
 
@@ -505,6 +506,36 @@ int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, 
 #undef LAUNCH_1DW
     VX_CHECK_LAUNCH();
     return vx_reduce_slabs(workspace, blocks, 4 * (int64_t)cfg->J, -1.0f, gitem, hs);
+}
+
+// ------------------------------------------------------------------------------------------------
+int vx_mvn_bbvi_forward(const vx_irt_cfg* cfg, int64_t nb, const int64_t* rows, int64_t gid0, const float* loc,
+                        const float* M, int32_t shared, const float* eps_in, float* x, float* eps, float* ent,
+                        void* hs) {
+    if (!cfg || cfg->D < 2 || cfg->D > 128 || !loc || !M || !x || !eps || !ent || nb < 0) return VX_EINVAL;
+    if (nb == 0) return VX_OK;
+    int64_t blocks = (nb + 3) / 4;
+    if (blocks > (int64_t)num_cu() * 8) blocks = (int64_t)num_cu() * 8;
+    hipLaunchKernelGGL(k_mvn_bbvi_fwd, dim3((unsigned)blocks), dim3(BB_THREADS), 0, (hipStream_t)hs, (int)cfg->D, nb, rows,
+                       gid0, loc, M, (int)shared, eps_in, cfg->seed, cfg->step, cfg->stream, x, eps, ent);
+    VX_CHECK_LAUNCH();
+    return VX_OK;
+}
+
+int vx_mvn_bbvi_backward(const vx_irt_cfg* cfg, int64_t nb, const int64_t* rows, const float* M, int32_t shared,
+                         const float* gx, const float* eps, float* gloc, float* gM, void* hs) {
+    if (!cfg || cfg->D < 2 || cfg->D > 128 || !M || !gx || !eps || !gloc || !gM || nb < 0) return VX_EINVAL;
+    if (nb == 0) return VX_OK;
+    int64_t blocks = (nb + 3) / 4;
+    const int64_t cap = shared ? (int64_t)num_cu() : (int64_t)num_cu() * 8;
+    if (blocks > cap) blocks = cap;
+    const size_t lds = shared ? sizeof(float) * (size_t)cfg->D * cfg->D : 0;
+    int rc = set_lds(k_mvn_bbvi_bwd, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mvn_bbvi_bwd, dim3((unsigned)blocks), dim3(BB_THREADS), lds, (hipStream_t)hs, (int)cfg->D, nb,
+                       cfg->scale, rows, M, (int)shared, gx, eps, gloc, gM);
+    VX_CHECK_LAUNCH();
+    return VX_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -91,6 +91,17 @@ class HipBackend(object):
                                   _hip.ptr(ws), _hip.stream_ptr())
         _hip.check(rc, "vx_irt1d_grad")
 
+    def mvn_bbvi_forward(self, cfg, nb, rows, gid0, loc, M, shared, eps_in, x, eps, ent):
+        rc = self.L.vx_mvn_bbvi_forward(ctypes.byref(cfg), nb, _hip.ptr(rows), gid0, _hip.ptr(loc), _hip.ptr(M),
+                                        int(shared), _hip.ptr(eps_in), _hip.ptr(x), _hip.ptr(eps), _hip.ptr(ent),
+                                        _hip.stream_ptr())
+        _hip.check(rc, "vx_mvn_bbvi_forward")
+
+    def mvn_bbvi_backward(self, cfg, nb, rows, M, shared, gx, eps, gloc, gM):
+        rc = self.L.vx_mvn_bbvi_backward(ctypes.byref(cfg), nb, _hip.ptr(rows), _hip.ptr(M), int(shared), _hip.ptr(gx),
+                                         _hip.ptr(eps), _hip.ptr(gloc), _hip.ptr(gM), _hip.stream_ptr())
+        _hip.check(rc, "vx_mvn_bbvi_backward")
+
     def norm_enc_forward(self, cfg, y, rows, nb, enc, out):
         rc = self.L.vx_norm_enc_forward(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb,
                                         _hip.ptr(enc["fc1.weight"]), _hip.ptr(enc["fc1.bias"]),
@@ -190,7 +201,14 @@ class _EngineBase(object):
         self.free = torch.ones(n_params, **f32)
         self.per_person = per_person
         if per_person:
-            self.pp_len = 2 * n_local
+            if not hasattr(self, "pp_shape"):
+                self.pp_shape = {self.pp_names[0]: (n_local, 1), self.pp_names[1]: (n_local, 1)}
+            self.pp_off, o = {}, 0
+            for nme in self.pp_names:
+                if nme in self.pp_shape:
+                    self.pp_off[nme] = o
+                    o += int(np.prod(self.pp_shape[nme]))
+            self.pp_len = o
             self.PP = torch.zeros(self.pp_len, **f32)
             self.GP = torch.zeros(self.pp_len, **f32)
             self.MP = torch.zeros(self.pp_len, **f32)
@@ -207,10 +225,10 @@ class _EngineBase(object):
         return buf[o:o + int(np.prod(self.shape[name]))]
 
     def unconstrained(self, name, buf=None):
-        if name in self.pp_names:
+        if self.per_person and name in self.pp_off:
             b = self.PP if buf is None else buf
-            n = self.n_local
-            return (b[:n] if name == self.pp_names[0] else b[n:]).reshape(n, 1)
+            o = self.pp_off[name]
+            return b[o:o + int(np.prod(self.pp_shape[name]))].reshape(self.pp_shape[name])
         return self.view(name, buf).reshape(self.shape[name])
 
     def _enc(self):
@@ -257,9 +275,8 @@ class _EngineBase(object):
         segs = _merge_segments(segs)
         self.be.adam(self.P, self.G, self.M, self.V, self.free, self.n_params, segs, self.t, lrs.betas, lrs.eps)
         if self.per_person:
-            n = self.n_local
-            segs = _merge_segments([(0, n, float(lrs.lr_of(self.pp_names[0]))),
-                                    (n, 2 * n, float(lrs.lr_of(self.pp_names[1])))])
+            segs = _merge_segments([(o, o + int(np.prod(self.pp_shape[nme])), float(lrs.lr_of(nme)))
+                                    for nme, o in self.pp_off.items()])
             self.be.adam(self.PP, self.GP, self.MP, self.VP, None, self.pp_len, segs, self.t, lrs.betas, lrs.eps)
 
     def step(self, lrs, rows=None, b_global=None, eps=None, num_particles=1):
@@ -310,8 +327,6 @@ class IrtEngine(_EngineBase):
         self.amortized, self.H, self.share_cov = bool(amortized), int(H) if amortized else 0, bool(share_cov)
         self.seed, self.group = int(seed), group
         J, Dd = self.J, self.D
-        if not self.amortized and Dd > 1:
-            raise NotImplementedError("BBVI with x_feature > 1 (per-person Cholesky rows) is not on the HIP path yet")
         self.off = {"a": 0, "b": Dd * J, "c": Dd * J + J, "d": Dd * J + 2 * J}
         self.shape = {"a": (Dd, J), "b": (1, J), "c": (1, J), "d": (1, J)}
         self.n_item = Dd * J + 3 * J
@@ -328,6 +343,15 @@ class IrtEngine(_EngineBase):
             self.n_enc = o - self.enc_off0
         else:
             o = self.n_item
+            if Dd > 1:                                    # VIRT.guide for x_feature > 1 (vi.py:706-723)
+                if self.share_cov:                        # one (D, D) Cholesky factor, replicated like an item parameter
+                    o = (self.n_item + 63) // 64 * 64
+                    self.off["x_scale"] = o
+                    self.shape["x_scale"] = (Dd, Dd)
+                    o += Dd * Dd
+                    self.pp_shape = {"x_local": (self.n_local, Dd)}
+                else:
+                    self.pp_shape = {"x_local": (self.n_local, Dd), "x_scale": (self.n_local, Dd, Dd)}
         self._alloc(o, self.n_local, per_person=not self.amortized)
         # reference initial values (vi.py:567-587)
         a_init = torch.ones(Dd, J) if a0 is None else torch.as_tensor(a0, dtype=torch.float32).reshape(Dd, J).clone()
@@ -365,17 +389,22 @@ class IrtEngine(_EngineBase):
             out.append("d")
         if self.amortized:
             out += ["encoder$$$" + k for k in ENC_KEYS]
+        elif self.D > 1 and self.share_cov:
+            out.append("x_scale")
         return out
 
     def all_names(self):
-        return self.names() + (list(self.pp_names) if self.per_person else [])
+        return self.names() + (list(self.pp_off) if self.per_person else [])
 
     def param(self, name):
         u = self.unconstrained(name)
         if name in ("c", "d"):
             return torch.sigmoid(u)
         if name == "x_scale":
-            return torch.exp(u)
+            if self.D == 1:
+                return torch.exp(u)
+            diag = torch.diagonal(u, dim1=-2, dim2=-1)                # lower_cholesky transform (vi.py:712,720)
+            return torch.tril(u, -1) + torch.diag_embed(torch.exp(diag))
         return u.clone()
 
     # -- one ELBO-gradient step ------------------------------------------------------------------
@@ -392,7 +421,31 @@ class IrtEngine(_EngineBase):
         a = self.view("a") if self.model != "irt_1pl" else None
         gitem = self.G[:self.n_item]
         lossslot = self.G[self.n_params:self.n_params + 1]
-        if self.D > 1:
+        if self.D > 1 and not self.amortized:
+            D, n = self.D, self.n_local
+            fw = {"x": self._buf("x", nb * D), "eps": self._buf("eps", nb * D), "ent": self._buf("ent", nb)}
+            gx, ll = self._buf("gx", nb * D), self._buf("ll", nb)
+            lik_ws = self._buf("lik_ws", be.lik_workspace(cfg, nb))
+            loc = self.PP[:n * D]
+            if self.share_cov:
+                Mq, gM = self.view("x_scale"), self.view("x_scale", self.G)
+            else:
+                Mq, gM = self.PP[n * D:], self.GP[n * D:]
+            with self._phase("guide_forward"):
+                be.mvn_bbvi_forward(cfg, nb, rows, self.gid0, loc, Mq, self.share_cov, eps, fw["x"], fw["eps"], fw["ent"])
+            with self._phase("likelihood"):
+                be.lik_grad(cfg, self.y, rows, nb, fw["x"], a, self.view("b"), c_un, d_un, gx, ll, gitem, lik_ws)
+            with self._phase("guide_backward"):
+                self.GP.zero_()                                       # dense per-person grads: zero off the batch
+                if self.share_cov:
+                    gM.zero_()
+                be.mvn_bbvi_backward(cfg, nb, rows, Mq, self.share_cov, gx, fw["eps"], self.GP[:n * D], gM)
+            tmp = self._buf("loss2", 2)
+            be.sum_into(ll, nb, -scale, tmp[0:1], self.sum_ws)
+            be.sum_into(fw["ent"], nb, -scale, tmp[1:2], self.sum_ws)
+            torch.add(tmp[0:1], tmp[1:2], out=lossslot)
+            self.last = {"fw": fw, "gx": gx, "ll": ll, "nb": nb}
+        elif self.D > 1:
             D, H = self.D, self.H
             fw = {"h": self._buf("h", nb * H), "x": self._buf("x", nb * D), "eps": self._buf("eps", nb * D),
                   "ldT": self._buf("ldT", nb * D), "ent": self._buf("ent", nb)}
