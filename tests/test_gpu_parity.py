@@ -121,6 +121,9 @@ def _random_problem(N, J, D, H, model, miss, seed):
     (129, 260, 7, 64, "irt_4pl", 0.2, None),
     (64, 33, 2, 16, "irt_3pl", 0.5, 17),
     (1000, 600, 12, 64, "irt_2pl", 0.59, None),     # J > 512: two item groups
+    (200, 131, 101, 32, "irt_4pl", 0.2, 77),        # D >= 64: register-resident likelihood kernel, ragged staging
+    (150, 260, 64, 64, "irt_3pl", 0.1, None),
+    (130, 516, 127, 64, "irt_2pl", 0.3, None),
 ])
 def test_mvn_amortized_step_vs_oracle(N, J, D, H, model, miss, B):
     from vipsy_amd.engine import IrtEngine, ENC_KEYS

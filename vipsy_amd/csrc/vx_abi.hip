@@ -8,6 +8,7 @@
 #include "k_mvn_enc_bwd.hip"
 #include "k_mvn_enc_bwd_fast.hip"
 #include "k_irt_lik.hip"
+#include "k_irt_lik_r.hip"
 #include "k_irt1d.hip"
 #include "k_hodina.hip"
 #include "k_norm_enc.hip"
@@ -226,6 +227,22 @@ static void lik_plan(const vx_irt_cfg* cfg, int64_t nb, int& kt, int& nch, int& 
     if (n_pr < 1) n_pr = 1;
 }
 
+// register-resident variant (k_irt_lik_r.hip): one 128-item chunk per workgroup, D + 1 in (64, 128]
+static bool lik_r_shape(const vx_irt_cfg* cfg) {
+    static int old = -1;
+    if (old < 0) { const char* e = getenv("VX_LIK"); old = (e && e[0] == 'o') ? 1 : 0; }
+    return !old && !force_generic() && cfg->D >= 64 && cfg->D <= 127;
+}
+static void lik_r_plan(const vx_irt_cfg* cfg, int64_t nb, int& groups, int& n_pr) {
+    groups = (cfg->J + LR_JC - 1) / LR_JC;
+    const int64_t n_ptiles = (nb + LR_P - 1) / LR_P;
+    int64_t want = num_cu() / groups;
+    if (want < 1) want = 1;
+    if (want > n_ptiles) want = n_ptiles;
+    if (want >= 8) want &= ~7LL;                          // whole XCD rounds (see the kernel's block decode)
+    n_pr = (int)(want < 1 ? 1 : want);
+}
+
 static bool lik_cfg_ok(const vx_irt_cfg* cfg) {
     return cfg && cfg->D >= 2 && cfg->D <= 127 && cfg->J >= 1 && cfg->model >= VX_IRT_2PL &&
            cfg->model <= VX_IRT_4PL;
@@ -235,6 +252,7 @@ int64_t vx_irt_lik_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
     if (!lik_cfg_ok(cfg) || nb < 0) return VX_EINVAL;
     int kt, nch, groups, n_pr;
     lik_plan(cfg, nb, kt, nch, groups, n_pr);
+    if (lik_r_shape(cfg)) lik_r_plan(cfg, nb, groups, n_pr);
     const int64_t slab_len = (int64_t)cfg->D * cfg->J + 3 * (int64_t)cfg->J;
     int64_t w = (int64_t)n_pr * slab_len;
     if (groups > 1) w += (int64_t)groups * nb * (cfg->D + 1);
@@ -247,6 +265,53 @@ int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows
     if (!lik_cfg_ok(cfg) || !y || !x || !a || !b || !gx || !ll || !gitem || !workspace || nb < 0) return VX_EINVAL;
     if (cfg->model >= VX_IRT_3PL && !c_un) return VX_EINVAL;
     if (cfg->model == VX_IRT_4PL && !d_un) return VX_EINVAL;
+    if (lik_r_shape(cfg)) {
+        int groups, n_pr;
+        lik_r_plan(cfg, nb, groups, n_pr);
+        LikRDims dm;
+        dm.D = cfg->D; dm.J = cfg->J; dm.K8 = (cfg->D + 8) & ~7; dm.model = cfg->model;
+        { const int nq = dm.K8 >> 3; dm.XS = 8 * (nq <= 13 ? 13 : 16) + 4; }
+        dm.groups = groups; dm.n_pr = n_pr; dm.Dc = cfg->Dc; dm.scale = cfg->scale; dm.nb = nb;
+        dm.slab_len = (int64_t)cfg->D * cfg->J + 3 * (int64_t)cfg->J;
+        dm.fast = (cfg->D % 4 == 0 && cfg->J % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(gx) &&
+                   aligned16(workspace)) ? 1 : 0;
+        float* slabs = workspace;
+        float* gx_part = groups > 1 ? workspace + (int64_t)n_pr * dm.slab_len : gx;
+        float* ll_part = groups > 1 ? gx_part + (int64_t)groups * nb * cfg->D : ll;
+        hipStream_t st = (hipStream_t)hs;
+        hipError_t he = hipMemsetAsync(slabs, 0, sizeof(float) * (size_t)n_pr * dm.slab_len, st);
+        if (he != hipSuccess) return (int)he;
+        if (nb > 0) {
+            const size_t lds = likr_lds_bytes(dm.XS);
+            const dim3 grid((unsigned)(groups * n_pr));
+            int rc = VX_EINVAL;
+            const int nq = dm.K8 >> 3;                     // 9..16; instantiated: 13, 16 (extra rows are zeros)
+#define LAUNCH_LIKR(GEN, NQ, FAST)                                                                              \
+    rc = set_lds(k_irt_lik_r<GEN, NQ, FAST>, lds);                                                              \
+    if (rc) return rc;                                                                                          \
+    hipLaunchKernelGGL((k_irt_lik_r<GEN, NQ, FAST>), grid, dim3(LR_THREADS), lds, st, dm, y, rows, x, a, b,     \
+                       c_un, d_un, gx_part, ll_part, slabs)
+#define DISPATCH_LIKR(GEN, FAST)                            \
+    if (nq <= 13) { LAUNCH_LIKR(GEN, 13, FAST); }           \
+    else { LAUNCH_LIKR(GEN, 16, FAST); }
+            const int fastv = dm.fast ? (rows ? 2 : 1) : 0;
+            if (cfg->model >= VX_IRT_3PL) {
+                if (fastv == 2) { DISPATCH_LIKR(1, 2) } else if (fastv == 1) { DISPATCH_LIKR(1, 1) } else { DISPATCH_LIKR(1, 0) }
+            } else {
+                if (fastv == 2) { DISPATCH_LIKR(0, 2) } else if (fastv == 1) { DISPATCH_LIKR(0, 1) } else { DISPATCH_LIKR(0, 0) }
+            }
+#undef DISPATCH_LIKR
+#undef LAUNCH_LIKR
+            VX_CHECK_LAUNCH();
+            if (groups > 1) {
+                int r2 = vx_reduce_slabs(gx_part, groups, nb * cfg->D, 1.0f, gx, hs);
+                if (r2) return r2;
+                r2 = vx_reduce_slabs(ll_part, groups, nb, 1.0f, ll, hs);
+                if (r2) return r2;
+            }
+        }
+        return vx_reduce_slabs(slabs, n_pr, dm.slab_len, -1.0f, gitem, hs);
+    }
     int kt, nch, groups, n_pr;
     lik_plan(cfg, nb, kt, nch, groups, n_pr);
     LikDims dm;

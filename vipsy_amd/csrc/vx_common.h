@@ -88,15 +88,21 @@ __device__ __forceinline__ void irt_cell(float z, unsigned y, float c, float d, 
     // reference's constant log Bern(0 | clamp(0))
     const bool obs = y < 2u;
     if (MODEL <= 2) {
+        // 19 VALU + 3 transcendental issues (VALU issue time adds to fp32-MFMA time on gfx950: count them)
         const float yf = (float)y;
         const float ZL = 15.942384719848633f;       // logit(1 - eps32)
-        const float zc = fminf(fmaxf(z, -ZL), ZL);
-        const float e = __expf(-fabsf(zc));
-        const float r = fast_rcp(1.0f + e);
-        const float sp = fmaxf(zc, 0.f) + __logf(1.0f + e);   // softplus(zc); abs. error <= 6e-8
+        const float zc = __builtin_amdgcn_fmed3f(z, -ZL, ZL);
+        const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(zc));   // exp(-|zc|) in (1e-7, 1]
+        const float t = 1.0f + e;                                                   // in (1, 2]: no denormal care
+        const float r = fast_rcp(t);
+        const float sp = fmaf(__builtin_amdgcn_logf(t), 0.6931471805599453f, fmaxf(zc, 0.f));   // softplus(zc)
         const float sg = (zc >= 0.f) ? r : e * r;
-        lp = obs ? fmaf(yf, zc, -sp) : (y == 255u ? VX_LOGP_MISSING : 0.f);
-        dz = (obs && zc == z) ? (yf - sg) : 0.f;              // zero gradient where the clamp is active
+        // not observed: 255 (missing) carries the reference's constant, 254 (outside the problem) nothing
+        const float mval = fmaf(yf, VX_LOGP_MISSING, -254.0f * VX_LOGP_MISSING);
+        float lp0 = fmaf(yf, zc, -sp), d0 = yf - sg;
+        asm("" : "+v"(lp0), "+v"(d0));                       // keep the chain branch-free (no exec-mask skip per cell)
+        lp = obs ? lp0 : mval;
+        dz = (obs && zc == z) ? d0 : 0.f;                    // zero gradient where the clamp is active
         dc = 0.f; dd = 0.f;
     } else {
         const float e = __expf(-fabsf(z));
@@ -160,6 +166,23 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
 __device__ __forceinline__ float lane_bcast(float v, int lane_uniform) {      // lane index must be wave-uniform
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane_uniform));
 }
+
+// ---------------------------------------------------------------------------------------------
+// Global -> LDS DMA (gfx950 global_load_lds_dword / dwordx4): lane i's 4 / 16 bytes land at lds + i * 4 / 16; lanes
+// switched off by EXEC move nothing.  `lds` must be wave-uniform.  Issued through inline asm on purpose: the compiler
+// then neither knows nor waits (vmcnt) for it at the next LDS read, so the transfer overlaps the MFMA phases; the
+// kernel owns the `s_waitcnt vmcnt(0)` (vx_wait_vmem) that must precede the barrier publishing the data.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lds_addr_uniform(const void* lds) {
+    return __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) const void*)lds);
+}
+__device__ __forceinline__ void dma16(const void* gptr, uint32_t lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ void dma4(const void* gptr, uint32_t lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gptr), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ void vx_wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0) only
 
 #define VX_CHECK_LAUNCH()                                  \
     do {                                                   \
