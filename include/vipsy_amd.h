@@ -77,7 +77,10 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y /*[n_local][J]*/,
                        const float* b21, const float* W22 /*[T][H]*/, const float* b22,
                        const float* eps_in, float* h /*[nb][H]*/, float* x /*[nb][D]*/,
                        float* eps /*[nb][D]*/, float* ldT /*[D][nb]*/, float* ent /*[nb]*/,
+                       float* hT /*[H][nb] or NULL*/, float* epsT /*[D][nb] or NULL*/,
                        float* packws /*vx_mvn_pack_floats(cfg) floats or NULL*/, void* hip_stream);
+/* hT / epsT: optional dimension-major copies of h and eps (person-contiguous rows) for the weight-gradient kernel
+ * of vx_mvn_enc_backward; written only by the packed fast path (H == 64, D % 4 == 0, J % 4 == 0). */
 /* `packws` holds this step's packed copy of the head weights (a re-ordering of fc22 | fc21 rows that the
  * fast kernels use, see vipsy_amd/csrc/k_pack.hip); forward fills it, the matching backward call reads it. */
 int64_t vx_mvn_pack_floats(const vx_irt_cfg* cfg);
@@ -94,8 +97,9 @@ int64_t vx_irt_lik_workspace_floats(const vx_irt_cfg* cfg, int64_t nb);
 int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
                     const float* x /*[nb][D]*/, const float* a /*[D][J]*/, const float* b /*[J]*/,
                     const float* c_un /*[J] or NULL*/, const float* d_un /*[J] or NULL*/,
-                    float* gx /*[nb][D]*/, float* ll /*[nb]*/, float* gitem /*[D*J + 3*J]*/,
-                    float* workspace, void* hip_stream);
+                    float* gx /*[nb][D] or NULL*/, float* gxT /*[D][nb] or NULL*/, float* ll /*[nb]*/,
+                    float* gitem /*[D*J + 3*J]*/, float* workspace, void* hip_stream);
+/* gx and gxT are the same gradient in person-major / dimension-major order; at least one must be given. */
 
 /* ---- amortized MVN guide, backward: encoder weight gradients of the LOSS from gx.
  * genc = d LOSS / d encoder parameters, flat in the nn.Linear order of vi.py:442-444:
@@ -105,7 +109,10 @@ int64_t vx_mvn_enc_bwd_workspace_floats(const vx_irt_cfg* cfg, int64_t nb);
 int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
                         const float* W21, const float* W22,
                         const float* h, const float* eps, const float* ldT, const float* gx,
+                        const float* hT /*or NULL*/, const float* epsT /*or NULL*/, const float* gxT /*or NULL*/,
                         float* genc, float* workspace, const float* packws, void* hip_stream);
+/* With hT, epsT and gxT (the dimension-major copies made by the forward / likelihood calls) the head weight
+ * gradients run on the DMA-staged kernel of k_mvn_bwd_t.hip; without them on the person-major one. */
 
 /* ---- D = 1 models (irt_1pl..4pl, Normal guide; vi.py:588-595, 677-684, 701-705), fused:
  * x = loc + exp(raw) eps, likelihood, prior, entropy, gradients w.r.t. loc/raw and the items.

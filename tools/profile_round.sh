@@ -1,0 +1,21 @@
+#!/bin/bash
+# Collect the per-round profile artefacts on the GPU box (run through gpurun from the repo root):
+#   kernel-trace stats, HBM traffic counters (separate passes), SQ counters; only the small summaries are kept.
+# usage: tools/profile_round.sh <tag> [bench.py args...]
+set -u
+TAG=$1; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o r -- python3 $R/bench.py --no-cpu-baseline --steps 5 --warmup 2 "$@" > $OUT/trace.log 2>&1
+python3 $R/tools/rocpd_stats.py /tmp/prof_$TAG/r_results.db $OUT/kernel_stats.csv > /dev/null
+i=0
+for C in "FETCH_SIZE" "WRITE_SIZE" \
+         "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" \
+         "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
+    i=$((i+1))
+    rocprofv3 --pmc $C -d /tmp/pmc_${TAG}_$i -o r -- python3 $R/bench.py --no-cpu-baseline --steps 1 --warmup 1 "$@" > $OUT/pmc_$i.log 2>&1
+done
+python3 $R/tools/rocpd_pmc.py /tmp/pmc_${TAG}_1/r_results.db /tmp/pmc_${TAG}_2/r_results.db /tmp/pmc_${TAG}_3/r_results.db /tmp/pmc_${TAG}_4/r_results.db --match k_ --json $OUT/pmc_counters.json > /dev/null
+rm -rf /tmp/prof_$TAG /tmp/pmc_${TAG}_*

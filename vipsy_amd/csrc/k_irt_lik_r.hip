@@ -25,6 +25,7 @@
 struct LikRDims {
     int D, J, K8, XS;        // K8 = (D + 1) rounded up to 8;  XS = K8 + 4 (== 4 mod 8)
     int model, fast, groups, n_pr;
+    int gxt;                 // 1: gx partials are written dimension-major [groups][D][nb] (for the guide backward)
     float Dc, scale;
     int64_t nb, slab_len;
 };
@@ -33,6 +34,8 @@ __host__ __device__ inline size_t likr_lds_bytes(int XS) {
     return sizeof(float) * ((size_t)2 * LR_P * XS + 2 * LR_P * LR_RS) + 2 * LR_P * LR_YS;
 }
 
+#ifndef VX_STATIC_FOR
+#define VX_STATIC_FOR
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
 template <int N, int I = 0, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -41,6 +44,7 @@ __device__ __forceinline__ void static_for(F&& f) {
         static_for<N, I + 1>(f);
     }
 }
+#endif
 
 // ABL: ablation bits for tools/lik_bench.hip only (0 in the library)
 template <int GEN, int NQ, int FAST, int ABL = 0>
@@ -170,7 +174,16 @@ __global__ __launch_bounds__(LR_THREADS) void k_irt_lik_r(
     auto store_gx = [&](int ph, const f32x16& gxa, int64_t i0, const float* xb) {
         const int p = 32 * ph + l31;
         const int64_t i = i0 + p;
-        if (i < dm.nb) {
+        if (dm.gxt) {                                                  // lanes = consecutive persons: 128-byte rows
+            if (i < dm.nb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int k = 32 * wave + crow32(r, half);
+                    if (k < D)
+                        gx_part[((int64_t)g * D + k) * dm.nb + i] = gxa[r] - (g == 0 ? dm.scale * xb[p * XS + k] : 0.f);
+                }
+            }
+        } else if (i < dm.nb) {
             float* dst = gx_part + ((int64_t)g * dm.nb + i) * D;
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {

@@ -37,7 +37,8 @@ __global__ __launch_bounds__(EP_THREADS, 2) void k_mvn_enc_fwd_p(
     const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ Wp,
     const float* __restrict__ bp, const uint32_t* __restrict__ gtab, const float* __restrict__ eps_in,
     uint64_t seed, uint32_t step, uint32_t stream, float* __restrict__ h_out, float* __restrict__ x_out,
-    float* __restrict__ eps_out, float* __restrict__ ldT, float* __restrict__ ent_out) {
+    float* __restrict__ eps_out, float* __restrict__ ldT, float* __restrict__ ent_out,
+    float* __restrict__ hT_out /*[64][nb] or null*/, float* __restrict__ epsT_out /*[D][nb] or null*/) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int H = 64;
     const int D = dm.D, J = dm.J;
@@ -132,6 +133,12 @@ __global__ __launch_bounds__(EP_THREADS, 2) void k_mvn_enc_fwd_p(
                 if (i < dm.nb) *(float4*)(h_out + i * H + hh0) = hv;
             }
         }
+        if (hT_out && i < dm.nb) {                            // dimension-major copy for the weight-gradient kernel
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hT_out[(int64_t)(32 * ht + crow32(r, half)) * dm.nb + i] = hreg[ht][r];
+        }
     }
     __builtin_amdgcn_wave_barrier();                          // response bytes no longer needed
     // ---------------------------------------------------------------- eps (zero padded to DS), x := 0
@@ -162,6 +169,9 @@ __global__ __launch_bounds__(EP_THREADS, 2) void k_mvn_enc_fwd_p(
         }
     }
     __builtin_amdgcn_wave_barrier();
+    if (epsT_out && i < dm.nb) {
+        for (int k = half; k < D; k += 2) epsT_out[(int64_t)k * dm.nb + i] = eps_lds[p * DS + k];
+    }
     // ---------------------------------------------------------------- phase B: packed head rows, 32 per tile
     float ent_acc = 0.f;
     {
@@ -200,9 +210,9 @@ __global__ __launch_bounds__(EP_THREADS, 2) void k_mvn_enc_fwd_p(
         // ---- OFF section: x[p][k] += sum_l M[p,(k,l)] eps[p,l]; the partial sum of the current k stays in a register
         uint32_t cur_k = 1;                                    // the first packed group belongs to k = 1
         float cur_part = 0.f;
-        auto flush = [&]() {
-            const float tot = cur_part + __shfl_xor(cur_part, 32, 64);
-            if (half == 0) xp[cur_k] += tot;
+        auto flush = [&]() {                                   // every k of the OFF section is flushed exactly once:
+            const float tot = half_sum32(cur_part);            // a plain store, no read-modify-write, no LDS shuffle
+            if (half == 0) xp[cur_k] = tot;
         };
         auto tile_off = [&](const float4 (&A)[2][4], float biasA, uint4 gc) {
             // eps reads are issued BEFORE the MFMA chain: an LDS read in the dependent path costs 20-45 % of the

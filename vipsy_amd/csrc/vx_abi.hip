@@ -13,6 +13,7 @@
 #include "k_hodina.hip"
 #include "k_norm_enc.hip"
 #include "k_mvn_bbvi.hip"
+#include "k_mvn_bwd_t.hip"
 
 #include <cstdlib>
 
@@ -152,7 +153,7 @@ int vx_adam_step(float* p, const float* g, float* m, float* v, const float* free
 int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, int64_t gid0,
                        const float* W1, const float* b1, const float* W21, const float* b21, const float* W22,
                        const float* b22, const float* eps_in, float* h, float* x, float* eps, float* ldT,
-                       float* ent, float* packws, void* hs) {
+                       float* ent, float* hT, float* epsT, float* packws, void* hs) {
     if (!enc_cfg_ok(cfg) || !y || !W1 || !b1 || !W21 || !b21 || !W22 || !b22 || !h || !x || !eps || !ldT || !ent ||
         nb < 0)
         return VX_EINVAL;
@@ -174,7 +175,7 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
         if (rc) return rc;
         const dim3 gridp((unsigned)((nb + EP_WAVES * EP_WP - 1) / (EP_WAVES * EP_WP)));
         hipLaunchKernelGGL(k_mvn_enc_fwd_p, gridp, dim3(EP_THREADS), ldsp, (hipStream_t)hs, dm, y, rows, gid0, W1, b1, Wp,
-                           bp, gtab, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent);
+                           bp, gtab, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT);
         VX_CHECK_LAUNCH();
         return VX_OK;
     }
@@ -256,13 +257,15 @@ int64_t vx_irt_lik_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
     const int64_t slab_len = (int64_t)cfg->D * cfg->J + 3 * (int64_t)cfg->J;
     int64_t w = (int64_t)n_pr * slab_len;
     if (groups > 1) w += (int64_t)groups * nb * (cfg->D + 1);
+    if (!lik_r_shape(cfg)) w += nb * cfg->D + 4;          // person-major gx when only gxT is asked for
     return w;
 }
 
 int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* x,
-                    const float* a, const float* b, const float* c_un, const float* d_un, float* gx, float* ll,
-                    float* gitem, float* workspace, void* hs) {
-    if (!lik_cfg_ok(cfg) || !y || !x || !a || !b || !gx || !ll || !gitem || !workspace || nb < 0) return VX_EINVAL;
+                    const float* a, const float* b, const float* c_un, const float* d_un, float* gx, float* gxT,
+                    float* ll, float* gitem, float* workspace, void* hs) {
+    if (!lik_cfg_ok(cfg) || !y || !x || !a || !b || (!gx && !gxT) || !ll || !gitem || !workspace || nb < 0)
+        return VX_EINVAL;
     if (cfg->model >= VX_IRT_3PL && !c_un) return VX_EINVAL;
     if (cfg->model == VX_IRT_4PL && !d_un) return VX_EINVAL;
     if (lik_r_shape(cfg)) {
@@ -273,10 +276,12 @@ int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows
         { const int nq = dm.K8 >> 3; dm.XS = 8 * (nq <= 13 ? 13 : 16) + 4; }
         dm.groups = groups; dm.n_pr = n_pr; dm.Dc = cfg->Dc; dm.scale = cfg->scale; dm.nb = nb;
         dm.slab_len = (int64_t)cfg->D * cfg->J + 3 * (int64_t)cfg->J;
-        dm.fast = (cfg->D % 4 == 0 && cfg->J % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(gx) &&
-                   aligned16(workspace)) ? 1 : 0;
+        dm.fast = (cfg->D % 4 == 0 && cfg->J % 4 == 0 && cfg->J >= 8 && aligned16(x) && aligned16(y) &&
+                   aligned16(gx) && aligned16(workspace)) ? 1 : 0;
+        dm.gxt = gxT ? 1 : 0;                              // partials (and their sum) dimension-major
         float* slabs = workspace;
-        float* gx_part = groups > 1 ? workspace + (int64_t)n_pr * dm.slab_len : gx;
+        float* gx_sum = gxT ? gxT : gx;
+        float* gx_part = groups > 1 ? workspace + (int64_t)n_pr * dm.slab_len : gx_sum;
         float* ll_part = groups > 1 ? gx_part + (int64_t)groups * nb * cfg->D : ll;
         hipStream_t st = (hipStream_t)hs;
         hipError_t he = hipMemsetAsync(slabs, 0, sizeof(float) * (size_t)n_pr * dm.slab_len, st);
@@ -304,14 +309,29 @@ int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows
 #undef LAUNCH_LIKR
             VX_CHECK_LAUNCH();
             if (groups > 1) {
-                int r2 = vx_reduce_slabs(gx_part, groups, nb * cfg->D, 1.0f, gx, hs);
+                int r2 = vx_reduce_slabs(gx_part, groups, nb * cfg->D, 1.0f, gx_sum, hs);
                 if (r2) return r2;
                 r2 = vx_reduce_slabs(ll_part, groups, nb, 1.0f, ll, hs);
                 if (r2) return r2;
             }
+            if (gxT && gx) {                               // both orders requested: gx[nb][D] = transpose(gxT[D][nb])
+                hipLaunchKernelGGL(k_transpose, dim3(num_cu() * 8), dim3(256), 0, st, gxT, gx, (int64_t)cfg->D, nb);
+                VX_CHECK_LAUNCH();
+            }
         }
         return vx_reduce_slabs(slabs, n_pr, dm.slab_len, -1.0f, gitem, hs);
     }
+    float* gx_tmp = nullptr;                               // person-major result of the kernels below
+    {
+        int kt0, nch0, groups0, n_pr0;
+        lik_plan(cfg, nb, kt0, nch0, groups0, n_pr0);
+        const int64_t slab_len0 = (int64_t)cfg->D * cfg->J + 3 * (int64_t)cfg->J;
+        int64_t used = (int64_t)n_pr0 * slab_len0;
+        if (groups0 > 1) used += (int64_t)groups0 * nb * (cfg->D + 1);
+        gx_tmp = workspace + ((used + 3) & ~(int64_t)3);
+    }
+    float* gxT_req = gxT;
+    if (!gx) gx = gx_tmp;
     int kt, nch, groups, n_pr;
     lik_plan(cfg, nb, kt, nch, groups, n_pr);
     LikDims dm;
@@ -356,6 +376,11 @@ int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows
             if (r2) return r2;
         }
     }
+    if (gxT_req && nb > 0) {
+        hipLaunchKernelGGL(k_transpose, dim3(num_cu() * 8), dim3(256), 0, (hipStream_t)hs, gx, gxT_req, nb,
+                           (int64_t)cfg->D);
+        VX_CHECK_LAUNCH();
+    }
     // loss gradients = -(d ELBO / d .)
     return vx_reduce_slabs(slabs, n_pr, dm.slab_len, -1.0f, gitem, hs);
 }
@@ -364,6 +389,19 @@ int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows
 static bool encb_fast_shape(const vx_irt_cfg* cfg) {
     return !force_generic() && cfg->H == 64 && cfg->D % 4 == 0 &&
            enc_bwdw_fast_lds_floats(cfg->D) * sizeof(float) <= 160 * 1024;
+}
+
+// dimension-major weight-gradient kernel (k_mvn_bwd_t.hip): packed shape, 16-byte aligned person rows
+static bool bwt_shape(const vx_irt_cfg* cfg, int64_t nb) {
+    static int old = -1;
+    if (old < 0) { const char* e = getenv("VX_BWDW"); old = (e && e[0] == 'o') ? 1 : 0; }
+    return !old && packed_ok(cfg) && nb % 4 == 0 && cfg->D <= 124 && bt_lds_bytes(cfg->D) <= 160 * 1024;
+}
+static void bwt_plan(const vx_irt_cfg* cfg, int64_t nb, int& n_rowslabs, int& n_prw) {
+    n_rowslabs = (pk_rows(cfg->D) + BT_ROWS - 1) / BT_ROWS;
+    const int64_t n_ptiles = (nb + BT_P - 1) / BT_P;
+    int64_t w = num_cu() / n_rowslabs; if (w < 1) w = 1;
+    n_prw = (int)(n_ptiles < w ? n_ptiles : w); if (n_prw < 1) n_prw = 1;
 }
 
 static void encb_plan(const vx_irt_cfg* cfg, int64_t nb, int& n_rowslabs, int& n_prw, int& n_jg, int& n_prf) {
@@ -397,12 +435,18 @@ int64_t vx_mvn_enc_bwd_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
     const int64_t D = cfg->D, J = cfg->J, H = cfg->H, T = tril_len(cfg->D);
     int64_t lenw = D * H + D + T * H + T;
     if (packed_ok(cfg) && (int64_t)pk_rows(cfg->D) * (H + 1) > lenw) lenw = (int64_t)pk_rows(cfg->D) * (H + 1);
+    if (bwt_shape(cfg, nb)) {                              // whichever of the two weight-gradient kernels runs
+        int ns, np;
+        bwt_plan(cfg, nb, ns, np);
+        if (np > n_prw) n_prw = np;
+    }
     return nb * H + (int64_t)n_prw * lenw + (int64_t)n_prf * (H * J + H);
 }
 
 int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
                         const float* W21, const float* W22, const float* h, const float* eps, const float* ldT,
-                        const float* gx, float* genc, float* workspace, const float* packws, void* hs) {
+                        const float* gx, const float* hT, const float* epsT, const float* gxT, float* genc,
+                        float* workspace, const float* packws, void* hs) {
     if (!enc_cfg_ok(cfg) || !y || !W21 || !W22 || !h || !eps || !ldT || !gx || !genc || !workspace || nb < 0)
         return VX_EINVAL;
     int n_rowslabs, n_prw, n_jg, n_prf;
@@ -415,9 +459,19 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                         aligned16(gx) && aligned16(workspace) && nb > 0;
     if (packed_ok(cfg) && !packed && nb > 0) return VX_EINVAL;      // the plan assumed the packed row space
     const int64_t lenw = (packed_ok(cfg) && Rp * (H + 1) > lenw_ref) ? Rp * (H + 1) : lenw_ref;
+    const bool use_t = packed && hT && epsT && gxT && bwt_shape(cfg, nb) && aligned16(hT) && aligned16(epsT) &&
+                       aligned16(gxT) && aligned16(ldT);
+    if (use_t) bwt_plan(cfg, nb, n_rowslabs, n_prw);
+    int n_prw_ws = n_prw;                                  // slab space as sized by vx_mvn_enc_bwd_workspace_floats
+    if (bwt_shape(cfg, nb)) {
+        int ns0, np0, nj0, nf0, ns1, np1;
+        encb_plan(cfg, nb, ns0, np0, nj0, nf0);
+        bwt_plan(cfg, nb, ns1, np1);
+        n_prw_ws = np0 > np1 ? np0 : np1;
+    }
     float* ghpre = workspace;
     float* slabs_w = ghpre + nb * H;
-    float* slabs_f = slabs_w + (int64_t)n_prw * lenw;
+    float* slabs_f = slabs_w + (int64_t)n_prw_ws * lenw;
     hipStream_t st = (hipStream_t)hs;
     int rc;
     if (packed) {
@@ -431,7 +485,14 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                                dm, cfg->scale, Wp, gtab, h, eps, ldT, gx, ghpre);
             VX_CHECK_LAUNCH();
         }
-        {
+        if (use_t) {
+            const size_t lds = bt_lds_bytes(dm.D);
+            rc = set_lds(k_mvn_enc_bwd_w_t, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_mvn_enc_bwd_w_t, dim3((unsigned)n_rowslabs, (unsigned)n_prw), dim3(BT_THREADS), lds, st,
+                               dm, cfg->scale, hT, epsT, ldT, gxT, gtab, slabs_w, Rp * (H + 1));
+            VX_CHECK_LAUNCH();
+        } else {
             const size_t lds = enc_bwdw_fast_lds_floats(dm.D) * sizeof(float);
             rc = set_lds(k_mvn_enc_bwd_w_fast<true>, lds);
             if (rc) return rc;

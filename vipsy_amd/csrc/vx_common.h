@@ -163,6 +163,13 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
     v = fmaxf(v, dpp_movv<0x143, 0xC>(v, v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// v[lane & 31] + v[(lane & 31) + 32] in every lane: gfx950 v_permlane32_swap (VALU, no LDS round trip).
+// (the clang builtin for it mis-assigns its second result on this toolchain, hence the asm)
+__device__ __forceinline__ float half_sum32(float v) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b;
+    asm("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "=&v"(b));
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
 __device__ __forceinline__ float lane_bcast(float v, int lane_uniform) {      // lane index must be wave-uniform
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane_uniform));
 }
@@ -178,6 +185,11 @@ __device__ __forceinline__ uint32_t lds_addr_uniform(const void* lds) {
 }
 __device__ __forceinline__ void dma16(const void* gptr, uint32_t lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_byte_addr) : "memory");
+}
+// scalar base + 32-bit per-lane byte offset (no 64-bit VALU address arithmetic per transfer)
+__device__ __forceinline__ void dma16s(const void* sbase_uniform, uint32_t voff, uint32_t lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase_uniform),
+                 "s"(lds_byte_addr) : "memory");
 }
 __device__ __forceinline__ void dma4(const void* gptr, uint32_t lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gptr), "s"(lds_byte_addr) : "memory");

@@ -44,6 +44,7 @@ class HipBackend(object):
                                        _hip.ptr(enc["fc22.weight"]), _hip.ptr(enc["fc22.bias"]),
                                        _hip.ptr(eps_in), _hip.ptr(out["h"]), _hip.ptr(out["x"]),
                                        _hip.ptr(out["eps"]), _hip.ptr(out["ldT"]), _hip.ptr(out["ent"]),
+                                       _hip.ptr(out.get("hT")), _hip.ptr(out.get("epsT")),
                                        _hip.ptr(out.get("packws")), _hip.stream_ptr())
         _hip.check(rc, "vx_mvn_enc_forward")
 
@@ -59,10 +60,10 @@ class HipBackend(object):
             raise _hip.VxError("vx_irt_lik_workspace_floats: unsupported configuration (code %d)" % n)
         return n
 
-    def lik_grad(self, cfg, y, rows, nb, x, a, b, c_un, d_un, gx, ll, gitem, ws):
+    def lik_grad(self, cfg, y, rows, nb, x, a, b, c_un, d_un, gx, ll, gitem, ws, gxT=None):
         rc = self.L.vx_irt_lik_grad(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb, _hip.ptr(x), _hip.ptr(a),
-                                    _hip.ptr(b), _hip.ptr(c_un), _hip.ptr(d_un), _hip.ptr(gx), _hip.ptr(ll),
-                                    _hip.ptr(gitem), _hip.ptr(ws), _hip.stream_ptr())
+                                    _hip.ptr(b), _hip.ptr(c_un), _hip.ptr(d_un), _hip.ptr(gx), _hip.ptr(gxT),
+                                    _hip.ptr(ll), _hip.ptr(gitem), _hip.ptr(ws), _hip.stream_ptr())
         _hip.check(rc, "vx_irt_lik_grad")
 
     def mvn_enc_bwd_workspace(self, cfg, nb):
@@ -71,10 +72,11 @@ class HipBackend(object):
             raise _hip.VxError("vx_mvn_enc_bwd_workspace_floats: unsupported configuration (code %d)" % n)
         return n
 
-    def mvn_enc_backward(self, cfg, y, rows, nb, enc, fw, gx, genc, ws):
+    def mvn_enc_backward(self, cfg, y, rows, nb, enc, fw, gx, genc, ws, gxT=None):
         rc = self.L.vx_mvn_enc_backward(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb,
                                         _hip.ptr(enc["fc21.weight"]), _hip.ptr(enc["fc22.weight"]),
                                         _hip.ptr(fw["h"]), _hip.ptr(fw["eps"]), _hip.ptr(fw["ldT"]), _hip.ptr(gx),
+                                        _hip.ptr(fw.get("hT")), _hip.ptr(fw.get("epsT")), _hip.ptr(gxT),
                                         _hip.ptr(genc), _hip.ptr(ws), _hip.ptr(fw.get("packws")), _hip.stream_ptr())
         _hip.check(rc, "vx_mvn_enc_backward")
 
@@ -449,8 +451,12 @@ class IrtEngine(_EngineBase):
             D, H = self.D, self.H
             fw = {"h": self._buf("h", nb * H), "x": self._buf("x", nb * D), "eps": self._buf("eps", nb * D),
                   "ldT": self._buf("ldT", nb * D), "ent": self._buf("ent", nb)}
+            gxT = None
             if hasattr(be, "mvn_pack_floats"):
                 fw["packws"] = self._buf("packws", be.mvn_pack_floats(cfg))
+                # dimension-major copies (person-contiguous rows) for the DMA-staged weight-gradient kernel
+                fw["hT"], fw["epsT"] = self._buf("hT", nb * H), self._buf("epsT", nb * D)
+                gxT = self._buf("gxT", nb * D)
             gx, ll = self._buf("gx", nb * D), self._buf("ll", nb)
             enc = self._enc()
             lik_ws = self._buf("lik_ws", be.lik_workspace(cfg, nb))
@@ -458,10 +464,18 @@ class IrtEngine(_EngineBase):
             with self._phase("guide_forward"):
                 be.mvn_enc_forward(cfg, self.y, rows, nb, self.gid0, enc, eps, fw)
             with self._phase("likelihood"):
-                be.lik_grad(cfg, self.y, rows, nb, fw["x"], a, self.view("b"), c_un, d_un, gx, ll, gitem, lik_ws)
+                if gxT is not None:
+                    be.lik_grad(cfg, self.y, rows, nb, fw["x"], a, self.view("b"), c_un, d_un, gx, ll, gitem, lik_ws,
+                                gxT=gxT)
+                else:
+                    be.lik_grad(cfg, self.y, rows, nb, fw["x"], a, self.view("b"), c_un, d_un, gx, ll, gitem, lik_ws)
             with self._phase("guide_backward"):
-                be.mvn_enc_backward(cfg, self.y, rows, nb, enc, fw, gx,
-                                    self.G[self.enc_off0:self.enc_off0 + self.n_enc], encb_ws)
+                if gxT is not None:
+                    be.mvn_enc_backward(cfg, self.y, rows, nb, enc, fw, gx,
+                                        self.G[self.enc_off0:self.enc_off0 + self.n_enc], encb_ws, gxT=gxT)
+                else:
+                    be.mvn_enc_backward(cfg, self.y, rows, nb, enc, fw, gx,
+                                        self.G[self.enc_off0:self.enc_off0 + self.n_enc], encb_ws)
             # loss = -scale * sum_i (ll_i + ent_i)
             tmp = self._buf("loss2", 2)
             be.sum_into(ll, nb, -scale, tmp[0:1], self.sum_ws)
