@@ -440,7 +440,7 @@ int64_t vx_mvn_enc_bwd_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
         bwt_plan(cfg, nb, ns, np);
         if (np > n_prw) n_prw = np;
     }
-    return nb * H + (int64_t)n_prw * lenw + (int64_t)n_prf * (H * J + H);
+    return nb * H + (int64_t)n_prw * lenw + (int64_t)n_prf * (H * J + H) + (bwt_shape(cfg, nb) ? nb * D + 4 : 0);
 }
 
 int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
@@ -489,8 +489,12 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
             const size_t lds = bt_lds_bytes(dm.D);
             rc = set_lds(k_mvn_enc_bwd_w_t, lds);
             if (rc) return rc;
+            float* gdT = slabs_f + (int64_t)n_prf * lenf;     // DIAG-row operand, dimension-major
+            hipLaunchKernelGGL(k_mvn_gd, dim3(num_cu() * 8), dim3(256), 0, st, (const float4*)gxT, (const float4*)epsT,
+                               (const float4*)ldT, cfg->scale, nb * D / 4, (float4*)gdT);
+            VX_CHECK_LAUNCH();
             hipLaunchKernelGGL(k_mvn_enc_bwd_w_t, dim3((unsigned)n_rowslabs, (unsigned)n_prw), dim3(BT_THREADS), lds, st,
-                               dm, cfg->scale, hT, epsT, ldT, gxT, gtab, slabs_w, Rp * (H + 1));
+                               dm, hT, epsT, gdT, gxT, gtab, slabs_w, Rp * (H + 1));
             VX_CHECK_LAUNCH();
         } else {
             const size_t lds = enc_bwdw_fast_lds_floats(dm.D) * sizeof(float);
