@@ -106,6 +106,9 @@ int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows
  *   [W1: H*J | b1: H | W21: D*H | b21: D | W22: T*H | b22: T],  T = D(D+1)/2. */
 int64_t vx_mvn_enc_param_floats(const vx_irt_cfg* cfg);          /* length of genc */
 int64_t vx_mvn_enc_bwd_workspace_floats(const vx_irt_cfg* cfg, int64_t nb);
+/* 1: this (cfg, nb) runs on the dimension-major kernels when hT, epsT and gxT are supplied (gx may then be NULL and
+ * the likelihood call needs to produce gxT only); 0: the person-major kernels, which need gx. */
+int vx_mvn_enc_bwd_layout(const vx_irt_cfg* cfg, int64_t nb);
 int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
                         const float* W21, const float* W22,
                         const float* h, const float* eps, const float* ldT, const float* gx,

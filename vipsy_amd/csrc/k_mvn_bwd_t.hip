@@ -257,3 +257,194 @@ __global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ in,
         __syncthreads();
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Hidden-layer gradient of the amortized MVN guide, person-stationary:
+//     gh^T[hh][p] = sum_r WpT[hh][r] V[r][p],       ghpre[p][hh] = gh * (1 - exp(-h))        (softplus', vi.py:449)
+// A workgroup keeps 128 persons (4 waves x 32) resident in LDS -- gxT [D][128] and eps [128][ES] -- and streams the
+// packed head weights in 64-row tiles (transposed copy WpT [64][Rp] from k_pack_heads; DMA, double buffered, each
+// 256-byte LDS row = hidden unit hh holds the tile's 16 chunks at slot c ^ (hh & 15)).  Per 8 MFMAs (4 packed rows
+// x both hidden tiles): two 16-byte weight reads, one 16-byte eps read, one 4-byte gx read and 4 multiplies.
+#define BH_P 128
+#define BH_THREADS 256
+#define BH_TR 64
+#define BH_WBUF (64 * BH_TR * 4)                                       // bytes of one weight tile
+
+__host__ __device__ inline int bh_es(int D) { int c = (D + 3) / 4 + 2; if ((c & 1) == 0) ++c; return 4 * c; }   // chunks odd
+#define BH_NBUF 3                                                      // weight tiles in flight: prefetch distance 2
+__host__ __device__ inline size_t bh_lds_bytes(int D) {
+    return BH_NBUF * (size_t)BH_WBUF + (size_t)D * BH_P * 4 + (size_t)BH_P * bh_es(D) * 4 + (size_t)pk_rows(D) / 8 * 4;
+}
+
+__global__ __launch_bounds__(BH_THREADS, 1) void k_mvn_enc_bwd_h_t(
+    EncDims dm, float scale, const float* __restrict__ WpT, const uint32_t* __restrict__ gtab,
+    const float* __restrict__ h_in, const float* __restrict__ eps_in, const float* __restrict__ ldT,
+    const float* __restrict__ gxT, float* __restrict__ ghpre_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_bh[];
+    constexpr int H = 64;
+    const int D = dm.D, ES = bh_es(D);
+    const int64_t nb = dm.nb;
+    char* Wt = smem_bh;                                                // [3][64 hh][64 r]
+    float* gx_lds = (float*)(smem_bh + BH_NBUF * BH_WBUF);             // [D][128]
+    float* eps_lds = gx_lds + D * BH_P;                                // [128][ES]
+    uint32_t* gt_lds = (uint32_t*)(eps_lds + BH_P * ES);               // [Rp / 8] group codes
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int64_t i0 = (int64_t)blockIdx.x * BH_P;
+    const int Rp = pk_rows(D), n_tiles = Rp / BH_TR, n_off = pk_off_total(D) / BH_TR;
+    const int offT = pk_off_total(D), sec = pk_sec(D);
+
+    // ---- resident person data (once per workgroup).  Persons past the batch read the last valid person: finite
+    // values whose results are never stored.
+    {
+        const int c128 = BH_P / 4;                                     // gxT rows: 32 chunks; one DMA = 2 rows
+        for (int j = wave; 2 * j < D; j += 4) {
+            int k = 2 * j + (lane >> 5);
+            if (k >= D) k = D - 1;
+            int64_t pp = i0 + 4 * (lane & 31);
+            if (pp + 4 > nb) pp = nb - 4;                              // nb % 4 == 0, nb >= 4
+            dma16(gxT + (int64_t)k * nb + pp, lds_addr_uniform(gx_lds + 2 * j * BH_P));
+        }
+        (void)c128;
+        const int ec = ES / 4, n_chunks = BH_P * ec;                   // eps tile as one contiguous chunk array
+        for (int j = wave; 64 * j < n_chunks; j += 4) {
+            const int ch = 64 * j + lane;
+            int pr = ch / ec, cc = ch - pr * ec;
+            if (pr >= BH_P) { pr = BH_P - 1; cc = 0; }
+            if (4 * cc >= D) cc = 0;                                   // pad chunks: any finite values
+            int64_t ii = i0 + pr;
+            if (ii >= nb) ii = nb - 1;
+            dma16(eps_in + ii * D + 4 * cc, lds_addr_uniform((char*)eps_lds + (size_t)j * 1024));
+        }
+    }
+    // ---- weight tiles: one DMA = 4 hidden rows x 16 chunks; wave w moves rows 16 w .. 16 w + 15
+    auto stage_w = [&](int tile, int b) {
+        const uint32_t lbase = lds_addr_uniform(Wt + b * BH_WBUF) + (uint32_t)wave * 4096u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int hh = 16 * wave + 4 * u + (lane >> 4);
+            const int c = (lane & 15) ^ (hh & 15);
+            dma16(WpT + (int64_t)hh * Rp + (int64_t)tile * BH_TR + 4 * c, lbase + (uint32_t)u * 1024u);
+        }
+    };
+    stage_w(0, 0);
+    if (n_tiles > 1) stage_w(1, 1);
+    for (int e = tid; e < Rp / 8; e += BH_THREADS) gt_lds[e] = gtab[e];
+
+    const int p = 32 * wave + l31;                                     // this lane's person (B / C column)
+    const int64_t i = i0 + p;
+    const float* gx_p = gx_lds + p;                                    // + k * BH_P
+    const float* eps_p = eps_lds + p * ES;
+    uint32_t aW[2][8];                                                 // weight chunk addresses of this lane (per q')
+#pragma unroll
+    for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int hh = 32 * ht + l31;
+            aW[ht][q] = (uint32_t)(hh * 256 + (((2 * q + half) ^ (hh & 15)) << 4));
+        }
+    f32x16 acc0 = zero16(), acc1 = zero16();
+
+    // OFF tile: 8 eight-row groups (q), 8 MFMAs each.  The operands of group q + 1 are read while the MFMAs of group q
+    // run (pinned scheduling regions); the group codes (k, l0) come from the LDS copy of gtab (a uniform address).
+    auto off_tile = [&](auto bc, int tile) {
+        constexpr int b = decltype(bc)::value;
+        const char* wb = Wt + b * BH_WBUF;
+        const uint4 gcA = *(const uint4*)(gt_lds + tile * (BH_TR / 8)), gcB = *(const uint4*)(gt_lds + tile * (BH_TR / 8) + 4);
+        const uint32_t gt[8] = {gcA.x, gcA.y, gcA.z, gcA.w, gcB.x, gcB.y, gcB.z, gcB.w};
+        uint32_t code[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) code[q] = __builtin_amdgcn_readfirstlane(gt[q]);
+        auto ld_g = [&](uint32_t c) { return gx_p[(int)((c >> 12) & 0xFFFFu) * BH_P]; };
+        auto ld_e = [&](uint32_t c) { return *(const f32x4*)(eps_p + (int)(c & 0xFFFu) + 4 * half); };
+        float gk = ld_g(code[0]);
+        f32x4 e4 = ld_e(code[0]);
+        f32x4 w0 = *(const f32x4*)(wb + aW[0][0]), w1 = *(const f32x4*)(wb + aW[1][0]);
+        static_for<8>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            float gn = gk;
+            f32x4 en = e4, wn0 = w0, wn1 = w1;
+            if constexpr (q + 1 < 8) {
+                gn = ld_g(code[q + 1]);
+                en = ld_e(code[q + 1]);
+                wn0 = *(const f32x4*)(wb + aW[0][q + 1]);
+                wn1 = *(const f32x4*)(wb + aW[1][q + 1]);
+            }
+            const f32x4 v = gk * e4;
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) {
+                acc0 = mfma32(w0[i2], v[i2], acc0);
+                acc1 = mfma32(w1[i2], v[i2], acc1);
+            }
+            gk = gn; e4 = en; w0 = wn0; w1 = wn1;
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    // DIAG / LOC sections (a handful of tiles): every eight-row group has one type; buffer index at run time
+    auto tail_tile = [&](int b, int tile) {
+        const char* wb = Wt + b * BH_WBUF;
+#pragma unroll 1
+        for (int q = 0; q < 8; ++q) {
+            const int r0 = tile * BH_TR + 8 * q;                       // first packed row of this 8-group (uniform)
+            const bool is_diag = r0 < offT + sec, is_loc = !is_diag && r0 < offT + 2 * sec;
+            const int k0 = r0 - (is_diag ? offT : offT + sec) + 4 * half;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) {
+                const int k = k0 + i2;
+                if ((is_diag || is_loc) && k < D) {
+                    float t = gx_p[k * BH_P];
+                    if (is_diag) t = fmaf(t * eps_p[k], ldT[(int64_t)k * nb + (i < nb ? i : nb - 1)], scale);
+                    v[i2] = t;
+                }
+            }
+            const uint32_t hx0 = (uint32_t)(l31 & 15), hx1 = hx0;      // (hh & 15) of both hidden tiles
+            const f32x4 w0 = *(const f32x4*)(wb + l31 * 256 + (((2 * q + half) ^ hx0) << 4));
+            const f32x4 w1 = *(const f32x4*)(wb + (32 + l31) * 256 + (((2 * q + half) ^ hx1) << 4));
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) {
+                acc0 = mfma32(w0[i2], v[i2], acc0);
+                acc1 = mfma32(w1[i2], v[i2], acc1);
+            }
+        }
+    };
+
+    // Weight tiles run three deep: before tile t is used only the transfers of tile t + 1 (this wave's 4 newest)
+    // may still be in flight -- vmcnt(4); the transfer of tile t + 2 is issued right after the barrier, into the
+    // buffer tile t - 1 has just left.  n_off is a multiple of 3 (the OFF section is padded to 192 rows).
+    auto wait_tile = [&](int tile) {
+        if (tile + 1 < n_tiles) __builtin_amdgcn_s_waitcnt(0x0F74);    // vmcnt(4)
+        else vx_wait_vmem();
+        __syncthreads();
+        if (tile + 2 < n_tiles) stage_w(tile + 2, (tile + 2) % BH_NBUF);
+    };
+    int tile = 0;
+    for (; tile + 2 < n_off; tile += 3) {
+        wait_tile(tile);
+        off_tile(std::integral_constant<int, 0>{}, tile);
+        wait_tile(tile + 1);
+        off_tile(std::integral_constant<int, 1>{}, tile + 1);
+        wait_tile(tile + 2);
+        off_tile(std::integral_constant<int, 2>{}, tile + 2);
+    }
+    for (; tile < n_tiles; ++tile) {
+        wait_tile(tile);
+        tail_tile(tile % BH_NBUF, tile);
+    }
+    // ---- ghpre = gh * softplus'(pre) = gh * (1 - exp(-h));  C layout: rows hh = crow32(r, half), cols p
+    if (i < nb) {
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int hh0 = 32 * ht + 8 * g + 4 * half;
+                const float4 hv = *(const float4*)(h_in + i * H + hh0);
+                float4 o;
+                o.x = (ht ? acc1 : acc0)[4 * g + 0] * (1.0f - __expf(-hv.x));
+                o.y = (ht ? acc1 : acc0)[4 * g + 1] * (1.0f - __expf(-hv.y));
+                o.z = (ht ? acc1 : acc0)[4 * g + 2] * (1.0f - __expf(-hv.z));
+                o.w = (ht ? acc1 : acc0)[4 * g + 3] * (1.0f - __expf(-hv.w));
+                *(float4*)(ghpre_out + i * H + hh0) = o;
+            }
+    }
+}

@@ -4,7 +4,8 @@
 // MFMA kernels a 32-row tile of that order mixes several (k, l) runs and forces a per-element decode.  The packed
 // order (rebuilt from the flat parameters by k_pack_heads every step, 1.4 MB, a few microseconds) is
 //   section OFF : for k = 1..D-1 the entries (k, 0..k-1), each k padded with zero rows to a multiple of 8;
-//                 the section itself padded to a multiple of 96 rows (the forward kernel walks it 3 tiles at a time)
+//                 the section itself padded to a multiple of 192 rows (the forward kernel walks it 3 tiles at a time,
+//                 the hidden-gradient kernel in 64-row tiles)
 //   section DIAG: (k,k) for k = 0..D-1, padded to a multiple of 32
 //   section LOC : fc21 rows k = 0..D-1, padded to a multiple of 32
 //   tail        : zero rows up to a multiple of 64
@@ -24,7 +25,7 @@ __host__ __device__ inline int pk_off_rows(int k) {          // packed rows befo
     return 8 * (8 * (q * (q + 1) / 2) + rem * (q + 1));
 }
 __host__ __device__ inline int pk_sec(int D) { return (D + 31) / 32 * 32; }
-__host__ __device__ inline int pk_off_total(int D) { return (pk_off_rows(D) + 95) / 96 * 96; }   // whole groups of 3 tiles
+__host__ __device__ inline int pk_off_total(int D) { return (pk_off_rows(D) + 191) / 192 * 192; }   // 3-tile groups (forward) and 64-row tiles (backward)
 __host__ __device__ inline int pk_rows(int D) { return (pk_off_total(D) + 2 * pk_sec(D) + 63) / 64 * 64; }
 
 // packed row -> (source row in the concatenated [W22 rows 0..T-1 | W21 rows T..T+D-1] space, or -1), group code
@@ -53,10 +54,10 @@ __device__ __forceinline__ void pk_decode(int pr, int D, int T, int& src, uint32
     }
 }
 
-// Wp[Rp][H] (H floats per row), bp[Rp], gtab[Rp/8]
+// Wp[Rp][H] (H floats per row), bp[Rp], gtab[Rp/8], WpT[H][Rp] (the transpose, for the hidden-gradient kernel)
 __global__ void k_pack_heads(int D, int H, const float* __restrict__ W21, const float* __restrict__ b21,
                              const float* __restrict__ W22, const float* __restrict__ b22, float* __restrict__ Wp,
-                             float* __restrict__ bp, uint32_t* __restrict__ gtab) {
+                             float* __restrict__ bp, uint32_t* __restrict__ gtab, float* __restrict__ WpT) {
     const int T = D * (D + 1) / 2, Rp = pk_rows(D);
     const int pr = blockIdx.x;
     if (pr >= Rp) return;
@@ -64,7 +65,11 @@ __global__ void k_pack_heads(int D, int H, const float* __restrict__ W21, const 
     uint32_t gcode;
     pk_decode(pr, D, T, src, gcode);
     const float* w = (src < 0) ? nullptr : (src < T ? W22 + (int64_t)src * H : W21 + (int64_t)(src - T) * H);
-    for (int hh = threadIdx.x; hh < H; hh += blockDim.x) Wp[(int64_t)pr * H + hh] = w ? w[hh] : 0.f;
+    for (int hh = threadIdx.x; hh < H; hh += blockDim.x) {
+        const float v = w ? w[hh] : 0.f;
+        Wp[(int64_t)pr * H + hh] = v;
+        if (WpT) WpT[(int64_t)hh * Rp + pr] = v;
+    }
     if (threadIdx.x == 0) {
         bp[pr] = (src < 0) ? 0.f : (src < T ? b22[src] : b21[src - T]);
         if ((pr & 7) == 0) gtab[pr >> 3] = gcode;

@@ -167,8 +167,9 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
         float* Wp = packws;
         float* bp = Wp + (int64_t)Rp * 64;
         uint32_t* gtab = (uint32_t*)(bp + Rp);
+        float* WpT = (float*)(gtab + Rp / 8 + 8);
         hipLaunchKernelGGL(k_pack_heads, dim3(Rp), dim3(64), 0, (hipStream_t)hs, (int)cfg->D, 64, W21, b21, W22, b22, Wp,
-                           bp, gtab);
+                           bp, gtab, WpT);
         VX_CHECK_LAUNCH();
         const size_t ldsp = enc_p_lds_floats(dm.D, dm.J) * sizeof(float);
         rc = set_lds(k_mvn_enc_fwd_p, ldsp);
@@ -416,10 +417,17 @@ static void encb_plan(const vx_irt_cfg* cfg, int64_t nb, int& n_rowslabs, int& n
     n_prf = (int)(n_ptiles < f ? n_ptiles : f); if (n_prf < 1) n_prf = 1;
 }
 
+int vx_mvn_enc_bwd_layout(const vx_irt_cfg* cfg, int64_t nb) {
+    if (!enc_cfg_ok(cfg) || nb < 0) return VX_EINVAL;
+    static int oldh = -1;
+    if (oldh < 0) { const char* e = getenv("VX_BWDH"); oldh = (e && e[0] == 'o') ? 1 : 0; }
+    return (bwt_shape(cfg, nb) && !oldh && nb >= 4 && bh_lds_bytes(cfg->D) <= 160 * 1024) ? 1 : 0;
+}
+
 int64_t vx_mvn_pack_floats(const vx_irt_cfg* cfg) {
     if (!enc_cfg_ok(cfg)) return VX_EINVAL;
     const int64_t Rp = pk_rows(cfg->D);
-    return Rp * 64 + Rp + Rp / 8 + 8;
+    return Rp * 64 + Rp + Rp / 8 + 8 + Rp * 64;            // Wp | bp | gtab | WpT
 }
 
 int64_t vx_mvn_enc_param_floats(const vx_irt_cfg* cfg) {
@@ -447,7 +455,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                         const float* W21, const float* W22, const float* h, const float* eps, const float* ldT,
                         const float* gx, const float* hT, const float* epsT, const float* gxT, float* genc,
                         float* workspace, const float* packws, void* hs) {
-    if (!enc_cfg_ok(cfg) || !y || !W21 || !W22 || !h || !eps || !ldT || !gx || !genc || !workspace || nb < 0)
+    if (!enc_cfg_ok(cfg) || !y || !W21 || !W22 || !h || !eps || !ldT || (!gx && !gxT) || !genc || !workspace || nb < 0)
         return VX_EINVAL;
     int n_rowslabs, n_prw, n_jg, n_prf;
     encb_plan(cfg, nb, n_rowslabs, n_prw, n_jg, n_prf);
@@ -477,7 +485,18 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     if (packed) {
         const float* Wp = packws;
         const uint32_t* gtab = (const uint32_t*)(packws + Rp * 64 + Rp);
-        {
+        static int oldh = -1;
+        if (oldh < 0) { const char* e = getenv("VX_BWDH"); oldh = (e && e[0] == 'o') ? 1 : 0; }
+        if (use_t && !oldh && nb >= 4 && bh_lds_bytes(dm.D) <= 160 * 1024) {
+            const float* WpT = (const float*)(gtab + Rp / 8 + 8);
+            const size_t lds = bh_lds_bytes(dm.D);
+            rc = set_lds(k_mvn_enc_bwd_h_t, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_mvn_enc_bwd_h_t, dim3((unsigned)((nb + BH_P - 1) / BH_P)), dim3(BH_THREADS), lds, st, dm,
+                               cfg->scale, WpT, gtab, h, eps, ldT, gxT, ghpre);
+            VX_CHECK_LAUNCH();
+        } else {
+            if (!gx) return VX_EINVAL;                     // the person-major kernel needs gx[nb][D]
             const size_t lds = enc_bwdh_p_lds_floats(dm.D) * sizeof(float);
             rc = set_lds(k_mvn_enc_bwd_h_p, lds);
             if (rc) return rc;

@@ -56,12 +56,14 @@ __device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint32_t step, ui
                                                 uint32_t block) {
     u32x4 w = philox4x32_10((uint32_t)gid, (uint32_t)((uint64_t)gid >> 32), step, (stream << 16) | block,
                             (uint32_t)seed, (uint32_t)(seed >> 32));
-    const float two_pi = 6.283185307179586f;
-    float r0 = sqrtf(-2.0f * logf(u01(w.x))), t0 = two_pi * u01(w.y);
-    float r1 = sqrtf(-2.0f * logf(u01(w.z))), t1 = two_pi * u01(w.w);
-    float s0, c0, s1, c1;
-    sincosf(t0, &s0, &c0);
-    sincosf(t1, &s1, &c1);
+    // Box-Muller on the hardware transcendentals: v_sin/v_cos take the angle in revolutions (the uniform itself, no
+    // range reduction), v_log is log2.  Absolute error of a normal ~1e-6, far inside the parity tolerance (2e-5);
+    // the library sincosf/logf cost ~300 VALU issues per call, and VALU time adds to MFMA time on this chip.
+    const float u0 = u01(w.x), u1 = u01(w.y), u2 = u01(w.z), u3 = u01(w.w);
+    const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));   // sqrt(-2 ln u)
+    const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
+    const float s0 = __builtin_amdgcn_sinf(u1), c0 = __builtin_amdgcn_cosf(u1);
+    const float s1 = __builtin_amdgcn_sinf(u3), c1 = __builtin_amdgcn_cosf(u3);
     f32x4 o;
     o[0] = r0 * c0; o[1] = r0 * s0; o[2] = r1 * c1; o[3] = r1 * s1;
     return o;

@@ -72,6 +72,9 @@ class HipBackend(object):
             raise _hip.VxError("vx_mvn_enc_bwd_workspace_floats: unsupported configuration (code %d)" % n)
         return n
 
+    def mvn_enc_bwd_layout(self, cfg, nb):
+        return int(self.L.vx_mvn_enc_bwd_layout(ctypes.byref(cfg), nb))
+
     def mvn_enc_backward(self, cfg, y, rows, nb, enc, fw, gx, genc, ws, gxT=None):
         rc = self.L.vx_mvn_enc_backward(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb,
                                         _hip.ptr(enc["fc21.weight"]), _hip.ptr(enc["fc22.weight"]),
@@ -458,6 +461,8 @@ class IrtEngine(_EngineBase):
                 fw["hT"], fw["epsT"] = self._buf("hT", nb * H), self._buf("epsT", nb * D)
                 gxT = self._buf("gxT", nb * D)
             gx, ll = self._buf("gx", nb * D), self._buf("ll", nb)
+            if gxT is not None and be.mvn_enc_bwd_layout(cfg, nb) == 1:
+                gx = None                                  # the backward kernels read gxT only
             enc = self._enc()
             lik_ws = self._buf("lik_ws", be.lik_workspace(cfg, nb))
             encb_ws = self._buf("encb_ws", be.mvn_enc_bwd_workspace(cfg, nb))
@@ -481,7 +486,7 @@ class IrtEngine(_EngineBase):
             be.sum_into(ll, nb, -scale, tmp[0:1], self.sum_ws)
             be.sum_into(fw["ent"], nb, -scale, tmp[1:2], self.sum_ws)
             torch.add(tmp[0:1], tmp[1:2], out=lossslot)
-            self.last = {"fw": fw, "gx": gx, "ll": ll, "nb": nb}
+            self.last = {"fw": fw, "gx": gx, "gxT": gxT, "ll": ll, "nb": nb}
         else:
             g1d, i1d_ws = self._buf("g1d", 4 * self.J), self._buf("i1d_ws", be.irt1d_workspace(cfg, nb))
             elbo = self._buf("elbo", nb)
