@@ -45,6 +45,22 @@ def enc_fwd_flops_per_person(J, D, H):
     return 2.0 * (J * H + H * D + H * T + T)
 
 
+def measured_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel on the headline workload, from the committed PMC summary
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied; see
+    profiles/r01_v3_hbm_traffic.json and tools/profile_round.sh).  None when the summary is not there."""
+    path = os.path.join(ROOT, "profiles", "r01_v3_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            kernels = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    for name, v in kernels.items():
+        if name.startswith(kernel_prefix):
+            return float(v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"])
+    return None
+
+
 def cpu_baseline(J, D, H, n_sample, min_seconds=10.0):
     """The CPU restatement of the reference step (oracle/vi_oracle.py, numpy float32, all host
     threads numpy's BLAS uses) on a bounded sample of the same workload: n_sample persons, full
@@ -173,9 +189,11 @@ def main():
         if D > 1 and "guide_forward" in phase_ms:
             fl = enc_fwd_flops_per_person(J, D, H) * n_local
             ach = fl / (phase_ms["guide_forward"] * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "k_mvn_enc_fwd", "bound": "mfma", "achieved": ach,
+            headline = args.workload == "irt2pl_100d_amortized_1Mx500" and world == 1 and not args.persons
+            out["roofline"] = {"kernel": "k_mvn_enc_fwd_p", "bound": "mfma", "achieved": ach,
                                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                               "traffic": None,
+                               "traffic": measured_traffic("k_mvn_enc_fwd_p") if headline else None,
+                               "traffic_source": "profiles/r01_v3_hbm_traffic.json (PMC, bytes per launch)" if headline else None,
                                "algorithmic_flops_per_launch": fl, "avg_launch_ms": phase_ms["guide_forward"]}
         elif "irt1d" in phase_ms or "hodina" in phase_ms:
             key = "irt1d" if "irt1d" in phase_ms else "hodina"
