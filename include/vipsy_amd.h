@@ -113,9 +113,13 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                         const float* W21, const float* W22,
                         const float* h, const float* eps, const float* ldT, const float* gx,
                         const float* hT /*or NULL*/, const float* epsT /*or NULL*/, const float* gxT /*or NULL*/,
+                        const uint8_t* yT /*[J][yT_stride] item-major copy of y, or NULL*/, int64_t yT_stride,
                         float* genc, float* workspace, const float* packws, void* hip_stream);
 /* With hT, epsT and gxT (the dimension-major copies made by the forward / likelihood calls) the head weight
- * gradients run on the DMA-staged kernel of k_mvn_bwd_t.hip; without them on the person-major one. */
+ * gradients run on the DMA-staged kernel of k_mvn_bwd_t.hip; without them on the person-major one.
+ * yT (full batch only, rows == NULL, yT_stride % 16 == 0): the responses item-major, which lets the fc1 weight
+ * gradient read 16 persons of an item with one 16-byte LDS load; the responses never change, so the host
+ * transposes them once. */
 
 /* ---- D = 1 models (irt_1pl..4pl, Normal guide; vi.py:588-595, 677-684, 701-705), fused:
  * x = loc + exp(raw) eps, likelihood, prior, entropy, gradients w.r.t. loc/raw and the items.

@@ -124,6 +124,9 @@ def _random_problem(N, J, D, H, model, miss, seed):
     (200, 131, 101, 32, "irt_4pl", 0.2, 77),        # D >= 64: register-resident likelihood kernel, ragged staging
     (150, 260, 64, 64, "irt_3pl", 0.1, None),
     (130, 516, 127, 64, "irt_2pl", 0.3, None),
+    (320, 500, 100, 64, "irt_2pl", 0.1, None),      # N % 16 == 0: item-major responses, dimension-major fc1 gradient
+    (1040, 516, 64, 64, "irt_3pl", 0.2, None),      # ... with two 512-item groups and a ragged last person tile
+    (64, 40, 8, 64, "irt_2pl", 0.0, None),
 ])
 def test_mvn_amortized_step_vs_oracle(N, J, D, H, model, miss, B):
     from vipsy_amd.engine import IrtEngine, ENC_KEYS

@@ -279,7 +279,8 @@ __host__ __device__ inline size_t bh_lds_bytes(int D) {
 __global__ __launch_bounds__(BH_THREADS, 1) void k_mvn_enc_bwd_h_t(
     EncDims dm, float scale, const float* __restrict__ WpT, const uint32_t* __restrict__ gtab,
     const float* __restrict__ h_in, const float* __restrict__ eps_in, const float* __restrict__ ldT,
-    const float* __restrict__ gxT, float* __restrict__ ghpre_out) {
+    const float* __restrict__ gxT, float* __restrict__ ghpre_out /*[nb][64] or null*/,
+    const float* __restrict__ hT /*[64][nb], with ghpreT_out*/, float* __restrict__ ghpreT_out /*[64][nb] or null*/) {
     extern __shared__ __attribute__((aligned(16))) char smem_bh[];
     constexpr int H = 64;
     const int D = dm.D, ES = bh_es(D);
@@ -432,7 +433,17 @@ __global__ __launch_bounds__(BH_THREADS, 1) void k_mvn_enc_bwd_h_t(
         tail_tile(tile % BH_NBUF, tile);
     }
     // ---- ghpre = gh * softplus'(pre) = gh * (1 - exp(-h));  C layout: rows hh = crow32(r, half), cols p
-    if (i < nb) {
+    if (ghpreT_out) {                                                  // dimension-major: 128-byte rows per half-wave
+        if (i < nb) {
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t o = (int64_t)(32 * ht + crow32(r, half)) * nb + i;
+                    ghpreT_out[o] = (ht ? acc1 : acc0)[r] * (1.0f - __expf(-hT[o]));
+                }
+        }
+    } else if (i < nb) {
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
@@ -446,5 +457,150 @@ __global__ __launch_bounds__(BH_THREADS, 1) void k_mvn_enc_bwd_h_t(
                 o.w = (ht ? acc1 : acc0)[4 * g + 3] * (1.0f - __expf(-hv.w));
                 *(float4*)(ghpre_out + i * H + hh0) = o;
             }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// fc1 weight gradient from dimension-major operands (full batch, no row gather):
+//     GW1[hh][j] = sum_p ghpreT[hh][p] yin[p][j],   Gb1[hh] = sum_p ghpreT[hh][p]         (yin = int8 -1 / 0 / 1)
+// yT [J][n] is the item-major copy of the response bytes (made once by the host; responses never change).
+// A wave owns 4 item tiles x both hidden tiles (128 AGPRs); 32-person tiles by DMA, double buffered:
+//   ghpreT rows in the bank-row-aware layout of bt_addr(); yT rows are 32 bytes = 2 chunks of 16 persons, chunk c of
+//   items 16 B .. 16 B + 15 shares bank row 2 B + c (slot = item & 15): a 16-byte read hands a lane the bytes of 16
+//   persons for its item.  Person order inside the MFMA steps: 16 c + 8 m + 4 half + i.
+#define F1_P 32
+#define F1_THREADS 256
+#define F1_JW 128                                                      // items per wave (4 tiles)
+#define F1_GBUF (64 * 128)                                             // bytes of the ghpreT tile
+__host__ __device__ inline int f1_jrows(int J) { return (J + 31) & ~31; }
+__host__ __device__ inline size_t f1_buf_bytes(int J) { return F1_GBUF + (size_t)f1_jrows(J) * 32; }
+__host__ __device__ inline size_t f1_lds_bytes(int J) { return 2 * f1_buf_bytes(J > 512 ? 512 : J); }
+
+__global__ __launch_bounds__(F1_THREADS, 1) void k_fc1_bwd_t(
+    EncDims dm, const uint8_t* __restrict__ yT, int64_t ystride, const float* __restrict__ ghpreT,
+    float* __restrict__ slabs, int64_t slab_len) {
+    extern __shared__ __attribute__((aligned(16))) char smem_f1[];
+    const int J = dm.J;
+    const int64_t nb = dm.nb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int jg0 = blockIdx.x * 512;                                  // items of this workgroup: jg0 .. jg0 + 511
+    const int jn = (J - jg0) < 512 ? (J - jg0) : 512;
+    const uint32_t BUF = (uint32_t)f1_buf_bytes(jn);
+    const int n_ydma = f1_jrows(jn) / 32;                              // one transfer = 32 item rows x 2 chunks
+    // per-lane LDS addresses
+    uint32_t aA[2][4];                                                 // ghpreT chunk 4c + 2m + half of rows l31, 32 + l31
+#pragma unroll
+    for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            aA[ht][u] = bt_addr(32 * ht + l31, 2 * u + half);
+        }
+    uint32_t aY[4][2];                                                 // yT chunk c of item 128 wave + 32 t + l31
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int jl = F1_JW * wave + 32 * t + l31;
+            aY[t][c] = (uint32_t)(F1_GBUF + ((jl >> 4) * 2 + c) * 256 + (jl & 15) * 16);
+        }
+    // per-lane DMA sources (tile-invariant part)
+    const float* gsrc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                                      // ghpreT: 8 transfers, wave w issues d = w, w + 4
+        const int d = wave + 4 * u;
+        const int i = 4 * (d & 1) + (lane >> 4), beta = (lane >> 3) & 1;
+        const int R = 16 * (d >> 1) + 8 * beta + i, c = (lane & 7) ^ i;
+        gsrc[u] = ghpreT + (int64_t)R * nb + 4 * c;
+    }
+    const uint8_t* ysrc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                                      // yT: n_ydma transfers
+        const int d = wave + 4 * u;
+        int j = jg0 + 32 * d + 16 * (lane >> 5) + (lane & 15);
+        if (j >= J) j = J - 1;
+        ysrc[u] = yT + (int64_t)j * ystride + 16 * ((lane >> 4) & 1);
+    }
+    auto stage = [&](int64_t tile, int b) {
+        const int64_t i0 = tile * F1_P;
+        const int pv = (int)((nb - i0) < F1_P ? (nb - i0) : F1_P);
+        const uint32_t lb = lds_addr_uniform(smem_f1 + b * BUF);
+        if (pv < F1_P) {                                               // last tile: absent persons have ghpre = 0
+            for (int e = tid; e < F1_GBUF / 4; e += F1_THREADS) ((float*)(smem_f1 + b * BUF))[e] = 0.f;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int d = wave + 4 * u;
+            const int c = (lane & 7) ^ (4 * (d & 1) + (lane >> 4));
+            if (pv == F1_P) dma16(gsrc[u] + i0, lb + (uint32_t)d * 1024u);
+            else if (4 * c < pv) dma16(gsrc[u] + i0, lb + (uint32_t)d * 1024u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int d = wave + 4 * u;
+            if (d < n_ydma) dma16(ysrc[u] + i0, lb + F1_GBUF + (uint32_t)d * 1024u);
+        }
+    };
+    f32x16 acc[4][2];
+    float bsum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { acc[t][0] = zero16(); acc[t][1] = zero16(); }
+
+    auto compute = [&](int b) {
+        const char* base = smem_f1 + b * BUF;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            uint4 yc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) yc[t] = *(const uint4*)(base + aY[t][c]);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const f32x4 g0 = *(const f32x4*)(base + aA[0][2 * c + m]);
+                const f32x4 g1 = *(const f32x4*)(base + aA[1][2 * c + m]);
+                bsum[0] += (g0[0] + g0[1]) + (g0[2] + g0[3]);
+                bsum[1] += (g1[0] + g1[1]) + (g1[2] + g1[3]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const uint32_t lo = m ? yc[t].z : yc[t].x, hi = m ? yc[t].w : yc[t].y;
+                    const int w = (int)(half ? hi : lo);               // bytes of persons 16c + 8m + 4half + 0..3
+                    const float y0 = (float)((w << 24) >> 24), y1 = (float)((w << 16) >> 24);
+                    const float y2 = (float)((w << 8) >> 24), y3 = (float)(w >> 24);
+                    acc[t][0] = mfma32(g0[0], y0, acc[t][0]); acc[t][1] = mfma32(g1[0], y0, acc[t][1]);
+                    acc[t][0] = mfma32(g0[1], y1, acc[t][0]); acc[t][1] = mfma32(g1[1], y1, acc[t][1]);
+                    acc[t][0] = mfma32(g0[2], y2, acc[t][0]); acc[t][1] = mfma32(g1[2], y2, acc[t][1]);
+                    acc[t][0] = mfma32(g0[3], y3, acc[t][0]); acc[t][1] = mfma32(g1[3], y3, acc[t][1]);
+                }
+            }
+        }
+    };
+    const int64_t n_ptiles = (nb + F1_P - 1) / F1_P;
+    int64_t tile = blockIdx.y;
+    int b = 0;
+    if (tile < n_ptiles) stage(tile, 0);
+    for (; tile < n_ptiles; tile += gridDim.y, b ^= 1) {
+        vx_wait_vmem();
+        __syncthreads();
+        if (tile + gridDim.y < n_ptiles) stage(tile + gridDim.y, b ^ 1);
+        compute(b);
+    }
+    // slab: [W1-grad: 64 * J | b1-grad: 64]
+    float* slab = slabs + (int64_t)blockIdx.y * slab_len;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int j = jg0 + F1_JW * wave + 32 * t + l31;
+        if (j < J) {
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab[(int64_t)(32 * ht + crow32(r, half)) * J + j] = acc[t][ht][r];
+        }
+    }
+    if (blockIdx.x == 0 && wave == 0) {                                // every wave holds the same sums
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+            const float s = half_sum32(bsum[ht]);
+            if (half == 0) slab[(int64_t)64 * J + 32 * ht + l31] = s;
+        }
     }
 }

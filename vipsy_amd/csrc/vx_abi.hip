@@ -472,8 +472,8 @@ int64_t vx_mvn_enc_bwd_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
 
 int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
                         const float* W21, const float* W22, const float* h, const float* eps, const float* ldT,
-                        const float* gx, const float* hT, const float* epsT, const float* gxT, float* genc,
-                        float* workspace, const float* packws, void* hs) {
+                        const float* gx, const float* hT, const float* epsT, const float* gxT, const uint8_t* yT,
+                        int64_t yT_stride, float* genc, float* workspace, const float* packws, void* hs) {
     if (!enc_cfg_ok(cfg) || !y || !W21 || !W22 || !h || !eps || !ldT || (!gx && !gxT) || !genc || !workspace || nb < 0)
         return VX_EINVAL;
     int n_rowslabs, n_prw, n_jg, n_prf;
@@ -501,6 +501,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     float* slabs_f = slabs_w + (int64_t)n_prw_ws * lenw;
     hipStream_t st = (hipStream_t)hs;
     int rc;
+    bool f1t = false;                                      // fc1 gradient on the dimension-major kernel (ghpre holds ghpreT)
     if (packed) {
         const float* Wp = packws;
         const uint32_t* gtab = (const uint32_t*)(packws + Rp * 64 + Rp);
@@ -511,8 +512,11 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
             const size_t lds = bh_lds_bytes(dm.D);
             rc = set_lds(k_mvn_enc_bwd_h_t, lds);
             if (rc) return rc;
+            f1t = yT && !rows && yT_stride % 16 == 0 && yT_stride >= nb && aligned16(yT) && cfg->J >= 32 &&
+                  f1_lds_bytes(cfg->J) <= 160 * 1024;
             hipLaunchKernelGGL(k_mvn_enc_bwd_h_t, dim3((unsigned)((nb + BH_P - 1) / BH_P)), dim3(BH_THREADS), lds, st, dm,
-                               cfg->scale, WpT, gtab, h, eps, ldT, gxT, ghpre);
+                               cfg->scale, WpT, gtab, h, eps, ldT, gxT, f1t ? (float*)nullptr : ghpre, hT,
+                               f1t ? ghpre : (float*)nullptr);
             VX_CHECK_LAUNCH();
         } else {
             if (!gx) return VX_EINVAL;                     // the person-major kernel needs gx[nb][D]
@@ -590,7 +594,14 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
             VX_CHECK_LAUNCH();
         }
     }
-    if (nb > 0) {
+    if (nb > 0 && f1t) {
+        const size_t lds = f1_lds_bytes(cfg->J);
+        rc = set_lds(k_fc1_bwd_t, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_fc1_bwd_t, dim3((unsigned)((cfg->J + 511) / 512), (unsigned)n_prf), dim3(F1_THREADS), lds, st, dm,
+                           yT, yT_stride, ghpre, slabs_f, lenf);
+        VX_CHECK_LAUNCH();
+    } else if (nb > 0) {
         {
             const size_t lds = fc1_bwd_lds_floats(dm.Hp) * sizeof(float);
             const dim3 grid((unsigned)n_jg, (unsigned)n_prf);

@@ -80,6 +80,7 @@ class HipBackend(object):
                                         _hip.ptr(enc["fc21.weight"]), _hip.ptr(enc["fc22.weight"]),
                                         _hip.ptr(fw["h"]), _hip.ptr(fw["eps"]), _hip.ptr(fw["ldT"]), _hip.ptr(gx),
                                         _hip.ptr(fw.get("hT")), _hip.ptr(fw.get("epsT")), _hip.ptr(gxT),
+                                        _hip.ptr(fw.get("yT")), int(fw["yT"].shape[1]) if fw.get("yT") is not None else 0,
                                         _hip.ptr(genc), _hip.ptr(ws), _hip.ptr(fw.get("packws")), _hip.stream_ptr())
         _hip.check(rc, "vx_mvn_enc_backward")
 
@@ -460,6 +461,10 @@ class IrtEngine(_EngineBase):
                 # dimension-major copies (person-contiguous rows) for the DMA-staged weight-gradient kernel
                 fw["hT"], fw["epsT"] = self._buf("hT", nb * H), self._buf("epsT", nb * D)
                 gxT = self._buf("gxT", nb * D)
+                if rows is None and self.n_local % 16 == 0:
+                    if getattr(self, "_yT", None) is None:          # item-major responses: made once, they never change
+                        self._yT = self.y.t().contiguous()
+                    fw["yT"] = self._yT
             gx, ll = self._buf("gx", nb * D), self._buf("ll", nb)
             if gxT is not None and be.mvn_enc_bwd_layout(cfg, nb) == 1:
                 gx = None                                  # the backward kernels read gxT only
