@@ -45,7 +45,6 @@ __global__ __launch_bounds__(EP_THREADS, 1) void k_mvn_enc_fwd_p(
     const int D = dm.D, J = dm.J;
     const int DS = pk_dse(D), DX = (D + 3) & ~3;
     const int YS = ef_ys(J);
-    const int dbg = dm.Hp - 64;                               // timing experiments only (VX_DBG); 0 in production
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     float* R1 = smem + wave * enc_p_wave_floats(D, J);
     int8_t* Yi = (int8_t*)R1;                                 // phase A
@@ -133,7 +132,7 @@ __global__ __launch_bounds__(EP_THREADS, 1) void k_mvn_enc_fwd_p(
         if (nfull > 0) {
             float4 A[4][2][4];
             loadA(A[0], 0); loadA(A[1], 1); loadA(A[2], 2);
-            const int nloop = (dbg & 4) ? (nfull < 4 ? nfull : 4) : nfull;
+            const int nloop = nfull;
             for (int c = 0; c < nloop; c += 4) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -191,11 +190,9 @@ __global__ __launch_bounds__(EP_THREADS, 1) void k_mvn_enc_fwd_p(
             f32x4 z;
             if (eps_in) {
                 z = *(const f32x4*)(eps_in + ii * D + 4 * blk);
-            } else if (!(dbg & 8)) {
+            } else {
                 const int64_t row = rows ? rows[ii] : ii;
                 z = philox_normal4(seed, step, stream, gid0 + row, (uint32_t)blk);
-            } else {
-                z = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             *(f32x4*)(eps_lds + pp * DS + 4 * blk) = z;
             if (i0 + pp < dm.nb) *(f32x4*)(eps_out + ii * D + 4 * blk) = z;
@@ -261,14 +258,16 @@ __global__ __launch_bounds__(EP_THREADS, 1) void k_mvn_enc_fwd_p(
                 kq[g] = (code >> 12) & 0xFFFFu;
                 e4[g] = *(const float4*)(ep + (code & 0xFFFu) + 4 * half);
             }
+            __builtin_amdgcn_sched_barrier(0);                 // keep the reads above the chain (the scheduler sinks them)
             const f32x16 a = mma(A, biasA);
-            if (dbg & 1) { cur_part += a[0]; return; }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {                      // rows (k, l0 + 4half + j) live in a[4g + j]
                 const float part = a[4 * g + 0] * e4[g].x + a[4 * g + 1] * e4[g].y + a[4 * g + 2] * e4[g].z +
                                    a[4 * g + 3] * e4[g].w;
-                if (kq[g] != cur_k) { flush(); cur_k = kq[g]; cur_part = part; }      // wave-uniform
-                else cur_part += part;
+                const bool changed = kq[g] != cur_k;                                  // wave-uniform, rare
+                if (__builtin_expect(changed, 0)) flush();                            // one-sided branch, falls through
+                cur_part = part + (changed ? 0.f : cur_part);
+                cur_k = kq[g];
             }
         };
         {
@@ -277,11 +276,7 @@ __global__ __launch_bounds__(EP_THREADS, 1) void k_mvn_enc_fwd_p(
             uint4 g0, g1, g2;
             prefetch(A0, bA0, g0, 0);
             prefetch(A1, bA1, g1, 1);
-            for (int tt = 0; tt < ((dbg & 16) ? 0 : n_off); tt += 3) {            // straight-line body; tiles n_off, n_off+1 exist (DIAG)
-                if (dbg & 2) {                                  // experiment: no weight loads at all
-                    tile_off(A0, bA0, g0); tile_off(A1, bA1, g1); tile_off(A0, bA0, g0);
-                    continue;
-                }
+            for (int tt = 0; tt < n_off; tt += 3) {            // straight-line body; tiles n_off, n_off+1 exist (DIAG)
                 prefetch(A2, bA2, g2, tt + 2);
                 tile_off(A0, bA0, g0);
                 prefetch(A0, bA0, g0, tt + 3);
@@ -290,49 +285,46 @@ __global__ __launch_bounds__(EP_THREADS, 1) void k_mvn_enc_fwd_p(
                 tile_off(A2, bA2, g2);
             }
             flush();
-        }
-        stamp(4);
-        // ---- DIAG section (exp(M_kk) eps_k, entropy, ldT) and LOC section (the loc head): 2 * n_sec tiles.  The
-        // weights of tile t + 1 are fetched while tile t runs; the 16 x entries a lane updates are read together,
-        // updated and written together (one LDS round trip per tile instead of one per entry).
-        {
-            float4 A[2][2][4];
-            float bA[2];
-            uint4 gcd[2];
+            stamp(4);
+            // ---- DIAG section (exp(M_kk) eps_k, entropy, ldT) and LOC section (the loc head): 2 * n_sec tiles, on the
+            // same three-deep weight ring (A0 / A1 already hold the first two of them).  The 16 x entries a lane
+            // updates are read together, updated and written together (one LDS round trip per tile).
             const int t_end = n_off + 2 * n_sec;
-            prefetch(A[0], bA[0], gcd[0], n_off);
-            for (int tt = n_off; tt < t_end; tt += 2) {
+            auto tile_sec = [&](const float4 (&A)[2][4], float biasA, int t2) {
+                const f32x16 a = mma(A, biasA);
+                const bool is_diag = t2 < n_off + n_sec;
+                const int k0 = 32 * (t2 - (is_diag ? n_off : n_off + n_sec));
+                float xo[16], ev[16];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int t2 = tt + u;
-                    if (t2 >= t_end) break;
-                    if (t2 + 1 < t_end) prefetch(A[u ^ 1], bA[u ^ 1], gcd[u ^ 1], t2 + 1);
-                    const f32x16 a = mma(A[u], bA[u]);
-                    const bool is_diag = t2 < n_off + n_sec;
-                    const int k0 = 32 * (t2 - (is_diag ? n_off : n_off + n_sec));
-                    float xo[16], ev[16];
+                for (int r = 0; r < 16; ++r) {
+                    int kk = k0 + crow32(r, half);
+                    kk = kk < D ? kk : D - 1;
+                    xo[r] = xp[kk];
+                    ev[r] = ep[kk];
+                }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int kk = k0 + crow32(r, half);
-                        kk = kk < D ? kk : D - 1;
-                        xo[r] = xp[kk];
-                        ev[r] = ep[kk];
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int kk = k0 + crow32(r, half);
-                        if (kk < D) {
-                            if (is_diag) {
-                                const float ld = __expf(a[r]);                         // exp(diag M): vi.py:686
-                                xp[kk] = fmaf(ld, ev[r], xo[r]);
-                                ent_acc += a[r];
-                                if (i < dm.nb) ldT[(int64_t)kk * dm.nb + i] = ld;
-                            } else {
-                                xp[kk] = xo[r] + a[r];                                 // loc head (vi.py:450)
-                            }
+                for (int r = 0; r < 16; ++r) {
+                    const int kk = k0 + crow32(r, half);
+                    if (kk < D) {
+                        if (is_diag) {
+                            const float ld = __expf(a[r]);                             // exp(diag M): vi.py:686
+                            xp[kk] = fmaf(ld, ev[r], xo[r]);
+                            ent_acc += a[r];
+                            if (i < dm.nb) ldT[(int64_t)kk * dm.nb + i] = ld;
+                        } else {
+                            xp[kk] = xo[r] + a[r];                                     // loc head (vi.py:450)
                         }
                     }
                 }
+            };
+            auto clampt = [&](int t2) { return t2 < t_end ? t2 : t_end - 1; };   // past the end: reload the last tile
+            for (int tt = n_off; tt < t_end; tt += 3) {
+                prefetch(A2, bA2, g2, clampt(tt + 2));
+                tile_sec(A0, bA0, tt);
+                prefetch(A0, bA0, g0, clampt(tt + 3));
+                if (tt + 1 < t_end) tile_sec(A1, bA1, tt + 1);
+                prefetch(A1, bA1, g1, clampt(tt + 4));
+                if (tt + 2 < t_end) tile_sec(A2, bA2, tt + 2);
             }
         }
     }

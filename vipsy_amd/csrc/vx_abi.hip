@@ -177,16 +177,16 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
         if (rc) return rc;
         const dim3 gridp((unsigned)((nb + EP_WAVES * EP_WP - 1) / (EP_WAVES * EP_WP)));
         long long* stamps = nullptr;
-        { const char* e = getenv("VX_DBG"); if (e) dm.Hp = 64 + atoi(e); }
-        if (getenv("VX_STAMPS")) { hipMalloc(&stamps, 2048 * 8 * sizeof(long long)); hipMemset(stamps, 0, 2048 * 8 * sizeof(long long)); }
+        if (getenv("VX_STAMPS") && hipMalloc(&stamps, 2048 * 8 * sizeof(long long)) == hipSuccess)
+            (void)hipMemset(stamps, 0, 2048 * 8 * sizeof(long long));
         hipLaunchKernelGGL(k_mvn_enc_fwd_p, gridp, dim3(EP_THREADS), ldsp, (hipStream_t)hs, dm, y, rows, gid0, W1, b1, Wp,
                            bp, gtab, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT, stamps);
         VX_CHECK_LAUNCH();
         if (stamps) {                                       // timing experiment: phase durations of wave 0 per workgroup
             static long long hst[2048 * 8];
-            hipDeviceSynchronize();
-            hipMemcpy(hst, stamps, sizeof(hst), hipMemcpyDeviceToHost);
-            hipFree(stamps);
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(hst, stamps, sizeof(hst), hipMemcpyDeviceToHost);
+            (void)hipFree(stamps);
             double acc[7] = {0, 0, 0, 0, 0, 0, 0};
             int nblk = 0;
             for (int b = 0; b < 2048 && b < (int)gridp.x; ++b) {
