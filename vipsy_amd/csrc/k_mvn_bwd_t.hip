@@ -279,9 +279,15 @@ __host__ __device__ inline size_t bh_lds_bytes(int D) {
 __global__ __launch_bounds__(BH_THREADS, 1) void k_mvn_enc_bwd_h_t(
     EncDims dm, float scale, const float* __restrict__ WpT, const uint32_t* __restrict__ gtab,
     const float* __restrict__ h_in, const float* __restrict__ eps_in, const float* __restrict__ ldT,
-    const float* __restrict__ gxT, float* __restrict__ ghpre_out /*[nb][64] or null*/,
-    const float* __restrict__ hT /*[64][nb], with ghpreT_out*/, float* __restrict__ ghpreT_out /*[64][nb] or null*/) {
+    const float* __restrict__ gxT, const float* __restrict__ gdT /*DIAG-row operand [D][nb]*/,
+    float* __restrict__ ghpre_out /*[nb][64] or null*/,
+    const float* __restrict__ hT /*[64][nb], with ghpreT_out*/, float* __restrict__ ghpreT_out /*[64][nb] or null*/,
+    long long* __restrict__ stamps /*timing experiments only, normally null*/) {
     extern __shared__ __attribute__((aligned(16))) char smem_bh[];
+    auto stamp = [&](int idx) {
+        if (stamps && threadIdx.x == 0 && blockIdx.x < 2048) stamps[blockIdx.x * 8 + idx] = (long long)__builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
     constexpr int H = 64;
     const int D = dm.D, ES = bh_es(D);
     const int64_t nb = dm.nb;
@@ -365,15 +371,21 @@ __global__ __launch_bounds__(BH_THREADS, 1) void k_mvn_enc_bwd_h_t(
             constexpr int q = decltype(qc)::value;
             float gn = gk;
             f32x4 en = e4, wn0 = w0, wn1 = w1;
+            const f32x4 v = gk * e4;
+            // LDS instructions issue beside a running MFMA (VALU ones do not): the reads of group q + 1 go right
+            // after the first MFMA of group q -- early enough to land before they are needed, not ahead of the chain
+            acc0 = mfma32(w0[0], v[0], acc0);
+            __builtin_amdgcn_sched_barrier(0);
             if constexpr (q + 1 < 8) {
                 gn = ld_g(code[q + 1]);
                 en = ld_e(code[q + 1]);
                 wn0 = *(const f32x4*)(wb + aW[0][q + 1]);
                 wn1 = *(const f32x4*)(wb + aW[1][q + 1]);
             }
-            const f32x4 v = gk * e4;
+            __builtin_amdgcn_sched_barrier(0);
+            acc1 = mfma32(w1[0], v[0], acc1);
 #pragma unroll
-            for (int i2 = 0; i2 < 4; ++i2) {
+            for (int i2 = 1; i2 < 4; ++i2) {
                 acc0 = mfma32(w0[i2], v[i2], acc0);
                 acc1 = mfma32(w1[i2], v[i2], acc1);
             }
@@ -381,27 +393,37 @@ __global__ __launch_bounds__(BH_THREADS, 1) void k_mvn_enc_bwd_h_t(
             __builtin_amdgcn_sched_barrier(0);
         });
     };
-    // DIAG / LOC sections (a handful of tiles): every eight-row group has one type; buffer index at run time
+    // DIAG / LOC sections (a handful of tiles): every eight-row group has one type; buffer index at run time.
+    // V = gd[p][k] (DIAG, made by k_mvn_gd) or gx[p][k] (LOC); the gdT tile is DMA'd over the eps region once the OFF
+    // section is done, so these tiles read LDS only.
+    const float* gd_p = eps_lds + p;                                   // + k * BH_P  (after stage_gd)
+    auto stage_gd = [&]() {
+        for (int j = wave; 2 * j < D; j += 4) {
+            int k = 2 * j + (lane >> 5);
+            if (k >= D) k = D - 1;
+            int64_t pp = i0 + 4 * (lane & 31);
+            if (pp + 4 > nb) pp = nb - 4;
+            dma16(gdT + (int64_t)k * nb + pp, lds_addr_uniform(eps_lds + 2 * j * BH_P));
+        }
+    };
     auto tail_tile = [&](int b, int tile) {
         const char* wb = Wt + b * BH_WBUF;
-#pragma unroll 1
+#pragma unroll 2
         for (int q = 0; q < 8; ++q) {
             const int r0 = tile * BH_TR + 8 * q;                       // first packed row of this 8-group (uniform)
             const bool is_diag = r0 < offT + sec, is_loc = !is_diag && r0 < offT + 2 * sec;
             const int k0 = r0 - (is_diag ? offT : offT + sec) + 4 * half;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const float* src = is_diag ? gd_p : gx_p;
+            f32x4 v;
 #pragma unroll
             for (int i2 = 0; i2 < 4; ++i2) {
                 const int k = k0 + i2;
-                if ((is_diag || is_loc) && k < D) {
-                    float t = gx_p[k * BH_P];
-                    if (is_diag) t = fmaf(t * eps_p[k], ldT[(int64_t)k * nb + (i < nb ? i : nb - 1)], scale);
-                    v[i2] = t;
-                }
+                const float t = src[(k < D ? k : D - 1) * BH_P];
+                v[i2] = ((is_diag || is_loc) && k < D) ? t : 0.f;
             }
-            const uint32_t hx0 = (uint32_t)(l31 & 15), hx1 = hx0;      // (hh & 15) of both hidden tiles
-            const f32x4 w0 = *(const f32x4*)(wb + l31 * 256 + (((2 * q + half) ^ hx0) << 4));
-            const f32x4 w1 = *(const f32x4*)(wb + (32 + l31) * 256 + (((2 * q + half) ^ hx1) << 4));
+            const uint32_t hx = (uint32_t)(l31 & 15);                  // (hh & 15) of both hidden tiles
+            const f32x4 w0 = *(const f32x4*)(wb + l31 * 256 + (((2 * q + half) ^ hx) << 4));
+            const f32x4 w1 = *(const f32x4*)(wb + (32 + l31) * 256 + (((2 * q + half) ^ hx) << 4));
 #pragma unroll
             for (int i2 = 0; i2 < 4; ++i2) {
                 acc0 = mfma32(w0[i2], v[i2], acc0);
@@ -419,6 +441,7 @@ __global__ __launch_bounds__(BH_THREADS, 1) void k_mvn_enc_bwd_h_t(
         __syncthreads();
         if (tile + 2 < n_tiles) stage_w(tile + 2, (tile + 2) % BH_NBUF);
     };
+    stamp(1);
     int tile = 0;
     for (; tile + 2 < n_off; tile += 3) {
         wait_tile(tile);
@@ -428,10 +451,20 @@ __global__ __launch_bounds__(BH_THREADS, 1) void k_mvn_enc_bwd_h_t(
         wait_tile(tile + 2);
         off_tile(std::integral_constant<int, 2>{}, tile + 2);
     }
+    stamp(2);
+    __syncthreads();                                                   // every wave is done with eps
+    stage_gd();
     for (; tile < n_tiles; ++tile) {
-        wait_tile(tile);
+        if (tile == n_off) {                                           // first tail tile: also wait for the gd tile
+            vx_wait_vmem();
+            __syncthreads();
+            if (tile + 2 < n_tiles) stage_w(tile + 2, (tile + 2) % BH_NBUF);
+        } else {
+            wait_tile(tile);
+        }
         tail_tile(tile % BH_NBUF, tile);
     }
+    stamp(3);
     // ---- ghpre = gh * softplus'(pre) = gh * (1 - exp(-h));  C layout: rows hh = crow32(r, half), cols p
     if (ghpreT_out) {                                                  // dimension-major: 128-byte rows per half-wave
         if (i < nb) {
@@ -458,6 +491,7 @@ __global__ __launch_bounds__(BH_THREADS, 1) void k_mvn_enc_bwd_h_t(
                 *(float4*)(ghpre_out + i * H + hh0) = o;
             }
     }
+    stamp(4);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -507,6 +507,12 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
         const uint32_t* gtab = (const uint32_t*)(packws + Rp * 64 + Rp);
         static int oldh = -1;
         if (oldh < 0) { const char* e = getenv("VX_BWDH"); oldh = (e && e[0] == 'o') ? 1 : 0; }
+        if (use_t) {                                        // DIAG-row operand of both dimension-major kernels
+            float* gdT0 = slabs_f + (int64_t)n_prf * lenf;
+            hipLaunchKernelGGL(k_mvn_gd, dim3(num_cu() * 8), dim3(256), 0, st, (const float4*)gxT, (const float4*)epsT,
+                               (const float4*)ldT, cfg->scale, nb * D / 4, (float4*)gdT0);
+            VX_CHECK_LAUNCH();
+        }
         if (use_t && !oldh && nb >= 4 && bh_lds_bytes(dm.D) <= 160 * 1024) {
             const float* WpT = (const float*)(gtab + Rp / 8 + 8);
             const size_t lds = bh_lds_bytes(dm.D);
@@ -514,10 +520,28 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
             if (rc) return rc;
             f1t = yT && !rows && yT_stride % 16 == 0 && yT_stride >= nb && aligned16(yT) && cfg->J >= 32 &&
                   f1_lds_bytes(cfg->J) <= 160 * 1024;
+            long long* stamps = nullptr;
+            if (getenv("VX_STAMPS") && hipMalloc(&stamps, 2048 * 8 * sizeof(long long)) == hipSuccess)
+                (void)hipMemset(stamps, 0, 2048 * 8 * sizeof(long long));
             hipLaunchKernelGGL(k_mvn_enc_bwd_h_t, dim3((unsigned)((nb + BH_P - 1) / BH_P)), dim3(BH_THREADS), lds, st, dm,
-                               cfg->scale, WpT, gtab, h, eps, ldT, gxT, f1t ? (float*)nullptr : ghpre, hT,
-                               f1t ? ghpre : (float*)nullptr);
+                               cfg->scale, WpT, gtab, h, eps, ldT, gxT, slabs_f + (int64_t)n_prf * lenf, f1t ? (float*)nullptr : ghpre, hT,
+                               f1t ? ghpre : (float*)nullptr, stamps);
             VX_CHECK_LAUNCH();
+            if (stamps) {                                   // timing experiment: phase durations of wave 0 per workgroup
+                static long long hst[2048 * 8];
+                (void)hipDeviceSynchronize();
+                (void)hipMemcpy(hst, stamps, sizeof(hst), hipMemcpyDeviceToHost);
+                (void)hipFree(stamps);
+                double acc[4] = {0, 0, 0, 0};
+                int nblk = 0;
+                for (int b = 0; b < 2048; ++b) {
+                    if (!hst[b * 8 + 4]) continue;
+                    for (int k2 = 0; k2 < 4; ++k2) acc[k2] += (double)(hst[b * 8 + k2 + 1] - hst[b * 8 + k2]);
+                    ++nblk;
+                }
+                if (nblk) fprintf(stderr, "bwd_h_t stamps (mean over %d blocks): prologue %.0f off %.0f tail %.0f out %.0f\n", nblk,
+                                  acc[0] / nblk, acc[1] / nblk, acc[2] / nblk, acc[3] / nblk);
+            }
         } else {
             if (!gx) return VX_EINVAL;                     // the person-major kernel needs gx[nb][D]
             const size_t lds = enc_bwdh_p_lds_floats(dm.D) * sizeof(float);
@@ -531,10 +555,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
             const size_t lds = bt_lds_bytes(dm.D);
             rc = set_lds(k_mvn_enc_bwd_w_t, lds);
             if (rc) return rc;
-            float* gdT = slabs_f + (int64_t)n_prf * lenf;     // DIAG-row operand, dimension-major
-            hipLaunchKernelGGL(k_mvn_gd, dim3(num_cu() * 8), dim3(256), 0, st, (const float4*)gxT, (const float4*)epsT,
-                               (const float4*)ldT, cfg->scale, nb * D / 4, (float4*)gdT);
-            VX_CHECK_LAUNCH();
+            float* gdT = slabs_f + (int64_t)n_prf * lenf;     // DIAG-row operand, dimension-major (made above)
             hipLaunchKernelGGL(k_mvn_enc_bwd_w_t, dim3((unsigned)n_rowslabs, (unsigned)n_prw), dim3(BT_THREADS), lds, st,
                                dm, hT, epsT, gdT, gxT, gtab, slabs_w, Rp * (H + 1));
             VX_CHECK_LAUNCH();
