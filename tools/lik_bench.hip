@@ -34,7 +34,7 @@ int main() {
     const int64_t nb = 1000000;
     LikRDims dm;
     dm.D = D; dm.J = J; dm.K8 = 104; dm.XS = 108; dm.model = 2; dm.fast = 1; dm.groups = 4; dm.n_pr = 64;
-    dm.Dc = 1.f; dm.scale = 1.f; dm.nb = nb; dm.slab_len = (int64_t)D * J + 3 * J;
+    dm.Dc = 1.f; dm.scale = 1.f; dm.nb = nb; dm.slab_len = (int64_t)D * J + 3 * J; dm.gxt = 1;
     uint8_t* y; float *x, *a, *b, *gxp, *llp, *slabs;
     hipMalloc(&y, nb * J); hipMalloc(&x, nb * D * 4); hipMalloc(&a, D * J * 4); hipMalloc(&b, J * 4);
     hipMalloc(&gxp, (size_t)dm.groups * nb * D * 4); hipMalloc(&llp, (size_t)dm.groups * nb * 4);

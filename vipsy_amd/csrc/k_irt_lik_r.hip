@@ -22,6 +22,9 @@
 #define LR_RS 132            // floats per R / LP row: 128 + 4 (== 4 mod 32: conflict-free 16-byte row reads)
 #define LR_YS 128            // response bytes per person row (dense: the DMA writes 8 rows per instruction)
 
+// DMA sources of the x_aug pad columns: chunk 0 = [1, 0, 0, 0] (the bias column of a present person), chunk 1 = zeros
+__device__ __attribute__((aligned(16))) const float lr_pad_chunks[8] = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
 struct LikRDims {
     int D, J, K8, XS;        // K8 = (D + 1) rounded up to 8;  XS = K8 + 4 (== 4 mod 8)
     int model, fast, groups, n_pr;
@@ -116,11 +119,32 @@ __global__ __launch_bounds__(LR_THREADS) void k_irt_lik_r(
     // The pad columns [D, XS) of x_aug ([1, 0, 0, ...]) and the response bytes past J (254 = outside the problem)
     // are never touched by the DMA: written once here, for both buffers.
     const bool jfull = j0 + LR_JC <= J;                                // block-uniform: no item edge in this chunk
-    for (int e = tid; e < 2 * LR_P * (XS - D); e += LR_THREADS) {
-        const int row = e / (XS - D), k = D + (e - row * (XS - D));
-        x_lds[row * XS + k] = (k == D) ? 1.0f : 0.f;
+    if (!FAST) {
+        for (int e = tid; e < 2 * LR_P * (XS - D); e += LR_THREADS) {
+            const int row = e / (XS - D), k = D + (e - row * (XS - D));
+            x_lds[row * XS + k] = (k == D) ? 1.0f : 0.f;
+        }
     }
     for (int e = tid; e < 2 * LR_P * (LR_YS / 4); e += LR_THREADS) ((uint32_t*)Yb)[e] = 0xFEFEFEFEu;
+    // FAST: the x_aug tile [64][XS] is one contiguous run of 64 * XS / 4 chunks = XS / 4 full-wave transfers (a partial
+    // EXEC mask makes a DMA several times slower); each lane's chunk is data, the [1,0,0,0] pad or zeros -- fixed per
+    // lane and transfer, only the person offset of the tile changes.  Wave w issues transfers w, w + 4, ...
+    constexpr int LR_MAXX = 9;                                         // XS <= 132: 33 transfers / 4 waves
+    const float* xbase[LR_MAXX];                                       // data: x + row * D + 4 cc; pad: the pad chunk
+    int xrow[LR_MAXX];                                                 // person row of the chunk; bit 8: chunk is data
+    if (FAST) {
+        const int cr = XS >> 2, c4 = D >> 2;
+#pragma unroll
+        for (int u = 0; u < LR_MAXX; ++u) {
+            const int ch = 64 * (wave + 4 * u) + lane;
+            int row = ch / cr;
+            const int cc = ch - row * cr;
+            const bool isdata = cc < c4;
+            if (row > LR_P - 1) row = LR_P - 1;
+            xbase[u] = isdata ? x + (int64_t)row * D + 4 * cc : lr_pad_chunks + (cc == c4 ? 0 : 4);
+            xrow[u] = row | (isdata ? 256 : 0);
+        }
+    }
     __syncthreads();
     auto stage = [&](int64_t tile, int buf) {
         float* xb = x_lds + buf * LR_P * XS;
@@ -128,10 +152,17 @@ __global__ __launch_bounds__(LR_THREADS) void k_irt_lik_r(
         const int64_t i0 = tile * LR_P;
         const int pv = (int)((dm.nb - i0) < LR_P ? (dm.nb - i0) : LR_P);
         if (FAST) {
-            const int c4 = D >> 2;
-            const float* xs = x + i0 * D + 4 * lane;
-            for (int r = wave; r < ((ABL & 128) ? 0 : pv); r += 4)
-                if (lane < c4) dma16(xs + (int64_t)r * D, lds_addr_uniform(xb + r * XS));
+            const int cr = XS >> 2;
+            const uint32_t xl = lds_addr_uniform(xb) + (uint32_t)wave * 1024u;
+            const int64_t off = i0 * D;
+#pragma unroll
+            for (int u = 0; u < LR_MAXX; ++u) {
+                if (wave + 4 * u < cr && !(ABL & 128)) {               // wave-uniform
+                    const float* src = xbase[u] + ((xrow[u] & 256) ? off : 0);
+                    if ((xrow[u] & 255) >= pv) src = lr_pad_chunks + 4;    // absent person (last tile): an all-zero row
+                    dma16(src, xl + (uint32_t)u * 4096u);
+                }
+            }
             if (ABL & 256) {
             } else if (jfull) {
                 for (int r8 = wave; 8 * r8 < pv; r8 += 4) {
@@ -164,7 +195,8 @@ __global__ __launch_bounds__(LR_THREADS) void k_irt_lik_r(
             }
         }
         if (pv < LR_P) {                                               // the last tile: absent persons are all-zero rows
-            for (int e = tid; e < (LR_P - pv) * XS; e += LR_THREADS) xb[pv * XS + e] = 0.f;
+            if (!FAST)
+                for (int e = tid; e < (LR_P - pv) * XS; e += LR_THREADS) xb[pv * XS + e] = 0.f;
             for (int e = tid; e < (LR_P - pv) * (LR_YS / 4); e += LR_THREADS)
                 ((uint32_t*)yb)[pv * (LR_YS / 4) + e] = 0xFEFEFEFEu;
         }

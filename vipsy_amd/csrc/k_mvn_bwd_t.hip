@@ -158,6 +158,11 @@ __device__ __forceinline__ void bwd_w_t_body(
             constexpr int s2 = decltype(sc)::value, t = s2 % BT_RT;
             constexpr int qn = (s2 + 1) / BT_RT, tn = (s2 + 1) % BT_RT;
             f32x4 gn = gc, en = ec;
+            const f32x4 v = gc * ec;
+            bsum[t] += (v[0] + v[1]) + (v[2] + v[3]);
+            // LDS instructions issue beside a running MFMA, VALU ones do not: next step's reads follow the first MFMA
+            acc[t][0] = mfma32(v[0], h0[0], acc[t][0]);
+            __builtin_amdgcn_sched_barrier(0);
             if constexpr (s2 + 1 < 4 * BT_RT) {
                 gn = *(const f32x4*)(base + aG[tn][qn]);
                 en = *(const f32x4*)(base + aE[tn][qn]);
@@ -166,10 +171,10 @@ __device__ __forceinline__ void bwd_w_t_body(
                     hn1 = *(const f32x4*)(base + aH[1][qn]);
                 }
             }
-            const f32x4 v = gc * ec;
-            bsum[t] += (v[0] + v[1]) + (v[2] + v[3]);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[t][1] = mfma32(v[0], h1[0], acc[t][1]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 1; i < 4; ++i) {
                 acc[t][0] = mfma32(v[i], h0[i], acc[t][0]);
                 acc[t][1] = mfma32(v[i], h1[i], acc[t][1]);
             }
