@@ -159,7 +159,8 @@ int vx_norm_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
 int64_t vx_norm_enc_bwd_workspace_floats(const vx_irt_cfg* cfg, int64_t nb);
 int vx_norm_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
                          const float* W21, const float* W22, const float* h, const float* gloc,
-                         const float* graw, float* genc, float* workspace, void* hip_stream);
+                         const float* graw, const uint8_t* yT /*[J][yT_stride] or NULL*/, int64_t yT_stride,
+                         float* genc, float* workspace, void* hip_stream);
 
 /* ---- HO-DINA with exact enumeration of the 2^K attribute patterns (VCHoDina / VaeCHoDina model,
  * vi.py:897-923, under TraceEnum_ELBO; guide theta ~ Normal(loc, exp(raw)), vi.py:925-934 / 968-981).

@@ -286,6 +286,8 @@ def test_hodina_step_vs_oracle(N, J, K, miss, B, amort):
     (700, 500, "irt_2pl", 0.59, 100),                # Irt2PLMissing.test_ai (test.py:311-327), J scaled
     (300, 100, "irt_4pl", 0.0, None),                # Irt4PL.test_ai
     (129, 37, "irt_1pl", 0.2, 64),
+    (320, 500, "irt_2pl", 0.3, None),                # N % 16 == 0, full batch: item-major responses in the fc1 gradient
+    (1040, 516, "irt_3pl", 0.1, None),               # ... two 512-item groups, ragged last person tile
 ])
 def test_irt1d_amortized_step_vs_oracle(N, J, model, miss, B):
     from vipsy_amd.engine import IrtEngine

@@ -470,3 +470,126 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void k_mvn_enc_bwd_h_p(
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// NormEncoder forward for hidden_dim == 64, J % 4 == 0 (vi.py:417-435): the fc1 phase of k_mvn_enc_fwd_p (DMA-staged
+// response rows, W1 on a 4-deep register ring, fp32 MFMA) followed by the two 1-row heads as per-lane dot products
+// over the 32 hidden units a lane holds (+ the half-wave sum).  One wave = 32 persons, no workgroup barrier.
+#define NE_THREADS 256
+#define NE_WAVES 4
+__host__ __device__ inline size_t norm_fast_wave_floats(int J) {
+    const size_t a = (size_t)EP_WP * ef_ys(J) / 4, b = (size_t)(((32 * J + 1023) / 1024) * 256);
+    return ((a > b ? a : b) + 3) & ~(size_t)3;
+}
+__global__ __launch_bounds__(NE_THREADS, 1) void k_norm_enc_fwd_fast(
+    EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, const float* __restrict__ W1,
+    const float* __restrict__ b1, const float* __restrict__ W21, const float* __restrict__ b21,
+    const float* __restrict__ W22, const float* __restrict__ b22, float* __restrict__ h_out,
+    float* __restrict__ loc_out, float* __restrict__ raw_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int H = 64;
+    const int J = dm.J, YS = ef_ys(J);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    float* R1 = smem + wave * norm_fast_wave_floats(J);
+    const int8_t* Yi = (const int8_t*)R1;
+    const int64_t i0 = ((int64_t)blockIdx.x * NE_WAVES + wave) * EP_WP;
+    const int p = l31;
+    const int64_t i = i0 + p;
+    if (i0 >= dm.nb) return;
+    const int n_ydma = (32 * J + 1023) / 1024;
+    const bool ydense = !rows && ((J >> 2) & 1) && i0 + EP_WP <= dm.nb && (i0 * J + (int64_t)n_ydma * 1024 <= dm.nb * (int64_t)J);
+    const int ysr = ydense ? J : YS;
+    if (ydense) {
+        const uint8_t* src = y + i0 * J + 16 * lane;
+        const uint32_t lb = lds_addr_uniform(R1);
+        for (int d = 0; d < n_ydma; ++d) dma16(src + d * 1024, lb + (uint32_t)d * 1024u);
+        vx_wait_vmem();
+    } else {
+        const int YW = YS / 4, JW = J / 4;
+        uint32_t* Yw = (uint32_t*)R1;
+        for (int e = lane; e < EP_WP * YW; e += 64) {
+            const int pp = e / YW, wq = e - pp * YW;
+            const int64_t ii = i0 + pp;
+            uint32_t v = 0u;
+            if (wq < JW && ii < dm.nb) {
+                const int64_t row = rows ? rows[ii] : ii;
+                v = *(const uint32_t*)(y + row * J + 4 * wq);              // bytes 0/1/255 == int8 0/1/-1 (vi.py:680-682)
+            }
+            Yw[e] = v;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    f32x16 acc0 = zero16(), acc1 = zero16();
+    const int nfull = J / 32;
+    auto loadA = [&](float4 (&A)[2][4], int c) {
+        c = c < nfull ? c : nfull - 1;
+        const int j0 = c * 32 + half * 16;
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+            const float* src = W1 + (int64_t)(32 * ht + l31) * J + j0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) A[ht][q] = *(const float4*)(src + 4 * q);
+        }
+    };
+    auto compute = [&](const float4 (&A)[2][4], int c) {
+        const int8_t* yp = Yi + p * ysr + c * 32 + half * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int w = *(const int*)(yp + 4 * q);
+            const float y0 = (float)((w << 24) >> 24), y1 = (float)((w << 16) >> 24);
+            const float y2 = (float)((w << 8) >> 24), y3 = (float)(w >> 24);
+            acc0 = mfma32(A[0][q].x, y0, acc0); acc1 = mfma32(A[1][q].x, y0, acc1);
+            acc0 = mfma32(A[0][q].y, y1, acc0); acc1 = mfma32(A[1][q].y, y1, acc1);
+            acc0 = mfma32(A[0][q].z, y2, acc0); acc1 = mfma32(A[1][q].z, y2, acc1);
+            acc0 = mfma32(A[0][q].w, y3, acc0); acc1 = mfma32(A[1][q].w, y3, acc1);
+        }
+    };
+    if (nfull > 0) {
+        float4 A[4][2][4];
+        loadA(A[0], 0); loadA(A[1], 1); loadA(A[2], 2);
+        for (int c = 0; c < nfull; c += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                loadA(A[(u + 3) & 3], c + u + 3);
+                if (c + u < nfull) compute(A[u], c + u);
+            }
+        }
+    }
+    if (nfull * 32 < J) {
+        float4 At[2][4];
+        const int j0 = nfull * 32 + half * 16;
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+            const float* src = W1 + (int64_t)(32 * ht + l31) * J + j0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                At[ht][q] = (j0 + 4 * q + 4 <= J) ? *(const float4*)(src + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        compute(At, nfull);
+    }
+    float sl = 0.f, sr = 0.f;                                 // partial loc / raw over this lane's 32 hidden units
+#pragma unroll
+    for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int hh0 = 32 * ht + 8 * g + 4 * half;
+            const float4 bb = *(const float4*)(b1 + hh0);
+            // the head rows sit behind odd-length bias segments in the flat parameter buffer: 4-byte loads
+            const float4 w21 = make_float4(W21[hh0], W21[hh0 + 1], W21[hh0 + 2], W21[hh0 + 3]);
+            const float4 w22 = make_float4(W22[hh0], W22[hh0 + 1], W22[hh0 + 2], W22[hh0 + 3]);
+            float4 hv;
+            hv.x = softplusf_((ht ? acc1 : acc0)[4 * g + 0] + bb.x);               // vi.py:432
+            hv.y = softplusf_((ht ? acc1 : acc0)[4 * g + 1] + bb.y);
+            hv.z = softplusf_((ht ? acc1 : acc0)[4 * g + 2] + bb.z);
+            hv.w = softplusf_((ht ? acc1 : acc0)[4 * g + 3] + bb.w);
+            sl += hv.x * w21.x + hv.y * w21.y + hv.z * w21.z + hv.w * w21.w;
+            sr += hv.x * w22.x + hv.y * w22.y + hv.z * w22.z + hv.w * w22.w;
+            if (i < dm.nb) *(float4*)(h_out + i * H + hh0) = hv;
+        }
+    sl = half_sum32(sl);
+    sr = half_sum32(sr);
+    if (half == 0 && i < dm.nb) {
+        loc_out[i] = sl + b21[0];
+        raw_out[i] = sr + b22[0];
+    }
+}

@@ -767,9 +767,19 @@ int vx_norm_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     if (nb == 0) return VX_OK;
     EncDims dm;
     dm.D = 1; dm.J = cfg->J; dm.H = cfg->H; dm.Hp = (cfg->H + 31) / 32 * 32; dm.DS = 3; dm.T = 1; dm.nb = nb;
+    int rc;
+    if (!force_generic() && cfg->H == 64 && cfg->J % 4 == 0 && aligned16(y) && aligned16(W1) && aligned16(b1) &&
+        aligned16(h) && NE_WAVES * norm_fast_wave_floats(cfg->J) * sizeof(float) <= 160 * 1024) {
+        const size_t ldsf = NE_WAVES * norm_fast_wave_floats(cfg->J) * sizeof(float);
+        rc = set_lds(k_norm_enc_fwd_fast, ldsf);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_norm_enc_fwd_fast, dim3((unsigned)((nb + NE_WAVES * EP_WP - 1) / (NE_WAVES * EP_WP))),
+                           dim3(NE_THREADS), ldsf, (hipStream_t)hs, dm, y, rows, W1, b1, W21, b21, W22, b22, h, loc, raw);
+        VX_CHECK_LAUNCH();
+        return VX_OK;
+    }
     const size_t lds = norm_enc_fwd_lds_floats(dm.Hp) * sizeof(float);
     const dim3 grid((unsigned)((nb + ENC_P - 1) / ENC_P));
-    int rc;
 #define LAUNCH_NF(HT)                                                                                        \
     rc = set_lds(k_norm_enc_fwd<HT>, lds);                                                                   \
     if (rc) return rc;                                                                                       \
@@ -786,12 +796,12 @@ int64_t vx_norm_enc_bwd_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
     int nblk, n_jg, n_prf;
     nenc_plan(cfg, nb, nblk, n_jg, n_prf);
     const int64_t H = cfg->H, J = cfg->J;
-    return nb * H + (int64_t)nblk * (2 * H + 2) + (int64_t)n_prf * (H * J + H);
+    return nb * H + (int64_t)nblk * (2 * H + 2) + (int64_t)n_prf * (H * J + H) + nb * H + 8;   // ghpre | slabs | ghpreT
 }
 
 int vx_norm_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* W21,
-                         const float* W22, const float* h, const float* gloc, const float* graw, float* genc,
-                         float* workspace, void* hs) {
+                         const float* W22, const float* h, const float* gloc, const float* graw, const uint8_t* yT,
+                         int64_t yT_stride, float* genc, float* workspace, void* hs) {
     if (!nenc_cfg_ok(cfg) || !y || !W21 || !W22 || !h || !gloc || !graw || !genc || !workspace || nb < 0)
         return VX_EINVAL;
     int nblk, n_jg, n_prf;
@@ -811,6 +821,22 @@ int vx_norm_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t*
         VX_CHECK_LAUNCH();
         EncDims dm;
         dm.D = 1; dm.J = cfg->J; dm.H = cfg->H; dm.Hp = (cfg->H + 31) / 32 * 32; dm.DS = 3; dm.T = 1; dm.nb = nb;
+        if (!force_generic() && yT && !rows && cfg->H == 64 && nb % 4 == 0 && yT_stride % 16 == 0 && yT_stride >= nb &&
+            aligned16(yT) && cfg->J >= 32 && aligned16(workspace) && f1_lds_bytes(cfg->J) <= 160 * 1024) {
+            // dimension-major fc1 gradient (k_fc1_bwd_t): ghpreT = transpose(ghpre) lives behind the slabs
+            float* ghpreT = slabs_f + (((int64_t)n_prf * lenf + 3) & ~(int64_t)3);
+            hipLaunchKernelGGL(k_transpose, dim3(num_cu() * 8), dim3(256), 0, st, ghpre, ghpreT, nb, H);
+            VX_CHECK_LAUNCH();
+            const size_t ldst = f1_lds_bytes(cfg->J);
+            rc = set_lds(k_fc1_bwd_t, ldst);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_fc1_bwd_t, dim3((unsigned)((cfg->J + 511) / 512), (unsigned)n_prf), dim3(F1_THREADS), ldst, st,
+                               dm, yT, yT_stride, ghpreT, slabs_f, lenf);
+            VX_CHECK_LAUNCH();
+            rc = vx_reduce_slabs(slabs_f, n_prf, lenf, -1.0f, genc, hs);
+            if (rc) return rc;
+            return vx_reduce_slabs(slabs_h, nblk, lenh, -1.0f, genc + lenf, hs);
+        }
         const size_t lds = fc1_bwd_lds_floats(dm.Hp) * sizeof(float);
         const dim3 grid((unsigned)n_jg, (unsigned)n_prf);
         const int f1fast = (!force_generic() && cfg->H == 64 && cfg->J % 4 == 0 && aligned16(ghpre) && aligned16(y)) ? 1 : 0;

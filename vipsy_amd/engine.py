@@ -123,10 +123,11 @@ class HipBackend(object):
             raise _hip.VxError("vx_norm_enc_bwd_workspace_floats: unsupported configuration (code %d)" % n)
         return n
 
-    def norm_enc_backward(self, cfg, y, rows, nb, enc, h, gloc, graw, genc, ws):
+    def norm_enc_backward(self, cfg, y, rows, nb, enc, h, gloc, graw, genc, ws, yT=None):
         rc = self.L.vx_norm_enc_backward(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb,
                                          _hip.ptr(enc["fc21.weight"]), _hip.ptr(enc["fc22.weight"]), _hip.ptr(h),
-                                         _hip.ptr(gloc), _hip.ptr(graw), _hip.ptr(genc), _hip.ptr(ws),
+                                         _hip.ptr(gloc), _hip.ptr(graw), _hip.ptr(yT),
+                                         int(yT.shape[1]) if yT is not None else 0, _hip.ptr(genc), _hip.ptr(ws),
                                          _hip.stream_ptr())
         _hip.check(rc, "vx_norm_enc_backward")
 
@@ -239,6 +240,15 @@ class _EngineBase(object):
 
     def _enc(self):
         return {k: self.view("encoder$$$" + k) for k in ENC_KEYS}
+
+    def _item_major_y(self, rows):
+        """Item-major copy of the responses ([J][n_local] bytes) for the dimension-major fc1 gradient kernel: made
+        once (the responses never change); only for full batches with 16-byte aligned person rows."""
+        if rows is not None or self.n_local % 16 != 0 or self.n_local == 0:
+            return None
+        if getattr(self, "_yT", None) is None:
+            self._yT = self.y.t().contiguous()
+        return self._yT
 
     def _buf(self, key, n):
         t = self._ws.get(key)
@@ -461,10 +471,9 @@ class IrtEngine(_EngineBase):
                 # dimension-major copies (person-contiguous rows) for the DMA-staged weight-gradient kernel
                 fw["hT"], fw["epsT"] = self._buf("hT", nb * H), self._buf("epsT", nb * D)
                 gxT = self._buf("gxT", nb * D)
-                if rows is None and self.n_local % 16 == 0:
-                    if getattr(self, "_yT", None) is None:          # item-major responses: made once, they never change
-                        self._yT = self.y.t().contiguous()
-                    fw["yT"] = self._yT
+                yT = self._item_major_y(rows)
+                if yT is not None:
+                    fw["yT"] = yT
             gx, ll = self._buf("gx", nb * D), self._buf("ll", nb)
             if gxT is not None and be.mvn_enc_bwd_layout(cfg, nb) == 1:
                 gx = None                                  # the backward kernels read gxT only
@@ -515,8 +524,13 @@ class IrtEngine(_EngineBase):
             gitem[self.off["b"]:self.off["b"] + 3 * J].copy_(g1d[J:4 * J])
             if self.amortized:
                 with self._phase("guide_backward"):
-                    be.norm_enc_backward(cfg, self.y, rows, nb, enc, fw["h"], gloc, graw,
-                                         self.G[self.enc_off0:self.enc_off0 + self.n_enc], nb_ws)
+                    yT = self._item_major_y(rows) if hasattr(be, "mvn_pack_floats") else None
+                    if yT is not None:
+                        be.norm_enc_backward(cfg, self.y, rows, nb, enc, fw["h"], gloc, graw,
+                                             self.G[self.enc_off0:self.enc_off0 + self.n_enc], nb_ws, yT=yT)
+                    else:
+                        be.norm_enc_backward(cfg, self.y, rows, nb, enc, fw["h"], gloc, graw,
+                                             self.G[self.enc_off0:self.enc_off0 + self.n_enc], nb_ws)
             else:
                 self._scatter_pp(rows, nb, gloc, graw)
             be.sum_into(elbo, nb, -scale, lossslot, self.sum_ws)
@@ -616,8 +630,13 @@ class HoDinaEngine(_EngineBase):
                            self.G[:self.n_item], ws)
         if self.amortized:
             with self._phase("guide_backward"):
-                be.norm_enc_backward(icfg, self.y, rows, nb, enc, fw["h"], gloc, graw,
-                                     self.G[self.enc_off0:self.enc_off0 + self.n_enc], nb_ws)
+                yT = self._item_major_y(rows) if hasattr(be, "mvn_pack_floats") else None
+                if yT is not None:
+                    be.norm_enc_backward(icfg, self.y, rows, nb, enc, fw["h"], gloc, graw,
+                                         self.G[self.enc_off0:self.enc_off0 + self.n_enc], nb_ws, yT=yT)
+                else:
+                    be.norm_enc_backward(icfg, self.y, rows, nb, enc, fw["h"], gloc, graw,
+                                         self.G[self.enc_off0:self.enc_off0 + self.n_enc], nb_ws)
         else:
             self._scatter_pp(rows, nb, gloc, graw)
         be.sum_into(elbo, nb, -scale, lossslot, self.sum_ws)
