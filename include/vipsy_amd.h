@@ -180,6 +180,15 @@ int vx_hodina_grad(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t* ro
                    const float* lam0, const float* lam1_un, const float* g_un, const float* s_un,
                    float* gloc, float* graw, float* elbo, float* gitem, float* workspace, void* hip_stream);
 
+/* ---- VCCDM: pattern-enumerated DINA / DINO with the uniform pattern prior and an empty guide (vi.py:819-865;
+ * dina vi.py:69-83, dino vi.py:86-101 -- the latter reproduced with its in-place sequencing: items that need a
+ * single attribute always get eta = 0).  cfg: K, J, scale (seed / step / stream unused).
+ *   elbo[nb] = log sum_c (1/C) prod_j Bern(y_ij | p_cj);  gitem = d LOSS / d [g_un: J | s_un: J]. */
+int64_t vx_ccdm_workspace_floats(const vx_hodina_cfg* cfg, int64_t nb);
+int vx_ccdm_grad(const vx_hodina_cfg* cfg, int32_t dino, const uint8_t* y, const int64_t* rows, int64_t nb,
+                 const float* q /*[K][J]*/, const float* g_un, const float* s_un, float* elbo, float* gitem,
+                 float* workspace, void* hip_stream);
+
 /* ---- slab reduction: out[i] = alpha * sum_s slabs[s][i]  (fixed order -> deterministic) */
 int vx_reduce_slabs(const float* slabs, int64_t n_slabs, int64_t len, float alpha, float* out,
                     void* hip_stream);

@@ -309,6 +309,51 @@ def dina_eta(K, q):
     return (yita == aa).astype(q.dtype), al
 
 
+def dino_eta(K, q):
+    """eta[c, j] of the reference's dino() (vi.py:86-101), INCLUDING its in-place sequencing: yita = (1 - attr) q;
+    `yita[yita < aa] = 1` runs first, then `yita[yita == aa] = 0` -- which also clears the entries the first statement
+    has just set to 1 whenever aa_j == 1.  Net effect: eta = 1 iff pattern c masters at least one attribute of item j
+    AND item j requires at least two attributes; single-attribute items always get eta = 0."""
+    al = all_attrs(K, q.dtype)
+    aa = np.broadcast_to((q ** 2).sum(axis=0), (al.shape[0], q.shape[1]))
+    yita = (1 - al) @ q
+    yita[yita < aa] = 1
+    yita[yita == aa] = 0
+    return yita.astype(q.dtype), al
+
+
+def ccdm_particle(spec, params, y_u8_full, idx, eps=None):
+    """Pattern-enumerated DINA / DINO with the uniform pattern prior (VCCDM.model, vi.py:840-859; empty guide,
+    TraceEnum_ELBO): ELBO = scale * sum_i log sum_c (1/C) prod_j Bern(y_ij | p_cj)."""
+    K, N = spec["K"], spec["N"]
+    dt = params["g"].dtype
+    q = spec["q"].astype(dt)
+    B = len(idx)
+    scale = dt.type(N) / dt.type(B)
+    y = y_u8_full[idx]
+    eta, _ = (dino_eta if spec.get("cdm", "dina") == "dino" else dina_eta)(K, q)      # (C,J)
+    C = eta.shape[0]
+    g_ = sigmoid(params["g"])
+    s_ = sigmoid(params["s"])
+    pr = np.full((1, C), 1.0 / C, dt)                             # Categorical(probs = 1/C): renormalise, clamp, log
+    pr = pr / pr.sum(axis=1, keepdims=True)
+    lg = np.log(np.clip(pr, EPS32, 1 - EPS32))
+    lp0, d0 = bernoulli_logprob_probs(np.broadcast_to(g_, y.shape).astype(dt), y)
+    lp1, d1 = bernoulli_logprob_probs(np.broadcast_to(1 - s_, y.shape).astype(dt), y)
+    Bc = lp0.sum(1, keepdims=True) + (lp1 - lp0) @ eta.T          # (B,C)
+    f = lg + Bc
+    fmax = f.max(axis=1, keepdims=True)
+    lse = fmax[:, 0] + np.log(np.exp(f - fmax).sum(axis=1))
+    elbo = scale * lse.sum()
+    r = np.exp(f - lse[:, None])
+    E = r @ eta
+    grads = {
+        "g": -scale * ((1 - E) * d0).sum(0, keepdims=True) * g_ * (1 - g_),
+        "s": -scale * (-(E * d1)).sum(0, keepdims=True) * s_ * (1 - s_),
+    }
+    return -elbo, grads
+
+
 def hodina_particle(spec, params, y_u8_full, idx, eps):
     K, N = spec["K"], spec["N"]
     dt = params["g"].dtype
@@ -379,7 +424,7 @@ def hodina_particle(spec, params, y_u8_full, idx, eps):
 # loss_and_grads over particles + optimiser
 # ------------------------------------------------------------------------------------------------
 def loss_and_grads(spec, params, y_u8, idx_list, eps_list):
-    fn = hodina_particle if spec.get("family") == "hodina" else irt_particle
+    fn = {"hodina": hodina_particle, "ccdm": ccdm_particle}.get(spec.get("family"), irt_particle)
     S = len(idx_list)
     loss, grads = 0.0, None
     for idx, eps in zip(idx_list, eps_list):
@@ -481,6 +526,11 @@ def init_hodina_params(spec, J, dtype=np.float32, encoder=None):
         p["theta_local"] = np.zeros((N, 1), dtype)
         p["theta_scale"] = np.zeros((N, 1), dtype)
     return p
+
+
+def init_ccdm_params(spec, J, dtype=np.float32):
+    return {"g": np.full((1, J), logit(np.asarray(0.1, dtype)), dtype),
+            "s": np.full((1, J), logit(np.asarray(0.1, dtype)), dtype)}
 
 
 def constrained(name, value):

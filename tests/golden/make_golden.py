@@ -222,6 +222,29 @@ def gen_elbo_cases():
               "lr_item": 1e-1, "lr_other": 1e-3})
 
 
+def gen_ccdm_cases():
+    """Pattern-enumerated DINA / DINO with a uniform prior over the 2^K patterns (VCCDM, vi.py:819-865)."""
+    g = torch.Generator().manual_seed(177)
+    torch.manual_seed(170)
+    ri = vi.RandomDina(sample_size=22, item_size=9, q_size=3)
+    y = add_missing(ri.y, 0.2, g)
+    m = vi.VCCDM(data=y, q=ri.q, model="dina", subsample_size=22)
+    run_case("vccdm_dina_k3", m, y, Adam({"lr": 1e-1}), TraceEnum_ELBO(num_particles=1), 3,
+             {"cls": "VCCDM", "cdm": "dina", "N": 22, "J": 9, "K": 3, "B": 22, "lr": 1e-1, "q": ri.q.numpy()})
+    torch.manual_seed(171)
+    ri = vi.RandomDina(sample_size=30, item_size=12, q_size=4)
+    y = ri.y
+    m = vi.VCCDM(data=y, q=ri.q, model="dina", subsample_size=13)
+    run_case("vccdm_dina_k4_sub", m, y, Adam({"lr": 1e-1}), TraceEnum_ELBO(num_particles=1), 3,
+             {"cls": "VCCDM", "cdm": "dina", "N": 30, "J": 12, "K": 4, "B": 13, "lr": 1e-1, "q": ri.q.numpy()})
+    torch.manual_seed(172)
+    ri = vi.RandomDino(sample_size=24, item_size=10, q_size=3)
+    y = add_missing(ri.y, 0.15, g)
+    m = vi.VCCDM(data=y, q=ri.q, model="dino", subsample_size=24)
+    run_case("vccdm_dino_k3", m, y, Adam({"lr": 1e-1}), TraceEnum_ELBO(num_particles=1), 3,
+             {"cls": "VCCDM", "cdm": "dino", "N": 24, "J": 10, "K": 3, "B": 24, "lr": 1e-1, "q": ri.q.numpy()})
+
+
 def gen_function_cases():
     """G1-G5 of SURVEY.md section 8c: pure-torch pieces of vi.py imported and evaluated."""
     rec = {}
@@ -305,5 +328,9 @@ def gen_function_cases():
 
 if __name__ == "__main__":
     torch.set_num_threads(1)
+    if len(sys.argv) > 1 and sys.argv[1] == "ccdm":     # only the cases added after the first batch
+        gen_ccdm_cases()
+        sys.exit(0)
     gen_function_cases()
     gen_elbo_cases()
+    gen_ccdm_cases()

@@ -49,6 +49,10 @@ def build(tag, dtype=np.float32):
         params = vo.init_irt_params(spec, J, dtype, encoder=enc if amort else None,
                                     b0=f["b0"] if "b0" in f else None)
         lr = _lr_irt(float(f["lr_item"]), float(f["lr_other"])) if "lr_item" in f else float(f["lr"])
+    elif cls == "VCCDM":
+        spec = {"family": "ccdm", "cdm": str(f["cdm"]), "K": int(f["K"]), "N": N, "amortized": False, "q": f["q"]}
+        params = vo.init_ccdm_params(spec, J, dtype)
+        lr = float(f["lr"])
     else:
         spec = {"family": "hodina", "K": int(f["K"]), "N": N, "amortized": amort, "q": f["q"]}
         params = vo.init_hodina_params(spec, J, dtype, encoder=enc if amort else None)
@@ -61,9 +65,12 @@ def build(tag, dtype=np.float32):
     steps = []
     for t in range(int(f["steps"])):
         S = int(f["s%d/n_particles" % t])
+        n_eps = S
+        if S == 0:                                          # a model with no reparameterised site (VCCDM): one particle
+            S = sum(1 for k in f if k.startswith("s%d/idx" % t))
         rec = {"loss": float(f["s%d/loss" % t]),
                "idx": [f["s%d/idx%d" % (t, k)] for k in range(S)],
-               "eps": [f["s%d/eps%d" % (t, k)] for k in range(S)],
+               "eps": [f["s%d/eps%d" % (t, k)] if k < n_eps else None for k in range(S)],
                "grad": {k.split("/grad/")[1]: f[k] for k in f if k.startswith("s%d/grad/" % t)},
                "param": {k.split("/param/")[1]: f[k] for k in f if k.startswith("s%d/param/" % t)}}
         steps.append(rec)

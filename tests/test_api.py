@@ -12,7 +12,7 @@ def test_surface_matches_reference_names():
               "HoDina"):
         assert hasattr(vi, n), n
     with pytest.raises(NotImplementedError):
-        vi.VCCDM(q=None, data=None)
+        vi.VaeCCDM(q=None, data=None)
     spec = vi.MultiStepLR({"optimizer": torch.optim.Adam, "optim_args": lambda m, n: {"lr": 1e-2 if n == "a" else 1e-3},
                            "milestones": [2], "gamma": 0.1}).spec()
     assert spec.lr_of("a") == 1e-2 and spec.lr_of("encoder$$$fc1.weight") == 1e-3
@@ -114,3 +114,30 @@ def test_config1_lsat6_bbvi_lands_near_the_known_answer():
     b = vi.param("b").cpu().numpy()[0]
     assert np.abs(a - np.array([0.8257, 0.7227, 0.8909, 0.6884, 0.6569])).max() < 0.15, a
     assert np.abs(b - np.array([2.7732, 0.9902, 0.2491, 1.2848, 2.0533])).max() < 0.15, b
+
+
+@pytest.mark.gpu
+def test_vccdm_dina_recovers_guess_and_slip():
+    """DinaTestCase-style call pattern (VCCDM(data=, q=).fit(...), test.py): N=3000, J=20, K=3."""
+    from vipsy_amd import vi
+    vi.clear_param_store()
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(11)
+    K, J, N = 3, 20, 3000
+    q = (rng.rand(K, J) < 0.5).astype(np.float32)
+    q[rng.randint(0, K, size=J), np.arange(J)] = 1.0
+    g, s = rng.uniform(0.05, 0.25, J), rng.uniform(0.05, 0.25, J)
+    attr = (rng.rand(N, K) < 0.5).astype(np.float32)
+    eta = ((attr @ q) == (q ** 2).sum(0)).astype(np.float32)
+    p = (1 - s) ** eta * g ** (1 - eta)
+    y = torch.from_numpy((rng.rand(N, J) < p).astype(np.float32)).to(dev)
+
+    class RI(object):
+        pass
+    RI.g, RI.s = torch.tensor(g, dtype=torch.float32).reshape(1, J), torch.tensor(s, dtype=torch.float32).reshape(1, J)
+    m = vi.VCCDM(data=y, q=torch.from_numpy(q), model="dina")
+    l0 = m.fit(optim=vi.Adam({"lr": 5e-2}), max_iter=1, progress=False)
+    l1 = m.fit(optim=vi.Adam({"lr": 5e-2}), max_iter=400, random_instance=RI, progress=False)
+    assert l1 < l0
+    assert float((vi.param("g").cpu() - RI.g).abs().mean()) < 0.03
+    assert float((vi.param("s").cpu() - RI.s).abs().mean()) < 0.04

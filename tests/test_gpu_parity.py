@@ -20,7 +20,10 @@ def _engine_from_fixture(tag):
     spec, params, opt, y, steps, B = gu.build(tag, np.float64)
     enc = {k.split("$$$")[1]: v for k, v in params.items() if k.startswith("encoder$$$")}
     yt = torch.from_numpy(y).to(_dev())
-    if spec["family"] == "hodina":
+    if spec["family"] == "ccdm":
+        from vipsy_amd.engine import CcdmEngine
+        eng = CcdmEngine(yt, spec["q"], cdm=spec["cdm"], seed=1)
+    elif spec["family"] == "hodina":
         eng = HoDinaEngine(yt, spec["q"], amortized=spec["amortized"], H=(enc["fc1.weight"].shape[0] if enc else 0),
                            encoder_init=enc if enc else None, seed=1)
     else:
@@ -67,7 +70,8 @@ GOLDEN_HIP = ["vaeirt_irt_2pl_d3", "vaeirt_irt_3pl_d2", "vaeirt_irt_4pl_d4",
               "virt_irt_1pl_d1", "virt_irt_2pl_d1", "virt_irt_3pl_d1", "virt_irt_4pl_d1", "virt_irt_2pl_d1_D1702",
               "vaeirt_irt_2pl_d1", "vaeirt_irt_4pl_d1",
               "vchodina_k3", "vchodina_k4_sub", "vchodina_k4_clamp", "vaechodina_k3",
-              "virt_irt_2pl_d3_perperson", "virt_irt_2pl_d3_share"]
+              "virt_irt_2pl_d3_perperson", "virt_irt_2pl_d3_share",
+              "vccdm_dina_k3", "vccdm_dina_k4_sub", "vccdm_dino_k3"]
 
 
 @pytest.mark.parametrize("tag", GOLDEN_HIP)
@@ -80,7 +84,7 @@ def test_hip_replays_reference_steps(tag):
         rows = torch.from_numpy(idx).to(_dev())
         full = len(idx) == spec["N"] and (idx == np.arange(spec["N"])).all()
         eng.loss_and_grads(None if full else rows, len(idx),
-                           torch.from_numpy(np.ascontiguousarray(eps, dtype=np.float32)).to(_dev()))
+                           None if eps is None else torch.from_numpy(np.ascontiguousarray(eps, dtype=np.float32)).to(_dev()))
         torch.cuda.synchronize()
         loss_o, g_o = vo.loss_and_grads(spec, params, y, [idx], [eps])
         loss_h = float(eng.G[eng.n_params].item())
@@ -342,3 +346,34 @@ def test_mvn_bbvi_step_vs_oracle(N, J, D, share, B):
             gh = gh * spec["a_free"]
         sc = max(1e-6, float(np.abs(go).max()))
         assert np.abs(gh - go).max() / sc < 3e-4, (name, np.abs(gh - go).max() / sc)
+
+
+@pytest.mark.parametrize("N,J,K,cdm,miss,B", [
+    (500, 30, 8, "dina", 0.0, None),                 # cfg5 shape without the higher-order layer
+    (333, 70, 5, "dino", 0.2, 100),
+    (129, 9, 10, "dina", 0.1, None),                 # K = 10: 16 patterns per lane
+    (64, 130, 3, "dino", 0.0, None),                 # J > 128: three item slots per lane
+])
+def test_ccdm_step_vs_oracle(N, J, K, cdm, miss, B):
+    """VCCDM (vi.py:819-865): enumerated DINA / DINO, uniform pattern prior, empty guide."""
+    from vipsy_amd.engine import CcdmEngine
+    rng = np.random.RandomState(N + J + K)
+    q = (rng.rand(K, J) < 0.4).astype(np.float32)
+    q[rng.randint(0, K, size=J), np.arange(J)] = 1.0          # every item needs at least one attribute
+    y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+    y[rng.rand(N, J) < miss] = 255
+    eng = CcdmEngine(torch.from_numpy(y).to(_dev()), q, cdm=cdm, seed=3)
+    eng.unconstrained("g").add_(torch.from_numpy(0.5 * rng.randn(1, J)).float().to(_dev()))
+    eng.unconstrained("s").add_(torch.from_numpy(0.5 * rng.randn(1, J)).float().to(_dev()))
+    idx = np.arange(N) if B is None else np.sort(rng.permutation(N)[:B])
+    rows = None if B is None else torch.from_numpy(idx).to(_dev())
+    eng.loss_and_grads(rows, len(idx))
+    torch.cuda.synchronize()
+    spec = {"family": "ccdm", "cdm": cdm, "K": K, "N": N, "amortized": False, "q": q}
+    params = {n: eng.unconstrained(n).cpu().numpy().astype(np.float64) for n in eng.names()}
+    loss_o, g_o = vo.loss_and_grads(spec, params, y, [idx], [None])
+    assert float(eng.G[eng.n_params].item()) == pytest.approx(loss_o, rel=2e-5)
+    for name, go in g_o.items():
+        gh = eng.unconstrained(name, eng.G).cpu().numpy()
+        sc = max(1e-6, float(np.abs(go).max()))
+        assert np.abs(gh - go).max() / sc < 2e-4, (name, np.abs(gh - go).max() / sc)

@@ -18,6 +18,9 @@ struct HoDinaDims {
     int K, J, C;
     float scale;
     int64_t nb;
+    // VCCDM (vi.py:819-865): uniform prior over the patterns, no theta / lambda; dino = the reference's dino()
+    // (vi.py:86-101) INCLUDING its in-place sequencing: eta = [item needs >= 2 attributes] * [c masters one of them]
+    int uniform_prior, dino;
 };
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -94,8 +97,8 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
         }
     }
     // ---- per-attribute constants in lane k
-    const float l0 = (lane < K) ? lam0[lane] : 0.f;
-    const float l1 = (lane < K) ? __expf(lam1_un[lane]) : 0.f;
+    const float l0 = (lane < K && !dm.uniform_prior) ? lam0[lane] : 0.f;
+    const float l1 = (lane < K && !dm.uniform_prior) ? __expf(lam1_un[lane]) : 0.f;
     float gl0 = 0.f, gl1 = 0.f;
 
     for (int64_t grp = wg; grp < n_groups; grp += n_waves) {
@@ -105,8 +108,10 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
         float lc = 0.f, rw = 0.f, e = 0.f;
         if (valid) {
             row = rows ? rows[i] : i;
-            lc = loc[i]; rw = raw[i];
-            e = eps_in ? eps_in[i] : philox_normal4(seed, step, stream, gid0 + row, 0u)[0];
+            if (!dm.uniform_prior) {
+                lc = loc[i]; rw = raw[i];
+                e = eps_in ? eps_in[i] : philox_normal4(seed, step, stream, gid0 + row, 0u)[0];
+            }
         }
         const float sig = __expf(rw);
         const float thv = lc + sig * e;
@@ -131,7 +136,8 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
                     bern_const(gj[u], og[u], yy, lp0, d0[u]);
                     bern_const(os[u], sj[u], yy, lp1, d1[u]);
                     base += lp0;
-                    atomicAdd(&tab[qpat[u]], lp1 - lp0);               // f(S) = sum of delta_j over items with q_j = S
+                    if (!dm.dino || __popc(qpat[u]) >= 2)
+                        atomicAdd(&tab[qpat[u]], lp1 - lp0);           // f(S) = sum of delta_j over items with q_j = S
                 }
             }
             base = wave_sum_dpp(base);
@@ -140,6 +146,17 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
 #pragma unroll
             for (int ii = 0; ii < CPL; ++ii) { const int c = CPL * lane + ii; Bc[ii] = (c < C) ? tab[c] : 0.f; }
             zeta<LOGCPL, false>(Bc, K, lane);
+            if (dm.dino) {
+                // eta_cj = [c meets q_j]: B_c = sum_j delta_j - sum_{q_j disjoint from c} delta_j = Z[full] - Z[~c]
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int ii = 0; ii < CPL; ++ii) { const int c = CPL * lane + ii; if (c < C) tab[c] = Bc[ii]; }
+                __builtin_amdgcn_wave_barrier();
+                const float zfull = tab[C - 1];
+#pragma unroll
+                for (int ii = 0; ii < CPL; ++ii) { const int c = CPL * lane + ii; Bc[ii] = (c < C) ? zfull - tab[(C - 1) ^ c] : 0.f; }
+                __builtin_amdgcn_wave_barrier();
+            }
             // -- attribute side (vi.py:911-912): t_k = theta lam1_k + lam0_k in lane k
             const float tk = th * l1 + l0;
             const float pik = sigmoidf_(tk);
@@ -158,7 +175,11 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
             float pr[CPL], fc[CPL], psum = 0.f;
             bool ins[CPL];
 #pragma unroll
-            for (int ii = 0; ii < CPL; ++ii) { const int c = CPL * lane + ii; pr[ii] = (c < C) ? __expf(Ac[ii]) : 0.f; psum += pr[ii]; }
+            for (int ii = 0; ii < CPL; ++ii) {
+                const int c = CPL * lane + ii;
+                pr[ii] = (c < C) ? (dm.uniform_prior ? 1.0f : __expf(Ac[ii])) : 0.f;       // Categorical(1 / C): vi.py:849
+                psum += pr[ii];
+            }
             psum = wave_sum_dpp(psum);
             float fmx = -3.0e38f;
 #pragma unroll
@@ -184,8 +205,10 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
             float rho[CPL];
 #pragma unroll
             for (int ii = 0; ii < CPL; ++ii) rho[ii] = (ins[ii] ? rc[ii] : 0.f) - pr[ii] * rins;
-            // -- E_j = sum_{c >= q_j} r_c : superset sums, then gather at q_j
-            zeta<LOGCPL, true>(rc, K, lane);
+            // -- E_j = sum_c r_c eta_cj.  DINA: superset sums gathered at q_j.  DINO: 1 - (subset sum at ~q_j), and 0
+            //    for items that need fewer than two attributes.
+            if (dm.dino) zeta<LOGCPL, false>(rc, K, lane);
+            else zeta<LOGCPL, true>(rc, K, lane);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int ii = 0; ii < CPL; ++ii) { const int c = CPL * lane + ii; if (c < C) tab[c] = rc[ii]; }
@@ -194,7 +217,8 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
             for (int u = 0; u < JPL; ++u) {
                 const int j = lane + 64 * u;
                 if (j < J) {
-                    const float E = tab[qpat[u]];
+                    float E = tab[qpat[u]];
+                    if (dm.dino) E = (__popc(qpat[u]) >= 2) ? 1.0f - tab[(C - 1) ^ qpat[u]] : 0.f;
                     gg[u] += (1.0f - E) * d0[u];                          // d/dg through patterns that do NOT master item j
                     gs[u] -= E * d1[u];                                   // d/ds: p = 1 - s
                 }
@@ -213,15 +237,19 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
             gth -= th;                                                    // prior N(0,1)
             if (lane == pp) {
                 my_gth = gth;
-                my_elbo = lse - 0.5f * th * th;                            // + 0.5 eps^2 + raw added below
+                my_elbo = dm.uniform_prior ? lse : lse - 0.5f * th * th;   // + 0.5 eps^2 + raw added below
             }
             __builtin_amdgcn_wave_barrier();
         }
         if (valid) {
-            const float gt = dm.scale * my_gth;
-            gloc[i] = -gt;
-            graw[i] = -(gt * sig * e + dm.scale);
-            elbo[i] = my_elbo + 0.5f * e * e + rw;
+            if (dm.uniform_prior) {
+                elbo[i] = my_elbo;
+            } else {
+                const float gt = dm.scale * my_gth;
+                gloc[i] = -gt;
+                graw[i] = -(gt * sig * e + dm.scale);
+                elbo[i] = my_elbo + 0.5f * e * e + rw;
+            }
         }
     }
     // ---- block reduction of item / attribute gradients -> one slab per block

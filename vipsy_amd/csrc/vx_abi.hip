@@ -881,6 +881,7 @@ int vx_hodina_grad(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t* ro
     const int blocks = hodina_blocks(nb);
     HoDinaDims dm;
     dm.K = cfg->K; dm.J = cfg->J; dm.C = 1 << cfg->K; dm.scale = cfg->scale; dm.nb = nb;
+    dm.uniform_prior = 0; dm.dino = 0;
     const int len = 2 * cfg->J + 2 * cfg->K;
     const int tabf = HD_WAVES * dm.C;
     const size_t lds = sizeof(float) * (size_t)(tabf > len ? tabf : len);
@@ -902,6 +903,46 @@ int vx_hodina_grad(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t* ro
 #undef LAUNCH_HD
     VX_CHECK_LAUNCH();
     return vx_reduce_slabs(workspace, blocks, len, -1.0f, gitem, hs);
+}
+
+// VCCDM (vi.py:819-865): the enumerated DINA / DINO with a uniform prior over the 2^K patterns -- the HO-DINA kernel
+// without its theta / lambda side.  gitem = d LOSS / d [g_un: J | s_un: J]; elbo[nb] = per-person log marginal.
+int64_t vx_ccdm_workspace_floats(const vx_hodina_cfg* cfg, int64_t nb) { return vx_hodina_workspace_floats(cfg, nb); }
+
+int vx_ccdm_grad(const vx_hodina_cfg* cfg, int32_t dino, const uint8_t* y, const int64_t* rows, int64_t nb,
+                 const float* q, const float* g_un, const float* s_un, float* elbo, float* gitem, float* workspace,
+                 void* hs) {
+    if (!hodina_cfg_ok(cfg) || !y || !q || !g_un || !s_un || !elbo || !gitem || !workspace || nb < 0) return VX_EINVAL;
+    const int blocks = hodina_blocks(nb);
+    HoDinaDims dm;
+    dm.K = cfg->K; dm.J = cfg->J; dm.C = 1 << cfg->K; dm.scale = cfg->scale; dm.nb = nb;
+    dm.uniform_prior = 1; dm.dino = dino ? 1 : 0;
+    const int len = 2 * cfg->J + 2 * cfg->K;                  // slab layout of k_hodina; the lambda tail stays zero
+    const int tabf = HD_WAVES * dm.C;
+    const size_t lds = sizeof(float) * (size_t)(tabf > len ? tabf : len);
+    hipStream_t st = (hipStream_t)hs;
+    const int logcpl = cfg->K <= 8 ? 2 : (cfg->K == 9 ? 3 : 4);
+    const int jpl = (cfg->J + 63) / 64;
+    const float* nul = nullptr;
+    float* fnul = nullptr;
+#define LAUNCH_CD(L, JP)                                                                                      \
+    hipLaunchKernelGGL((k_hodina<L, JP>), dim3(blocks), dim3(HD_THREADS), lds, st, dm, y, rows, (int64_t)0, nul, nul, \
+                       nul, (uint64_t)0, 0u, 0u, q, nul, nul, g_un, s_un, fnul, fnul, elbo, workspace)
+#define DISPATCH_CD(L)                               \
+    if (jpl <= 1) { LAUNCH_CD(L, 1); }               \
+    else if (jpl <= 2) { LAUNCH_CD(L, 2); }          \
+    else if (jpl <= 4) { LAUNCH_CD(L, 4); }          \
+    else if (jpl <= 8) { LAUNCH_CD(L, 8); }          \
+    else { LAUNCH_CD(L, 16); }
+    if (logcpl == 2) { DISPATCH_CD(2) } else if (logcpl == 3) { DISPATCH_CD(3) } else { DISPATCH_CD(4) }
+#undef DISPATCH_CD
+#undef LAUNCH_CD
+    VX_CHECK_LAUNCH();
+    // the slabs carry [g | s | lam0 | lam1]: reduce the first 2 J entries of each
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(grid_1d(2 * cfg->J, 64)), dim3(256), 0, st, workspace, (int64_t)blocks,
+                       (int64_t)len, (int64_t)(2 * cfg->J), -1.0f, gitem);
+    VX_CHECK_LAUNCH();
+    return VX_OK;
 }
 
 }  // extern "C"

@@ -148,6 +148,17 @@ class HipBackend(object):
                                    _hip.ptr(gitem), _hip.ptr(ws), _hip.stream_ptr())
         _hip.check(rc, "vx_hodina_grad")
 
+    def ccdm_workspace(self, cfg, nb):
+        n = self.L.vx_ccdm_workspace_floats(ctypes.byref(cfg), nb)
+        if n < 0:
+            raise _hip.VxError("vx_ccdm_workspace_floats: unsupported configuration (code %d)" % n)
+        return n
+
+    def ccdm_grad(self, cfg, dino, y, rows, nb, q, g, s_, elbo, gitem, ws):
+        rc = self.L.vx_ccdm_grad(ctypes.byref(cfg), int(dino), _hip.ptr(y), _hip.ptr(rows), nb, _hip.ptr(q), _hip.ptr(g),
+                                 _hip.ptr(s_), _hip.ptr(elbo), _hip.ptr(gitem), _hip.ptr(ws), _hip.stream_ptr())
+        _hip.check(rc, "vx_ccdm_grad")
+
     def sum_into(self, v, n, alpha, out, ws):
         rc = self.L.vx_sum(_hip.ptr(v), n, alpha, _hip.ptr(out), _hip.ptr(ws), _hip.stream_ptr())
         _hip.check(rc, "vx_sum")
@@ -640,6 +651,62 @@ class HoDinaEngine(_EngineBase):
         else:
             self._scatter_pp(rows, nb, gloc, graw)
         be.sum_into(elbo, nb, -scale, lossslot, self.sum_ws)
+        self.last = {"elbo": elbo, "nb": nb}
+
+
+class CcdmEngine(_EngineBase):
+    """Pattern-enumerated DINA / DINO with the uniform pattern prior and an empty guide (VCCDM, vi.py:819-865).
+    Flat parameter buffer: [g_un: J | s_un: J]; no per-person state, no random numbers."""
+
+    pp_names = ()
+
+    def __init__(self, y_u8, q, cdm="dina", n_global=None, gid0=0, seed=1234, group=None, backend=None):
+        if cdm not in ("dina", "dino"):
+            raise ValueError("model must be 'dina' or 'dino' (BaseCDM.CDM_FUN, vi.py:728-731)")
+        self.be = backend if backend is not None else HipBackend()
+        self.y = y_u8.contiguous()
+        assert self.y.dtype == torch.uint8 and self.y.dim() == 2
+        self.dev = self.y.device
+        self.n_local, self.J = self.y.shape
+        self.N = int(n_global) if n_global is not None else self.n_local
+        self.gid0 = int(gid0)
+        q = torch.as_tensor(q, dtype=torch.float32)
+        assert q.dim() == 2 and q.shape[1] == self.J
+        if not bool(((q == 0) | (q == 1)).all()):
+            raise ValueError("the Q-matrix must be binary (the subset tests of vi.py:78-81, 96-100 assume it)")
+        self.K = int(q.shape[0])
+        self.q = q.to(self.dev).contiguous()
+        self.cdm, self.amortized, self.H = cdm, False, 0
+        self.seed, self.group = int(seed), group
+        J = self.J
+        self.off = {"g": 0, "s": J}
+        self.shape = {"g": (1, J), "s": (1, J)}
+        self.n_item = 2 * J
+        self._alloc(self.n_item, self.n_local, per_person=False)
+        self.view("g").fill_(float(np.float32(_logit(np.float32(0.1)))))      # vi.py:844-845: g = s = 0.1
+        self.view("s").fill_(float(np.float32(_logit(np.float32(0.1)))))
+
+    def names(self):
+        return ["g", "s"]
+
+    def all_names(self):
+        return self.names()
+
+    def param(self, name):
+        return torch.sigmoid(self.unconstrained(name))
+
+    def loss_and_grads(self, rows=None, b_global=None, eps=None, stream_id=0):
+        be = self.be
+        nb = self.n_local if rows is None else int(rows.numel())
+        Bg = int(b_global) if b_global is not None else (self.N if rows is None else nb)
+        scale = float(self.N) / float(Bg)
+        cfg = be.hodina_cfg(self.K, self.J, 0, scale, self.seed, self.t, stream_id)
+        elbo = self._buf("elbo", nb)
+        ws = self._buf("cd_ws", be.ccdm_workspace(cfg, nb))
+        with self._phase("ccdm"):
+            be.ccdm_grad(cfg, self.cdm == "dino", self.y, rows, nb, self.q, self.view("g"), self.view("s"), elbo,
+                         self.G[:self.n_item], ws)
+        be.sum_into(elbo, nb, -scale, self.G[self.n_params:self.n_params + 1], self.sum_ws)
         self.last = {"elbo": elbo, "nb": nb}
 
 

@@ -10,14 +10,14 @@ pyro.clear_param_store, test.py:66,73-87), so the reference's demos read the sam
 
 What runs underneath is NOT pyro: every iteration is one vipsy_amd.engine step, i.e. the HIP kernels behind
 include/vipsy_amd.h (no CPU fallback).  Classes of the reference that are outside the accelerated path
-(VCDM, VaeCDM, VCCDM, VaeCCDM: SURVEY.md section 8f-3) raise NotImplementedError with that explanation.
+(VCDM, VaeCDM, VaeCCDM: SURVEY.md section 8f-3) raise NotImplementedError with that explanation; VCCDM is built.
 """
 import math
 
 import numpy as np
 import torch
 
-from .engine import IrtEngine, HoDinaEngine, LrSpec
+from .engine import CcdmEngine, IrtEngine, HoDinaEngine, LrSpec
 
 _STORE = {}          # name -> engine that owns the parameter (the process-global store of the reference)
 
@@ -254,7 +254,37 @@ def _out_of_scope(name, cite):
 
 VCDM = _out_of_scope("VCDM", "vi.py:807-816")
 VaeCDM = _out_of_scope("VaeCDM", "vi.py:785-804")
-VCCDM = _out_of_scope("VCCDM", "vi.py:819-863")
+
+
+class VCCDM(BasePsy):
+    """Pattern-enumerated DINA / DINO with the uniform pattern prior (vi.py:819-865; BaseCDM ctor vi.py:733-743:
+    q, model='dina'|'dino'; fit defaults vi.py:758, 863-864: Adam lr 1e-3, TraceEnum_ELBO(1), 5000 iterations)."""
+
+    def __init__(self, q=None, model="dina", *args, **kwargs):
+        if q is None or kwargs.get("data") is None:
+            raise NotImplementedError("VCCDM needs q and data (vi.py:733-743)")
+        super().__init__(*args, **kwargs)
+        self.q, self._model = q, model
+        self.attr_size = int(q.shape[0])
+        self.engine = CcdmEngine(self.data, q, cdm=model, n_global=self.sample_size, gid0=self.gid0, seed=self.seed)
+        self._register()
+        self._ri = None
+
+    def fit(self, optim=None, loss=None, max_iter=5000, random_instance=None, progress=True):
+        optim = optim if optim is not None else Adam({"lr": 1e-3})
+        loss = loss if loss is not None else TraceEnum_ELBO(num_particles=1)
+        self._ri = random_instance
+        return self._loop(optim, loss, max_iter, progress)
+
+    def _postfix(self):
+        ri, out = self._ri, {}
+        if ri is None:
+            return out
+        for n in ("g", "s"):
+            out[n] = "{0:.4f}".format(float((param(n) - getattr(ri, n).to(self.device)).abs().mean()))   # vi.py:775-779
+        return out
+
+
 VaeCCDM = _out_of_scope("VaeCCDM", "vi.py:866-891")
 
 
