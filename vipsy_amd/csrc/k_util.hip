@@ -49,6 +49,20 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ 
     }
 }
 
+// few slabs, long rows (the 4 item-chunk partials of gx at 1M persons: 2 GB): 16-byte streaming loads, slabs added in
+// ascending order -> deterministic; HBM-bound
+__global__ __launch_bounds__(256) void k_reduce_few(const float4* __restrict__ slabs, int n_slabs, int64_t stride4,
+                                                    int64_t len4, float alpha, float4* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 acc = slabs[i];
+        for (int s = 1; s < n_slabs; ++s) {
+            const float4 v = slabs[(int64_t)s * stride4 + i];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        out[i] = make_float4(alpha * acc.x, alpha * acc.y, alpha * acc.z, alpha * acc.w);
+    }
+}
+
 // two-stage fixed-order sum: stage 1 -> partial[blockIdx], stage 2 (1 block) -> out[0]
 __global__ void k_sum_stage1(const float* __restrict__ v, int64_t n, float* __restrict__ partial) {
     __shared__ float red[256 / VX_WAVE];

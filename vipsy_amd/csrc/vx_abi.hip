@@ -112,6 +112,12 @@ int vx_philox_raw(uint32_t* out, int64_t gid0, int64_t n, uint64_t seed, uint32_
 int vx_reduce_slabs(const float* slabs, int64_t n_slabs, int64_t len, float alpha, float* out, void* hs) {
     if (!slabs || !out || n_slabs < 1 || len < 0) return VX_EINVAL;
     if (len == 0) return VX_OK;
+    if (n_slabs <= 8 && len >= (1 << 16) && len % 4 == 0 && aligned16(slabs) && aligned16(out)) {
+        hipLaunchKernelGGL(k_reduce_few, dim3(num_cu() * 8), dim3(256), 0, (hipStream_t)hs, (const float4*)slabs,
+                           (int)n_slabs, len / 4, len / 4, alpha, (float4*)out);
+        VX_CHECK_LAUNCH();
+        return VX_OK;
+    }
     hipLaunchKernelGGL(k_reduce_slabs, dim3(grid_1d(len, 64)), dim3(256), 0, (hipStream_t)hs, slabs, n_slabs,
                        len, len, alpha, out);
     VX_CHECK_LAUNCH();
