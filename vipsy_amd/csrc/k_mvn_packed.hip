@@ -294,26 +294,32 @@ __global__ __launch_bounds__(EP_THREADS, 1) void k_mvn_enc_fwd_p(
                 const f32x16 a = mma(A, biasA);
                 const bool is_diag = t2 < n_off + n_sec;
                 const int k0 = 32 * (t2 - (is_diag ? n_off : n_off + n_sec));
+                const bool allv = k0 + 32 <= D;                        // wave-uniform: no per-entry bounds below
                 float xo[16], ev[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     int kk = k0 + crow32(r, half);
-                    kk = kk < D ? kk : D - 1;
+                    kk = (allv || kk < D) ? kk : D - 1;
                     xo[r] = xp[kk];
                     ev[r] = ep[kk];
                 }
+                if (is_diag) {                                         // exp(diag M) eps_k, entropy, ldT  (vi.py:686)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kk = k0 + crow32(r, half);
-                    if (kk < D) {
-                        if (is_diag) {
-                            const float ld = __expf(a[r]);                             // exp(diag M): vi.py:686
+                    for (int r = 0; r < 16; ++r) {
+                        const int kk = k0 + crow32(r, half);
+                        const float ld = __expf(a[r]);
+                        const bool ok = allv || kk < D;
+                        if (ok) {
                             xp[kk] = fmaf(ld, ev[r], xo[r]);
                             ent_acc += a[r];
                             if (i < dm.nb) ldT[(int64_t)kk * dm.nb + i] = ld;
-                        } else {
-                            xp[kk] = xo[r] + a[r];                                     // loc head (vi.py:450)
                         }
+                    }
+                } else {                                               // loc head (vi.py:450)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kk = k0 + crow32(r, half);
+                        if (allv || kk < D) xp[kk] = xo[r] + a[r];
                     }
                 }
             };
