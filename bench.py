@@ -48,8 +48,8 @@ def enc_fwd_flops_per_person(J, D, H):
 def measured_traffic(kernel_prefix):
     """HBM bytes per launch of the dominant kernel on the headline workload, from the committed PMC summary
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied; see
-    profiles/r01_v3_hbm_traffic.json and tools/profile_round.sh).  None when the summary is not there."""
-    path = os.path.join(ROOT, "profiles", "r01_v3_hbm_traffic.json")
+    profiles/r01_v4_hbm_traffic.json and tools/profile_round.sh).  None when the summary is not there."""
+    path = os.path.join(ROOT, "profiles", "r01_v4_hbm_traffic.json")
     try:
         with open(path) as f:
             kernels = json.load(f)["kernels"]
@@ -193,7 +193,7 @@ def main():
             out["roofline"] = {"kernel": "k_mvn_enc_fwd_p", "bound": "mfma", "achieved": ach,
                                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                                "traffic": measured_traffic("k_mvn_enc_fwd_p") if headline else None,
-                               "traffic_source": "profiles/r01_v3_hbm_traffic.json (PMC, bytes per launch)" if headline else None,
+                               "traffic_source": "profiles/r01_v4_hbm_traffic.json (PMC, bytes per launch)" if headline else None,
                                "algorithmic_flops_per_launch": fl, "avg_launch_ms": phase_ms["guide_forward"]}
         elif "irt1d" in phase_ms or "hodina" in phase_ms:
             key = "irt1d" if "irt1d" in phase_ms else "hodina"
