@@ -214,8 +214,8 @@ def test_entry_points_reject_bad_arguments():
 
 
 def test_generic_and_fast_kernels_agree():
-    """The specialised fast kernels (hidden 64, J % 4 == 0) against the shape-generic ones
-    (VX_FORCE_GENERIC=1 in a child process) on the headline shape."""
+    """The specialised kernels (dimension-major / packed / person-major generations, selected by the VX_* switches)
+    against the shape-generic ones (VX_FORCE_GENERIC=1 in a child process) on the headline shape."""
     import json
     import os
     import subprocess
@@ -225,7 +225,7 @@ import json, os, sys, numpy as np, torch
 sys.path.insert(0, %r)
 from vipsy_amd.engine import IrtEngine
 rng = np.random.RandomState(5)
-N, J, D, H = 500, 500, 100, 64
+N, J, D, H = 512, 500, 100, 64
 y = rng.randint(0, 2, size=(N, J)).astype(np.uint8); y[rng.rand(N, J) < 0.2] = 255
 eng = IrtEngine(torch.from_numpy(y).cuda(), model="irt_2pl", D=D, amortized=True, H=H, seed=21)
 eng.unconstrained("b").copy_(torch.from_numpy(0.5 * rng.randn(1, J)).float())
@@ -236,13 +236,16 @@ out = {"loss": float(eng.G[eng.n_params].item()), "g": eng.G[:eng.n_params].doub
 print("RESULT" + json.dumps(out))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for mode in ("0", "1", "fast"):
-        env = dict(os.environ, VX_FORCE_GENERIC="1" if mode == "1" else "0", VX_MVN="fast" if mode == "fast" else "packed")
+    switches = {"0": {}, "1": {"VX_FORCE_GENERIC": "1"}, "fast": {"VX_MVN": "fast"}, "bwdw": {"VX_BWDW": "old"},
+                "bwdh": {"VX_BWDH": "old"}, "lik": {"VX_LIK": "old"}}
+    for mode, extra in switches.items():
+        env = dict(os.environ, VX_FORCE_GENERIC="0", VX_MVN="packed")
+        env.update(extra)
         p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][0]
         res[mode] = json.loads(line[6:])
-    for m in ("0", "fast"):                            # packed-layout kernels, reference-order fast kernels
+    for m in ("0", "fast", "bwdw", "bwdh", "lik"):     # every kernel generation against the shape-generic ones
         assert res[m]["loss"] == pytest.approx(res["1"]["loss"], rel=1e-6)
         x0, x1 = np.array(res[m]["x"]), np.array(res["1"]["x"])
         np.testing.assert_allclose(x0, x1, atol=2e-5, rtol=1e-5)
