@@ -253,12 +253,15 @@ class _EngineBase(object):
         return {k: self.view("encoder$$$" + k) for k in ENC_KEYS}
 
     def _item_major_y(self, rows):
-        """Item-major copy of the responses ([J][n_local] bytes) for the dimension-major fc1 gradient kernel: made
-        once (the responses never change); only for full batches with 16-byte aligned person rows."""
-        if rows is not None or self.n_local % 16 != 0 or self.n_local == 0:
+        """Item-major copy of the responses ([J][stride] bytes, stride = n_local rounded up to 16, zero padded) for the
+        dimension-major fc1 gradient kernel: made once (the responses never change); full batches only."""
+        if rows is not None or self.n_local == 0:
             return None
         if getattr(self, "_yT", None) is None:
-            self._yT = self.y.t().contiguous()
+            stride = (self.n_local + 15) // 16 * 16
+            yT = torch.zeros((self.J, stride), dtype=torch.uint8, device=self.dev)
+            yT[:, :self.n_local] = self.y.t()
+            self._yT = yT
         return self._yT
 
     def _buf(self, key, n):
