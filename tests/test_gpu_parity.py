@@ -131,6 +131,9 @@ def _random_problem(N, J, D, H, model, miss, seed):
     (320, 500, 100, 64, "irt_2pl", 0.1, None),      # N % 16 == 0: item-major responses, dimension-major fc1 gradient
     (1040, 516, 64, 64, "irt_3pl", 0.2, None),      # ... with two 512-item groups and a ragged last person tile
     (64, 40, 8, 64, "irt_2pl", 0.0, None),
+    (36, 40, 8, 64, "irt_2pl", 0.1, None),          # a single ragged person tile in every dimension-major kernel
+    (4, 36, 4, 64, "irt_2pl", 0.0, None),           # the smallest batch those kernels accept
+    (2000, 500, 100, 64, "irt_2pl", 0.0, 1000),     # headline shape with a row gather (subsample): FAST == 2 staging
 ])
 def test_mvn_amortized_step_vs_oracle(N, J, D, H, model, miss, B):
     from vipsy_amd.engine import IrtEngine, ENC_KEYS
