@@ -162,6 +162,19 @@ int vx_norm_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t*
                          const float* graw, const uint8_t* yT /*[J][yT_stride] or NULL*/, int64_t yT_stride,
                          float* genc, float* workspace, void* hip_stream);
 
+/* ---- D = 1 models on OBSERVED cells only (full batch; for heavily masked data, BASELINE config 4).  The responses
+ * never change, so the host compacts them once (vipsy_amd/engine.py::_sparse_lists):
+ *   pent [n_groups][L][64] uint16: entry e of person 64 g + lane = item | y << 15, 0xFFFF = padding;
+ *   glen [n_groups]: longest list in the group;  ient [nnz] uint32: person | y << 31 grouped by item,
+ *   ioff [J + 1]: item j owns ient[ioff[j] .. ioff[j+1]).
+ * Same outputs as vx_irt1d_grad.  workspace: vx_irt1d_sparse_workspace_floats(cfg, nb) floats.  J <= 1024. */
+int64_t vx_irt1d_sparse_workspace_floats(const vx_irt_cfg* cfg, int64_t nb);
+int vx_irt1d_sparse_grad(const vx_irt_cfg* cfg, const uint16_t* pent, const int32_t* glen, int32_t L,
+                         const uint32_t* ient, const int64_t* ioff, int64_t nb, int64_t gid0, const float* loc,
+                         const float* raw, const float* eps_in, const float* a, const float* b, const float* c_un,
+                         const float* d_un, float* gloc, float* graw, float* elbo, float* gitem, float* workspace,
+                         void* hip_stream);
+
 /* ---- HO-DINA with exact enumeration of the 2^K attribute patterns (VCHoDina / VaeCHoDina model,
  * vi.py:897-923, under TraceEnum_ELBO; guide theta ~ Normal(loc, exp(raw)), vi.py:925-934 / 968-981).
  *   q: [K][J] float 0/1 Q-matrix (vi.py:741);  lam0 [K], lam1_un [K] (positive -> exp), g_un / s_un [J]

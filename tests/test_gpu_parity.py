@@ -177,6 +177,10 @@ def test_mvn_amortized_step_vs_oracle(N, J, D, H, model, miss, B):
     (777, 1000, "irt_2pl", 0.59, 100),               # Irt2PLMissing.test_ai shape (test.py:311-319)
     (100, 65, "irt_1pl", 0.1, 33),
     (100, 129, "irt_3pl", 0.1, None),
+    (2000, 500, "irt_2pl", 0.9, None),               # >= 50 % missing, full batch: observed-cell lists (k_irt1d_sparse.hip)
+    (777, 130, "irt_4pl", 0.7, None),
+    (300, 37, "irt_1pl", 0.6, None),
+    (640, 200, "irt_3pl", 0.95, None),
 ])
 def test_irt1d_step_vs_oracle(N, J, model, miss, B):
     from vipsy_amd.engine import IrtEngine

@@ -7,6 +7,7 @@ torch here is plumbing: it owns device buffers and the process group.  All arith
 is in the HIP kernels behind vipsy_amd/_hip.py.
 """
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -96,6 +97,20 @@ class HipBackend(object):
                                   _hip.ptr(d_un), _hip.ptr(gloc), _hip.ptr(graw), _hip.ptr(elbo), _hip.ptr(gitem),
                                   _hip.ptr(ws), _hip.stream_ptr())
         _hip.check(rc, "vx_irt1d_grad")
+
+    def irt1d_sparse_workspace(self, cfg, nb):
+        n = self.L.vx_irt1d_sparse_workspace_floats(ctypes.byref(cfg), nb)
+        if n < 0:
+            raise _hip.VxError("vx_irt1d_sparse_workspace_floats: unsupported configuration (code %d)" % n)
+        return n
+
+    def irt1d_sparse_grad(self, cfg, lists, nb, gid0, loc, raw, eps_in, a, b, c_un, d_un, gloc, graw, elbo, gitem, ws):
+        rc = self.L.vx_irt1d_sparse_grad(ctypes.byref(cfg), _hip.ptr(lists["pent"]), _hip.ptr(lists["glen"]),
+                                         int(lists["L"]), _hip.ptr(lists["ient"]), _hip.ptr(lists["ioff"]), nb, gid0,
+                                         _hip.ptr(loc), _hip.ptr(raw), _hip.ptr(eps_in), _hip.ptr(a), _hip.ptr(b),
+                                         _hip.ptr(c_un), _hip.ptr(d_un), _hip.ptr(gloc), _hip.ptr(graw), _hip.ptr(elbo),
+                                         _hip.ptr(gitem), _hip.ptr(ws), _hip.stream_ptr())
+        _hip.check(rc, "vx_irt1d_sparse_grad")
 
     def mvn_bbvi_forward(self, cfg, nb, rows, gid0, loc, M, shared, eps_in, x, eps, ent):
         rc = self.L.vx_mvn_bbvi_forward(ctypes.byref(cfg), nb, _hip.ptr(rows), gid0, _hip.ptr(loc), _hip.ptr(M),
@@ -263,6 +278,40 @@ class _EngineBase(object):
             yT[:, :self.n_local] = self.y.t()
             self._yT = yT
         return self._yT
+
+    def _sparse_lists(self, rows):
+        """Observed-cell lists for the D = 1 kernels (include/vipsy_amd.h, vx_irt1d_sparse_grad): built once -- the
+        responses never change -- and only when most cells are missing and the batch is the whole shard."""
+        if rows is not None or self.n_local == 0 or self.J > 1024 or os.environ.get("VX_SPARSE", "") == "off":
+            return None
+        if getattr(self, "_sp", None) is None:
+            y, n, J = self.y, self.n_local, self.J
+            frac = float((y == 255).sum().item()) / float(n * J)
+            if frac < 0.5:
+                self._sp = False
+            else:
+                ng = (n + 63) // 64
+                cnt = torch.zeros(ng * 64, dtype=torch.int64, device=self.dev)
+                cnt[:n] = (y != 255).sum(1)
+                L = max(1, int(cnt.max().item()))
+                pent = torch.full((ng * 64, L), -1, dtype=torch.int16, device=self.dev)          # 0xFFFF = padding
+                ar = torch.arange(L, device=self.dev)[None, :]
+                for lo in range(0, n, 65536):                                                     # bounded temporaries
+                    hi = min(n, lo + 65536)
+                    yc = y[lo:hi]
+                    order = torch.argsort((yc == 255).to(torch.uint8), dim=1, stable=True)[:, :L]  # observed items first
+                    code = order.to(torch.int32) | ((torch.gather(yc, 1, order) == 1).to(torch.int32) << 15)
+                    code = torch.where(ar < cnt[lo:hi, None], code, torch.full_like(code, 0xFFFF))
+                    pent[lo:hi] = code.to(torch.int16)                                            # wraps: bit pattern kept
+                pent = pent.reshape(ng, 64, L).permute(0, 2, 1).contiguous()
+                glen = cnt.reshape(ng, 64).max(1).values.to(torch.int32).contiguous()
+                nz = (y != 255).t().nonzero()                                                     # (item, person), sorted
+                yb = (y.t()[nz[:, 0], nz[:, 1]] == 1).to(torch.int64)
+                ient = (nz[:, 1] | (yb << 31)).to(torch.int32).contiguous()                       # wraps: bit 31 = y
+                ioff = torch.zeros(J + 1, dtype=torch.int64, device=self.dev)
+                ioff[1:] = torch.cumsum(torch.bincount(nz[:, 0], minlength=J), 0)
+                self._sp = {"pent": pent, "glen": glen, "L": L, "ient": ient, "ioff": ioff, "missing": frac}
+        return self._sp or None
 
     def _buf(self, key, n):
         t = self._ws.get(key)
@@ -529,9 +578,15 @@ class IrtEngine(_EngineBase):
                 loc, raw = fw["loc"], fw["raw"]
             else:
                 loc, raw, gloc, graw = self._gather_pp(rows, nb)
+            lists = self._sparse_lists(rows) if hasattr(be, "irt1d_sparse_grad") else None
             with self._phase("irt1d"):
-                be.irt1d_grad(cfg, self.y, rows, nb, self.gid0, loc, raw, eps, a, self.view("b"), c_un, d_un,
-                              gloc, graw, elbo, g1d, i1d_ws)
+                if lists is not None:                      # mostly-missing responses: observed cells only
+                    sp_ws = self._buf("i1d_sp_ws", be.irt1d_sparse_workspace(cfg, nb))
+                    be.irt1d_sparse_grad(cfg, lists, nb, self.gid0, loc, raw, eps, a, self.view("b"), c_un, d_un,
+                                         gloc, graw, elbo, g1d, sp_ws)
+                else:
+                    be.irt1d_grad(cfg, self.y, rows, nb, self.gid0, loc, raw, eps, a, self.view("b"), c_un, d_un,
+                                  gloc, graw, elbo, g1d, i1d_ws)
             J = self.J
             gitem.zero_()
             gitem[self.off["a"]:self.off["a"] + J].copy_(g1d[0:J])
