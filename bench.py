@@ -186,6 +186,8 @@ def main():
             "person_rows_per_s": N * args.steps / dt,
             "loss_last": loss_v, "phase_ms": phase_ms,
         }
+        if os.environ.get("VX_BF16X3", "") == "1":          # opt-in kernel variant: say so in the line itself
+            out["config"]["opt_in"] = "VX_BF16X3=1 (weight-gradient GEMM as 3-term bf16 splitting on the bf16 MFMA, fp32 accumulate)"
         if D > 1 and "guide_forward" in phase_ms:
             fl = enc_fwd_flops_per_person(J, D, H) * n_local
             ach = fl / (phase_ms["guide_forward"] * 1e-3) / 1e12

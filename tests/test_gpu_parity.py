@@ -244,7 +244,7 @@ print("RESULT" + json.dumps(out))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     switches = {"0": {}, "1": {"VX_FORCE_GENERIC": "1"}, "fast": {"VX_MVN": "fast"}, "bwdw": {"VX_BWDW": "old"},
-                "bwdh": {"VX_BWDH": "old"}, "lik": {"VX_LIK": "old"}}
+                "bwdh": {"VX_BWDH": "old"}, "lik": {"VX_LIK": "old"}, "bf16x3": {"VX_BF16X3": "1"}}
     for mode, extra in switches.items():
         env = dict(os.environ, VX_FORCE_GENERIC="0", VX_MVN="packed")
         env.update(extra)
@@ -252,7 +252,8 @@ print("RESULT" + json.dumps(out))
         assert p.returncode == 0, p.stderr[-2000:]
         line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][0]
         res[mode] = json.loads(line[6:])
-    for m in ("0", "fast", "bwdw", "bwdh", "lik"):     # every kernel generation against the shape-generic ones
+    # every kernel generation -- and the opt-in bf16x3 weight-gradient kernel -- against the shape-generic ones
+    for m in ("0", "fast", "bwdw", "bwdh", "lik", "bf16x3"):
         assert res[m]["loss"] == pytest.approx(res["1"]["loss"], rel=1e-6)
         x0, x1 = np.array(res[m]["x"]), np.array(res["1"]["x"])
         np.testing.assert_allclose(x0, x1, atol=2e-5, rtol=1e-5)

@@ -1,0 +1,341 @@
+// OPT-IN variant (VX_BF16X3=1) of k_mvn_enc_bwd_w_t: the same head weight gradients
+//     gWp[r][hh] = sum_p V[r][p] h[p][hh],   V = (G or GD row) * (E row or ones),
+// with every fp32 product computed as THREE bf16 terms per operand and SIX cross products on the bf16 MFMA
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulate).  tools/bf16x3_ubench.hip: the result is closer to
+// the fp64 value than the exact fp32 MFMA chain (8.5e-8 vs 1.5e-7 of sum |a b|) at a third of the matrix-pipe time,
+// and a bf16 MFMA holds the vector issue port for 8 of its 32 cycles only, so the splitting of V runs in its shadow.
+//   h  : split once per step into three bf16 arrays hs[3][64][nb] (k_split3_bf16), staged by DMA, 16-byte fragments;
+//   V  : fp32 product as before (8 persons per lane half and chunk), then split in registers.
+// Fragment layout of the 32x32x16 MFMA: lane (r = lane & 31, h = lane >> 5) holds A[row r][k = 8h + j] and
+// B[k = 8h + j][col r], j = 0..7; here k = person within a 16-person chunk.
+// (included by vx_abi.hip after k_mvn_bwd_t.hip, whose row layout and helpers it shares)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
+
+// row map (128-byte row units): G [0, DR) | E [DR, 2 DR) | H area: 3 splits x 64 rows x 64 bytes = 96 units |
+// GD [2 DR + 96, 3 DR + 96) | C (ones, zeros) [3 DR + 96, 3 DR + 112)
+__host__ __device__ inline int bb_row_H(int D) { return 2 * bt_dr(D); }
+__host__ __device__ inline int bb_row_GD(int D) { return 2 * bt_dr(D) + 96; }
+__host__ __device__ inline int bb_row_ones(int D) { return 3 * bt_dr(D) + 96; }
+__host__ __device__ inline int bb_rows(int D) { return 3 * bt_dr(D) + 112; }
+#define BB_BUF 63488
+__host__ __device__ inline size_t bb_lds_bytes(int D) { return (size_t)BB_BUF + (size_t)bb_rows(D) * 128; }
+// byte offset inside the H area of hidden row hh of split s3, 16-byte slot s (persons 8 s .. 8 s + 7 of the tile):
+// four rows share a 256-byte bank row; the slot is XORed with (hh >> 2) & 3 so that the 16 lanes of a ds_read_b128
+// group (hh = 0-3, 12-15, 20-27 (+32)) land on 16 different slots
+__host__ __device__ inline uint32_t bb_haddr(int s3, int hh, int s) {
+    return (uint32_t)(s3 * 4096 + (hh >> 2) * 256 + ((((hh & 3) << 2) | (s ^ ((hh >> 2) & 3))) << 4));
+}
+
+// hs[s][i] (s = 0, 1, 2) = the three bf16 terms of v[i], round-to-nearest at each stage: v = h + m + l up to 2^-24
+__global__ void k_split3_bf16(const float* __restrict__ v, int64_t n, uint16_t* __restrict__ hs) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = v[i];
+        const __bf16 h = (__bf16)x;
+        const float r1 = x - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const __bf16 l = (__bf16)(r1 - (float)m);
+        hs[i] = __builtin_bit_cast(uint16_t, h);
+        hs[n + i] = __builtin_bit_cast(uint16_t, m);
+        hs[2 * n + i] = __builtin_bit_cast(uint16_t, l);
+    }
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// eight fp32 values -> three bf16 fragments (h, m, l)
+__device__ __forceinline__ void split3_frag(const float (&v)[8], bf16x8& fh, bf16x8& fm, bf16x8& fl) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)v[j];
+        const float r1 = v[j] - (float)h;
+        const __bf16 m = (__bf16)r1;
+        fh[j] = h; fm[j] = m; fl[j] = (__bf16)(r1 - (float)m);
+    }
+}
+
+__global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
+    EncDims dm, const uint16_t* __restrict__ hs /*[3][64][nb] bf16*/, const float* __restrict__ epsT,
+    const float* __restrict__ gdT, const float* __restrict__ gxT, const uint32_t* __restrict__ gtab,
+    float* __restrict__ slabs, int64_t slab_len) {
+    extern __shared__ __attribute__((aligned(16))) char smem_bb[];
+    const int D = dm.D;
+    const int64_t nb = dm.nb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    constexpr uint32_t BUF = BB_BUF;
+    const int Rp = pk_rows(D);
+    int rb_, blk_pr;
+    bt_decode(rb_, blk_pr);
+    const int64_t rbase = (int64_t)rb_ * BT_ROWS + (int64_t)wave * BT_RT * 32;
+    const int rE = bt_row_E(D), rH = bb_row_H(D), rGD = bb_row_GD(D), rOnes = bb_row_ones(D), rZero = rOnes + 1;
+    const bool need_gd = (int64_t)(rb_ + 1) * BT_ROWS > pk_off_total(D);
+
+    // ---- per-lane LDS addresses: fp32 rows, persons 16 c + 8 half + 0..7 = chunks 4c + 2 half and + 1
+    uint32_t aG[BT_RT][2], aE[BT_RT][2], aHf[3][2][2];                 // [..][chunk c]; H: [split][hidden tile][chunk]
+#pragma unroll
+    for (int t = 0; t < BT_RT; ++t) {
+        const int64_t pr = rbase + 32 * t + l31;
+        int g = rZero, e = rOnes;
+        if (pr < Rp) {
+            const uint32_t code = gtab[pr >> 3];
+            const uint32_t type = code >> 28, k = (code >> 12) & 0xFFFFu, l0 = code & 0xFFFu, jx = (uint32_t)(pr & 7);
+            if (type == PK_OFF) { if (l0 + jx < k) { g = (int)k; e = rE + (int)(l0 + jx); } }
+            else if (type == PK_LOC) { if (k + jx < (uint32_t)D) g = (int)(k + jx); }
+            else if (type == PK_DIAG) { if (k + jx < (uint32_t)D) g = rGD + (int)(k + jx); }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { aG[t][c] = bt_addr(g, 4 * c + 2 * half); aE[t][c] = bt_addr(e, 4 * c + 2 * half); }
+    }
+    // second 16-byte piece of a row's pair: chunk index + 1 = slot XOR 1 (4c + 2 half is even)
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) aHf[s3][ht][c] = (uint32_t)rH * 128u + bb_haddr(s3, 32 * ht + l31, 2 * c + half);
+
+    for (int b = 0; b < 2; ++b) {
+        if (tid < 64) *(float*)(smem_bb + b * BUF + bt_addr(rOnes + (tid >> 5), (tid & 31) >> 2) + 4 * (tid & 3)) = (tid < 32) ? 1.0f : 0.f;
+    }
+    f32x16 acc[BT_RT][2];
+    float bsum[BT_RT];
+#pragma unroll
+    for (int t = 0; t < BT_RT; ++t) { bsum[t] = 0.f; acc[t][0] = zero16(); acc[t][1] = zero16(); }
+
+    const int64_t n_ptiles = (nb + BT_P - 1) / BT_P;
+    // DMA transfers of 1 KB (see k_mvn_bwd_t.hip): d < rH / 8: G / E rows; the next 12: the H area (4 per split);
+    // then GD rows.  Per-lane global addresses are fixed; only the person offset of the tile is added.
+    constexpr int BB_MAXD = 15;
+    const int dH0 = rH / 8, dGD0 = rGD / 8;
+    const int n_dma = need_gd ? rOnes / 8 : dGD0;
+    // scalar region base (+ the tile's person offset, on the scalar unit) + fixed 32-bit per-lane byte offset
+    uint32_t voff[BB_MAXD];
+#pragma unroll
+    for (int u = 0; u < BB_MAXD; ++u) {
+        const int d = wave + 4 * u;
+        if (d >= dH0 && d < dGD0) {                                    // H area: 16 hidden rows of one split
+            const int dd = d - dH0, s3 = dd >> 2;
+            const int hh = 16 * (dd & 3) + 4 * (lane >> 4) + ((lane & 15) >> 2);
+            const int s = (lane & 3) ^ ((hh >> 2) & 3);
+            voff[u] = (uint32_t)((((int64_t)s3 * 64 + hh) * nb + 8 * s) * 2);
+        } else {
+            const int i = 4 * (d & 1) + (lane >> 4), beta = (lane >> 3) & 1;
+            const int R = 16 * (d >> 1) + 8 * beta + i;
+            const int c = (lane & 7) ^ i;
+            int rl = R >= rGD ? R - rGD : R >= rE ? R - rE : R;
+            if (rl >= D) rl = D - 1;                                   // padding rows of a region: a harmless duplicate
+            voff[u] = (uint32_t)(((int64_t)rl * nb + 4 * c) * 4);
+        }
+    }
+    auto stage = [&](int64_t tile, int b) __attribute__((always_inline)) {
+        const int64_t i0 = tile * BT_P;
+        const int pv = (int)((nb - i0) < BT_P ? (nb - i0) : BT_P);
+        const uint32_t lbase = lds_addr_uniform(smem_bb + b * BUF) + (uint32_t)wave * 1024u;
+        const float *sG = gxT + i0, *sE = epsT + i0, *sGD = gdT + i0;
+        const uint16_t* sH = hs + i0;
+        if (pv < BT_P) {                                               // the last tile: absent persons are zeros
+            for (int e = tid; e < bb_rows(D) * 32; e += BT_THREADS) {
+                const int row = e >> 5;
+                if (row != rOnes) ((float*)(smem_bb + b * BUF))[e] = 0.f;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < BB_MAXD; ++u) {
+            const int d = wave + 4 * u;
+            if (d < n_dma) {
+                const bool isH = d >= dH0 && d < dGD0;
+                const void* sb = d >= dGD0 ? (const void*)sGD : isH ? (const void*)sH : d >= rE / 8 ? (const void*)sE : (const void*)sG;
+                if (pv == BT_P) {
+                    dma16s(sb, voff[u], lbase + (uint32_t)u * 4096u);
+                } else {                                               // persons of this lane's 16 bytes: 8 (H) or 4 (fp32)
+                    int p0;
+                    if (isH) {
+                        const int hh = 16 * ((d - dH0) & 3) + 4 * (lane >> 4) + ((lane & 15) >> 2);
+                        p0 = 8 * ((lane & 3) ^ ((hh >> 2) & 3));
+                    } else {
+                        p0 = 4 * ((lane & 7) ^ (4 * (d & 1) + (lane >> 4)));
+                    }
+                    if (p0 < pv) dma16s(sb, voff[u], lbase + (uint32_t)u * 4096u);
+                }
+            }
+        }
+    };
+
+    // ---- compute: 2 chunks x BT_RT row tiles = 8 groups per tile, 12 MFMAs per group.  The fragments of group g + 1
+    // (4 LDS reads, 4 products, 4 x (split of an element pair), the bias sum) are made in the shadow of the MFMAs of
+    // group g, a few vector instructions after each MFMA; every slice is a pinned scheduling region.  The barrier of a
+    // tile sits before its LAST group, whose operands are in registers already: behind it the buffer is free for the
+    // DMA of the tile after next, and the prefetch of that group reads the next tile from the other buffer.
+    // Vector instructions in the shadow of a bf16 MFMA (tools/slice_ubench.hip): about five single-pass ones are free;
+    // v_pk_*_f32 are NOT (they wait for the matrix pipe) and v_cvt_pk_bf16_f32 takes two passes.  So the split is by
+    // truncation -- h = top 8 mantissa bits, m = top 8 of the rest, l = the last 8: v = h + m + l exactly -- with
+    // and / sub / v_perm_b32 (packs the upper halves of two dwords) only.
+    // Every instruction of a slice is a volatile asm statement: the optimizer otherwise re-vectorizes the scalar
+    // arithmetic into v_pk_*_f32 across slices and sinks whole slices out of the MFMA shadow.
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    uint32_t fq[2][3][4];                                              // [parity of the group][h, m, l][element pair]
+    bf16x8 hf[2][3][2];                                                // [parity of the chunk][split][hidden tile]
+    f32x4 rg0, rg1, re0, re1;
+    float pv_[8], pr_[8], s0, s1, s2, s3;
+    const uint32_t psel = 0x07060302u;                                 // v_perm_b32: upper halves of (src0, src1)
+    auto amul = [](float x, float y) -> float { float d; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; };
+    auto aadd = [](float x, float y) -> float { float d; asm volatile("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; };
+    auto arem = [](float x) -> float {                                 // x - (x with the low 16 bits cleared)
+        float t, d;
+        asm volatile("v_and_b32 %1, 0xffff0000, %2\n\tv_sub_f32 %0, %2, %1" : "=v"(d), "=&v"(t) : "v"(x));
+        return d;
+    };
+    auto pack_hi = [&](float x1, float x0) -> uint32_t {
+        uint32_t d; asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(x1), "v"(x0), "s"(psel)); return d; };
+    auto read_raw = [&](const char* rb, uint32_t ag, uint32_t ae) __attribute__((always_inline)) {
+        rg0 = *(const f32x4*)(rb + ag); rg1 = *(const f32x4*)(rb + (ag ^ 16u));
+        re0 = *(const f32x4*)(rb + ae); re1 = *(const f32x4*)(rb + (ae ^ 16u));
+    };
+    auto products0 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pv_[j] = amul(rg0[j], re0[j]);
+        s0 = aadd(pv_[0], pv_[1]); s1 = aadd(pv_[2], pv_[3]);
+    };
+    auto products1 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pv_[4 + j] = amul(rg1[j], re1[j]);
+        s2 = aadd(pv_[4], pv_[5]); s3 = aadd(pv_[6], pv_[7]);
+    };
+    auto split_a = [&](auto pc, auto nc) __attribute__((always_inline)) {
+        constexpr int p = decltype(pc)::value, nx = decltype(nc)::value;
+        fq[nx][0][p] = pack_hi(pv_[2 * p + 1], pv_[2 * p]);
+        pr_[2 * p] = arem(pv_[2 * p]);
+        pr_[2 * p + 1] = arem(pv_[2 * p + 1]);
+    };
+    auto split_b = [&](auto pc, auto nc) __attribute__((always_inline)) {
+        constexpr int p = decltype(pc)::value, nx = decltype(nc)::value;
+        fq[nx][1][p] = pack_hi(pr_[2 * p + 1], pr_[2 * p]);
+        const float l0 = arem(pr_[2 * p]), l1 = arem(pr_[2 * p + 1]);
+        fq[nx][2][p] = pack_hi(l1, l0);
+    };
+    auto frag = [&](auto cc, auto kc) -> bf16x8 {
+        constexpr int cu = decltype(cc)::value, k = decltype(kc)::value;
+        return __builtin_bit_cast(bf16x8, u32x4{fq[cu][k][0], fq[cu][k][1], fq[cu][k][2], fq[cu][k][3]});
+    };
+    auto tile_body = [&](auto bc, bool has_next, int64_t stage_tile) {
+        constexpr int b = decltype(bc)::value;
+        static_for<2 * BT_RT>([&](auto gc) {
+            constexpr int gi = decltype(gc)::value, c = gi / BT_RT, t = gi % BT_RT, cur = gi & 1, nxt = cur ^ 1;
+            constexpr int gn = (gi + 1) % (2 * BT_RT), cn = gn / BT_RT, tn = gn % BT_RT;
+            constexpr bool last = gi == 2 * BT_RT - 1;
+            if constexpr (last) {
+                vx_wait_vmem();
+                __syncthreads();                                       // next tile landed; this tile's buffer is free
+                if (stage_tile >= 0) stage(stage_tile, b);
+            }
+            const char* rb = smem_bb + (last ? 1 - b : b) * BUF;
+            constexpr std::integral_constant<int, cur> curc{};
+            constexpr std::integral_constant<int, nxt> nxtc{};
+            const bf16x8 vh = frag(curc, std::integral_constant<int, 0>{}), vm = frag(curc, std::integral_constant<int, 1>{}), vl = frag(curc, std::integral_constant<int, 2>{});
+            __builtin_amdgcn_sched_barrier(0);
+            acc[t][0] = mfma_bf16(vh, hf[c][0][0], acc[t][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            read_raw(rb, aG[tn][cn], aE[tn][cn]);
+            if constexpr (t == BT_RT - 1) {
+#pragma unroll
+                for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+                    for (int ht = 0; ht < 2; ++ht) hf[cn][s3][ht] = *(const bf16x8*)(rb + aHf[s3][ht][cn]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[t][1] = mfma_bf16(vh, hf[c][0][1], acc[t][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[t][0] = mfma_bf16(vh, hf[c][1][0], acc[t][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            products0();
+            __builtin_amdgcn_sched_barrier(0);
+            acc[t][1] = mfma_bf16(vh, hf[c][1][1], acc[t][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            products1();
+            __builtin_amdgcn_sched_barrier(0);
+            acc[t][0] = mfma_bf16(vh, hf[c][2][0], acc[t][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            split_a(std::integral_constant<int, 0>{}, nxtc); s0 = aadd(s0, s1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[t][1] = mfma_bf16(vh, hf[c][2][1], acc[t][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            split_b(std::integral_constant<int, 0>{}, nxtc);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[t][0] = mfma_bf16(vm, hf[c][0][0], acc[t][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            split_a(std::integral_constant<int, 1>{}, nxtc); s2 = aadd(s2, s3);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[t][1] = mfma_bf16(vm, hf[c][0][1], acc[t][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            split_b(std::integral_constant<int, 1>{}, nxtc);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[t][0] = mfma_bf16(vm, hf[c][1][0], acc[t][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            split_a(std::integral_constant<int, 2>{}, nxtc); s0 = aadd(s0, s2);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[t][1] = mfma_bf16(vm, hf[c][1][1], acc[t][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            split_b(std::integral_constant<int, 2>{}, nxtc);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[t][0] = mfma_bf16(vl, hf[c][0][0], acc[t][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            split_a(std::integral_constant<int, 3>{}, nxtc);
+            if constexpr (last) bsum[tn] = aadd(bsum[tn], has_next ? s0 : 0.f); else bsum[tn] = aadd(bsum[tn], s0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[t][1] = mfma_bf16(vl, hf[c][0][1], acc[t][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            split_b(std::integral_constant<int, 3>{}, nxtc);
+            __builtin_amdgcn_sched_barrier(0);
+            
+        });
+    };
+
+    const int64_t t0 = blk_pr, GS = gridDim.y;
+    if (t0 < n_ptiles) {
+        stage(t0, 0);
+        if (t0 + GS < n_ptiles) stage(t0 + GS, 1);
+        vx_wait_vmem();
+        __syncthreads();
+        // fragments of the first group, outside the pipeline
+        read_raw(smem_bb, aG[0][0], aE[0][0]);
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht) hf[0][s3][ht] = *(const bf16x8*)(smem_bb + aHf[s3][ht][0]);
+        products0();
+        products1();
+        static_for<4>([&](auto pc) { split_a(pc, std::integral_constant<int, 0>{}); split_b(pc, std::integral_constant<int, 0>{}); });
+        bsum[0] += (s0 + s1) + (s2 + s3);
+        int64_t tile = t0;
+        while (tile < n_ptiles) {
+            tile_body(std::integral_constant<int, 0>{}, tile + GS < n_ptiles, tile + 2 * GS < n_ptiles ? tile + 2 * GS : (int64_t)-1);
+            tile += GS;
+            if (tile < n_ptiles) {
+                tile_body(std::integral_constant<int, 1>{}, tile + GS < n_ptiles, tile + 2 * GS < n_ptiles ? tile + 2 * GS : (int64_t)-1);
+                tile += GS;
+            }
+        }
+    }
+
+    float* slab = slabs + (int64_t)blk_pr * slab_len;
+#pragma unroll
+    for (int t = 0; t < BT_RT; ++t) {
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+            const int hh = 32 * ht + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = rbase + 32 * t + crow32(r, half);
+                if (row < Rp) slab[row * 64 + hh] = acc[t][ht][r];
+            }
+        }
+        const float bt = half_sum32(bsum[t]);
+        const int64_t row = rbase + 32 * t + l31;
+        if (half == 0 && row < Rp) slab[(int64_t)Rp * 64 + row] = bt;
+    }
+}

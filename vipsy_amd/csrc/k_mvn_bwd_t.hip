@@ -57,6 +57,19 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 #endif
 
+// workgroup -> (row block rb, person range pr).  The grid is (row blocks, person ranges); the hardware deals the linear
+// workgroup ids round-robin over the 8 XCDs, and the row blocks of one person range all read the same tiles.  They
+// are placed on consecutive slots of ONE XCD (a group straddles two XCDs at most), so that the re-reads are served by
+// that XCD's L2 instead of crossing the fabric once per XCD.
+__device__ __forceinline__ void bt_decode(int& rb, int& pr) {
+    const int n_rb = gridDim.x, nblk = gridDim.x * gridDim.y;
+    const int id = blockIdx.x + n_rb * blockIdx.y, x = id & 7;
+    int p = id >> 3;                                                   // slot within the XCD
+    for (int xx = 0; xx < x; ++xx) p += (nblk - xx + 7) >> 3;          // + the slots of the XCDs before it
+    pr = p / n_rb;
+    rb = p - pr * n_rb;
+}
+
 __device__ __forceinline__ void bwd_w_t_body(
     const EncDims& dm, const float* __restrict__ hT, const float* __restrict__ epsT, const float* __restrict__ gdT,
     const float* __restrict__ gxT, const uint32_t* __restrict__ gtab, float* __restrict__ slabs, int64_t slab_len,
@@ -67,10 +80,12 @@ __device__ __forceinline__ void bwd_w_t_body(
     const int half = lane >> 5, l31 = lane & 31;
     constexpr uint32_t BUF = BT_BUF;
     const int Rp = pk_rows(D);
-    const int64_t rbase = (int64_t)blockIdx.x * BT_ROWS + (int64_t)wave * BT_RT * 32;
+    int rb_, pr_;
+    bt_decode(rb_, pr_);
+    const int64_t rbase = (int64_t)rb_ * BT_ROWS + (int64_t)wave * BT_RT * 32;
     const int rE = bt_row_E(D), rH = bt_row_H(D), rGD = bt_row_GD(D), rOnes = bt_row_ones(D), rZero = bt_row_zero(D);
     // workgroups whose rows reach into the DIAG section also stage the GD region (block-uniform)
-    const bool need_gd = (int64_t)(blockIdx.x + 1) * BT_ROWS > pk_off_total(D);
+    const bool need_gd = (int64_t)(rb_ + 1) * BT_ROWS > pk_off_total(D);
 
     // ---- per-lane row description -> LDS byte addresses of the 4 chunk pairs (q = 0..3) of each operand row
     auto chunk_addr = [&](int row, int q) -> uint32_t { return bt_addr(row, 2 * q + half); };   // chunk 2q + half
@@ -184,7 +199,7 @@ __device__ __forceinline__ void bwd_w_t_body(
         });
     };
 
-    int64_t tile = blockIdx.y;
+    int64_t tile = pr_;
     if (tile < n_ptiles) stage(tile, 0);
     // two tiles per trip so that the buffer index is a compile-time constant (LDS offsets become immediates)
     while (tile < n_ptiles) {
@@ -204,7 +219,7 @@ __device__ __forceinline__ void bwd_w_t_body(
     }
 
     // ---- slab of this person range: [Wp-grad: Rp*H | bp-grad: Rp]
-    float* slab = slabs + (int64_t)blockIdx.y * slab_len;
+    float* slab = slabs + (int64_t)pr_ * slab_len;
 #pragma unroll
     for (int t = 0; t < BT_RT; ++t) {
 #pragma unroll

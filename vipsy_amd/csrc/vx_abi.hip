@@ -15,6 +15,7 @@
 #include "k_norm_enc.hip"
 #include "k_mvn_bbvi.hip"
 #include "k_mvn_bwd_t.hip"
+#include "k_mvn_bwd_b.hip"
 
 #include <cstdlib>
 #include <cstdio>
@@ -424,6 +425,12 @@ static bool bwt_shape(const vx_irt_cfg* cfg, int64_t nb) {
     if (old < 0) { const char* e = getenv("VX_BWDW"); old = (e && e[0] == 'o') ? 1 : 0; }
     return !old && packed_ok(cfg) && nb % 4 == 0 && cfg->D <= 124 && bt_lds_bytes(cfg->D) <= 160 * 1024;
 }
+// opt-in (VX_BF16X3=1): the weight-gradient kernel on the bf16 MFMA with three-term operand splitting (k_mvn_bwd_b.hip)
+static bool bwb_shape(const vx_irt_cfg* cfg, int64_t nb) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("VX_BF16X3"); on = (e && e[0] == '1') ? 1 : 0; }
+    return on && bwt_shape(cfg, nb) && nb % 8 == 0 && nb < ((int64_t)1 << 23) && bb_lds_bytes(cfg->D) <= 160 * 1024;
+}
 static void bwt_plan(const vx_irt_cfg* cfg, int64_t nb, int& n_rowslabs, int& n_prw) {
     n_rowslabs = (pk_rows(cfg->D) + BT_ROWS - 1) / BT_ROWS;
     const int64_t n_ptiles = (nb + BT_P - 1) / BT_P;
@@ -474,7 +481,8 @@ int64_t vx_mvn_enc_bwd_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
         bwt_plan(cfg, nb, ns, np);
         if (np > n_prw) n_prw = np;
     }
-    return nb * H + (int64_t)n_prw * lenw + (int64_t)n_prf * (H * J + H) + (bwt_shape(cfg, nb) ? nb * D + 4 : 0);
+    return nb * H + (int64_t)n_prw * lenw + (int64_t)n_prf * (H * J + H) + (bwt_shape(cfg, nb) ? nb * D + 4 : 0) +
+           (bwb_shape(cfg, nb) ? nb * 96 : 0);             // three bf16 copies of hT
 }
 
 int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
@@ -558,7 +566,18 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                                dm, cfg->scale, Wp, gtab, h, eps, ldT, gx, ghpre);
             VX_CHECK_LAUNCH();
         }
-        if (use_t) {
+        if (use_t && bwb_shape(cfg, nb)) {
+            float* gdT = slabs_f + (int64_t)n_prf * lenf;
+            uint16_t* hs3 = (uint16_t*)(gdT + nb * D + 4);
+            hipLaunchKernelGGL(k_split3_bf16, dim3(num_cu() * 8), dim3(256), 0, st, hT, nb * 64, hs3);
+            VX_CHECK_LAUNCH();
+            const size_t lds = bb_lds_bytes(dm.D);
+            rc = set_lds(k_mvn_enc_bwd_w_b, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_mvn_enc_bwd_w_b, dim3((unsigned)n_rowslabs, (unsigned)n_prw), dim3(BT_THREADS), lds, st,
+                               dm, hs3, epsT, gdT, gxT, gtab, slabs_w, Rp * (H + 1));
+            VX_CHECK_LAUNCH();
+        } else if (use_t) {
             const size_t lds = bt_lds_bytes(dm.D);
             rc = set_lds(k_mvn_enc_bwd_w_t, lds);
             if (rc) return rc;

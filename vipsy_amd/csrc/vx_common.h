@@ -194,8 +194,11 @@ __device__ __forceinline__ void dma16(const void* gptr, uint32_t lds_byte_addr) 
 }
 // scalar base + 32-bit per-lane byte offset (no 64-bit VALU address arithmetic per transfer)
 __device__ __forceinline__ void dma16s(const void* sbase_uniform, uint32_t voff, uint32_t lds_byte_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase_uniform),
-                 "s"(lds_byte_addr) : "memory");
+    const uint64_t a = (uint64_t)sbase_uniform;
+    const uint64_t sa = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sa),
+                 "s"(__builtin_amdgcn_readfirstlane((int)lds_byte_addr)) : "memory");
 }
 __device__ __forceinline__ void dma4(const void* gptr, uint32_t lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gptr), "s"(lds_byte_addr) : "memory");
