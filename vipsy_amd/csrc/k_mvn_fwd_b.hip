@@ -1,0 +1,436 @@
+// Amortized MVN guide forward with the head GEMM on the bf16 MFMA (three-term operand splitting, fp32 accumulate):
+// the same mathematics and outputs as k_mvn_enc_fwd_p (k_mvn_packed.hip; vi.py:448-455,686-693).
+//   M[p, r] = bias[r] + sum_hh Wp[r][hh] h[p][hh]  is computed as six bf16 products per 16-deep k-step
+//   (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid) on v_mfma_f32_32x32x16_bf16: 24 MFMAs of 32 cycles per 32x32 tile
+//   instead of 33 fp32 MFMAs of 64 cycles, at the accuracy of the fp32 chain (tools/bf16x3_ubench.hip).
+// Both operands are reused, so the splitting costs nothing in the loop:
+//   Wp : split once per step by k_pack_heads_b into a per-tile IMAGE that is exactly the LDS layout the fragments
+//        are read from (12 KB of bf16 fragments + 256 B of bias / group codes per 32-row tile);
+//   h  : split once per 32-person wave tile, in registers; the C layout of the fc1 MFMA already is the B fragment
+//        order (k-step s, lane half, element j  <->  hidden unit 16 s + 8 (j >> 2) + 4 half + (j & 3)).
+// One weight stream per WORKGROUP: a tile image arrives by global->LDS DMA (12 KB split over the 4 waves + a private
+// 256-byte bias/code copy per wave: 4 transfers per wave and tile, so `s_waitcnt vmcnt(8)` counts whole tiles), in a
+// 4-stage ring, one barrier per tile.  Every wave pulls the fragments of tile t + 1 into registers while the MFMAs of
+// tile t run, and does the epsilon epilogue of tile t - 1 between them (the bf16 MFMA leaves the vector port free for
+// 24 of its 32 cycles).
+// (included by vx_abi.hip after k_mvn_packed.hip and k_mvn_bwd_b.hip)
+
+#define FB_THREADS 256
+#define FB_WAVES 4
+#define FB_WP 32
+#define FB_NST 4
+#define FB_A_BYTES 12288
+#define FB_AUX_BYTES 256
+#define FB_IMG_BYTES (FB_A_BYTES + FB_AUX_BYTES)                     // tile image in global memory
+#define FB_STAGE_BYTES (FB_A_BYTES + FB_WAVES * FB_AUX_BYTES)        // one ring stage in LDS
+
+__host__ __device__ inline int fb_tiles(int D) { return (pk_off_total(D) + 2 * pk_sec(D)) / 32; }
+__host__ __device__ inline int64_t fb_img_floats(int D) { return (int64_t)fb_tiles(D) * (FB_IMG_BYTES / 4); }
+__host__ __device__ inline size_t fb_lds_bytes(int D, int J) {
+    return FB_WAVES * enc_p_wave_floats(D, J) * sizeof(float) + (size_t)FB_NST * FB_STAGE_BYTES;
+}
+
+// tile image: fragment (split sp, k-step s) at byte (sp * 4 + s) * 1024 + lane * 16, lane = 32 half + row;
+// element j of it = Wp[32 T + row][16 s + 8 (j >> 2) + 4 half + (j & 3)];  aux: bias in accumulator order
+// [half][g] x float4 at FB_A_BYTES, the 4 group codes at FB_A_BYTES + 128
+__global__ void k_pack_heads_b(int n_tiles, const float* __restrict__ Wp, const float* __restrict__ bp,
+                               const uint32_t* __restrict__ gtab, uint8_t* __restrict__ img) {
+    const int T = blockIdx.x;
+    if (T >= n_tiles) return;
+    uint8_t* out = img + (int64_t)T * FB_IMG_BYTES;
+    for (int e = threadIdx.x; e < 4 * 64 * 8; e += blockDim.x) {          // (s, lane, j)
+        const int j = e & 7, lane = (e >> 3) & 63, s = e >> 9;
+        const int half = lane >> 5, row = lane & 31;
+        const float v = Wp[((int64_t)T * 32 + row) * 64 + 16 * s + 8 * (j >> 2) + 4 * half + (j & 3)];
+        const __bf16 h = (__bf16)v;
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const __bf16 l = (__bf16)(r1 - (float)m);
+        uint16_t* o = (uint16_t*)(out + s * 1024 + lane * 16) + j;
+        o[0] = __builtin_bit_cast(uint16_t, h);
+        o[2048] = __builtin_bit_cast(uint16_t, m);                        // + 4 fragments = 4096 bytes
+        o[4096] = __builtin_bit_cast(uint16_t, l);
+    }
+    for (int e = threadIdx.x; e < FB_AUX_BYTES / 4; e += blockDim.x) {
+        uint32_t w = 0u;
+        if (e < 32) {
+            const int half = e >> 4, g = (e >> 2) & 3, j = e & 3;
+            w = __builtin_bit_cast(uint32_t, bp[T * 32 + 8 * g + 4 * half + j]);
+        } else if (e < 36) {
+            w = gtab[4 * T + (e - 32)];
+        }
+        ((uint32_t*)(out + FB_A_BYTES))[e] = w;
+    }
+}
+
+// eight fp32 values -> three bf16 fragments by truncation: v = hi + mid + lo exactly (8 + 8 + 8 significand bits)
+__device__ __forceinline__ void fb_split8(const float* v, bf16x8& fh, bf16x8& fm, bf16x8& fl) {
+    typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+    u32x4v ph, pm, pl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t hb[2], mb[2], lb[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float x = v[2 * q + e];
+            hb[e] = __builtin_bit_cast(uint32_t, x) & 0xffff0000u;
+            const float r1 = x - __builtin_bit_cast(float, hb[e]);
+            mb[e] = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
+            const float r2 = r1 - __builtin_bit_cast(float, mb[e]);
+            lb[e] = __builtin_bit_cast(uint32_t, r2) & 0xffff0000u;
+        }
+        ph[q] = hb[1] | (hb[0] >> 16);
+        pm[q] = mb[1] | (mb[0] >> 16);
+        pl[q] = lb[1] | (lb[0] >> 16);
+    }
+    fh = __builtin_bit_cast(bf16x8, ph);
+    fm = __builtin_bit_cast(bf16x8, pm);
+    fl = __builtin_bit_cast(bf16x8, pl);
+}
+
+__global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
+    EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, int64_t gid0,
+    const float* __restrict__ W1, const float* __restrict__ b1, const uint8_t* __restrict__ img,
+    const float* __restrict__ eps_in, uint64_t seed, uint32_t step, uint32_t stream, float* __restrict__ h_out,
+    float* __restrict__ x_out, float* __restrict__ eps_out, float* __restrict__ ldT, float* __restrict__ ent_out,
+    float* __restrict__ hT_out /*[64][nb] or null*/, float* __restrict__ epsT_out /*[D][nb] or null*/) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int H = 64;
+    const int D = dm.D, J = dm.J;
+    const int DS = pk_dse(D), DX = (D + 3) & ~3;
+    const int YS = ef_ys(J);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    float* R1 = smem + wave * enc_p_wave_floats(D, J);
+    int8_t* Yi = (int8_t*)R1;                                 // phase A
+    float* eps_lds = R1;                                      // phase B  [32][DS]
+    float* x_lds = R1 + FB_WP * DS;                           //          [32][DX]
+    const char* ring = (const char*)(smem + FB_WAVES * enc_p_wave_floats(D, J));
+    const uint32_t ring_lds = lds_addr_uniform(ring);
+    const int64_t i0 = ((int64_t)blockIdx.x * FB_WAVES + wave) * FB_WP;
+    const int p = l31;
+    const int64_t i = i0 + p;
+    // NOTE: no early exit -- every wave takes part in the workgroup barriers of the weight ring; waves (and lanes)
+    // past the last person compute on clamped inputs and store nothing.
+    const bool wave_live = i0 < dm.nb;
+
+    const int n_off = pk_off_total(D) / 32;                   // multiple of 6
+    const int n_sec = pk_sec(D) / 32;
+    const int t_end = n_off + 2 * n_sec;
+    // ---- weight ring: this wave's 4 transfers of a tile (3 x 1 KB of the fragment image + its 256-byte aux copy)
+    const uint32_t voffA = (uint32_t)(wave * 1024 + lane * 16);
+    auto stage_tile = [&](int t) __attribute__((always_inline)) {
+        const int tc = t < t_end ? t : t_end - 1;             // past the end: a harmless duplicate of the last tile
+        const uint8_t* src = img + (int64_t)tc * FB_IMG_BYTES;
+        const uint32_t sb = ring_lds + (uint32_t)(t & (FB_NST - 1)) * FB_STAGE_BYTES;
+        dma16s(src, voffA, sb + (uint32_t)wave * 1024u);
+        dma16s(src, voffA + 4096u, sb + (uint32_t)wave * 1024u + 4096u);
+        dma16s(src, voffA + 8192u, sb + (uint32_t)wave * 1024u + 8192u);
+        dma4(src + FB_A_BYTES + 4 * lane, sb + FB_A_BYTES + (uint32_t)wave * FB_AUX_BYTES);
+    };
+    stage_tile(0); stage_tile(1); stage_tile(2); stage_tile(3);   // in flight during staging / fc1 / eps
+
+    // ---------------------------------------------------------------- stage this wave's response rows (bytes)
+    const int n_ydma = (32 * J + 1023) / 1024;
+    const bool ydense = !rows && ((J >> 2) & 1) && i0 + FB_WP <= dm.nb && (i0 * J + (int64_t)n_ydma * 1024 <= dm.nb * (int64_t)J) &&
+                        (size_t)n_ydma * 1024 <= enc_p_wave_floats(D, J) * sizeof(float);
+    const int ysr = ydense ? J : YS;                          // LDS row stride of the response bytes
+    if (ydense) {
+        const uint8_t* src = y + i0 * J + 16 * lane;
+        const uint32_t lb = lds_addr_uniform(R1);
+        for (int d = 0; d < n_ydma; ++d) dma16(src + d * 1024, lb + (uint32_t)d * 1024u);
+        vx_wait_vmem();
+    } else {
+        const int YW = YS / 4, JW = J / 4;
+        uint32_t* Yw = (uint32_t*)R1;
+        for (int base = 0; base < FB_WP * YW; base += 64 * 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int idx = base + q * 64 + lane;
+                v[q] = 0u;
+                if (idx < FB_WP * YW) {
+                    const int pp = idx / YW, wq = idx - pp * YW;
+                    const int64_t ii = i0 + pp;
+                    if (wq < JW && ii < dm.nb) {
+                        const int64_t row = rows ? rows[ii] : ii;
+                        v[q] = *(const uint32_t*)(y + row * J + 4 * wq);    // bytes 0/1/255 == int8 0/1/-1 (vi.py:689-691)
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int idx = base + q * 64 + lane;
+                if (idx < FB_WP * YW) Yw[idx] = v[q];
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---------------------------------------------------------------- phase A: fc1 (+ softplus), both hidden tiles
+    bf16x8 hb[3][4];                                          // [split][k-step]: B fragments of every head tile
+    {
+        f32x16 hreg[2];
+        f32x16 acc0 = zero16(), acc1 = zero16();
+        const int nfull = J / 32;
+        auto loadA = [&](float4 (&A)[2][4], int c) {
+            c = c < nfull ? c : nfull - 1;
+            const int j0 = c * 32 + half * 16;
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht) {
+                const float* src = W1 + (int64_t)(32 * ht + l31) * J + j0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) A[ht][q] = *(const float4*)(src + 4 * q);
+            }
+        };
+        auto compute = [&](const float4 (&A)[2][4], int c) {
+            const int8_t* yp = Yi + p * ysr + c * 32 + half * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int w = *(const int*)(yp + 4 * q);
+                const float y0 = (float)((w << 24) >> 24), y1 = (float)((w << 16) >> 24);
+                const float y2 = (float)((w << 8) >> 24), y3 = (float)(w >> 24);
+                acc0 = mfma32(A[0][q].x, y0, acc0); acc1 = mfma32(A[1][q].x, y0, acc1);
+                acc0 = mfma32(A[0][q].y, y1, acc0); acc1 = mfma32(A[1][q].y, y1, acc1);
+                acc0 = mfma32(A[0][q].z, y2, acc0); acc1 = mfma32(A[1][q].z, y2, acc1);
+                acc0 = mfma32(A[0][q].w, y3, acc0); acc1 = mfma32(A[1][q].w, y3, acc1);
+            }
+        };
+        if (nfull > 0) {
+            float4 A[4][2][4];
+            loadA(A[0], 0); loadA(A[1], 1); loadA(A[2], 2);
+            for (int c = 0; c < nfull; c += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    loadA(A[(u + 3) & 3], c + u + 3);
+                    if (c + u < nfull) compute(A[u], c + u);
+                }
+            }
+        }
+        if (nfull * 32 < J) {                                 // ragged last chunk: items past J contribute nothing
+            float4 At[2][4];
+            const int j0 = nfull * 32 + half * 16;
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht) {
+                const float* src = W1 + (int64_t)(32 * ht + l31) * J + j0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    At[ht][q] = (j0 + 4 * q + 4 <= J) ? *(const float4*)(src + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            compute(At, nfull);
+        }
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int hh0 = 32 * ht + 8 * g + 4 * half;
+                const float4 bb = *(const float4*)(b1 + hh0);
+                float4 hv;
+                hv.x = softplusf_((ht ? acc1 : acc0)[4 * g + 0] + bb.x);            // vi.py:449
+                hv.y = softplusf_((ht ? acc1 : acc0)[4 * g + 1] + bb.y);
+                hv.z = softplusf_((ht ? acc1 : acc0)[4 * g + 2] + bb.z);
+                hv.w = softplusf_((ht ? acc1 : acc0)[4 * g + 3] + bb.w);
+                hreg[ht][4 * g + 0] = hv.x; hreg[ht][4 * g + 1] = hv.y;
+                hreg[ht][4 * g + 2] = hv.z; hreg[ht][4 * g + 3] = hv.w;
+                if (i < dm.nb) *(float4*)(h_out + i * H + hh0) = hv;
+            }
+        }
+        if (hT_out && i < dm.nb) {                            // dimension-major copy for the weight-gradient kernel
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hT_out[(int64_t)(32 * ht + crow32(r, half)) * dm.nb + i] = hreg[ht][r];
+        }
+        // k-step s of the head GEMM takes accumulator registers 8 (s & 1) .. + 7 of hidden tile s >> 1
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = hreg[s >> 1][8 * (s & 1) + j];
+            fb_split8(v, hb[0][s], hb[1][s], hb[2][s]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();                          // response bytes no longer needed
+    // ---------------------------------------------------------------- eps (zero padded to DS), x := 0
+    {
+        for (int e = lane; e < FB_WP * (DS + DX); e += 64) R1[e] = 0.f;
+        __builtin_amdgcn_wave_barrier();
+        const int nblk = D >> 2;                               // D % 4 == 0 on this path
+        for (int e = lane; e < FB_WP * nblk; e += 64) {
+            const int pp = e / nblk, blk = e - pp * nblk;
+            int64_t ii = i0 + pp;
+            if (ii >= dm.nb) ii = dm.nb - 1;                   // absent persons: any finite values, never stored
+            f32x4 z;
+            if (eps_in) {
+                z = *(const f32x4*)(eps_in + ii * D + 4 * blk);
+            } else {
+                const int64_t row = rows ? rows[ii] : ii;
+                z = philox_normal4(seed, step, stream, gid0 + row, (uint32_t)blk);
+            }
+            *(f32x4*)(eps_lds + pp * DS + 4 * blk) = z;
+            if (i0 + pp < dm.nb) *(f32x4*)(eps_out + ii * D + 4 * blk) = z;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (epsT_out && i < dm.nb) {                              // dimension-major copy: 128-byte rows per half-wave
+#pragma unroll 4
+        for (int k = half; k < D; k += 2) epsT_out[(int64_t)k * dm.nb + i] = eps_lds[p * DS + k];
+    }
+    // ---------------------------------------------------------------- phase B: packed head rows, 32 per tile
+    float ent_acc = 0.f;
+    const float* ep = eps_lds + p * DS;
+    float* xp = x_lds + p * DX;
+    const uint32_t aux_off = FB_A_BYTES + (uint32_t)wave * FB_AUX_BYTES;
+    struct TileRegs { bf16x8 a[3][4]; f32x16 bias; uint32_t code[4]; float4 e4[4]; };
+    // everything a wave needs of tile t comes out of the ring into registers one tile ahead
+    auto pull = [&](TileRegs& R, int t, bool want_eps) __attribute__((always_inline)) {
+        const char* sb = ring + (size_t)(t & (FB_NST - 1)) * FB_STAGE_BYTES;
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) R.a[sp][s] = *(const bf16x8*)(sb + (sp * 4 + s) * 1024 + lane * 16);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 bv = *(const f32x4*)(sb + aux_off + (half * 4 + g) * 16);
+            R.bias[4 * g + 0] = bv[0]; R.bias[4 * g + 1] = bv[1]; R.bias[4 * g + 2] = bv[2]; R.bias[4 * g + 3] = bv[3];
+        }
+        const uint4 gc = *(const uint4*)(sb + aux_off + 128);
+        R.code[0] = __builtin_amdgcn_readfirstlane(gc.x); R.code[1] = __builtin_amdgcn_readfirstlane(gc.y);
+        R.code[2] = __builtin_amdgcn_readfirstlane(gc.z); R.code[3] = __builtin_amdgcn_readfirstlane(gc.w);
+        if (want_eps) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) R.e4[g] = *(const float4*)(ep + (R.code[g] & 0xFFFu) + 4 * half);
+        }
+    };
+    // products in order of increasing magnitude; the accumulator starts from the bias
+    auto mma_lo = [&](const TileRegs& R) __attribute__((always_inline)) -> f32x16 {
+        f32x16 a = R.bias;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[2][s], hb[0][s], a);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[0][s], hb[2][s], a);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[1][s], hb[1][s], a);
+        return a;
+    };
+    auto mma_hi = [&](const TileRegs& R, f32x16 a) __attribute__((always_inline)) -> f32x16 {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[1][s], hb[0][s], a);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[0][s], hb[1][s], a);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[0][s], hb[0][s], a);
+        return a;
+    };
+    // ---- OFF section: x[p][k] += sum_l M[p,(k,l)] eps[p,l]; the partial sum of the current k stays in a register
+    uint32_t cur_k = 1;                                        // the first packed group belongs to k = 1
+    float cur_part = 0.f;
+    auto flush = [&]() {                                       // every k of the OFF section is flushed exactly once
+        const float tot = half_sum32(cur_part);
+        if (half == 0) xp[cur_k] = tot;
+    };
+    auto epi_off = [&](const f32x16& a, const uint32_t (&code)[4], const float4 (&e4)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                          // rows (k, l0 + 4half + j) live in a[4g + j]
+            const uint32_t kq = (code[g] >> 12) & 0xFFFFu;
+            const float part = a[4 * g + 0] * e4[g].x + a[4 * g + 1] * e4[g].y + a[4 * g + 2] * e4[g].z +
+                               a[4 * g + 3] * e4[g].w;
+            const bool changed = kq != cur_k;                                     // wave-uniform, rare
+            if (__builtin_expect(changed, 0)) flush();                            // one-sided branch, falls through
+            cur_part = part + (changed ? 0.f : cur_part);
+            cur_k = kq;
+        }
+    };
+
+    vx_wait_vmem();                                            // stores of the phases above + tiles 0..3 of the ring
+    __syncthreads();
+    TileRegs RA, RB;
+    pull(RA, 0, true);
+    // epilogue operands of the tile before the current one; "tile -1": zeros under the first k (adds nothing)
+    f32x16 accP = zero16();
+    uint32_t codeP[4] = {1u << 12, 1u << 12, 1u << 12, 1u << 12};
+    float4 e4P[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) e4P[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto off_iter = [&](TileRegs& Rc, TileRegs& Rn, int t) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_waitcnt(0x0F78);                    // vmcnt(8): tile t + 1 has landed (t + 2, t + 3 in flight)
+        __syncthreads();                                       // ... for every wave; the stage of tile t is free
+        stage_tile(t + FB_NST);
+        pull(Rn, t + 1, true);
+        f32x16 a = mma_lo(Rc);
+        epi_off(accP, codeP, e4P);
+        a = mma_hi(Rc, a);
+        accP = a;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { codeP[g] = Rc.code[g]; e4P[g] = Rc.e4[g]; }
+    };
+    for (int t = 0; t < n_off; t += 2) {
+        off_iter(RA, RB, t);
+        off_iter(RB, RA, t + 1);
+    }
+    epi_off(accP, codeP, e4P);
+    flush();
+    // ---- DIAG section (exp(M_kk) eps_k, entropy, ldT) and LOC section (the loc head): 2 * n_sec tiles; RA holds the
+    // first of them.  The 16 x entries a lane updates are read together, updated and written together.
+    auto tile_sec = [&](const f32x16& a, int t2) __attribute__((always_inline)) {
+        const bool is_diag = t2 < n_off + n_sec;
+        const int k0 = 32 * (t2 - (is_diag ? n_off : n_off + n_sec));
+        const bool allv = k0 + 32 <= D;                        // wave-uniform: no per-entry bounds below
+        float xo[16], ev[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int kk = k0 + crow32(r, half);
+            kk = (allv || kk < D) ? kk : D - 1;
+            xo[r] = xp[kk];
+            ev[r] = ep[kk];
+        }
+        if (is_diag) {                                         // exp(diag M) eps_k, entropy, ldT  (vi.py:686)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = k0 + crow32(r, half);
+                const float ld = __expf(a[r]);
+                const bool ok = allv || kk < D;
+                if (ok) {
+                    xp[kk] = fmaf(ld, ev[r], xo[r]);
+                    ent_acc += a[r];
+                    if (i < dm.nb) ldT[(int64_t)kk * dm.nb + i] = ld;
+                }
+            }
+        } else {                                               // loc head (vi.py:450)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = k0 + crow32(r, half);
+                if (allv || kk < D) xp[kk] = xo[r] + a[r];
+            }
+        }
+    };
+    auto sec_iter = [&](TileRegs& Rc, TileRegs& Rn, int t) __attribute__((always_inline)) {
+        vx_wait_vmem();
+        __syncthreads();
+        if (t + FB_NST < t_end) stage_tile(t + FB_NST);
+        if (t + 1 < t_end) pull(Rn, t + 1, false);
+        const f32x16 a = mma_hi(Rc, mma_lo(Rc));
+        tile_sec(a, t);
+    };
+    for (int t = n_off; t < t_end; t += 2) {                   // n_off and t_end are even
+        sec_iter(RA, RB, t);
+        sec_iter(RB, RA, t + 1);
+    }
+    vx_wait_vmem();                                            // no DMA may still be in flight when the LDS is released
+    __builtin_amdgcn_wave_barrier();
+    // ---------------------------------------------------------------- write x, entropy part
+    if (wave_live) {
+        const int pv = (int)((dm.nb - i0) < FB_WP ? (dm.nb - i0) : FB_WP);
+        const int c4 = D >> 2;
+        for (int e = lane; e < pv * c4; e += 64) {
+            const int pp = e / c4, c = e - pp * c4;
+            *(f32x4*)(x_out + (i0 + pp) * D + 4 * c) = *(const f32x4*)(x_lds + pp * DX + 4 * c);
+        }
+        ent_acc += __shfl_xor(ent_acc, 32, 64);
+        if (half == 0 && i < dm.nb) {
+            float s = 0.f;
+            for (int k = 0; k < D; ++k) { const float e = eps_lds[p * DS + k]; s += e * e; }
+            ent_out[i] = 0.5f * s + ent_acc;                  // -log q + const = 0.5|eps|^2 + sum_k M_kk
+        }
+    }
+}

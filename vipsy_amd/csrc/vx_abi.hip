@@ -16,6 +16,7 @@
 #include "k_mvn_bbvi.hip"
 #include "k_mvn_bwd_t.hip"
 #include "k_mvn_bwd_b.hip"
+#include "k_mvn_fwd_b.hip"
 
 #include <cstdlib>
 #include <cstdio>
@@ -77,6 +78,20 @@ bool packed_ok(const vx_irt_cfg* cfg) {
     return v == 1 && !force_generic() && cfg->H == 64 && cfg->J % 4 == 0 && cfg->D % 4 == 0 &&
            enc_p_lds_floats(cfg->D, cfg->J) * sizeof(float) <= 160 * 1024 &&
            enc_bwdw_fast_lds_floats(cfg->D) * sizeof(float) <= 160 * 1024;
+}
+
+// bf16x3 kernels (three-term bf16 operand splitting on the bf16 MFMA, fp32 accumulate): VX_BF16X3 = 1 (all of them),
+// f (guide forward only), w (weight gradient only), 0 / unset (fp32-MFMA kernels)
+int bf16x3_mode() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("VX_BF16X3");
+        v = !e ? 0 : (e[0] == '1' ? 3 : e[0] == 'f' ? 1 : e[0] == 'w' ? 2 : 0);
+    }
+    return v;
+}
+bool fwb_shape(const vx_irt_cfg* cfg) {
+    return (bf16x3_mode() & 1) && packed_ok(cfg) && fb_lds_bytes(cfg->D, cfg->J) <= 160 * 1024;
 }
 
 bool enc_cfg_ok(const vx_irt_cfg* cfg) {
@@ -180,6 +195,20 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
         hipLaunchKernelGGL(k_pack_heads, dim3(Rp), dim3(64), 0, (hipStream_t)hs, (int)cfg->D, 64, W21, b21, W22, b22, Wp,
                            bp, gtab, WpT);
         VX_CHECK_LAUNCH();
+        if (fwb_shape(cfg)) {
+            uint8_t* img = (uint8_t*)(WpT + (int64_t)Rp * 64);
+            const int n_tiles = fb_tiles(dm.D);
+            hipLaunchKernelGGL(k_pack_heads_b, dim3(n_tiles), dim3(256), 0, (hipStream_t)hs, n_tiles, Wp, bp, gtab, img);
+            VX_CHECK_LAUNCH();
+            const size_t ldsb = fb_lds_bytes(dm.D, dm.J);
+            rc = set_lds(k_mvn_enc_fwd_b, ldsb);
+            if (rc) return rc;
+            const dim3 gridb((unsigned)((nb + FB_WAVES * FB_WP - 1) / (FB_WAVES * FB_WP)));
+            hipLaunchKernelGGL(k_mvn_enc_fwd_b, gridb, dim3(FB_THREADS), ldsb, (hipStream_t)hs, dm, y, rows, gid0, W1, b1,
+                               (const uint8_t*)img, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT);
+            VX_CHECK_LAUNCH();
+            return VX_OK;
+        }
         const size_t ldsp = enc_p_lds_floats(dm.D, dm.J) * sizeof(float);
         rc = set_lds(k_mvn_enc_fwd_p, ldsp);
         if (rc) return rc;
@@ -427,8 +456,7 @@ static bool bwt_shape(const vx_irt_cfg* cfg, int64_t nb) {
 }
 // opt-in (VX_BF16X3=1): the weight-gradient kernel on the bf16 MFMA with three-term operand splitting (k_mvn_bwd_b.hip)
 static bool bwb_shape(const vx_irt_cfg* cfg, int64_t nb) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("VX_BF16X3"); on = (e && e[0] == '1') ? 1 : 0; }
+    const bool on = (bf16x3_mode() & 2) != 0;
     return on && bwt_shape(cfg, nb) && nb % 8 == 0 && nb < ((int64_t)1 << 23) && bb_lds_bytes(cfg->D) <= 160 * 1024;
 }
 static void bwt_plan(const vx_irt_cfg* cfg, int64_t nb, int& n_rowslabs, int& n_prw) {
@@ -460,7 +488,7 @@ int vx_mvn_enc_bwd_layout(const vx_irt_cfg* cfg, int64_t nb) {
 int64_t vx_mvn_pack_floats(const vx_irt_cfg* cfg) {
     if (!enc_cfg_ok(cfg)) return VX_EINVAL;
     const int64_t Rp = pk_rows(cfg->D);
-    return Rp * 64 + Rp + Rp / 8 + 8 + Rp * 64;            // Wp | bp | gtab | WpT
+    return Rp * 64 + Rp + Rp / 8 + 8 + Rp * 64 + fb_img_floats(cfg->D);   // Wp | bp | gtab | WpT | bf16x3 tile images
 }
 
 int64_t vx_mvn_enc_param_floats(const vx_irt_cfg* cfg) {
