@@ -25,7 +25,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: dense bf16 matrix peak
+# an fp32 product computed as three bf16 terms per operand costs six bf16 MFMA products:
+PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_HBM_GBS = 8000.0
+PROFILE_TAG = "r01_v5"
 
 WORKLOADS = {
     # name: (model, N, J, D, H, amortized, missing)
@@ -45,11 +49,28 @@ def enc_fwd_flops_per_person(J, D, H):
     return 2.0 * (J * H + H * D + H * T + T)
 
 
+def kernel_model(name, J, D, H):
+    """Algorithmic flops per person (S = 1) and the MFMA peak that bounds each large kernel of the amortized
+    multidimensional step (2 flops per multiply-add)."""
+    T = D * (D + 1) // 2
+    heads = 2.0 * (H * D + H * T)
+    table = {
+        "k_mvn_enc_fwd_b": (enc_fwd_flops_per_person(J, D, H), PEAK_BF16X3_TFLOPS, "f32 via bf16x3 on the bf16 MFMA"),
+        "k_mvn_enc_fwd_p": (enc_fwd_flops_per_person(J, D, H), PEAK_F32_MFMA_TFLOPS, "f32 MFMA"),
+        "k_mvn_enc_bwd_h_t": (heads, PEAK_F32_MFMA_TFLOPS, "f32 MFMA"),
+        "k_mvn_enc_bwd_h_b": (heads, PEAK_BF16X3_TFLOPS, "f32 via bf16x3 on the bf16 MFMA"),
+        "k_mvn_enc_bwd_w_t": (heads, PEAK_F32_MFMA_TFLOPS, "f32 MFMA"),
+        "k_mvn_enc_bwd_w_b": (heads, PEAK_BF16X3_TFLOPS, "f32 via bf16x3 on the bf16 MFMA"),
+        "k_irt_lik_r": (2.0 * 3 * (D + 1) * J, PEAK_F32_MFMA_TFLOPS, "f32 MFMA"),        # Z, gx, GA
+    }
+    return table.get(name)
+
+
 def measured_traffic(kernel_prefix):
     """HBM bytes per launch of the dominant kernel on the headline workload, from the committed PMC summary
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied; see
-    profiles/r01_v4_hbm_traffic.json and tools/profile_round.sh).  None when the summary is not there."""
-    path = os.path.join(ROOT, "profiles", "r01_v4_hbm_traffic.json")
+    profiles/<tag>_hbm_traffic.json and tools/profile_round.sh).  None when the summary is not there."""
+    path = os.path.join(ROOT, "profiles", PROFILE_TAG + "_hbm_traffic.json")
     try:
         with open(path) as f:
             kernels = json.load(f)["kernels"]
@@ -153,6 +174,8 @@ def main():
     # per-phase HIP events on the launch stream (torch's current stream == the stream handed to the C ABI)
     ev = []
     eng.events = ev
+    from vipsy_amd import _hip
+    _hip.lib().vx_prof_enable(1)                            # HIP events on the launch stream around the large kernels
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -161,6 +184,13 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     eng.events = None
+    kernel_ms = {}
+    import ctypes
+    for slot in range(_hip.lib().vx_prof_count()):
+        nm, ms, cnt = ctypes.create_string_buffer(64), ctypes.c_float(0), ctypes.c_int(0)
+        if _hip.lib().vx_prof_read(slot, nm, 64, ctypes.byref(ms), ctypes.byref(cnt)) == 0 and cnt.value:
+            kernel_ms[nm.value.decode()] = float(ms.value)
+    _hip.lib().vx_prof_enable(0)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -186,17 +216,28 @@ def main():
             "person_rows_per_s": N * args.steps / dt,
             "loss_last": loss_v, "phase_ms": phase_ms,
         }
-        if os.environ.get("VX_BF16X3", "") == "1":          # opt-in kernel variant: say so in the line itself
-            out["config"]["opt_in"] = "VX_BF16X3=1 (weight-gradient GEMM as 3-term bf16 splitting on the bf16 MFMA, fp32 accumulate)"
-        if D > 1 and "guide_forward" in phase_ms:
-            fl = enc_fwd_flops_per_person(J, D, H) * n_local
-            ach = fl / (phase_ms["guide_forward"] * 1e-3) / 1e12
+        if os.environ.get("VX_BF16X3"):                     # non-default kernel selection: say so in the line itself
+            out["config"]["kernel_switch"] = "VX_BF16X3=" + os.environ["VX_BF16X3"]
+        if kernel_ms:
+            out["kernel_ms"] = kernel_ms
+        priced = {k: v for k, v in kernel_ms.items() if kernel_model(k, J, D, H)}
+        if D > 1 and priced:
+            # the dominant kernel = the one with the largest mean duration inside the timed steps (HIP events recorded
+            # by the library on the launch stream, vx_prof_*); achieved = algorithmic flops per launch / that duration
+            name = max(priced, key=priced.get)
+            fl_pp, peak, arith = kernel_model(name, J, D, H)
+            fl = fl_pp * n_local
+            ach = fl / (priced[name] * 1e-3) / 1e12
             headline = args.workload == "irt2pl_100d_amortized_1Mx500" and world == 1 and not args.persons
-            out["roofline"] = {"kernel": "k_mvn_enc_fwd_p", "bound": "mfma", "achieved": ach,
-                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                               "traffic": measured_traffic("k_mvn_enc_fwd_p") if headline else None,
-                               "traffic_source": "profiles/r01_v4_hbm_traffic.json (PMC, bytes per launch)" if headline else None,
-                               "algorithmic_flops_per_launch": fl, "avg_launch_ms": phase_ms["guide_forward"]}
+            traffic = measured_traffic(name) if headline else None
+            out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                               "frac": ach / peak, "traffic": traffic,
+                               "traffic_source": ("profiles/%s_hbm_traffic.json (PMC, bytes per launch)" % PROFILE_TAG)
+                                                 if traffic is not None else None,
+                               "arithmetic": arith,
+                               "peak_basis": "dense bf16 MFMA peak 2500 / 6 products per f32 product"
+                                             if peak == PEAK_BF16X3_TFLOPS else "dense f32 MFMA peak",
+                               "algorithmic_flops_per_launch": fl, "avg_launch_ms": priced[name]}
         elif "irt1d" in phase_ms or "hodina" in phase_ms:
             key = "irt1d" if "irt1d" in phase_ms else "hodina"
             by = (J + 48.0) * n_local                       # y row + 6 fp32 r/w per person

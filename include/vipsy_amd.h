@@ -56,6 +56,14 @@ typedef struct vx_irt_cfg {
 int vx_abi_version(void);
 const char* vx_build_info(void);
 
+/* ---- Measurement aid (no reference counterpart; used by bench.py only).  While enabled, the entry points record a
+ * pair of HIP events on their launch stream around each of the large kernels; vx_prof_read synchronises on them and
+ * returns the kernel's name, its mean duration and the number of launches seen since vx_prof_enable(1).  Disabled
+ * (the default) nothing is recorded and no entry point synchronises. */
+int vx_prof_enable(int on);
+int vx_prof_count(void);
+int vx_prof_read(int slot, char* name, int name_cap, float* mean_ms, int* launches);
+
 /* ---- RNG: eps[i, d] = N(0,1) keyed by the GLOBAL person id (Philox4x32-10 + Box-Muller).
  * gids == NULL means gid = gid0 + i.  Also used by tests to hand the oracle identical eps. */
 int vx_philox_normals(float* eps /*[n][D]*/, const int64_t* gids, int64_t gid0, int64_t n, int32_t D,

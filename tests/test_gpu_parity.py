@@ -244,7 +244,8 @@ print("RESULT" + json.dumps(out))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     switches = {"0": {}, "1": {"VX_FORCE_GENERIC": "1"}, "fast": {"VX_MVN": "fast"}, "bwdw": {"VX_BWDW": "old"},
-                "bwdh": {"VX_BWDH": "old"}, "lik": {"VX_LIK": "old"}, "bf16x3": {"VX_BF16X3": "1"}}
+                "bwdh": {"VX_BWDH": "old"}, "lik": {"VX_LIK": "old"}, "fp32": {"VX_BF16X3": "0"},
+                "b3f": {"VX_BF16X3": "f"}, "b3w": {"VX_BF16X3": "w"}}
     for mode, extra in switches.items():
         env = dict(os.environ, VX_FORCE_GENERIC="0", VX_MVN="packed")
         env.update(extra)
@@ -252,8 +253,9 @@ print("RESULT" + json.dumps(out))
         assert p.returncode == 0, p.stderr[-2000:]
         line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][0]
         res[mode] = json.loads(line[6:])
-    # every kernel generation -- and the opt-in bf16x3 weight-gradient kernel -- against the shape-generic ones
-    for m in ("0", "fast", "bwdw", "bwdh", "lik", "bf16x3"):
+    # every kernel generation -- the default bf16x3 kernels ("0"), the fp32-MFMA ones and the mixed selections --
+    # against the shape-generic ones
+    for m in ("0", "fast", "bwdw", "bwdh", "lik", "fp32", "b3f", "b3w"):
         assert res[m]["loss"] == pytest.approx(res["1"]["loss"], rel=1e-6)
         x0, x1 = np.array(res[m]["x"]), np.array(res["1"]["x"])
         np.testing.assert_allclose(x0, x1, atol=2e-5, rtol=1e-5)

@@ -1,4 +1,4 @@
-"""A/B of the opt-in bf16x3 weight-gradient kernel (VX_BF16X3=1) against the fp32-MFMA one and the shape-generic
+"""A/B of the bf16x3 kernels (the default) against the fp32-MFMA ones (VX_BF16X3=0) and the shape-generic
 kernels: each mode in a child process (the switches are read once per process).  Run on a GPU box."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,7 +18,7 @@ np.save(sys.argv[2], eng.G[:eng.n_params + 1].double().cpu().numpy())
 ''' % ROOT
 for N in (512, 520, 1000, 4096):
     g = {}
-    for mode, extra in {"fp32": {}, "bf16x3": {"VX_BF16X3": "1"}, "generic": {"VX_FORCE_GENERIC": "1"}}.items():
+    for mode, extra in {"fp32": {"VX_BF16X3": "0"}, "bf16x3": {"VX_BF16X3": "1"}, "generic": {"VX_FORCE_GENERIC": "1"}}.items():
         env = dict(os.environ, VX_FORCE_GENERIC="0"); env.update(extra)
         out = "/tmp/bfx_%s.npy" % mode
         p = subprocess.run([sys.executable, "-c", CODE, str(N), out], env=env, capture_output=True, text=True, timeout=600)

@@ -5,12 +5,12 @@
 //   instead of 33 fp32 MFMAs of 64 cycles, at the accuracy of the fp32 chain (tools/bf16x3_ubench.hip).
 // Both operands are reused, so the splitting costs nothing in the loop:
 //   Wp : split once per step by k_pack_heads_b into a per-tile IMAGE that is exactly the LDS layout the fragments
-//        are read from (12 KB of bf16 fragments + 256 B of bias / group codes per 32-row tile);
+//        are read from (12 KB of bf16 fragments + a bias fragment per 32-row tile);
 //   h  : split once per 32-person wave tile, in registers; the C layout of the fc1 MFMA already is the B fragment
 //        order (k-step s, lane half, element j  <->  hidden unit 16 s + 8 (j >> 2) + 4 half + (j & 3)).
-// One weight stream per WORKGROUP: a tile image arrives by global->LDS DMA (12 KB split over the 4 waves + a private
-// 256-byte bias/code copy per wave: 4 transfers per wave and tile, so `s_waitcnt vmcnt(8)` counts whole tiles), in a
-// 4-stage ring, one barrier per tile.  Every wave pulls the fragments of tile t + 1 into registers while the MFMAs of
+// One weight stream per WORKGROUP: a tile image arrives by global->LDS DMA (12 KB split over the 4 waves + the 1 KB
+// bias fragment, which every wave transfers: 4 transfers per wave and tile, so `s_waitcnt vmcnt(8)` counts whole
+// tiles), in a 4-stage ring, one barrier per tile.  Every wave pulls the fragments of tile t + 1 into registers while the MFMAs of
 // tile t run, and does the epsilon epilogue of tile t - 1 between them (the bf16 MFMA leaves the vector port free for
 // 24 of its 32 cycles).
 // (included by vx_abi.hip after k_mvn_packed.hip and k_mvn_bwd_b.hip)
@@ -20,24 +20,33 @@
 #define FB_WP 32
 #define FB_NST 4
 #define FB_A_BYTES 12288
-#define FB_AUX_BYTES 256
+#define FB_AUX_BYTES 1024                                            // the bias fragment
 #define FB_IMG_BYTES (FB_A_BYTES + FB_AUX_BYTES)                     // tile image in global memory
-#define FB_STAGE_BYTES (FB_A_BYTES + FB_WAVES * FB_AUX_BYTES)        // one ring stage in LDS
+#define FB_STAGE_BYTES FB_IMG_BYTES                                  // one ring stage in LDS
 
 __host__ __device__ inline int fb_tiles(int D) { return (pk_off_total(D) + 2 * pk_sec(D)) / 32; }
-__host__ __device__ inline int64_t fb_img_floats(int D) { return (int64_t)fb_tiles(D) * (FB_IMG_BYTES / 4); }
+__host__ __device__ inline int64_t fb_img_floats(int D) {               // tile images + the OFF group table
+    return (int64_t)fb_tiles(D) * (FB_IMG_BYTES / 4) + pk_off_total(D) / 8 + 8;
+}
 __host__ __device__ inline size_t fb_lds_bytes(int D, int J) {
-    return FB_WAVES * enc_p_wave_floats(D, J) * sizeof(float) + (size_t)FB_NST * FB_STAGE_BYTES;
+    return FB_WAVES * enc_p_wave_floats(D, J) * sizeof(float) + (size_t)FB_NST * FB_STAGE_BYTES +
+           (size_t)(pk_off_total(D) / 8 + 4) / 4 * 16;                  // wave regions | weight ring | OFF group table
 }
 
 // tile image: fragment (split sp, k-step s) at byte (sp * 4 + s) * 1024 + lane * 16, lane = 32 half + row;
-// element j of it = Wp[32 T + row][16 s + 8 (j >> 2) + 4 half + (j & 3)];  aux: bias in accumulator order
-// [half][g] x float4 at FB_A_BYTES, the 4 group codes at FB_A_BYTES + 128
-__global__ void k_pack_heads_b(int n_tiles, const float* __restrict__ Wp, const float* __restrict__ bp,
-                               const uint32_t* __restrict__ gtab, uint8_t* __restrict__ img) {
+// element j of it = Wp[32 T + row][16 s + 8 (j >> 2) + 4 half + (j & 3)];  a 13th fragment at FB_A_BYTES carries the bias
+// gt2[group] (OFF groups only): byte offset of eps[l0] | byte offset of x[k] << 12 | (last group of its k) << 31
+__global__ void k_pack_heads_b(int n_tiles, int n_off_groups, const float* __restrict__ Wp, const float* __restrict__ bp,
+                               const uint32_t* __restrict__ gtab, uint8_t* __restrict__ img, uint32_t* __restrict__ gt2) {
     const int T = blockIdx.x;
     if (T >= n_tiles) return;
     uint8_t* out = img + (int64_t)T * FB_IMG_BYTES;
+    if (threadIdx.x < 4 && 4 * T + (int)threadIdx.x < n_off_groups) {
+        const int G = 4 * T + threadIdx.x;
+        const uint32_t c = gtab[G], k = (c >> 12) & 0xFFFFu, l0 = c & 0xFFFu;
+        const bool last = (G + 1 == n_off_groups) || (((gtab[G + 1] >> 12) & 0xFFFFu) != k);
+        gt2[G] = (4u * l0) | ((4u * k) << 12) | (last ? 0x80000000u : 0u);
+    }
     for (int e = threadIdx.x; e < 4 * 64 * 8; e += blockDim.x) {          // (s, lane, j)
         const int j = e & 7, lane = (e >> 3) & 63, s = e >> 9;
         const int half = lane >> 5, row = lane & 31;
@@ -51,15 +60,20 @@ __global__ void k_pack_heads_b(int n_tiles, const float* __restrict__ Wp, const 
         o[2048] = __builtin_bit_cast(uint16_t, m);                        // + 4 fragments = 4096 bytes
         o[4096] = __builtin_bit_cast(uint16_t, l);
     }
-    for (int e = threadIdx.x; e < FB_AUX_BYTES / 4; e += blockDim.x) {
-        uint32_t w = 0u;
-        if (e < 32) {
-            const int half = e >> 4, g = (e >> 2) & 3, j = e & 3;
-            w = __builtin_bit_cast(uint32_t, bp[T * 32 + 8 * g + 4 * half + j]);
-        } else if (e < 36) {
-            w = gtab[4 * T + (e - 32)];
+    // bias fragment (13th): lane = row (half 0), elements 0..2 = the three bf16 terms of the row's bias, the rest zero;
+    // one MFMA against a fragment of ones starts the accumulator chain from the bias
+    for (int e = threadIdx.x; e < FB_AUX_BYTES / 2; e += blockDim.x) {
+        const int j = e & 7, lane = e >> 3;
+        uint16_t w = 0;
+        if (lane < 32 && j < 3) {
+            const float v = bp[T * 32 + lane];
+            const __bf16 h = (__bf16)v;
+            const float r1 = v - (float)h;
+            const __bf16 m = (__bf16)r1;
+            const __bf16 l = (__bf16)(r1 - (float)m);
+            w = __builtin_bit_cast(uint16_t, j == 0 ? h : j == 1 ? m : l);
         }
-        ((uint32_t*)(out + FB_A_BYTES))[e] = w;
+        ((uint16_t*)(out + FB_A_BYTES))[e] = w;
     }
 }
 
@@ -91,15 +105,20 @@ __device__ __forceinline__ void fb_split8(const float* v, bf16x8& fh, bf16x8& fm
 __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, int64_t gid0,
     const float* __restrict__ W1, const float* __restrict__ b1, const uint8_t* __restrict__ img,
-    const float* __restrict__ eps_in, uint64_t seed, uint32_t step, uint32_t stream, float* __restrict__ h_out,
+    const uint32_t* __restrict__ gt2, const float* __restrict__ eps_in, uint64_t seed, uint32_t step, uint32_t stream, float* __restrict__ h_out,
     float* __restrict__ x_out, float* __restrict__ eps_out, float* __restrict__ ldT, float* __restrict__ ent_out,
-    float* __restrict__ hT_out /*[64][nb] or null*/, float* __restrict__ epsT_out /*[D][nb] or null*/) {
+    float* __restrict__ hT_out /*[64][nb] or null*/, float* __restrict__ epsT_out /*[D][nb] or null*/,
+    long long* __restrict__ stamps /*timing experiments only, normally null*/) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int H = 64;
     const int D = dm.D, J = dm.J;
     const int DS = pk_dse(D), DX = (D + 3) & ~3;
     const int YS = ef_ys(J);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto stamp = [&](int idx) {
+        if (stamps && tid == 0 && blockIdx.x < 2048) stamps[blockIdx.x * 8 + idx] = (long long)__builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
     const int half = lane >> 5, l31 = lane & 31;
     float* R1 = smem + wave * enc_p_wave_floats(D, J);
     int8_t* Yi = (int8_t*)R1;                                 // phase A
@@ -107,6 +126,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     float* x_lds = R1 + FB_WP * DS;                           //          [32][DX]
     const char* ring = (const char*)(smem + FB_WAVES * enc_p_wave_floats(D, J));
     const uint32_t ring_lds = lds_addr_uniform(ring);
+    uint32_t* gt_lds = (uint32_t*)(ring + (size_t)FB_NST * FB_STAGE_BYTES);
     const int64_t i0 = ((int64_t)blockIdx.x * FB_WAVES + wave) * FB_WP;
     const int p = l31;
     const int64_t i = i0 + p;
@@ -126,9 +146,10 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         dma16s(src, voffA, sb + (uint32_t)wave * 1024u);
         dma16s(src, voffA + 4096u, sb + (uint32_t)wave * 1024u + 4096u);
         dma16s(src, voffA + 8192u, sb + (uint32_t)wave * 1024u + 8192u);
-        dma4(src + FB_A_BYTES + 4 * lane, sb + FB_A_BYTES + (uint32_t)wave * FB_AUX_BYTES);
+        dma16s(src, (uint32_t)(FB_A_BYTES + lane * 16), sb + FB_A_BYTES);   // the bias fragment: every wave, same bytes
     };
     stage_tile(0); stage_tile(1); stage_tile(2); stage_tile(3);   // in flight during staging / fc1 / eps
+    for (int e = tid; e < 4 * n_off; e += FB_THREADS) gt_lds[e] = gt2[e];   // published by the barrier before the OFF loop
 
     // ---------------------------------------------------------------- stage this wave's response rows (bytes)
     const int n_ydma = (32 * J + 1023) / 1024;
@@ -166,6 +187,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         }
     }
     __builtin_amdgcn_wave_barrier();
+    stamp(1);
     // ---------------------------------------------------------------- phase A: fc1 (+ softplus), both hidden tiles
     bf16x8 hb[3][4];                                          // [split][k-step]: B fragments of every head tile
     {
@@ -250,6 +272,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         }
     }
     __builtin_amdgcn_wave_barrier();                          // response bytes no longer needed
+    stamp(2);
     // ---------------------------------------------------------------- eps (zero padded to DS), x := 0
     {
         for (int e = lane; e < FB_WP * (DS + DX); e += 64) R1[e] = 0.f;
@@ -279,31 +302,21 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     float ent_acc = 0.f;
     const float* ep = eps_lds + p * DS;
     float* xp = x_lds + p * DX;
-    const uint32_t aux_off = FB_A_BYTES + (uint32_t)wave * FB_AUX_BYTES;
-    struct TileRegs { bf16x8 a[3][4]; f32x16 bias; uint32_t code[4]; float4 e4[4]; };
-    // everything a wave needs of tile t comes out of the ring into registers one tile ahead
-    auto pull = [&](TileRegs& R, int t, bool want_eps) __attribute__((always_inline)) {
+    struct TileRegs { bf16x8 a[3][4]; bf16x8 bias; };
+    // the fragments of tile t come out of the ring into registers one tile ahead
+    auto pull = [&](TileRegs& R, int t) __attribute__((always_inline)) {
         const char* sb = ring + (size_t)(t & (FB_NST - 1)) * FB_STAGE_BYTES;
+        R.bias = *(const bf16x8*)(sb + FB_A_BYTES + lane * 16);
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp)
+        for (int sp = 2; sp >= 0; --sp)
 #pragma unroll
             for (int s = 0; s < 4; ++s) R.a[sp][s] = *(const bf16x8*)(sb + (sp * 4 + s) * 1024 + lane * 16);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 bv = *(const f32x4*)(sb + aux_off + (half * 4 + g) * 16);
-            R.bias[4 * g + 0] = bv[0]; R.bias[4 * g + 1] = bv[1]; R.bias[4 * g + 2] = bv[2]; R.bias[4 * g + 3] = bv[3];
-        }
-        const uint4 gc = *(const uint4*)(sb + aux_off + 128);
-        R.code[0] = __builtin_amdgcn_readfirstlane(gc.x); R.code[1] = __builtin_amdgcn_readfirstlane(gc.y);
-        R.code[2] = __builtin_amdgcn_readfirstlane(gc.z); R.code[3] = __builtin_amdgcn_readfirstlane(gc.w);
-        if (want_eps) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) R.e4[g] = *(const float4*)(ep + (R.code[g] & 0xFFFu) + 4 * half);
-        }
     };
-    // products in order of increasing magnitude; the accumulator starts from the bias
+    typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
+    const bf16x8 ones8 = __builtin_bit_cast(bf16x8, u32x4w{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+    // the chain starts from the bias (one MFMA against ones); products in order of increasing magnitude
     auto mma_lo = [&](const TileRegs& R) __attribute__((always_inline)) -> f32x16 {
-        f32x16 a = R.bias;
+        f32x16 a = mfma_bf16(R.bias, ones8, zero16());
 #pragma unroll
         for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[2][s], hb[0][s], a);
 #pragma unroll
@@ -321,55 +334,95 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[0][s], hb[0][s], a);
         return a;
     };
-    // ---- OFF section: x[p][k] += sum_l M[p,(k,l)] eps[p,l]; the partial sum of the current k stays in a register
-    uint32_t cur_k = 1;                                        // the first packed group belongs to k = 1
+    // ---- OFF section: x[p][k] += sum_l M[p,(k,l)] eps[p,l]; the partial sum of the current k stays in a register and
+    // is stored when the group table says the k ends (4 group words per tile from a copy of the table in LDS).
+    // One wave per SIMD issues one instruction every ~4 cycles whatever its kind, so the loop is written for a small
+    // instruction count per tile (~150 beside the 25 MFMAs), not only for few vector instructions.
     float cur_part = 0.f;
-    auto flush = [&]() {                                       // every k of the OFF section is flushed exactly once
-        const float tot = half_sum32(cur_part);
-        if (half == 0) xp[cur_k] = tot;
+    const char* ep_h = (const char*)(ep + 4 * half);
+    char* xp_b = (char*)xp;
+    struct EpiOps { float4 e4[4]; };
+    auto epi_read = [&](EpiOps& E, const uint4& c) __attribute__((always_inline)) {
+        E.e4[0] = *(const float4*)(ep_h + (c.x & 0xFFFu));
+        E.e4[1] = *(const float4*)(ep_h + (c.y & 0xFFFu));
+        E.e4[2] = *(const float4*)(ep_h + (c.z & 0xFFFu));
+        E.e4[3] = *(const float4*)(ep_h + (c.w & 0xFFFu));
     };
-    auto epi_off = [&](const f32x16& a, const uint32_t (&code)[4], const float4 (&e4)[4]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {                          // rows (k, l0 + 4half + j) live in a[4g + j]
-            const uint32_t kq = (code[g] >> 12) & 0xFFFFu;
-            const float part = a[4 * g + 0] * e4[g].x + a[4 * g + 1] * e4[g].y + a[4 * g + 2] * e4[g].z +
-                               a[4 * g + 3] * e4[g].w;
-            const bool changed = kq != cur_k;                                     // wave-uniform, rare
-            if (__builtin_expect(changed, 0)) flush();                            // one-sided branch, falls through
-            cur_part = part + (changed ? 0.f : cur_part);
-            cur_k = kq;
+    auto epi_group = [&](const f32x16& a, const float4& e, uint32_t code, int g) __attribute__((always_inline)) {
+        // rows (k, l0 + 4half + j) live in a[4g + j]
+        cur_part = fmaf(a[4 * g + 0], e.x, cur_part);
+        cur_part = fmaf(a[4 * g + 1], e.y, cur_part);
+        cur_part = fmaf(a[4 * g + 2], e.z, cur_part);
+        cur_part = fmaf(a[4 * g + 3], e.w, cur_part);
+        if (__builtin_expect((int)code < 0, 0)) {                                 // wave-uniform, rare: the k ends here
+            const float tot = half_sum32(cur_part);
+            if (half == 0) *(float*)(xp_b + ((code >> 12) & 0xFFFu)) = tot;
+            cur_part = 0.f;
         }
     };
 
     vx_wait_vmem();                                            // stores of the phases above + tiles 0..3 of the ring
     __syncthreads();
+    stamp(3);
     TileRegs RA, RB;
-    pull(RA, 0, true);
-    // epilogue operands of the tile before the current one; "tile -1": zeros under the first k (adds nothing)
-    f32x16 accP = zero16();
-    uint32_t codeP[4] = {1u << 12, 1u << 12, 1u << 12, 1u << 12};
-    float4 e4P[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) e4P[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    pull(RA, 0);
+    f32x16 accP = zero16();                                    // accumulator of the tile before the current one
+    uint4 codeP = make_uint4(0, 0, 0, 0);                      // its group words
 
-    auto off_iter = [&](TileRegs& Rc, TileRegs& Rn, int t) __attribute__((always_inline)) {
+    auto off_iter = [&](TileRegs& Rc, TileRegs& Rn, int t, auto firstc) __attribute__((always_inline)) {
+        constexpr bool first = decltype(firstc)::value;
         __builtin_amdgcn_s_waitcnt(0x0F78);                    // vmcnt(8): tile t + 1 has landed (t + 2, t + 3 in flight)
         __syncthreads();                                       // ... for every wave; the stage of tile t is free
         stage_tile(t + FB_NST);
-        pull(Rn, t + 1, true);
-        f32x16 a = mma_lo(Rc);
-        epi_off(accP, codeP, e4P);
-        a = mma_hi(Rc, a);
-        accP = a;
+        EpiOps E;
+        if constexpr (!first) epi_read(E, codeP);
+        pull(Rn, t + 1);
+        // the chain starts from the bias (one MFMA against ones); products in order of increasing magnitude; the
+        // epilogue of the previous tile goes between its five parts
+        f32x16 a = mfma_bf16(Rc.bias, ones8, zero16());
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { codeP[g] = Rc.code[g]; e4P[g] = Rc.e4[g]; }
+        for (int s = 0; s < 4; ++s) a = mfma_bf16(Rc.a[2][s], hb[0][s], a);
+        if constexpr (!first) epi_group(accP, E.e4[0], codeP.x, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a = mfma_bf16(Rc.a[1][s], hb[1][s], a);
+        a = mfma_bf16(Rc.a[0][0], hb[2][0], a);
+        if constexpr (!first) epi_group(accP, E.e4[1], codeP.y, 1);
+#pragma unroll
+        for (int s = 1; s < 4; ++s) a = mfma_bf16(Rc.a[0][s], hb[2][s], a);
+        a = mfma_bf16(Rc.a[1][0], hb[0][0], a);
+        a = mfma_bf16(Rc.a[1][1], hb[0][1], a);
+        if constexpr (!first) epi_group(accP, E.e4[2], codeP.z, 2);
+        a = mfma_bf16(Rc.a[1][2], hb[0][2], a);
+        a = mfma_bf16(Rc.a[1][3], hb[0][3], a);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) a = mfma_bf16(Rc.a[0][s], hb[1][s], a);
+        if constexpr (!first) epi_group(accP, E.e4[3], codeP.w, 3);
+        a = mfma_bf16(Rc.a[0][3], hb[1][3], a);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a = mfma_bf16(Rc.a[0][s], hb[0][s], a);
+        accP = a;
+        // the group words of this tile, for its epilogue in the next iteration, from the table in LDS (a scalar load
+        // would share lgkmcnt with the LDS reads and return out of order: while one is outstanding every LDS wait
+        // becomes lgkmcnt(0))
+        const uint4 cv = *(const uint4*)(gt_lds + 4 * t);
+        codeP.x = __builtin_amdgcn_readfirstlane(cv.x); codeP.y = __builtin_amdgcn_readfirstlane(cv.y);
+        codeP.z = __builtin_amdgcn_readfirstlane(cv.z); codeP.w = __builtin_amdgcn_readfirstlane(cv.w);
     };
-    for (int t = 0; t < n_off; t += 2) {
-        off_iter(RA, RB, t);
-        off_iter(RB, RA, t + 1);
+    off_iter(RA, RB, 0, std::true_type{});
+    off_iter(RB, RA, 1, std::false_type{});
+    for (int t = 2; t < n_off; t += 2) {
+        off_iter(RA, RB, t, std::false_type{});
+        off_iter(RB, RA, t + 1, std::false_type{});
     }
-    epi_off(accP, codeP, e4P);
-    flush();
+    {
+        EpiOps E;
+        epi_read(E, codeP);
+        epi_group(accP, E.e4[0], codeP.x, 0);
+        epi_group(accP, E.e4[1], codeP.y, 1);
+        epi_group(accP, E.e4[2], codeP.z, 2);
+        epi_group(accP, E.e4[3], codeP.w, 3);
+    }
+    stamp(4);
     // ---- DIAG section (exp(M_kk) eps_k, entropy, ldT) and LOC section (the loc head): 2 * n_sec tiles; RA holds the
     // first of them.  The 16 x entries a lane updates are read together, updated and written together.
     auto tile_sec = [&](const f32x16& a, int t2) __attribute__((always_inline)) {
@@ -408,7 +461,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         vx_wait_vmem();
         __syncthreads();
         if (t + FB_NST < t_end) stage_tile(t + FB_NST);
-        if (t + 1 < t_end) pull(Rn, t + 1, false);
+        if (t + 1 < t_end) pull(Rn, t + 1);
         const f32x16 a = mma_hi(Rc, mma_lo(Rc));
         tile_sec(a, t);
     };
@@ -418,6 +471,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     }
     vx_wait_vmem();                                            // no DMA may still be in flight when the LDS is released
     __builtin_amdgcn_wave_barrier();
+    stamp(5);
     // ---------------------------------------------------------------- write x, entropy part
     if (wave_live) {
         const int pv = (int)((dm.nb - i0) < FB_WP ? (dm.nb - i0) : FB_WP);
@@ -433,4 +487,5 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
             ent_out[i] = 0.5f * s + ent_acc;                  // -log q + const = 0.5|eps|^2 + sum_k M_kk
         }
     }
+    stamp(6);
 }
