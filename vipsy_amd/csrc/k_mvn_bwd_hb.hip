@@ -1,0 +1,238 @@
+// Hidden-layer gradient of the amortized MVN guide on the bf16 MFMA (three-term operand splitting, fp32 accumulate):
+// the same result as k_mvn_enc_bwd_h_t (k_mvn_bwd_t.hip),
+//     gh[p][hh] = sum_r Wp[r][hh] V[r][p],    ghpre = gh * (1 - exp(-h))                          (autograd of vi.py:448-455)
+// but V is never formed.  For the off-diagonal rows V[(k,l)][p] = gx[p][k] eps[p][l] is a rank-one product, so
+//     gh[p][:] = sum_k gx[p][k] U_k[p][:],      U_k[p][hh] = sum_{l<k} W22[(k,l)][hh] eps[p][l]
+// and U_k is a GEMM whose per-person operand is eps alone: split ONCE per 32-person wave tile into bf16x3 fragments
+// that stay in registers for every k (the V of the fp32 kernel needed a multiply -- and would need a three-way split
+// -- per element).  The weights are split once per step into per-unit images (k_pack_heads_hb).  The multiplication by
+// gx[p][k] is a 32-FMA epilogue per k on the accumulator.  DIAG rows (operand gd = gx eps e^M + scale, k_mvn_gd) and
+// LOC rows (operand gx) are two more small GEMMs straight into the gh accumulator.
+//   MFMA 32x32x16: C rows = hidden units (two tiles of 32), columns = persons; contraction index = l (or k).
+//   unit (k, s) = the 16 contraction indices l = 16 s .. 16 s + 15 of one k: 6 fragments of 1 KB (2 hidden tiles x 3
+//   splits), 12 MFMAs.  Units stream through a ring of 8 slots in LDS by DMA, shared by the 4 waves of the workgroup
+//   (pairs of units = 12 transfers = 3 per wave, so `vmcnt(3)` counts whole pairs); one barrier per pair.
+//   k runs in blocks of 16 so that the number of units per k -- and with it every fragment register -- is static.
+// (included by vx_abi.hip after k_mvn_fwd_b.hip)
+
+#define HB_THREADS 256
+#define HB_UNIT_BYTES 6144
+#define HB_NSLOT 8
+#define HB_NS 8                                                        // k-steps of 16 covering D <= 128
+
+__host__ __device__ inline int hb_units_off(int D) {
+    int n = 0;
+    for (int k = 1; k < D; ++k) n += (k + 15) / 16;
+    return n;
+}
+__host__ __device__ inline int hb_units(int D) { return hb_units_off(D) + 2 * ((D + 15) / 16); }
+__host__ __device__ inline int64_t hb_img_floats(int D) { return (int64_t)hb_units(D) * (HB_UNIT_BYTES / 4); }
+__host__ __device__ inline size_t hb_lds_bytes(int D) {
+    return (size_t)4 * D * 32 * sizeof(float) + (size_t)HB_NSLOT * HB_UNIT_BYTES;
+}
+
+// unit image: fragment (hidden tile ht, split sp) at byte (ht * 3 + sp) * 1024 + lane * 16, lane = 32 half + row;
+// element j = the weight of hidden unit 32 ht + row for contraction index c = 16 s + 8 half + j:
+//   OFF unit (k, s): W22[(k, c)] for c < k;   DIAG unit s: W22[(c, c)];   LOC unit s: W21[c]       (zero past the end)
+__global__ void k_pack_heads_hb(int D, const float* __restrict__ W21, const float* __restrict__ W22,
+                                uint8_t* __restrict__ img) {
+    const int n_off = hb_units_off(D), ns = (D + 15) / 16;
+    const int u = blockIdx.x;
+    if (u >= n_off + 2 * ns) return;
+    int type = 0, k = 0, s = 0;                                        // 0 OFF, 1 DIAG, 2 LOC
+    if (u < n_off) {
+        int rem = u;
+        for (k = 1; k < D; ++k) {
+            const int n = (k + 15) / 16;
+            if (rem < n) break;
+            rem -= n;
+        }
+        s = rem;
+    } else {
+        type = (u - n_off) < ns ? 1 : 2;
+        s = (u - n_off) % ns;
+    }
+    uint8_t* out = img + (int64_t)u * HB_UNIT_BYTES;
+    for (int e = threadIdx.x; e < 2 * 64 * 8; e += blockDim.x) {       // (ht, lane, j)
+        const int j = e & 7, lane = (e >> 3) & 63, ht = e >> 9;
+        const int half = lane >> 5, hh = 32 * ht + (lane & 31);
+        const int c = 16 * s + 8 * half + j;
+        float v = 0.f;
+        if (type == 0) { if (c < k) v = W22[((int64_t)k * (k + 1) / 2 + c) * 64 + hh]; }
+        else if (type == 1) { if (c < D) v = W22[((int64_t)c * (c + 1) / 2 + c) * 64 + hh]; }
+        else { if (c < D) v = W21[(int64_t)c * 64 + hh]; }
+        const __bf16 h = (__bf16)v;
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const __bf16 l = (__bf16)(r1 - (float)m);
+        uint16_t* o = (uint16_t*)(out + (ht * 3) * 1024 + lane * 16) + j;
+        o[0] = __builtin_bit_cast(uint16_t, h);
+        o[512] = __builtin_bit_cast(uint16_t, m);
+        o[1024] = __builtin_bit_cast(uint16_t, l);
+    }
+}
+
+__global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
+    EncDims dm, const uint8_t* __restrict__ img, const float* __restrict__ h_in, const float* __restrict__ eps_in,
+    const float* __restrict__ gxT, const float* __restrict__ gdT /*DIAG-row operand [D][nb]*/,
+    float* __restrict__ ghpre_out /*[nb][64] or null*/, const float* __restrict__ hT /*[64][nb], with ghpreT_out*/,
+    float* __restrict__ ghpreT_out /*[64][nb] or null*/) {
+    extern __shared__ __attribute__((aligned(16))) char smem_hb[];
+    constexpr int H = 64;
+    const int D = dm.D;
+    const int64_t nb = dm.nb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    float* gx_lds = (float*)smem_hb + (size_t)wave * D * 32;           // [D][32] of this wave
+    const char* ring = smem_hb + (size_t)4 * D * 32 * sizeof(float);
+    const uint32_t ring_lds = lds_addr_uniform(ring);
+    const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    const int64_t i = i0 + l31;
+    const int64_t ic = i < nb ? i : nb - 1;                            // absent persons: a valid one, never stored
+    const int n_units = hb_units(D), n_pairs = (n_units + 1) / 2;
+    const int ns = (D + 15) / 16;
+
+    // ---- weight ring: pair q = units 2q, 2q + 1 -> slots (2q) % 8, (2q + 1) % 8; this wave moves pieces w, w + 4, w + 8
+    const uint32_t voff = (uint32_t)(wave * 1024 + lane * 16);
+    auto stage_pair = [&](int q) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int piece = wave + 4 * c;                            // 0..11: unit piece / 6, fragment piece % 6
+            int u = 2 * q + (piece >= 6 ? 1 : 0);
+            const uint32_t dst = ring_lds + (uint32_t)(u & (HB_NSLOT - 1)) * HB_UNIT_BYTES + (uint32_t)(piece % 6) * 1024u;
+            if (u >= n_units) u = n_units - 1;                         // past the end: a harmless duplicate
+            dma16s(img + (int64_t)u * HB_UNIT_BYTES, (uint32_t)((piece % 6) * 1024 + lane * 16), dst);
+        }
+    };
+    (void)voff;
+    stage_pair(0); stage_pair(1); stage_pair(2);
+
+    // ---- this wave's gx tile [D][32] (lanes = persons: 128-byte rows of gxT)
+    for (int k = half; k < D; k += 2) gx_lds[k * 32 + l31] = gxT[(int64_t)k * nb + ic];
+
+    // ---- B fragments: contraction index c = 16 s + 8 half + j of person ic, three bf16 terms each
+    bf16x8 bf[3][HB_NS];
+    {
+        const float* er = eps_in + ic * D;
+#pragma unroll
+        for (int s = 0; s < HB_NS; ++s) {
+            float v[8];
+            const int c0 = 16 * s + 8 * half;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                if (c0 + 4 * q + 4 <= D) t = *(const f32x4*)(er + c0 + 4 * q);      // D % 4 == 0 on this path
+                v[4 * q + 0] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+            }
+            fb_split8(v, bf[0][s], bf[1][s], bf[2][s]);
+        }
+    }
+    auto frags_from_T = [&](const float* __restrict__ srcT) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < HB_NS; ++s) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = 16 * s + 8 * half + j;
+                v[j] = (c < D) ? srcT[(int64_t)c * nb + ic] : 0.f;
+            }
+            fb_split8(v, bf[0][s], bf[1][s], bf[2][s]);
+        }
+    };
+
+    f32x16 gh0 = zero16(), gh1 = zero16();
+    bf16x8 A[6];                                                       // fragments of the CURRENT unit: [ht * 3 + split]
+    int u = 0;                                                         // unit counter (uniform)
+    auto slot_of = [&](int uu) -> const char* { return ring + (size_t)(uu & (HB_NSLOT - 1)) * HB_UNIT_BYTES; };
+    auto read_ht = [&](int uu, int ht) __attribute__((always_inline)) {
+        const char* sb = slot_of(uu) + ht * 3072 + lane * 16;
+        A[3 * ht + 0] = *(const bf16x8*)(sb);
+        A[3 * ht + 1] = *(const bf16x8*)(sb + 1024);
+        A[3 * ht + 2] = *(const bf16x8*)(sb + 2048);
+    };
+    // pair boundary: pair q + 1 has landed for every wave, the slots of pair q - 1 are free for pair q + 3
+    auto sync_pair = [&](int q) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_waitcnt(0x0F73);                            // vmcnt(3): only pair q + 2 may be in flight
+        __syncthreads();
+        stage_pair(q + 3);
+    };
+    // one unit: 6 products per hidden tile (small terms first); the fragments of the NEXT unit are requested as soon as
+    // the registers are free: hidden tile 0 after the first six MFMAs, hidden tile 1 at the end
+    auto unit = [&](auto sc, f32x16& U0, f32x16& U1) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value;
+        if ((u & 1) == 0) sync_pair(u >> 1);
+        U0 = mfma_bf16(A[2], bf[0][s], U0);
+        U0 = mfma_bf16(A[0], bf[2][s], U0);
+        U0 = mfma_bf16(A[1], bf[1][s], U0);
+        U0 = mfma_bf16(A[1], bf[0][s], U0);
+        U0 = mfma_bf16(A[0], bf[1][s], U0);
+        U0 = mfma_bf16(A[0], bf[0][s], U0);
+        read_ht(u + 1, 0);
+        U1 = mfma_bf16(A[5], bf[0][s], U1);
+        U1 = mfma_bf16(A[3], bf[2][s], U1);
+        U1 = mfma_bf16(A[4], bf[1][s], U1);
+        U1 = mfma_bf16(A[4], bf[0][s], U1);
+        U1 = mfma_bf16(A[3], bf[1][s], U1);
+        U1 = mfma_bf16(A[3], bf[0][s], U1);
+        read_ht(u + 1, 1);
+        ++u;
+    };
+
+    vx_wait_vmem();                                                    // pairs 0..2 of the ring (and nothing else)
+    __syncthreads();
+    read_ht(0, 0);
+    read_ht(0, 1);
+    // NOTE: sync_pair(0) at unit 0 waits vmcnt(3) with nothing in flight and stages pair 3
+
+    // ---- OFF rows: k in blocks of 16; block kb has kb + 1 units per k
+    static_for<HB_NS>([&](auto kbc) {
+        constexpr int kb = decltype(kbc)::value;
+        const int k_lo = 16 * kb + 1, k_hi = (16 * kb + 16 < D - 1) ? 16 * kb + 16 : D - 1;
+        for (int k = k_lo; k <= k_hi; ++k) {
+            f32x16 U0 = zero16(), U1 = zero16();
+            static_for<kb + 1>([&](auto sc) { unit(sc, U0, U1); });
+            const float gk = gx_lds[k * 32 + l31];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { gh0[r] = fmaf(gk, U0[r], gh0[r]); gh1[r] = fmaf(gk, U1[r], gh1[r]); }
+        }
+    });
+    // ---- DIAG rows (operand gd) and LOC rows (operand gx): straight into the accumulators
+    frags_from_T(gdT);
+    static_for<HB_NS>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if (s < ns) unit(sc, gh0, gh1);
+    });
+    frags_from_T(gxT);
+    static_for<HB_NS>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if (s < ns) unit(sc, gh0, gh1);
+    });
+    vx_wait_vmem();                                                    // no DMA may be in flight when the LDS is released
+
+    // ---- ghpre = gh * softplus'(pre) = gh * (1 - exp(-h));  C layout: rows hh = crow32(r, half), cols p
+    if (ghpreT_out) {                                                  // dimension-major: 128-byte rows per half-wave
+        if (i < nb) {
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t o = (int64_t)(32 * ht + crow32(r, half)) * nb + i;
+                    ghpreT_out[o] = (ht ? gh1 : gh0)[r] * (1.0f - __expf(-hT[o]));
+                }
+        }
+    } else if (i < nb) {
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int hh0 = 32 * ht + 8 * g + 4 * half;
+                const float4 hv = *(const float4*)(h_in + i * H + hh0);
+                float4 o;
+                o.x = (ht ? gh1 : gh0)[4 * g + 0] * (1.0f - __expf(-hv.x));
+                o.y = (ht ? gh1 : gh0)[4 * g + 1] * (1.0f - __expf(-hv.y));
+                o.z = (ht ? gh1 : gh0)[4 * g + 2] * (1.0f - __expf(-hv.z));
+                o.w = (ht ? gh1 : gh0)[4 * g + 3] * (1.0f - __expf(-hv.w));
+                *(float4*)(ghpre_out + i * H + hh0) = o;
+            }
+    }
+}

@@ -17,6 +17,7 @@
 #include "k_mvn_bwd_t.hip"
 #include "k_mvn_bwd_b.hip"
 #include "k_mvn_fwd_b.hip"
+#include "k_mvn_bwd_hb.hip"
 
 #include <cstdlib>
 #include <cstring>
@@ -84,13 +85,13 @@ bool packed_ok(const vx_irt_cfg* cfg) {
 }
 
 // bf16x3 kernels (three-term bf16 operand splitting on the bf16 MFMA, fp32 accumulate; results at the accuracy of the
-// fp32-MFMA chain): the default.  VX_BF16X3 = 0 selects the fp32-MFMA kernels, f / w only the guide forward / only the
-// weight gradient on the bf16 MFMA.
+// fp32-MFMA chain): the default.  VX_BF16X3 = 0 selects the fp32-MFMA kernels, f / w / h only the guide forward / the
+// weight gradient / the hidden gradient on the bf16 MFMA.
 int bf16x3_mode() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("VX_BF16X3");
-        v = (!e || e[0] == '1') ? 3 : (e[0] == 'f' ? 1 : e[0] == 'w' ? 2 : 0);
+        v = (!e || e[0] == '1') ? 7 : (e[0] == 'f' ? 1 : e[0] == 'w' ? 2 : e[0] == 'h' ? 4 : 0);
     }
     return v;
 }
@@ -534,6 +535,9 @@ static bool bwb_shape(const vx_irt_cfg* cfg, int64_t nb) {
     const bool on = (bf16x3_mode() & 2) != 0;
     return on && bwt_shape(cfg, nb) && nb % 8 == 0 && nb < ((int64_t)1 << 23) && bb_lds_bytes(cfg->D) <= 160 * 1024;
 }
+static bool bwhb_shape(const vx_irt_cfg* cfg, int64_t nb) {
+    return (bf16x3_mode() & 4) && bwt_shape(cfg, nb) && nb >= 4 && cfg->D <= 16 * HB_NS && hb_lds_bytes(cfg->D) <= 160 * 1024;
+}
 static void bwt_plan(const vx_irt_cfg* cfg, int64_t nb, int& n_rowslabs, int& n_prw) {
     n_rowslabs = (pk_rows(cfg->D) + BT_ROWS - 1) / BT_ROWS;
     const int64_t n_ptiles = (nb + BT_P - 1) / BT_P;
@@ -585,7 +589,8 @@ int64_t vx_mvn_enc_bwd_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
         if (np > n_prw) n_prw = np;
     }
     return nb * H + (int64_t)n_prw * lenw + (int64_t)n_prf * (H * J + H) + (bwt_shape(cfg, nb) ? nb * D + 4 : 0) +
-           (bwb_shape(cfg, nb) ? nb * 96 : 0);             // three bf16 copies of hT
+           (bwb_shape(cfg, nb) ? nb * 96 : 0) +            // three bf16 copies of hT
+           (bwhb_shape(cfg, nb) ? hb_img_floats(cfg->D) : 0);   // unit images of the hidden-gradient kernel
 }
 
 int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
@@ -638,6 +643,20 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
             if (rc) return rc;
             f1t = yT && !rows && yT_stride % 16 == 0 && yT_stride >= nb && aligned16(yT) && cfg->J >= 32 &&
                   f1_lds_bytes(cfg->J) <= 160 * 1024;
+            if (bwhb_shape(cfg, nb)) {
+                float* gdT1 = slabs_f + (int64_t)n_prf * lenf;
+                uint8_t* himg = (uint8_t*)(gdT1 + nb * D + 4 + (bwb_shape(cfg, nb) ? nb * 96 : 0));
+                hipLaunchKernelGGL(k_pack_heads_hb, dim3(hb_units(dm.D)), dim3(256), 0, st, dm.D, W21, W22, himg);
+                VX_CHECK_LAUNCH();
+                const size_t ldsh = hb_lds_bytes(dm.D);
+                rc = set_lds(k_mvn_enc_bwd_h_b, ldsh);
+                if (rc) return rc;
+                ProfScope ps("k_mvn_enc_bwd_h_b", st);
+                hipLaunchKernelGGL(k_mvn_enc_bwd_h_b, dim3((unsigned)((nb + 127) / 128)), dim3(HB_THREADS), ldsh, st, dm,
+                                   (const uint8_t*)himg, h, eps, gxT, (const float*)gdT1, f1t ? (float*)nullptr : ghpre, hT,
+                                   f1t ? ghpre : (float*)nullptr);
+                VX_CHECK_LAUNCH();
+            } else {
             long long* stamps = nullptr;
             if (getenv("VX_STAMPS") && hipMalloc(&stamps, 2048 * 8 * sizeof(long long)) == hipSuccess)
                 (void)hipMemset(stamps, 0, 2048 * 8 * sizeof(long long));
@@ -660,6 +679,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                 }
                 if (nblk) fprintf(stderr, "bwd_h_t stamps (mean over %d blocks): prologue %.0f off %.0f tail %.0f out %.0f\n", nblk,
                                   acc[0] / nblk, acc[1] / nblk, acc[2] / nblk, acc[3] / nblk);
+            }
             }
         } else {
             if (!gx) return VX_EINVAL;                     // the person-major kernel needs gx[nb][D]
