@@ -18,4 +18,18 @@ for C in "FETCH_SIZE" "WRITE_SIZE" \
     rocprofv3 --pmc $C -d /tmp/pmc_${TAG}_$i -o r -- python3 $R/bench.py --no-cpu-baseline --steps 1 --warmup 1 "$@" > $OUT/pmc_$i.log 2>&1
 done
 python3 $R/tools/rocpd_pmc.py /tmp/pmc_${TAG}_1/r_results.db /tmp/pmc_${TAG}_2/r_results.db /tmp/pmc_${TAG}_3/r_results.db /tmp/pmc_${TAG}_4/r_results.db --match k_ --json $OUT/pmc_counters.json > /dev/null
+# HBM bytes per launch (MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE count KB; on gfx950 FETCH_SIZE reports
+# half of the bytes of wide streaming reads, so it is doubled)
+python3 - "$OUT/pmc_counters.json" "$OUT/hbm_traffic.json" <<'PY'
+import json, sys
+c = json.load(open(sys.argv[1]))
+out = {"note": "per launch; hbm_read_bytes_corrected = FETCH_SIZE KB x 1024 x 2 (gfx950), hbm_write_bytes = WRITE_SIZE KB x 1024",
+       "kernels": {}}
+for k, v in c.items():
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        out["kernels"][k] = {"FETCH_SIZE_KB": v["FETCH_SIZE"], "WRITE_SIZE_KB": v["WRITE_SIZE"],
+                             "hbm_read_bytes_corrected": v["FETCH_SIZE"] * 1024 * 2,
+                             "hbm_write_bytes": v["WRITE_SIZE"] * 1024}
+json.dump(out, open(sys.argv[2], "w"), indent=1, sort_keys=True)
+PY
 rm -rf /tmp/prof_$TAG /tmp/pmc_${TAG}_*

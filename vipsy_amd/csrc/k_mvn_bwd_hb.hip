@@ -10,12 +10,15 @@
 // LOC rows (operand gx) are two more small GEMMs straight into the gh accumulator.
 //   MFMA 32x32x16: C rows = hidden units (two tiles of 32), columns = persons; contraction index = l (or k).
 //   unit (k, s) = the 16 contraction indices l = 16 s .. 16 s + 15 of one k: 6 fragments of 1 KB (2 hidden tiles x 3
-//   splits), 12 MFMAs.  Units stream through a ring of 8 slots in LDS by DMA, shared by the 4 waves of the workgroup
-//   (pairs of units = 12 transfers = 3 per wave, so `vmcnt(3)` counts whole pairs); one barrier per pair.
+//   splits), 12 MFMAs.  Units stream through a ring of 8 slots in LDS by DMA, shared by the 8 waves of the workgroup
+//   (pairs of units = 12 transfers = 3 for each of the waves 0..3, so `vmcnt(3)` counts whole pairs); one barrier per
+//   pair.  Two waves per SIMD (the kernel fits 256 registers): what one wave cannot overlap -- the epilogue per k,
+//   LDS waits, the barrier -- runs under the other wave's MFMAs.
 //   k runs in blocks of 16 so that the number of units per k -- and with it every fragment register -- is static.
 // (included by vx_abi.hip after k_mvn_fwd_b.hip)
 
-#define HB_THREADS 256
+#define HB_THREADS 512
+#define HB_WAVES 8                                                     // two per SIMD: one wave's epilogue / waits under the other's MFMAs
 #define HB_UNIT_BYTES 6144
 #define HB_NSLOT 8
 #define HB_NS 8                                                        // k-steps of 16 covering D <= 128
@@ -28,7 +31,7 @@ __host__ __device__ inline int hb_units_off(int D) {
 __host__ __device__ inline int hb_units(int D) { return hb_units_off(D) + 2 * ((D + 15) / 16); }
 __host__ __device__ inline int64_t hb_img_floats(int D) { return (int64_t)hb_units(D) * (HB_UNIT_BYTES / 4); }
 __host__ __device__ inline size_t hb_lds_bytes(int D) {
-    return (size_t)4 * D * 32 * sizeof(float) + (size_t)HB_NSLOT * HB_UNIT_BYTES;
+    return (size_t)HB_WAVES * D * 32 * sizeof(float) + (size_t)HB_NSLOT * HB_UNIT_BYTES;
 }
 
 // unit image: fragment (hidden tile ht, split sp) at byte (ht * 3 + sp) * 1024 + lane * 16, lane = 32 half + row;
@@ -84,9 +87,9 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     float* gx_lds = (float*)smem_hb + (size_t)wave * D * 32;           // [D][32] of this wave
-    const char* ring = smem_hb + (size_t)4 * D * 32 * sizeof(float);
+    const char* ring = smem_hb + (size_t)HB_WAVES * D * 32 * sizeof(float);
     const uint32_t ring_lds = lds_addr_uniform(ring);
-    const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    const int64_t i0 = ((int64_t)blockIdx.x * HB_WAVES + wave) * 32;
     const int64_t i = i0 + l31;
     const int64_t ic = i < nb ? i : nb - 1;                            // absent persons: a valid one, never stored
     const int n_units = hb_units(D), n_pairs = (n_units + 1) / 2;
@@ -95,6 +98,7 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
     // ---- weight ring: pair q = units 2q, 2q + 1 -> slots (2q) % 8, (2q + 1) % 8; this wave moves pieces w, w + 4, w + 8
     const uint32_t voff = (uint32_t)(wave * 1024 + lane * 16);
     auto stage_pair = [&](int q) __attribute__((always_inline)) {
+        if (wave >= 4) return;                                         // waves 0..3 feed the ring for all eight
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int piece = wave + 4 * c;                            // 0..11: unit piece / 6, fragment piece % 6
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
     };
     // pair boundary: pair q + 1 has landed for every wave, the slots of pair q - 1 are free for pair q + 3
     auto sync_pair = [&](int q) __attribute__((always_inline)) {
-        __builtin_amdgcn_s_waitcnt(0x0F73);                            // vmcnt(3): only pair q + 2 may be in flight
+        if (wave < 4) __builtin_amdgcn_s_waitcnt(0x0F73);              // vmcnt(3): only pair q + 2 may be in flight
         __syncthreads();
         stage_pair(q + 3);
     };

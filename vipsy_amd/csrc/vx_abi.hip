@@ -652,7 +652,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                 rc = set_lds(k_mvn_enc_bwd_h_b, ldsh);
                 if (rc) return rc;
                 ProfScope ps("k_mvn_enc_bwd_h_b", st);
-                hipLaunchKernelGGL(k_mvn_enc_bwd_h_b, dim3((unsigned)((nb + 127) / 128)), dim3(HB_THREADS), ldsh, st, dm,
+                hipLaunchKernelGGL(k_mvn_enc_bwd_h_b, dim3((unsigned)((nb + 32 * HB_WAVES - 1) / (32 * HB_WAVES))), dim3(HB_THREADS), ldsh, st, dm,
                                    (const uint8_t*)himg, h, eps, gxT, (const float*)gdT1, f1t ? (float*)nullptr : ghpre, hT,
                                    f1t ? ghpre : (float*)nullptr);
                 VX_CHECK_LAUNCH();
