@@ -26,7 +26,7 @@
 
 __host__ __device__ inline int fb_tiles(int D) { return (pk_off_total(D) + 2 * pk_sec(D)) / 32; }
 __host__ __device__ inline int64_t fb_img_floats(int D) {               // tile images + the OFF group table
-    return (int64_t)fb_tiles(D) * (FB_IMG_BYTES / 4) + pk_off_total(D) / 8 + 8;
+    return (int64_t)fb_tiles(D) * (FB_IMG_BYTES / 4) + (pk_off_total(D) / 8 + 8 + 3) / 4 * 4;
 }
 __host__ __device__ inline size_t fb_lds_bytes(int D, int J) {
     return FB_WAVES * enc_p_wave_floats(D, J) * sizeof(float) + (size_t)FB_NST * FB_STAGE_BYTES +
@@ -77,6 +77,29 @@ __global__ void k_pack_heads_b(int n_tiles, int n_off_groups, const float* __res
     }
 }
 
+// fc1 weights as k-step images: k-step ks (items 16 ks .. + 15), fragment (hidden tile ht, split sp) at byte
+// ks * 6144 + (ht * 3 + sp) * 1024 + lane * 16, lane = 32 half + row; element j = W1[32 ht + row][16 ks + 8 half + j]
+// (zero past J)
+__host__ __device__ inline int64_t fb_w1img_floats(int J) { return (int64_t)((J + 15) / 16) * (6144 / 4); }
+__global__ void k_pack_w1_b(int J, const float* __restrict__ W1, uint8_t* __restrict__ w1img) {
+    const int ks = blockIdx.x;
+    uint8_t* out = w1img + (int64_t)ks * 6144;
+    for (int e = threadIdx.x; e < 2 * 64 * 8; e += blockDim.x) {       // (ht, lane, j)
+        const int j = e & 7, lane = (e >> 3) & 63, ht = e >> 9;
+        const int half = lane >> 5, hh = 32 * ht + (lane & 31);
+        const int it = 16 * ks + 8 * half + j;
+        const float v = it < J ? W1[(int64_t)hh * J + it] : 0.f;
+        const __bf16 h = (__bf16)v;
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const __bf16 l = (__bf16)(r1 - (float)m);
+        uint16_t* o = (uint16_t*)(out + (ht * 3) * 1024 + lane * 16) + j;
+        o[0] = __builtin_bit_cast(uint16_t, h);
+        o[512] = __builtin_bit_cast(uint16_t, m);
+        o[1024] = __builtin_bit_cast(uint16_t, l);
+    }
+}
+
 // eight fp32 values -> three bf16 fragments by truncation: v = hi + mid + lo exactly (8 + 8 + 8 significand bits)
 __device__ __forceinline__ void fb_split8(const float* v, bf16x8& fh, bf16x8& fm, bf16x8& fl) {
     typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
@@ -104,12 +127,13 @@ __device__ __forceinline__ void fb_split8(const float* v, bf16x8& fh, bf16x8& fm
 
 __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, int64_t gid0,
-    const float* __restrict__ W1, const float* __restrict__ b1, const uint8_t* __restrict__ img,
+    const uint8_t* __restrict__ w1img, const float* __restrict__ b1, const uint8_t* __restrict__ img,
     const uint32_t* __restrict__ gt2, const float* __restrict__ eps_in, uint64_t seed, uint32_t step, uint32_t stream, float* __restrict__ h_out,
     float* __restrict__ x_out, float* __restrict__ eps_out, float* __restrict__ ldT, float* __restrict__ ent_out,
     float* __restrict__ hT_out /*[64][nb] or null*/, float* __restrict__ epsT_out /*[D][nb] or null*/,
     long long* __restrict__ stamps /*timing experiments only, normally null*/) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
     constexpr int H = 64;
     const int D = dm.D, J = dm.J;
     const int DS = pk_dse(D), DX = (D + 3) & ~3;
@@ -193,52 +217,44 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     {
         f32x16 hreg[2];
         f32x16 acc0 = zero16(), acc1 = zero16();
-        const int nfull = J / 32;
-        auto loadA = [&](float4 (&A)[2][4], int c) {
-            c = c < nfull ? c : nfull - 1;
-            const int j0 = c * 32 + half * 16;
+        // pre[hh][p] = sum_j W1[hh][j] yin[p][j] on the bf16 MFMA: the response bytes (-1 / 0 / 1) are exact in bf16, so
+        // three products per 16-item k-step and hidden tile (W1 hi, mid, lo -- split once per step into w1img by
+        // k_pack_w1_b); the six 16-byte fragments of a k-step go global -> registers three k-steps ahead.
+        const int n_ks = (J + 15) / 16;
+        auto loadA = [&](bf16x8 (&Af)[6], int ks) __attribute__((always_inline)) {
+            ks = ks < n_ks ? ks : n_ks - 1;                   // past the end: reload the last k-step (never used)
+            const uint8_t* src = w1img + (int64_t)ks * 6144 + lane * 16;
 #pragma unroll
-            for (int ht = 0; ht < 2; ++ht) {
-                const float* src = W1 + (int64_t)(32 * ht + l31) * J + j0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) A[ht][q] = *(const float4*)(src + 4 * q);
-            }
+            for (int f = 0; f < 6; ++f) Af[f] = *(const bf16x8*)(src + f * 1024);
         };
-        auto compute = [&](const float4 (&A)[2][4], int c) {
-            const int8_t* yp = Yi + p * ysr + c * 32 + half * 16;
+        typedef uint32_t u32x2w __attribute__((ext_vector_type(2)));
+        auto compute = [&](const bf16x8 (&Af)[6], int ks) __attribute__((always_inline)) {
+            // B fragment: items 16 ks + 8 half + 0..7 of person p; byte b in {0, 1, 255} -> bf16 {0, 1, -1}:
+            // (b & 1) * 0x3F80 | (b & 0x80) << 8, two bytes per dword
+            const uint32_t* yw = (const uint32_t*)(Yi + p * ysr + 16 * ks + 8 * half);   // rows are 4-byte aligned
+            const u32x2w w = {yw[0], yw[1]};
+            u32x4w q;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int w = *(const int*)(yp + 4 * q);
-                const float y0 = (float)((w << 24) >> 24), y1 = (float)((w << 16) >> 24);
-                const float y2 = (float)((w << 8) >> 24), y3 = (float)(w >> 24);
-                acc0 = mfma32(A[0][q].x, y0, acc0); acc1 = mfma32(A[1][q].x, y0, acc1);
-                acc0 = mfma32(A[0][q].y, y1, acc0); acc1 = mfma32(A[1][q].y, y1, acc1);
-                acc0 = mfma32(A[0][q].z, y2, acc0); acc1 = mfma32(A[1][q].z, y2, acc1);
-                acc0 = mfma32(A[0][q].w, y3, acc0); acc1 = mfma32(A[1][q].w, y3, acc1);
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t src = w[d >> 1];
+                const uint32_t t = (d & 1) ? __builtin_amdgcn_perm(0u, src, 0x0c030c02u) : __builtin_amdgcn_perm(0u, src, 0x0c010c00u);
+                q[d] = (t & 0x00010001u) * 0x3F80u | ((t & 0x00800080u) << 8);
             }
+            const bf16x8 yb = __builtin_bit_cast(bf16x8, q);
+            acc0 = mfma_bf16(Af[2], yb, acc0); acc1 = mfma_bf16(Af[5], yb, acc1);
+            acc0 = mfma_bf16(Af[1], yb, acc0); acc1 = mfma_bf16(Af[4], yb, acc1);
+            acc0 = mfma_bf16(Af[0], yb, acc0); acc1 = mfma_bf16(Af[3], yb, acc1);
         };
-        if (nfull > 0) {
-            float4 A[4][2][4];
+        {
+            bf16x8 A[4][6];
             loadA(A[0], 0); loadA(A[1], 1); loadA(A[2], 2);
-            for (int c = 0; c < nfull; c += 4) {
+            for (int c = 0; c < n_ks; c += 4) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     loadA(A[(u + 3) & 3], c + u + 3);
-                    if (c + u < nfull) compute(A[u], c + u);
+                    if (c + u < n_ks) compute(A[u], c + u);
                 }
             }
-        }
-        if (nfull * 32 < J) {                                 // ragged last chunk: items past J contribute nothing
-            float4 At[2][4];
-            const int j0 = nfull * 32 + half * 16;
-#pragma unroll
-            for (int ht = 0; ht < 2; ++ht) {
-                const float* src = W1 + (int64_t)(32 * ht + l31) * J + j0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    At[ht][q] = (j0 + 4 * q + 4 <= J) ? *(const float4*)(src + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            compute(At, nfull);
         }
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht) {
@@ -312,7 +328,6 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
 #pragma unroll
             for (int s = 0; s < 4; ++s) R.a[sp][s] = *(const bf16x8*)(sb + (sp * 4 + s) * 1024 + lane * 16);
     };
-    typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
     const bf16x8 ones8 = __builtin_bit_cast(bf16x8, u32x4w{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
     // the chain starts from the bias (one MFMA against ones); products in order of increasing magnitude
     auto mma_lo = [&](const TileRegs& R) __attribute__((always_inline)) -> f32x16 {

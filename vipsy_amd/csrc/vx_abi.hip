@@ -283,6 +283,9 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
             uint8_t* img = (uint8_t*)(WpT + (int64_t)Rp * 64);
             const int n_tiles = fb_tiles(dm.D);
             uint32_t* gt2 = (uint32_t*)(img + (int64_t)n_tiles * FB_IMG_BYTES);
+            uint8_t* w1img = img + fb_img_floats(dm.D) * 4;
+            hipLaunchKernelGGL(k_pack_w1_b, dim3((dm.J + 15) / 16), dim3(256), 0, (hipStream_t)hs, dm.J, W1, w1img);
+            VX_CHECK_LAUNCH();
             hipLaunchKernelGGL(k_pack_heads_b, dim3(n_tiles), dim3(256), 0, (hipStream_t)hs, n_tiles,
                                pk_off_total(dm.D) / 8, Wp, bp, gtab, img, gt2);
             VX_CHECK_LAUNCH();
@@ -292,8 +295,8 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
             const dim3 gridb((unsigned)((nb + FB_WAVES * FB_WP - 1) / (FB_WAVES * FB_WP)));
             long long* stamps = stamps_alloc();
             ProfScope ps("k_mvn_enc_fwd_b", (hipStream_t)hs);
-            hipLaunchKernelGGL(k_mvn_enc_fwd_b, gridb, dim3(FB_THREADS), ldsb, (hipStream_t)hs, dm, y, rows, gid0, W1, b1,
-                               (const uint8_t*)img, (const uint32_t*)gt2, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT,
+            hipLaunchKernelGGL(k_mvn_enc_fwd_b, gridb, dim3(FB_THREADS), ldsb, (hipStream_t)hs, dm, y, rows, gid0,
+                               (const uint8_t*)w1img, b1, (const uint8_t*)img, (const uint32_t*)gt2, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT,
                                stamps);
             VX_CHECK_LAUNCH();
             stamps_report(stamps, "fwd_b", gridb.x);
@@ -567,7 +570,8 @@ int vx_mvn_enc_bwd_layout(const vx_irt_cfg* cfg, int64_t nb) {
 int64_t vx_mvn_pack_floats(const vx_irt_cfg* cfg) {
     if (!enc_cfg_ok(cfg)) return VX_EINVAL;
     const int64_t Rp = pk_rows(cfg->D);
-    return Rp * 64 + Rp + Rp / 8 + 8 + Rp * 64 + fb_img_floats(cfg->D);   // Wp | bp | gtab | WpT | bf16x3 tile images
+    // Wp | bp | gtab | WpT | bf16x3 tile images of the heads | bf16x3 k-step images of fc1
+    return Rp * 64 + Rp + Rp / 8 + 8 + Rp * 64 + fb_img_floats(cfg->D) + fb_w1img_floats(cfg->J);
 }
 
 int64_t vx_mvn_enc_param_floats(const vx_irt_cfg* cfg) {
