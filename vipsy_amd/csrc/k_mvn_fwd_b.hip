@@ -443,32 +443,27 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     auto tile_sec = [&](const f32x16& a, int t2) __attribute__((always_inline)) {
         const bool is_diag = t2 < n_off + n_sec;
         const int k0 = 32 * (t2 - (is_diag ? n_off : n_off + n_sec));
-        const bool allv = k0 + 32 <= D;                        // wave-uniform: no per-entry bounds below
-        float xo[16], ev[16];
+        // accumulator registers 4g .. 4g + 3 of a lane are the four consecutive k = k0 + 8g + 4half + 0..3: 16-byte LDS
+        // accesses; D % 4 == 0, so a group of four is inside D or outside it as a whole (wave-uniform per lane half)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int kk = k0 + crow32(r, half);
-            kk = (allv || kk < D) ? kk : D - 1;
-            xo[r] = xp[kk];
-            ev[r] = ep[kk];
-        }
-        if (is_diag) {                                         // exp(diag M) eps_k, entropy, ldT  (vi.py:686)
+        for (int g = 0; g < 4; ++g) {
+            const int kk = k0 + 8 * g + 4 * half;
+            if (kk < D) {
+                f32x4 xo = *(const f32x4*)(xp + kk);
+                if (is_diag) {                                 // exp(diag M) eps_k, entropy, ldT  (vi.py:686)
+                    const f32x4 ev = *(const f32x4*)(ep + kk);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kk = k0 + crow32(r, half);
-                const float ld = __expf(a[r]);
-                const bool ok = allv || kk < D;
-                if (ok) {
-                    xp[kk] = fmaf(ld, ev[r], xo[r]);
-                    ent_acc += a[r];
-                    if (i < dm.nb) ldT[(int64_t)kk * dm.nb + i] = ld;
+                    for (int j = 0; j < 4; ++j) {
+                        const float ld = __expf(a[4 * g + j]);
+                        xo[j] = fmaf(ld, ev[j], xo[j]);
+                        ent_acc += a[4 * g + j];
+                        if (i < dm.nb) ldT[(int64_t)(kk + j) * dm.nb + i] = ld;
+                    }
+                } else {                                       // loc head (vi.py:450)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xo[j] += a[4 * g + j];
                 }
-            }
-        } else {                                               // loc head (vi.py:450)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kk = k0 + crow32(r, half);
-                if (allv || kk < D) xp[kk] = xo[r] + a[r];
+                *(f32x4*)(xp + kk) = xo;
             }
         }
     };
