@@ -180,12 +180,38 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     const bool ydense = !rows && ((J >> 2) & 1) && i0 + FB_WP <= dm.nb && (i0 * J + (int64_t)n_ydma * 1024 <= dm.nb * (int64_t)J) &&
                         (size_t)n_ydma * 1024 <= enc_p_wave_floats(D, J) * sizeof(float);
     const int ysr = ydense ? J : YS;                          // LDS row stride of the response bytes
+    // the normals of this wave's 32 persons (D / 4 Philox blocks each) are drawn into registers while the response
+    // rows are in flight: the draw needs no memory, the DMA latency at the head of the workgroup is otherwise exposed
+    constexpr int FB_EQ = 16;                                 // 32 * (D / 4) / 64 <= 16 for D <= 128
+    f32x4 zq[FB_EQ];
+    const int nblk = D >> 2;                                  // D % 4 == 0 on this path
+    auto draw_eps = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < FB_EQ; ++q) {
+            const int e = lane + 64 * q;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            if (e < FB_WP * nblk) {
+                const int pp = e / nblk, blk = e - pp * nblk;
+                int64_t ii = i0 + pp;
+                if (ii >= dm.nb) ii = dm.nb - 1;              // absent persons: any finite values, never stored
+                if (eps_in) {
+                    z = *(const f32x4*)(eps_in + ii * D + 4 * blk);
+                } else {
+                    const int64_t row = rows ? rows[ii] : ii;
+                    z = philox_normal4(seed, step, stream, gid0 + row, (uint32_t)blk);
+                }
+            }
+            zq[q] = z;
+        }
+    };
     if (ydense) {
         const uint8_t* src = y + i0 * J + 16 * lane;
         const uint32_t lb = lds_addr_uniform(R1);
         for (int d = 0; d < n_ydma; ++d) dma16(src + d * 1024, lb + (uint32_t)d * 1024u);
+        draw_eps();
         vx_wait_vmem();
     } else {
+        draw_eps();
         const int YW = YS / 4, JW = J / 4;
         uint32_t* Yw = (uint32_t*)R1;
         for (int base = 0; base < FB_WP * YW; base += 64 * 8) {
@@ -293,20 +319,14 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     {
         for (int e = lane; e < FB_WP * (DS + DX); e += 64) R1[e] = 0.f;
         __builtin_amdgcn_wave_barrier();
-        const int nblk = D >> 2;                               // D % 4 == 0 on this path
-        for (int e = lane; e < FB_WP * nblk; e += 64) {
-            const int pp = e / nblk, blk = e - pp * nblk;
-            int64_t ii = i0 + pp;
-            if (ii >= dm.nb) ii = dm.nb - 1;                   // absent persons: any finite values, never stored
-            f32x4 z;
-            if (eps_in) {
-                z = *(const f32x4*)(eps_in + ii * D + 4 * blk);
-            } else {
-                const int64_t row = rows ? rows[ii] : ii;
-                z = philox_normal4(seed, step, stream, gid0 + row, (uint32_t)blk);
+#pragma unroll
+        for (int q = 0; q < FB_EQ; ++q) {
+            const int e = lane + 64 * q;
+            if (e < FB_WP * nblk) {
+                const int pp = e / nblk, blk = e - pp * nblk;
+                *(f32x4*)(eps_lds + pp * DS + 4 * blk) = zq[q];
+                if (i0 + pp < dm.nb) *(f32x4*)(eps_out + (i0 + pp) * D + 4 * blk) = zq[q];
             }
-            *(f32x4*)(eps_lds + pp * DS + 4 * blk) = z;
-            if (i0 + pp < dm.nb) *(f32x4*)(eps_out + ii * D + 4 * blk) = z;
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -376,7 +396,10 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         }
     };
 
-    vx_wait_vmem();                                            // stores of the phases above + tiles 0..3 of the ring
+    // Tiles 0..3 of the ring were requested at the head of the kernel; loads complete in order and the fc1 phase has
+    // waited for W1 fragments requested after them, so they have landed -- no `vmcnt(0)` here: it would expose the
+    // completion latency of the output stores above (h, hT, eps, epsT; measured: no difference either way).  Stores
+    // still outstanding only make the counted waits of the first iterations stricter.
     __syncthreads();
     stamp(3);
     TileRegs RA, RB;

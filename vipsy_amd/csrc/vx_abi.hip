@@ -96,7 +96,7 @@ int bf16x3_mode() {
     return v;
 }
 bool fwb_shape(const vx_irt_cfg* cfg) {
-    return (bf16x3_mode() & 1) && packed_ok(cfg) && fb_lds_bytes(cfg->D, cfg->J) <= 160 * 1024;
+    return (bf16x3_mode() & 1) && packed_ok(cfg) && cfg->D <= 128 && fb_lds_bytes(cfg->D, cfg->J) <= 160 * 1024;
 }
 
 bool enc_cfg_ok(const vx_irt_cfg* cfg) {
