@@ -134,6 +134,13 @@ def _random_problem(N, J, D, H, model, miss, seed):
     (36, 40, 8, 64, "irt_2pl", 0.1, None),          # a single ragged person tile in every dimension-major kernel
     (4, 36, 4, 64, "irt_2pl", 0.0, None),           # the smallest batch those kernels accept
     (2000, 500, 100, 64, "irt_2pl", 0.0, 1000),     # headline shape with a row gather (subsample): FAST == 2 staging
+    # shapes aimed at the static structure of the bf16x3 kernels: k-blocks of 16 in the hidden gradient (one block,
+    # two blocks, all eight), a partial last DIAG / LOC tile, fc1 k-steps with a ragged tail, a ragged last person tile
+    (260, 48, 16, 64, "irt_2pl", 0.1, None),
+    (200, 64, 20, 64, "irt_3pl", 0.2, None),
+    (136, 100, 124, 64, "irt_2pl", 0.1, None),
+    (300, 260, 112, 64, "irt_4pl", 0.3, 104),
+    (264, 36, 36, 64, "irt_2pl", 0.0, None),
 ])
 def test_mvn_amortized_step_vs_oracle(N, J, D, H, model, miss, B):
     from vipsy_amd.engine import IrtEngine, ENC_KEYS
