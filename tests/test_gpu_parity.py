@@ -252,7 +252,8 @@ print("RESULT" + json.dumps(out))
     res = {}
     switches = {"0": {}, "1": {"VX_FORCE_GENERIC": "1"}, "fast": {"VX_MVN": "fast"}, "bwdw": {"VX_BWDW": "old"},
                 "bwdh": {"VX_BWDH": "old"}, "lik": {"VX_LIK": "old"}, "fp32": {"VX_BF16X3": "0"},
-                "b3f": {"VX_BF16X3": "f"}, "b3w": {"VX_BF16X3": "w"}, "b3h": {"VX_BF16X3": "h"}}
+                "b3f": {"VX_BF16X3": "f"}, "b3w": {"VX_BF16X3": "w"}, "b3h": {"VX_BF16X3": "h"},
+                "b3g": {"VX_BF16X3": "g"}}
     for mode, extra in switches.items():
         env = dict(os.environ, VX_FORCE_GENERIC="0", VX_MVN="packed")
         env.update(extra)
@@ -262,7 +263,7 @@ print("RESULT" + json.dumps(out))
         res[mode] = json.loads(line[6:])
     # every kernel generation -- the default bf16x3 kernels ("0"), the fp32-MFMA ones and the mixed selections --
     # against the shape-generic ones
-    for m in ("0", "fast", "bwdw", "bwdh", "lik", "fp32", "b3f", "b3w", "b3h"):
+    for m in ("0", "fast", "bwdw", "bwdh", "lik", "fp32", "b3f", "b3w", "b3h", "b3g"):
         assert res[m]["loss"] == pytest.approx(res["1"]["loss"], rel=1e-6)
         x0, x1 = np.array(res[m]["x"]), np.array(res["1"]["x"])
         np.testing.assert_allclose(x0, x1, atol=2e-5, rtol=1e-5)

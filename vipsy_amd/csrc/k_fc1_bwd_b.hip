@@ -1,0 +1,113 @@
+// fc1 weight gradient on the bf16 MFMA, from dimension-major operands (full batch, no row gather): the same result and
+// slab format as k_fc1_bwd_t (k_mvn_bwd_t.hip),
+//     GW1[hh][j] = sum_p ghpreT[hh][p] yin[p][j],   Gb1[hh] = sum_p ghpreT[hh][p]         (yin = int8 -1 / 0 / 1)
+// MFMA 32x32x16: C rows = hidden units, columns = items, contraction index = persons (16 per k-step).
+//   B = the response bytes of 8 consecutive persons of an item row of yT: exact in bf16, converted in registers;
+//   A = 8 consecutive persons of a ghpreT row, split into three bf16 terms in registers -> 3 products per k-step.
+//   The bias gradient is the column of a virtual item J whose responses are all 1.
+// A wave owns 4 item tiles x both hidden tiles (128 accumulator registers); operands go global -> registers one
+// k-step ahead (consecutive k-steps of a lane continue in the same cache lines); no LDS.
+// (included by vx_abi.hip after k_mvn_fwd_b.hip)
+
+#define F1B_THREADS 256
+
+__global__ __launch_bounds__(F1B_THREADS, 1) void k_fc1_bwd_b(
+    EncDims dm, const uint8_t* __restrict__ yT, int64_t ystride, const float* __restrict__ ghpreT,
+    float* __restrict__ slabs, int64_t slab_len) {
+    typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2w __attribute__((ext_vector_type(2)));
+    const int J = dm.J;
+    const int64_t nb = dm.nb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int jw0 = blockIdx.x * 512 + 128 * wave;                     // items of this wave: jw0 .. jw0 + 127 (item J = bias)
+    if (jw0 > J) return;                                               // waves share nothing
+    const uint8_t* yrow[4];
+    int kind[4];                                                       // 0: response row, 1: ones (the bias column), 2: nothing
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int j = jw0 + 32 * t + l31;
+        kind[t] = j < J ? 0 : (j == J ? 1 : 2);
+        yrow[t] = yT + (int64_t)(j < J ? j : 0) * ystride + 8 * half;
+    }
+    const float* grow[2] = {ghpreT + (int64_t)l31 * nb + 8 * half, ghpreT + (int64_t)(32 + l31) * nb + 8 * half};
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { acc[t][0] = zero16(); acc[t][1] = zero16(); }
+
+    struct Ops { f32x4 g[2][2]; u32x2w y[4]; };
+    auto load = [&](Ops& o, int64_t ks) __attribute__((always_inline)) {
+        const int64_t p0 = 16 * ks;                                    // this lane: persons p0 + 8 half + 0..7
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (p0 + 8 * half + 4 * q + 4 <= nb) v = *(const f32x4*)(grow[ht] + p0 + 4 * q);   // nb % 4 == 0
+                o.g[ht][q] = v;
+            }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o.y[t] = *(const u32x2w*)(yrow[t] + p0);     // ystride % 16 == 0, >= nb rounded to 16
+    };
+    auto compute = [&](const Ops& o) __attribute__((always_inline)) {
+        bf16x8 a[2][3];
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+            const float v[8] = {o.g[ht][0][0], o.g[ht][0][1], o.g[ht][0][2], o.g[ht][0][3],
+                                o.g[ht][1][0], o.g[ht][1][1], o.g[ht][1][2], o.g[ht][1][3]};
+            fb_split8(v, a[ht][0], a[ht][1], a[ht][2]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            u32x4w q;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {                              // byte b in {0, 1, 255} -> bf16 {0, 1, -1}
+                const uint32_t src = o.y[t][d >> 1];
+                const uint32_t w = (d & 1) ? __builtin_amdgcn_perm(0u, src, 0x0c030c02u) : __builtin_amdgcn_perm(0u, src, 0x0c010c00u);
+                q[d] = (w & 0x00010001u) * 0x3F80u | ((w & 0x00800080u) << 8);
+                if (kind[t] == 1) q[d] = 0x3F803F80u;
+                if (kind[t] == 2) q[d] = 0u;
+            }
+            const bf16x8 yb = __builtin_bit_cast(bf16x8, q);
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht) {
+                acc[t][ht] = mfma_bf16(a[ht][2], yb, acc[t][ht]);
+                acc[t][ht] = mfma_bf16(a[ht][1], yb, acc[t][ht]);
+                acc[t][ht] = mfma_bf16(a[ht][0], yb, acc[t][ht]);
+            }
+        }
+    };
+    // a workgroup walks a CONTIGUOUS range of k-steps: consecutive loads of a lane continue in the same cache lines
+    const int64_t n_ks = (nb + 15) / 16, per = (n_ks + gridDim.y - 1) / gridDim.y;
+    int64_t ks = (int64_t)blockIdx.y * per;
+    const int64_t ks_end = (ks + per < n_ks) ? ks + per : n_ks;
+    if (ks < ks_end) {
+        Ops oa, ob;
+        load(oa, ks);
+        while (true) {
+            if (ks + 1 < ks_end) load(ob, ks + 1);
+            compute(oa);
+            if (++ks >= ks_end) break;
+            if (ks + 1 < ks_end) load(oa, ks + 1);
+            compute(ob);
+            if (++ks >= ks_end) break;
+        }
+    }
+    // slab: [W1-grad: 64 * J | b1-grad: 64]
+    float* slab = slabs + (int64_t)blockIdx.y * slab_len;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int j = jw0 + 32 * t + l31;
+        if (j <= J) {
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int hh = 32 * ht + crow32(r, half);
+                    if (j < J) slab[(int64_t)hh * J + j] = acc[t][ht][r];
+                    else slab[(int64_t)64 * J + hh] = acc[t][ht][r];
+                }
+        }
+    }
+}

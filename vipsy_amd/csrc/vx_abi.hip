@@ -18,6 +18,7 @@
 #include "k_mvn_bwd_b.hip"
 #include "k_mvn_fwd_b.hip"
 #include "k_mvn_bwd_hb.hip"
+#include "k_fc1_bwd_b.hip"
 
 #include <cstdlib>
 #include <cstring>
@@ -85,13 +86,13 @@ bool packed_ok(const vx_irt_cfg* cfg) {
 }
 
 // bf16x3 kernels (three-term bf16 operand splitting on the bf16 MFMA, fp32 accumulate; results at the accuracy of the
-// fp32-MFMA chain): the default.  VX_BF16X3 = 0 selects the fp32-MFMA kernels, f / w / h only the guide forward / the
-// weight gradient / the hidden gradient on the bf16 MFMA.
+// fp32-MFMA chain): the default.  VX_BF16X3 = 0 selects the fp32-MFMA kernels, f / w / h / g only the guide forward / the
+// head weight gradient / the hidden gradient / the fc1 weight gradient on the bf16 MFMA.
 int bf16x3_mode() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("VX_BF16X3");
-        v = (!e || e[0] == '1') ? 7 : (e[0] == 'f' ? 1 : e[0] == 'w' ? 2 : e[0] == 'h' ? 4 : 0);
+        v = (!e || e[0] == '1') ? 15 : (e[0] == 'f' ? 1 : e[0] == 'w' ? 2 : e[0] == 'h' ? 4 : e[0] == 'g' ? 8 : 0);
     }
     return v;
 }
@@ -771,7 +772,12 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
             VX_CHECK_LAUNCH();
         }
     }
-    if (nb > 0 && f1t) {
+    if (nb > 0 && f1t && (bf16x3_mode() & 8)) {
+        ProfScope ps("k_fc1_bwd_b", st);
+        hipLaunchKernelGGL(k_fc1_bwd_b, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0, st, dm,
+                           yT, yT_stride, ghpre, slabs_f, lenf);
+        VX_CHECK_LAUNCH();
+    } else if (nb > 0 && f1t) {
         const size_t lds = f1_lds_bytes(cfg->J);
         rc = set_lds(k_fc1_bwd_t, lds);
         if (rc) return rc;
@@ -1027,11 +1033,16 @@ int vx_norm_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t*
             float* ghpreT = slabs_f + (((int64_t)n_prf * lenf + 3) & ~(int64_t)3);
             hipLaunchKernelGGL(k_transpose, dim3(num_cu() * 8), dim3(256), 0, st, ghpre, ghpreT, nb, H);
             VX_CHECK_LAUNCH();
-            const size_t ldst = f1_lds_bytes(cfg->J);
-            rc = set_lds(k_fc1_bwd_t, ldst);
-            if (rc) return rc;
-            hipLaunchKernelGGL(k_fc1_bwd_t, dim3((unsigned)((cfg->J + 511) / 512), (unsigned)n_prf), dim3(F1_THREADS), ldst, st,
-                               dm, yT, yT_stride, ghpreT, slabs_f, lenf);
+            if (bf16x3_mode() & 8) {
+                hipLaunchKernelGGL(k_fc1_bwd_b, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0,
+                                   st, dm, yT, yT_stride, ghpreT, slabs_f, lenf);
+            } else {
+                const size_t ldst = f1_lds_bytes(cfg->J);
+                rc = set_lds(k_fc1_bwd_t, ldst);
+                if (rc) return rc;
+                hipLaunchKernelGGL(k_fc1_bwd_t, dim3((unsigned)((cfg->J + 511) / 512), (unsigned)n_prf), dim3(F1_THREADS), ldst, st,
+                                   dm, yT, yT_stride, ghpreT, slabs_f, lenf);
+            }
             VX_CHECK_LAUNCH();
             rc = vx_reduce_slabs(slabs_f, n_prf, lenf, -1.0f, genc, hs);
             if (rc) return rc;
