@@ -1,0 +1,69 @@
+"""Worker for tests/test_gpu_dist.py: the REAL HipBackend with the persons sharded over the ranks of a process group
+(RCCL when every rank has its own device, gloo when the ranks have to share one GPU)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from vipsy_amd.engine import IrtEngine, HoDinaEngine, LrSpec          # noqa: E402
+
+
+def main():
+    case, out_path = sys.argv[1], sys.argv[2]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    n_dev = torch.cuda.device_count()
+    dev = torch.device("cuda", rank % n_dev)
+    torch.cuda.set_device(dev)
+    group = None
+    if world > 1:
+        if n_dev >= world:
+            torch.distributed.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend="gloo", rank=rank, world_size=world)
+        group = torch.distributed.group.WORLD
+    rng = np.random.RandomState(321)
+    if case == "mvn":
+        N, J, D, H = 1056, 72, 8, 64
+    elif case == "irt1d":
+        N, J, D, H = 1000, 37, 1, 0
+    else:
+        N, J, D, H = 900, 30, 4, 0                     # hodina: D is K
+    y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+    y[rng.rand(N, J) < 0.15] = 255
+    per = (N + world - 1) // world
+    lo, hi = rank * per, min(N, rank * per + per)
+    yt = torch.from_numpy(y[lo:hi]).to(dev)
+    if case == "hodina":
+        q = (rng.rand(D, J) < 0.5).astype(np.float32)
+        q[0, q.sum(0) == 0] = 1
+        eng = HoDinaEngine(yt, q, n_global=N, gid0=lo, seed=77, group=group)
+    else:
+        eng = IrtEngine(yt, model="irt_2pl" if case == "mvn" else "irt_4pl", D=D, n_global=N, gid0=lo,
+                        amortized=(case == "mvn"), H=H, seed=77, group=group)
+    lrs = LrSpec(lambda m, n: {"lr": 1e-2 if n in ("a", "b", "g", "s") else 3e-3})
+    losses = []
+    for t in range(4):
+        if t == 2:                                      # one subsampled step: the same global draw on every rank
+            idx = np.sort(np.random.RandomState(1000 + t).permutation(N)[:N // 2])
+            mine = idx[(idx >= lo) & (idx < hi)] - lo
+            losses.append(float(eng.step(lrs, rows=torch.from_numpy(mine.astype(np.int64)).to(dev), b_global=len(idx))))
+        else:
+            losses.append(float(eng.step(lrs)))
+    torch.cuda.synchronize()
+    res = {"loss": losses, "P": eng.P.double().cpu().numpy().tolist(),
+           "backend": "nccl" if (world > 1 and n_dev >= world) else ("gloo" if world > 1 else "none")}
+    if eng.per_person:
+        res["PP"] = eng.PP.double().cpu().numpy().tolist()
+    with open(out_path + ".%d" % rank, "w") as f:
+        json.dump(res, f)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -33,8 +33,9 @@ def main():
                "fc22.bias": 0.05 * rng.randn(D * (D + 1) // 2)}
     per = (N + world - 1) // world
     lo, hi = rank * per, min(N, rank * per + per)
+    group = torch.distributed.group.WORLD if world > 1 else None       # sharding is explicit, never inferred
     eng = IrtEngine(torch.from_numpy(y[lo:hi]), model=model, D=D, n_global=N, gid0=lo, amortized=amort, H=8,
-                    encoder_init=enc, seed=77, backend=OracleBackend())
+                    encoder_init=enc, seed=77, backend=OracleBackend(), group=group, observed_lists=False)
     lrs = LrSpec(lambda m, n: {"lr": 1e-2 if n in ("a", "b") else 3e-3})
     losses = []
     # global subsample drawn identically on every rank, then intersected with the local shard

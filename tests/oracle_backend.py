@@ -93,11 +93,18 @@ class OracleBackend(object):
         x = loc + np.einsum("bij,bj->bi", L, eps)
         _put(out["h"], cache[2]); _put(out["x"], x); _put(out["eps"], eps)
         _put(out["ldT"], np.exp(diag).T.copy()); _put(out["ent"], 0.5 * (eps ** 2).sum(1) + diag.sum(1))
+        _put(out["hT"], cache[2].T.copy()); _put(out["epsT"], eps.T.copy())
+
+    def mvn_pack_floats(self, cfg):
+        return 1
+
+    def mvn_enc_bwd_layout(self, cfg, nb):
+        return 0                                            # person-major gx is what this backend's backward reads
 
     def lik_workspace(self, cfg, nb):
         return 1
 
-    def lik_grad(self, cfg, y, rows, nb, x, a, b, c_un, d_un, gx, ll, gitem, ws):
+    def lik_grad(self, cfg, y, rows, nb, x, a, b, c_un, d_un, gx, ll, gitem, ws, gxT=None):
         model, D, J = CODE_MODEL[cfg.model], cfg.D, cfg.J
         r = self._rows(rows, nb)
         yy = y.cpu().numpy()[r]
@@ -106,6 +113,8 @@ class OracleBackend(object):
         d = vo.sigmoid(_np(d_un, (1, J))) if d_un is not None else None
         lls, g = vo.irt_loglik(model, xx, _np(a, (D, J)), _np(b, (1, J)), c, d, cfg.Dc, yy)
         _put(gx, cfg.scale * (g["x"] - xx))
+        if gxT is not None:
+            _put(gxT, (cfg.scale * (g["x"] - xx)).T.copy())
         _put(ll, lls - 0.5 * (xx ** 2).sum(1))
         out = np.zeros(D * J + 3 * J)
         out[:D * J] = -cfg.scale * g["a"].reshape(-1)
@@ -119,7 +128,7 @@ class OracleBackend(object):
     def mvn_enc_bwd_workspace(self, cfg, nb):
         return 1
 
-    def mvn_enc_backward(self, cfg, y, rows, nb, enc, fw, gx, genc, ws):
+    def mvn_enc_backward(self, cfg, y, rows, nb, enc, fw, gx, genc, ws, gxT=None):
         D, J, H = cfg.D, cfg.J, cfg.H
         T = D * (D + 1) // 2
         r = self._rows(rows, nb)

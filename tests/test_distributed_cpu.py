@@ -39,3 +39,31 @@ def test_two_ranks_match_one_rank(case, port, tmp_path):
         raw = np.concatenate([np.array(r["PP"])[len(r["PP"]) // 2:] for r in two])
         np.testing.assert_allclose(loc, np.array(one["PP"])[:n], rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(raw, np.array(one["PP"])[n:], rtol=1e-4, atol=1e-6)
+
+
+def test_harness_replications_over_two_ranks(tmp_path):
+    """Replications spread over ranks (test.py:94-127 farms them to a process pool): every replication owns its problem
+    -- no all-reduce between different data sets -- and an uneven try_count (3 over 2 ranks) neither hangs nor changes
+    any error: the summary equals the single-process one bit for bit."""
+    import torch
+    from vipsy_amd import harness
+    worker = os.path.join(ROOT, "tests", "_harness_worker.py")
+    rng = np.random.RandomState(5)
+    for k in range(3):
+        y = rng.randint(0, 2, size=(40, 6)).astype(np.uint8)
+        y[rng.rand(40, 6) < 0.1] = 255
+        harness.save_case(str(tmp_path), "2pl", y, {"a": torch.rand(1, 6) + 0.5, "b": torch.randn(1, 6)}, 1, file_postfix=k)
+    res = {}
+    for world, port in ((1, 29631), (2, 29633)):
+        out = str(tmp_path / ("h_w%d" % world))
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        if world == 1:
+            cmd = [sys.executable, worker, str(tmp_path), out, "3"]
+        else:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), worker, str(tmp_path), out, "3"]
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        res[world] = [json.load(open(out + ".%d" % r)) for r in range(world)]
+    assert res[2][0] == res[2][1] == res[1][0]
+    assert set(res[1][0]) == {"a", "b"}

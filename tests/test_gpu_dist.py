@@ -1,0 +1,61 @@
+"""The sharded step on the real HIP path: world 2 against world 1 (tests/test_distributed_cpu.py covers the same host
+logic with the oracle backend on CPU).  With two devices visible the ranks use RCCL (backend nccl); on a one-GPU box
+both ranks share cuda:0 and exchange through gloo -- everything but the RCCL transport is what the 8-GPU run executes."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "_dist_gpu_worker.py")
+
+
+def _run(case, world, tmp_path, port):
+    out = str(tmp_path / ("%s_w%d" % (case, world)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if world == 1:
+        cmd = [sys.executable, WORKER, case, out]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER, case, out]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return [json.load(open(out + ".%d" % r)) for r in range(world)]
+
+
+@pytest.mark.parametrize("case,port", [("mvn", 29711), ("irt1d", 29713), ("hodina", 29715)])
+def test_hip_two_ranks_match_one_rank(case, port, tmp_path):
+    one = _run(case, 1, tmp_path, port)[0]
+    two = _run(case, 2, tmp_path, port + 1)
+    for r in two:
+        np.testing.assert_allclose(r["loss"], one["loss"], rtol=2e-5)
+        np.testing.assert_allclose(r["P"], one["P"], rtol=2e-4, atol=2e-6)    # fp32 summation order differs by shard
+    np.testing.assert_allclose(two[0]["P"], two[1]["P"], rtol=0, atol=0)       # replicated state: bit-identical
+    if "PP" in one:
+        n_one = len(one["PP"]) // 2
+        loc = np.concatenate([np.array(r["PP"])[:len(r["PP"]) // 2] for r in two])
+        raw = np.concatenate([np.array(r["PP"])[len(r["PP"]) // 2:] for r in two])
+        np.testing.assert_allclose(loc, np.array(one["PP"])[:n_one], rtol=2e-4, atol=2e-6)
+        np.testing.assert_allclose(raw, np.array(one["PP"])[n_one:], rtol=2e-4, atol=2e-6)
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` must start its own ranks (the driver's command) and print one JSON line with
+    n_gpus == 2; RCCL when two devices are visible, the gloo rehearsal on a one-GPU box."""
+    import torch
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--persons", "65536", "--no-cpu-baseline", "--dist-backend", backend],
+                       capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["persons_per_rank"] == 32768

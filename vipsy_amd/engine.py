@@ -198,17 +198,31 @@ class LrSpec(object):
         self.lr, self.milestones, self.gamma, self.betas, self.eps = lr, tuple(milestones), gamma, betas, eps
         self.epoch = 0
 
-    def lr_of(self, name):
+    def args_of(self, name):
+        """The torch.optim.Adam kwargs of one tensor: `lr` may be a float, a dict, or pyro's
+        callable(module_name, param_name) -> dict; betas / eps ride in the same dict (torch defaults otherwise)."""
         if callable(self.lr):
             module = name.split("$$$")[0]
             stripped = name.split("$$$")[1] if "$$$" in name else name
-            base = self.lr(module, stripped)["lr"]
+            d = dict(self.lr(module, stripped))
         elif isinstance(self.lr, dict):
-            base = self.lr["lr"]
+            d = dict(self.lr)
         else:
-            base = self.lr
+            d = {"lr": self.lr}
+        unknown = set(d) - {"lr", "betas", "eps"}
+        if unknown:
+            raise NotImplementedError("Adam option(s) %s are not on the HIP path" % sorted(unknown))
+        return d
+
+    def lr_of(self, name):
+        base = self.args_of(name)["lr"]
         k = sum(1 for m in self.milestones if m <= self.epoch)
         return base * self.gamma ** k
+
+    def hyper_of(self, name):
+        d = self.args_of(name)
+        b = d.get("betas", self.betas)
+        return (float(b[0]), float(b[1])), float(d.get("eps", self.eps))
 
     def scheduler_step(self):
         self.epoch += 1
@@ -282,7 +296,7 @@ class _EngineBase(object):
     def _sparse_lists(self, rows):
         """Observed-cell lists for the D = 1 kernels (include/vipsy_amd.h, vx_irt1d_sparse_grad): built once -- the
         responses never change -- and only when most cells are missing and the batch is the whole shard."""
-        if rows is not None or self.n_local == 0 or self.J > 1024 or os.environ.get("VX_SPARSE", "") == "off":
+        if rows is not None or self.n_local == 0 or self.J > 1024 or not self.observed_lists:
             return None
         if getattr(self, "_sp", None) is None:
             y, n, J = self.y, self.n_local, self.J
@@ -341,22 +355,34 @@ class _EngineBase(object):
             self.GP[n:].index_add_(0, rows, graw[:nb])
 
     def allreduce(self):
-        if self.group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
-            torch.distributed.all_reduce(self.G, group=self.group)
+        """The one exchange of a step: SUM of [gradients | loss] over the ranks that share this problem.  Sharding is
+        explicit -- `group` handed to the constructor -- never inferred from global torch.distributed state, so that
+        independent problems (replications, vipsy_amd/harness.py) can run side by side under one process group."""
+        if self.group is not None:
+            if self.G.is_cuda and torch.distributed.get_backend(self.group) == "gloo":
+                host = self.G.cpu()                          # rehearsal of N ranks on fewer GPUs: gloo reduces on the host
+                torch.distributed.all_reduce(host, group=self.group)
+                self.G.copy_(host)
+            else:                                            # the product path: RCCL (backend "nccl") on the device buffer
+                torch.distributed.all_reduce(self.G, group=self.group)
 
     def apply_optim(self, lrs):
         """Adam on the unconstrained leaves with the `free` mask (vi.py:508-514)."""
         self.t += 1
-        segs = []
+        by_hyper = {}
         for name in self.names():
             o = self.off[name]
-            segs.append((o, o + int(np.prod(self.shape[name])), float(lrs.lr_of(name))))
-        segs = _merge_segments(segs)
-        self.be.adam(self.P, self.G, self.M, self.V, self.free, self.n_params, segs, self.t, lrs.betas, lrs.eps)
+            by_hyper.setdefault(lrs.hyper_of(name), []).append(
+                (o, o + int(np.prod(self.shape[name])), float(lrs.lr_of(name))))
+        for (betas, eps), segs in by_hyper.items():         # one launch per distinct (betas, eps): normally one
+            self.be.adam(self.P, self.G, self.M, self.V, self.free, self.n_params, _merge_segments(segs), self.t, betas, eps)
         if self.per_person:
-            segs = _merge_segments([(o, o + int(np.prod(self.pp_shape[nme])), float(lrs.lr_of(nme)))
-                                    for nme, o in self.pp_off.items()])
-            self.be.adam(self.PP, self.GP, self.MP, self.VP, None, self.pp_len, segs, self.t, lrs.betas, lrs.eps)
+            by_hyper = {}
+            for nme, o in self.pp_off.items():
+                by_hyper.setdefault(lrs.hyper_of(nme), []).append(
+                    (o, o + int(np.prod(self.pp_shape[nme])), float(lrs.lr_of(nme))))
+            for (betas, eps), segs in by_hyper.items():
+                self.be.adam(self.PP, self.GP, self.MP, self.VP, None, self.pp_len, _merge_segments(segs), self.t, betas, eps)
 
     def step(self, lrs, rows=None, b_global=None, eps=None, num_particles=1):
         """loss_and_grads + optimiser, the body of SVI.step (vi.py:505-516).  `rows` (and `eps`) may be
@@ -394,8 +420,12 @@ class IrtEngine(_EngineBase):
 
     def __init__(self, y_u8, model="irt_2pl", D=1, Dc=1.0, n_global=None, gid0=0, amortized=False, H=64,
                  share_cov=False, a_free=None, a0=None, b0=None, encoder_init=None, seed=1234, group=None,
-                 backend=None):
+                 backend=None, observed_lists=True):
+        """group: the torch.distributed process group whose ranks SHARE this problem (each holds a contiguous shard of
+        persons: y_u8 = rows gid0 .. gid0 + n_local of the n_global); None = this process owns the whole problem.
+        observed_lists: D = 1, full batch, >= 50 % missing -> step on compacted lists of observed cells."""
         self.be = backend if backend is not None else HipBackend()
+        self.observed_lists = bool(observed_lists)
         self.y = y_u8.contiguous()
         assert self.y.dtype == torch.uint8 and self.y.dim() == 2
         self.dev = self.y.device
@@ -438,8 +468,7 @@ class IrtEngine(_EngineBase):
             af = torch.ones(Dd, J)
             for i in range(Dd):
                 af[i, J - i:] = 0                                  # vi.py:570-572
-            if a0 is None:
-                a_init = a_init * af
+            a_init = a_init * af                                   # also a user-supplied a0 is zeroed there (vi.py:571)
             a_free = af
         if model != "irt_1pl":
             self.view("a").copy_(a_init.reshape(-1))
@@ -528,17 +557,15 @@ class IrtEngine(_EngineBase):
             D, H = self.D, self.H
             fw = {"h": self._buf("h", nb * H), "x": self._buf("x", nb * D), "eps": self._buf("eps", nb * D),
                   "ldT": self._buf("ldT", nb * D), "ent": self._buf("ent", nb)}
-            gxT = None
-            if hasattr(be, "mvn_pack_floats"):
-                fw["packws"] = self._buf("packws", be.mvn_pack_floats(cfg))
-                # dimension-major copies (person-contiguous rows) for the DMA-staged weight-gradient kernel
-                fw["hT"], fw["epsT"] = self._buf("hT", nb * H), self._buf("epsT", nb * D)
-                gxT = self._buf("gxT", nb * D)
-                yT = self._item_major_y(rows)
-                if yT is not None:
-                    fw["yT"] = yT
+            fw["packws"] = self._buf("packws", be.mvn_pack_floats(cfg))
+            # dimension-major copies (person-contiguous rows) for the DMA-staged weight-gradient kernel
+            fw["hT"], fw["epsT"] = self._buf("hT", nb * H), self._buf("epsT", nb * D)
+            gxT = self._buf("gxT", nb * D)
+            yT = self._item_major_y(rows)
+            if yT is not None:
+                fw["yT"] = yT
             gx, ll = self._buf("gx", nb * D), self._buf("ll", nb)
-            if gxT is not None and be.mvn_enc_bwd_layout(cfg, nb) == 1:
+            if be.mvn_enc_bwd_layout(cfg, nb) == 1:
                 gx = None                                  # the backward kernels read gxT only
             enc = self._enc()
             lik_ws = self._buf("lik_ws", be.lik_workspace(cfg, nb))
@@ -546,18 +573,11 @@ class IrtEngine(_EngineBase):
             with self._phase("guide_forward"):
                 be.mvn_enc_forward(cfg, self.y, rows, nb, self.gid0, enc, eps, fw)
             with self._phase("likelihood"):
-                if gxT is not None:
-                    be.lik_grad(cfg, self.y, rows, nb, fw["x"], a, self.view("b"), c_un, d_un, gx, ll, gitem, lik_ws,
-                                gxT=gxT)
-                else:
-                    be.lik_grad(cfg, self.y, rows, nb, fw["x"], a, self.view("b"), c_un, d_un, gx, ll, gitem, lik_ws)
+                be.lik_grad(cfg, self.y, rows, nb, fw["x"], a, self.view("b"), c_un, d_un, gx, ll, gitem, lik_ws,
+                            gxT=gxT)
             with self._phase("guide_backward"):
-                if gxT is not None:
-                    be.mvn_enc_backward(cfg, self.y, rows, nb, enc, fw, gx,
-                                        self.G[self.enc_off0:self.enc_off0 + self.n_enc], encb_ws, gxT=gxT)
-                else:
-                    be.mvn_enc_backward(cfg, self.y, rows, nb, enc, fw, gx,
-                                        self.G[self.enc_off0:self.enc_off0 + self.n_enc], encb_ws)
+                be.mvn_enc_backward(cfg, self.y, rows, nb, enc, fw, gx,
+                                    self.G[self.enc_off0:self.enc_off0 + self.n_enc], encb_ws, gxT=gxT)
             # loss = -scale * sum_i (ll_i + ent_i)
             tmp = self._buf("loss2", 2)
             be.sum_into(ll, nb, -scale, tmp[0:1], self.sum_ws)
@@ -578,7 +598,7 @@ class IrtEngine(_EngineBase):
                 loc, raw = fw["loc"], fw["raw"]
             else:
                 loc, raw, gloc, graw = self._gather_pp(rows, nb)
-            lists = self._sparse_lists(rows) if hasattr(be, "irt1d_sparse_grad") else None
+            lists = self._sparse_lists(rows)
             with self._phase("irt1d"):
                 if lists is not None:                      # mostly-missing responses: observed cells only
                     sp_ws = self._buf("i1d_sp_ws", be.irt1d_sparse_workspace(cfg, nb))
@@ -593,13 +613,9 @@ class IrtEngine(_EngineBase):
             gitem[self.off["b"]:self.off["b"] + 3 * J].copy_(g1d[J:4 * J])
             if self.amortized:
                 with self._phase("guide_backward"):
-                    yT = self._item_major_y(rows) if hasattr(be, "mvn_pack_floats") else None
-                    if yT is not None:
-                        be.norm_enc_backward(cfg, self.y, rows, nb, enc, fw["h"], gloc, graw,
-                                             self.G[self.enc_off0:self.enc_off0 + self.n_enc], nb_ws, yT=yT)
-                    else:
-                        be.norm_enc_backward(cfg, self.y, rows, nb, enc, fw["h"], gloc, graw,
-                                             self.G[self.enc_off0:self.enc_off0 + self.n_enc], nb_ws)
+                    be.norm_enc_backward(cfg, self.y, rows, nb, enc, fw["h"], gloc, graw,
+                                         self.G[self.enc_off0:self.enc_off0 + self.n_enc], nb_ws,
+                                         yT=self._item_major_y(rows))
             else:
                 self._scatter_pp(rows, nb, gloc, graw)
             be.sum_into(elbo, nb, -scale, lossslot, self.sum_ws)
@@ -699,13 +715,9 @@ class HoDinaEngine(_EngineBase):
                            self.G[:self.n_item], ws)
         if self.amortized:
             with self._phase("guide_backward"):
-                yT = self._item_major_y(rows) if hasattr(be, "mvn_pack_floats") else None
-                if yT is not None:
-                    be.norm_enc_backward(icfg, self.y, rows, nb, enc, fw["h"], gloc, graw,
-                                         self.G[self.enc_off0:self.enc_off0 + self.n_enc], nb_ws, yT=yT)
-                else:
-                    be.norm_enc_backward(icfg, self.y, rows, nb, enc, fw["h"], gloc, graw,
-                                         self.G[self.enc_off0:self.enc_off0 + self.n_enc], nb_ws)
+                be.norm_enc_backward(icfg, self.y, rows, nb, enc, fw["h"], gloc, graw,
+                                     self.G[self.enc_off0:self.enc_off0 + self.n_enc], nb_ws,
+                                     yT=self._item_major_y(rows))
         else:
             self._scatter_pp(rows, nb, gloc, graw)
         be.sum_into(elbo, nb, -scale, lossslot, self.sum_ws)

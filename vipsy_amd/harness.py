@@ -99,10 +99,12 @@ def print_rmse(res_lt):
 
 def multiprocess_article_test_load_data_util(model_name, sample_size, item_size, x_feature_size, vi_class=None,
                                              try_count=10, vi_class_kwargs=None, vi_fit_kwargs=None, process_size=None,
-                                             start_idx=0, folder=None):
+                                             start_idx=0, folder=None, device=None):
     """`try_count` replications (test.py:94-127).  The reference farms them to a CPU process pool; here a replication
     saturates a GPU, so they run one after the other -- or, under torch.distributed, replication k runs on rank
-    k % world and rank 0 gathers the errors (replications are independent: no collective on the data path)."""
+    k % world and rank 0 gathers the errors.  Every replication is built WITHOUT a process group (the model classes
+    share a problem across ranks only when handed `group=`), so nothing inside a fit is collective and ranks may run
+    different numbers of replications; the single all_gather_object at the end is the only exchange."""
     import torch.distributed as dist
     world, rank = (dist.get_world_size(), dist.get_rank()) if dist.is_available() and dist.is_initialized() else (1, 0)
     mine = []
@@ -111,7 +113,7 @@ def multiprocess_article_test_load_data_util(model_name, sample_size, item_size,
             mine.append((i, article_test_load_data_util(model_name, sample_size, item_size, x_feature_size,
                                                          file_postfix=i, vi_class=vi_class,
                                                          vi_class_kwargs=vi_class_kwargs, vi_fit_kwargs=vi_fit_kwargs,
-                                                         folder=folder)))
+                                                         folder=folder, device=device)))
     if world > 1:
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)

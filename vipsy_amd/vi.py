@@ -42,10 +42,7 @@ class Adam(object):
         self.optim_args = optim_args
 
     def spec(self):
-        a = self.optim_args
-        if callable(a):
-            return LrSpec(a)
-        return LrSpec(float(a["lr"]), betas=tuple(a.get("betas", (0.9, 0.999))), eps=float(a.get("eps", 1e-8)))
+        return LrSpec(self.optim_args)                  # lr / betas / eps per tensor, dict or callable alike
 
 
 class PyroLRScheduler(object):
@@ -62,9 +59,8 @@ class MultiStepLR(PyroLRScheduler):
         self.args = args
 
     def spec(self):
-        a = self.args["optim_args"]
-        lr = a if callable(a) else float(a["lr"])
-        return LrSpec(lr, milestones=tuple(self.args.get("milestones", ())), gamma=float(self.args.get("gamma", 0.1)))
+        return LrSpec(self.args["optim_args"], milestones=tuple(self.args.get("milestones", ())),
+                      gamma=float(self.args.get("gamma", 0.1)))
 
 
 class Trace_ELBO(object):
@@ -94,11 +90,19 @@ def to_u8(data, device):
 
 
 class BasePsy(object):
-    """vi.py:521-533.  With torch.distributed initialised, `data` is THIS rank's shard of persons and
-    `sample_size_global` / `gid0` place it in the global plate."""
+    """vi.py:521-533.  Multi-GPU is explicit: pass `group` (a torch.distributed process group, e.g.
+    torch.distributed.group.WORLD) and `data` is THIS rank's shard of persons, placed in the global plate by
+    `sample_size_global` / `gid0`.  Without `group` the object owns its whole problem even when a process group is up
+    (independent replications on different ranks, vipsy_amd/harness.py)."""
 
-    def __init__(self, data, subsample_size=None, sample_size_global=None, gid0=0, seed=1234, device=None, **kwargs):
-        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    def __init__(self, data, subsample_size=None, sample_size_global=None, gid0=0, seed=1234, device=None, group=None,
+                 **kwargs):
+        if device is None:
+            if torch.is_tensor(data) and (data.device.type != "cpu" or kwargs.get("backend") is not None):
+                device = data.device
+            else:
+                device = torch.device("cuda", torch.cuda.current_device())
+        dev = torch.device(device)
         self.data = to_u8(data, dev)
         self.sample_size_local = int(self.data.shape[0])
         self.sample_size = int(sample_size_global) if sample_size_global is not None else self.sample_size_local
@@ -106,9 +110,16 @@ class BasePsy(object):
         self.subsample_size = int(subsample_size) if subsample_size is not None else self.sample_size
         self.gid0, self.seed, self.device = int(gid0), int(seed), dev
         self.kwargs = kwargs
-        self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        self.group = group
+        self.world = torch.distributed.get_world_size(group) if group is not None else 1
+        if self.world == 1 and self.sample_size != self.sample_size_local:
+            raise ValueError("sample_size_global differs from the rows of `data` but no `group` shares the problem")
         self._gen = torch.Generator(device=dev)
         self._gen.manual_seed(self.seed * 7919 + self.gid0)
+        # engine keyword arguments shared by every model class (`backend` is the test seam of tests/oracle_backend.py)
+        self._eng_kw = {"n_global": self.sample_size, "gid0": self.gid0, "seed": self.seed, "group": group}
+        if kwargs.get("backend") is not None:
+            self._eng_kw["backend"] = kwargs["backend"]
 
     def _register(self):
         for n in self.engine.all_names():
@@ -163,10 +174,11 @@ class BaseIRT(BasePsy):
     def __init__(self, model="irt_2pl", x_feature=1, share_cov=False, D=1, hidden_dim=64, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self._model, self.x_feature, self.share_cov, self.D = model, int(x_feature), share_cov, D
-        self.engine = IrtEngine(self.data, model=model, D=self.x_feature, Dc=float(D), n_global=self.sample_size,
-                                gid0=self.gid0, amortized=self.amortized, H=hidden_dim, share_cov=share_cov,
-                                a_free=self.kwargs.get("a_free"), a0=self.kwargs.get("a0"), b0=self.kwargs.get("b0"),
-                                encoder_init=self.kwargs.get("encoder_init"), seed=self.seed)
+        self.engine = IrtEngine(self.data, model=model, D=self.x_feature, Dc=float(D), amortized=self.amortized,
+                                H=hidden_dim, share_cov=share_cov, a_free=self.kwargs.get("a_free"),
+                                a0=self.kwargs.get("a0"), b0=self.kwargs.get("b0"),
+                                encoder_init=self.kwargs.get("encoder_init"),
+                                observed_lists=self.kwargs.get("observed_lists", True), **self._eng_kw)
         self._register()
         self._ri = None
 
@@ -211,8 +223,8 @@ class _HoDinaBase(BasePsy):
         super().__init__(*args, **kwargs)
         self.q = q
         self.attr_size = int(q.shape[0])
-        self.engine = HoDinaEngine(self.data, q, n_global=self.sample_size, gid0=self.gid0, amortized=self.amortized,
-                                   H=hidden_dim, encoder_init=self.kwargs.get("encoder_init"), seed=self.seed)
+        self.engine = HoDinaEngine(self.data, q, amortized=self.amortized, H=hidden_dim,
+                                   encoder_init=self.kwargs.get("encoder_init"), **self._eng_kw)
         self._register()
         self._ri = None
 
@@ -266,7 +278,7 @@ class VCCDM(BasePsy):
         super().__init__(*args, **kwargs)
         self.q, self._model = q, model
         self.attr_size = int(q.shape[0])
-        self.engine = CcdmEngine(self.data, q, cdm=model, n_global=self.sample_size, gid0=self.gid0, seed=self.seed)
+        self.engine = CcdmEngine(self.data, q, cdm=model, **self._eng_kw)
         self._register()
         self._ri = None
 
