@@ -245,6 +245,59 @@ def gen_ccdm_cases():
              {"cls": "VCCDM", "cdm": "dino", "N": 24, "J": 10, "K": 3, "B": 24, "lr": 1e-1, "q": ri.q.numpy()})
 
 
+def gen_round2_cases():
+    """Fixtures added in round 2: the CFA call pattern (custom a_free / a0 masks, several particles; test.py:418-430),
+    an encoder of the reference's default width with more than 128 items, a width that is neither 8 nor 64, and
+    HO-DINA with more than 128 items."""
+    import random
+    g = torch.Generator().manual_seed(277)
+    # ---- CFA: VIRT(x_feature=2, a_free=mask.T, a0=mask.T), Trace_ELBO(num_particles=3) on the first rows of the
+    # reference's own ex5.2.dat (float64 in the reference, test.py:419,428; responses are 0/1)
+    data = np.loadtxt("/root/reference/ex5.2.dat")[:36]
+    y = torch.from_numpy(data).float()
+    mask = torch.FloatTensor([[1, 0], [1, 0], [1, 0], [0, 1], [0, 1], [0, 1]])
+    torch.manual_seed(200)
+    m = vi.VIRT(data=y, model="irt_2pl", subsample_size=12, x_feature=2, a_free=mask.T, a0=mask.T.clone())
+    run_case("virt_cfa_d2_particles3", m, y, Adam({"lr": 1e-2}), Trace_ELBO(num_particles=3), 2,
+             {"model": "irt_2pl", "cls": "VIRT", "N": 36, "J": 6, "D": 2, "B": 12, "lr": 1e-2, "S": 3,
+              "a_free": mask.T.numpy(), "a0": mask.T.numpy()})
+    # ---- VaeIRT, hidden_dim = 64 (the reference default, vi.py:661), J = 130 > 128, D = 2
+    torch.manual_seed(201)
+    np.random.seed(201)
+    random.seed(201)
+    ri = vi.RandomMilIrt2PL(sample_size=24, item_size=130, x_feature=2)
+    y = add_missing(ri.y, 0.1, g)
+    m = vi.VaeIRT(data=y, model="irt_2pl", subsample_size=9, x_feature=2, hidden_dim=64)
+    run_case("vaeirt_irt_2pl_d2_h64_j130", m, y, Adam(lr_fn), Trace_ELBO(num_particles=1), 2,
+             {"model": "irt_2pl", "cls": "VaeIRT", "N": 24, "J": 130, "D": 2, "B": 9, "H": 64,
+              "lr_item": 1e-2, "lr_other": 1e-3})
+    # ---- VaeIRT, hidden_dim = 24 (neither 8 nor 64), D = 3, 4PL
+    torch.manual_seed(202)
+    np.random.seed(202)
+    random.seed(202)
+    ri = vi.RandomMilIrt4PL(sample_size=20, item_size=13, x_feature=3)
+    y = add_missing(ri.y, 0.15, g)
+    m = vi.VaeIRT(data=y, model="irt_4pl", subsample_size=20, x_feature=3, hidden_dim=24)
+    run_case("vaeirt_irt_4pl_d3_h24", m, y, Adam(lr_fn), Trace_ELBO(num_particles=1), 2,
+             {"model": "irt_4pl", "cls": "VaeIRT", "N": 20, "J": 13, "D": 3, "B": 20, "H": 24,
+              "lr_item": 1e-2, "lr_other": 1e-3})
+    # ---- NormEncoder width 24, D = 1
+    torch.manual_seed(203)
+    ri = vi.RandomIrt2PL(sample_size=28, item_size=10)
+    y = add_missing(ri.y, 0.2, g)
+    m = vi.VaeIRT(data=y, model="irt_2pl", subsample_size=11, hidden_dim=24)
+    run_case("vaeirt_irt_2pl_d1_h24", m, y, Adam(lr_fn), Trace_ELBO(num_particles=1), 2,
+             {"model": "irt_2pl", "cls": "VaeIRT", "N": 28, "J": 10, "D": 1, "B": 11, "H": 24,
+              "lr_item": 1e-2, "lr_other": 1e-3})
+    # ---- HO-DINA with J = 130 > 128 items
+    torch.manual_seed(204)
+    ri = vi.RandomHoDina(sample_size=48, item_size=130, q_size=3)
+    y = add_missing(ri.y, 0.1, g)
+    m = vi.VCHoDina(data=y, q=ri.q, subsample_size=48)
+    run_case("vchodina_k3_j130", m, y, Adam({"lr": 1e-1}), TraceEnum_ELBO(num_particles=1), 2,
+             {"cls": "VCHoDina", "N": 48, "J": 130, "K": 3, "B": 48, "lr": 1e-1, "q": ri.q.numpy()})
+
+
 def gen_function_cases():
     """G1-G5 of SURVEY.md section 8c: pure-torch pieces of vi.py imported and evaluated."""
     rec = {}
@@ -331,6 +384,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ccdm":     # only the cases added after the first batch
         gen_ccdm_cases()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "r2":       # only the round-2 additions
+        gen_round2_cases()
+        sys.exit(0)
     gen_function_cases()
     gen_elbo_cases()
     gen_ccdm_cases()
+    gen_round2_cases()

@@ -45,9 +45,9 @@ def build(tag, dtype=np.float32):
         D = int(f["D"])
         spec = {"family": "irt", "model": str(f["model"]), "D": D, "Dc": float(f["Dc"]) if "Dc" in f else 1.0,
                 "N": N, "amortized": amort, "share_cov": bool(f["share_cov"]) if "share_cov" in f else False,
-                "a_free": vo.default_a_free(D, J)}
+                "a_free": f["a_free"].astype(bool) if "a_free" in f else vo.default_a_free(D, J)}
         params = vo.init_irt_params(spec, J, dtype, encoder=enc if amort else None,
-                                    b0=f["b0"] if "b0" in f else None)
+                                    b0=f["b0"] if "b0" in f else None, a0=f["a0"] if "a0" in f else None)
         lr = _lr_irt(float(f["lr_item"]), float(f["lr_other"])) if "lr_item" in f else float(f["lr"])
     elif cls == "VCCDM":
         spec = {"family": "ccdm", "cdm": str(f["cdm"]), "K": int(f["K"]), "N": N, "amortized": False, "q": f["q"]}
@@ -75,3 +75,16 @@ def build(tag, dtype=np.float32):
                "param": {k.split("/param/")[1]: f[k] for k in f if k.startswith("s%d/param/" % t)}}
         steps.append(rec)
     return spec, params, opt, f["y"], steps, B
+
+
+def adam_conditioned(steps, t, name, rel=1e-4):
+    """Entries of parameter `name` whose Adam trajectory up to step t is well conditioned: Adam's update is
+    g / (sqrt(v) + 1e-8), so an entry whose gradient is at float32-noise level (|g| below `rel` of the tensor's largest
+    gradient at some step so far) moves by +-lr on the SIGN OF THE NOISE -- in the reference's own float32 run too.
+    Such entries (e.g. a slip parameter of an item whose gradient terms cancel) carry no parity information."""
+    ok = None
+    for u in range(t + 1):
+        g = np.abs(steps[u]["grad"][name])
+        m = (g == 0) | (g >= rel * max(float(g.max()), 1e-30))      # exact zeros (frozen / off-batch entries) are exact
+        ok = m if ok is None else (ok & m)
+    return ok
