@@ -10,7 +10,6 @@
 // B[k = 8h + j][col r], j = 0..7; here k = person within a 16-person chunk.
 // (included by vx_abi.hip after k_mvn_bwd_t.hip, whose row layout and helpers it shares)
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
 
 // row map (128-byte row units): G [0, DR) | E [DR, 2 DR) | H area: 3 splits x 64 rows x 64 bytes = 96 units |
@@ -42,20 +41,6 @@ __global__ void k_split3_bf16(const float* __restrict__ v, int64_t n, uint16_t* 
     }
 }
 
-__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
-// eight fp32 values -> three bf16 fragments (h, m, l)
-__device__ __forceinline__ void split3_frag(const float (&v)[8], bf16x8& fh, bf16x8& fm, bf16x8& fl) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 h = (__bf16)v[j];
-        const float r1 = v[j] - (float)h;
-        const __bf16 m = (__bf16)r1;
-        fh[j] = h; fm[j] = m; fl[j] = (__bf16)(r1 - (float)m);
-    }
-}
 
 __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
     EncDims dm, const uint16_t* __restrict__ hs /*[3][64][nb] bf16*/, const float* __restrict__ epsT,

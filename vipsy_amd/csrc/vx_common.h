@@ -30,6 +30,28 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 
 // ---------------------------------------------------------------------------------------------
+// bf16 MFMA 32x32x16 (v_mfma_f32_32x32x16_bf16, 32 cycles / SIMD), fp32 accumulate:
+//   A: lane l holds A[m = l & 31][k = 8 (l >> 5) + j], B: lane l holds B[k = 8 (l >> 5) + j][n = l & 31], j = 0..7
+//   C: as the fp32 form above.
+// bf16x3: an fp32 operand as three bf16 terms v = h + m + l (round-to-nearest at each stage, exact to 2^-24);
+// six cross products (h h, h m, m h, h l, l h, m m) reproduce the fp32 product chain.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// eight fp32 values -> three bf16 fragments (h, m, l)
+__device__ __forceinline__ void split3_frag(const float (&v)[8], bf16x8& fh, bf16x8& fm, bf16x8& fl) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)v[j];
+        const float r1 = v[j] - (float)h;
+        const __bf16 m = (__bf16)r1;
+        fh[j] = h; fm[j] = m; fl[j] = (__bf16)(r1 - (float)m);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Philox4x32-10 (same spec as oracle/vi_oracle.py::philox4x32_10)
 // ---------------------------------------------------------------------------------------------
 struct u32x4 { uint32_t x, y, z, w; };
