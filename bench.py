@@ -62,6 +62,7 @@ def kernel_model(name, J, D, H):
         "k_mvn_enc_bwd_w_t": (heads, PEAK_F32_MFMA_TFLOPS, "f32 MFMA"),
         "k_mvn_enc_bwd_w_b": (heads, PEAK_BF16X3_TFLOPS, "f32 via bf16x3 on the bf16 MFMA"),
         "k_irt_lik_r": (2.0 * 3 * (D + 1) * J, PEAK_F32_MFMA_TFLOPS, "f32 MFMA"),        # Z, gx, GA
+        "k_irt_lik_b": (2.0 * 3 * (D + 1) * J, PEAK_BF16X3_TFLOPS, "f32 via bf16x3 on the bf16 MFMA"),
     }
     return table.get(name)
 

@@ -36,7 +36,7 @@ extern "C" {
 #define VX_OK 0
 #define VX_EINVAL (-1)       /* bad argument / unsupported shape */
 #define VX_EUNIMPL (-2)
-#define VX_ABI_VERSION 1
+#define VX_ABI_VERSION 2
 
 enum vx_model { VX_IRT_1PL = 1, VX_IRT_2PL = 2, VX_IRT_3PL = 3, VX_IRT_4PL = 4 }; /* vi.py:538-543 */
 
@@ -106,8 +106,13 @@ int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows
                     const float* x /*[nb][D]*/, const float* a /*[D][J]*/, const float* b /*[J]*/,
                     const float* c_un /*[J] or NULL*/, const float* d_un /*[J] or NULL*/,
                     float* gx /*[nb][D] or NULL*/, float* gxT /*[D][nb] or NULL*/, float* ll /*[nb]*/,
-                    float* gitem /*[D*J + 3*J]*/, float* workspace, void* hip_stream);
-/* gx and gxT are the same gradient in person-major / dimension-major order; at least one must be given. */
+                    float* gitem /*[D*J + 3*J]*/, float* workspace,
+                    const uint8_t* yT /*[J + 1][yT_stride] or NULL*/, int64_t yT_stride, void* hip_stream);
+/* gx and gxT are the same gradient in person-major / dimension-major order; at least one must be given.
+ * yT (optional, full batches only: rows == NULL): the responses item-major -- row j = item j over the batch rows, row J
+ * and every column past nb filled with 254 ("outside the problem"), yT_stride % 64 == 0 and >= nb rounded up to 64.
+ * With it, 96 <= D <= 111 runs on the bf16-MFMA kernel (k_irt_lik_b.hip: fp32 results by three-term operand
+ * splitting); the same buffer serves vx_mvn_enc_backward / vx_norm_enc_backward (which read rows 0..J-1). */
 
 /* ---- amortized MVN guide, backward: encoder weight gradients of the LOSS from gx.
  * genc = d LOSS / d encoder parameters, flat in the nn.Linear order of vi.py:442-444:
@@ -121,7 +126,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                         const float* W21, const float* W22,
                         const float* h, const float* eps, const float* ldT, const float* gx,
                         const float* hT /*or NULL*/, const float* epsT /*or NULL*/, const float* gxT /*or NULL*/,
-                        const uint8_t* yT /*[J][yT_stride] item-major copy of y, or NULL*/, int64_t yT_stride,
+                        const uint8_t* yT /*[>= J][yT_stride] item-major copy of y (pad bytes 0 or 254), or NULL*/, int64_t yT_stride,
                         float* genc, float* workspace, const float* packws, void* hip_stream);
 /* With hT, epsT and gxT (the dimension-major copies made by the forward / likelihood calls) the head weight
  * gradients run on the DMA-staged kernel of k_mvn_bwd_t.hip; without them on the person-major one.

@@ -104,7 +104,7 @@ class OracleBackend(object):
     def lik_workspace(self, cfg, nb):
         return 1
 
-    def lik_grad(self, cfg, y, rows, nb, x, a, b, c_un, d_un, gx, ll, gitem, ws, gxT=None):
+    def lik_grad(self, cfg, y, rows, nb, x, a, b, c_un, d_un, gx, ll, gitem, ws, gxT=None, yT=None):
         model, D, J = CODE_MODEL[cfg.model], cfg.D, cfg.J
         r = self._rows(rows, nb)
         yy = y.cpu().numpy()[r]

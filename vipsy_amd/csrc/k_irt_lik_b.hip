@@ -13,6 +13,12 @@
 //     gx^T[k,p] = sum_j a[k,j] R[p,j]             A <- aG registers (split once),            B <- R image [item][person]
 //                                                 in LDS (8-byte packed writes), read back transposed (tr_b16)
 //
+// The loop is software-pipelined ACROSS person tiles so that the cell epilogue (vector work) always runs beside 96
+// MFMAs that do not depend on it:
+//     top barrier | Z of persons 32..63 (t)      | GA, gx of persons 0..31 (t)  beside  cells of persons 32..63 (t)
+//     mid barrier | Z of persons 0..31 (t + 1)   | gx, GA of persons 32..63 (t) beside  cells of persons 0..31 (t + 1)
+// (two barriers per tile; two x buffers suffice because tile t + 1 is first read after the mid barrier of tile t).
+//
 // Every operand that does not change from one person tile to the next lives in registers as bf16x3 fragments (a for Z:
 // 84, a for gx: 96 VGPRs); x arrives ALREADY split (k_lik_ximg, or the guide-forward kernel writes the image): one image
 // of [person][k] rows serves the row reads of Z and the column reads of GA (cdna_hip_programming.md T10).
@@ -33,7 +39,8 @@
 #define LB_XT_BYTES (3 * LB_PLANE)                 // 43008
 #define LB_RPLANE 8192                             // R image plane: [128 items][32 persons] bf16
 #define LB_YS 128
-#define LB_LDS_BYTES (2 * LB_XT_BYTES + 6 * LB_RPLANE + LB_P * LB_YS + LB_P * 64 * 4)     // 159744
+#define LB_YT_BYTES (LB_JC * LB_P)                 // response bytes of one tile, item-major: [128 items][64 persons]
+#define LB_LDS_BYTES (2 * LB_XT_BYTES + 6 * LB_RPLANE + 2 * LB_YT_BYTES + LB_P * 32 * 4)     // 159744
 
 struct LikBDims {
     int D, J, model, groups, n_pr, gxt;
@@ -60,9 +67,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 #endif
 
-// x fp32 [nb][D] -> tile images (the three bf16 terms of x_aug) + xsq[i] = |x_i|^2; persons past nb: all-zero rows
-__global__ __launch_bounds__(256) void k_lik_ximg(int D, int64_t nb, const float* __restrict__ x, uint8_t* __restrict__ img,
-                                                  float* __restrict__ xsq) {
+// x fp32 [nb][D] -> tile images (the three bf16 terms of x_aug); persons past nb: all-zero rows
+__global__ __launch_bounds__(256) void k_lik_ximg(int D, int64_t nb, const float* __restrict__ x, uint8_t* __restrict__ img) {
     const int64_t tile = blockIdx.x;
     uint8_t* out = img + tile * LB_XT_BYTES;
     for (int e = threadIdx.x; e < LB_P * 2 * LB_NKS; e += blockDim.x) {
@@ -81,59 +87,87 @@ __global__ __launch_bounds__(256) void k_lik_ximg(int D, int64_t nb, const float
         *(bf16x8*)(out + LB_PLANE + o) = fm;
         *(bf16x8*)(out + 2 * LB_PLANE + o) = fl;
     }
-    if (threadIdx.x < LB_P) {
-        const int64_t i = tile * LB_P + threadIdx.x;
-        if (i < nb) {
-            float s = 0.f;
-            for (int k = 0; k < D; ++k) { const float t = x[i * D + k]; s = fmaf(t, t, s); }
-            xsq[i] = s;
-        }
-    }
 }
 
 typedef short lb_s16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t lb_u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t lb_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char lb_lds;                 // LDS pointers stay in their address space: constant
+                                                                       // offsets then fold into the DS instruction's offset field
 
 // transposed LDS read (ds_read_b64_tr_b16): per 16-lane group a block of 4 rows x 16 columns of 16-bit elements; lane
 // 4q + p of the group supplies the address of row q, columns 4p..4p+3; lane i receives column i, row q in element q
-__device__ __forceinline__ lb_u32x2 lb_tr_read(uint32_t lds_byte_addr) {
-    const lb_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lb_s16x4*)lds_byte_addr);
+__device__ __forceinline__ lb_u32x2 lb_tr_read(lb_lds* p) {
+    const lb_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lb_s16x4*)p);
     return __builtin_bit_cast(lb_u32x2, v);
 }
 __device__ __forceinline__ bf16x8 lb_frag(lb_u32x2 lo, lb_u32x2 hi) {
     const lb_u32x4 q = {lo[0], lo[1], hi[0], hi[1]};
     return __builtin_bit_cast(bf16x8, q);
 }
+__device__ __forceinline__ bf16x8 lb_read128(lb_lds* p) { return *(__attribute__((address_space(3))) const bf16x8*)p; }
 
-// two fp32 values -> their three bf16 terms, packed pairwise (element 0 in the low half)
+// two fp32 values -> their three bf16 terms, packed pairwise (element 0 in the low half); one v_cvt_pk_bf16_f32 per term
 __device__ __forceinline__ void lb_split_pair(float a, float b, uint32_t& ph, uint32_t& pm, uint32_t& pl) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    const __bf16 ah = (__bf16)a, bh = (__bf16)b;
-    const float ar = a - (float)ah, br = b - (float)bh;
-    const __bf16 am = (__bf16)ar, bm = (__bf16)br;
-    const __bf16 al = (__bf16)(ar - (float)am), bl = (__bf16)(br - (float)bm);
-    const bf16x2 vh = {ah, bh}, vm = {am, bm}, vl = {al, bl};
-    ph = __builtin_bit_cast(uint32_t, vh);
-    pm = __builtin_bit_cast(uint32_t, vm);
-    pl = __builtin_bit_cast(uint32_t, vl);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    // the conversions are paired (one instruction per term), the residuals are scalar on purpose: packed f32 adds cost
+    // more issue time beside MFMAs than two plain ones (MI355X_MICROARCH.md, 'price of one filler')
+    ph = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a, b}, bf16x2));
+    float a1 = a - __builtin_bit_cast(float, ph << 16), b1 = b - __builtin_bit_cast(float, ph & 0xffff0000u);
+    asm("" : "+v"(a1), "+v"(b1));
+    pm = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a1, b1}, bf16x2));
+    float a2 = a1 - __builtin_bit_cast(float, pm << 16), b2 = b1 - __builtin_bit_cast(float, pm & 0xffff0000u);
+    asm("" : "+v"(a2), "+v"(b2));
+    pl = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a2, b2}, bf16x2));
 }
 
-// GEN: 3PL / 4PL cell; ROWS: the batch is a row gather (rows != null)
-template <int GEN, int ROWS>
+// scheduling hint for one region: interleave its MFMAs with the vector work of the region (a bf16 MFMA holds the vector
+// issue port for 8 of its 32 cycles only; work placed AFTER a burst of MFMAs does not overlap them)
+#define LB_MASK_VALU 0x002
+#define LB_MASK_MFMA 0x008
+#define LB_MASK_DSR 0x100
+template <int N_MFMA, int VALU_PER, int DSR_FIRST>
+__device__ __forceinline__ void lb_interleave() {
+    if constexpr (DSR_FIRST > 0) __builtin_amdgcn_sched_group_barrier(LB_MASK_DSR, DSR_FIRST, 0);
+#pragma unroll
+    for (int i = 0; i < N_MFMA; ++i) {
+        __builtin_amdgcn_sched_group_barrier(LB_MASK_MFMA, 1, 0);
+        if constexpr (VALU_PER > 0) __builtin_amdgcn_sched_group_barrier(LB_MASK_VALU, VALU_PER, 0);
+    }
+}
+
+// partial gx / ll layout (dimension-major, padded so that no store needs a guard):
+//   gx_part[groups][LB_DP][nbp], ll_part[groups][nbp], nbp = person count rounded up to whole tiles.
+// They hold the LIKELIHOOD part only; k_lik_reduce_parts adds the N(0, I) prior on x (- scale x, - 0.5 |x|^2).
+#define LB_DP 128
+
+// yT: the responses item-major, [J + 1][yT_stride] bytes: row j = item j over the batch rows (columns past nb: 254), row J
+// all 254 ("outside the problem": what the lanes of items past J read); yT_stride % 64 == 0, yT_stride >= nbp.
+// ABL: ablation bits for tools/likb_test.hip only (0 in the library): 1 no cell math, 2 no barriers, 4 no DMA,
+// 8 no scheduling hints, 16 no output stores, 32 phase stamps
+template <int GEN, int ABL = 0>
 __global__ __launch_bounds__(LB_THREADS, 1) void k_irt_lik_b(
-    LikBDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, const uint8_t* __restrict__ ximg,
-    const float* __restrict__ xsq, const float* __restrict__ a, const float* __restrict__ b,
-    const float* __restrict__ c_un, const float* __restrict__ d_un, float* __restrict__ gx_part /*[groups][nb][D] or [groups][D][nb]*/,
-    float* __restrict__ ll_part /*[groups][nb]*/, float* __restrict__ slabs) {
+    LikBDims dm, const uint8_t* __restrict__ yT, int64_t yT_stride, const uint8_t* __restrict__ ximg,
+    const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c_un,
+    const float* __restrict__ d_un, float* __restrict__ gx_part, float* __restrict__ ll_part, float* __restrict__ slabs,
+    long long* __restrict__ stamps = nullptr /*ABL & 32 only*/) {
     extern __shared__ __attribute__((aligned(16))) char smem_lb[];
     const int D = dm.D, J = dm.J;
-    char* xbuf = smem_lb;                                           // [2][3 planes][14336]
-    char* Rimg = xbuf + 2 * LB_XT_BYTES;                            // [2 person halves][3 planes][128 items][64 B]
-    uint8_t* Yb = (uint8_t*)(Rimg + 6 * LB_RPLANE);                 // [64][128]
-    float* LPp = (float*)(Yb + LB_P * LB_YS);                       // [64 persons][64 item pairs]
-    const uint32_t xbuf_l = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem_lb;   // LDS byte addresses
-    const uint32_t Rimg_l = xbuf_l + 2 * LB_XT_BYTES, Yb_l = Rimg_l + 6 * LB_RPLANE;
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    auto stamp = [&](int idx) {
+        if constexpr (ABL & 32) {
+            const long long now = (long long)__builtin_amdgcn_s_memtime();
+            tacc[idx] += now - tlast;
+            tlast = now;
+        }
+    };
+    lb_lds* const smem = (lb_lds*)smem_lb;
+    lb_lds* const Rimg = smem + 2 * LB_XT_BYTES;                    // [2 person halves][3 planes][128 items][64 B]
+    lb_lds* const Yb = Rimg + 6 * LB_RPLANE;                        // [2][128 items][64 persons] response bytes
+    lb_lds* const LPb = Yb + 2 * LB_YT_BYTES;                       // [64 persons][32 item quads] fp32
+    const uint32_t smem_l = (uint32_t)(size_t)smem;
+    const uint32_t Yb_l = smem_l + 2 * LB_XT_BYTES + 6 * LB_RPLANE;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     // XCD-aware decode: the `groups` workgroups that share a person tile sit on one XCD (same L2)
@@ -147,9 +181,11 @@ __global__ __launch_bounds__(LB_THREADS, 1) void k_irt_lik_b(
         pr = blockIdx.x / dm.groups;
     }
     const int j0 = g * LB_JC;
-    const int jw = j0 + 32 * wave + l31;                            // this lane's item (Z / epilogue / GA column)
+    const int jl = 32 * wave + l31;                                 // this lane's item within the chunk
+    const int jw = j0 + jl;                                         // ... in the problem (Z / epilogue / GA column)
     const bool jv = jw < J;
     const int64_t n_ptiles = (dm.nb + LB_P - 1) / LB_P;
+    const int64_t nbp = n_ptiles * LB_P;
 
     // ---- register-resident item operands, split once
     bf16x8 aZ[3][LB_NKS], aG[3][8];
@@ -190,7 +226,7 @@ __global__ __launch_bounds__(LB_THREADS, 1) void k_irt_lik_b(
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) ga[kt] = zero16();
 
-    // ---- per-lane LDS byte offsets (everything else is an immediate)
+    // ---- per-lane LDS byte offsets inside a tile image / the R image (everything else is an immediate)
     // Z row reads: person row p = 32 ph + l31, chunk 2 s + half
     uint32_t zE[2], zO[2], z6[2];
 #pragma unroll
@@ -201,298 +237,315 @@ __global__ __launch_bounds__(LB_THREADS, 1) void k_irt_lik_b(
         zO[ph] = base + 16u * ((2 + half) ^ xr);
         z6[ph] = (uint32_t)(p >> 3) * (256u * LB_NKS) + 1536u + 32u * (p & 7) + 16u * (half ^ ((p >> 4) & 1));
     }
-    // transposed reads: 16-lane group (half, gl), lane 4 q + pp of the group
+    // transposed reads: 16-lane group (half, gl), lane 4 q4 + pp of the group
     const int gl = (lane >> 4) & 1, q4 = (lane & 15) >> 2, pp = lane & 3;
     uint32_t gaB[2], ga3[2], rB[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        // GA: person row P = 32 ph + 16 s' + 8 e + 4 half + q4, latent columns 32 kt + 16 gl + 4 pp .. + 3
+        // GA: person row P = 32 ph + 16 s2 + 8 e + 4 half + q4, latent columns 32 kt + 16 gl + 4 pp .. + 3
         gaB[e] = 64u * (4 * half + q4) + 16u * ((2 * gl + (pp >> 1)) ^ (2 * e + half)) + 8u * (pp & 1);
+        // k-tile 3 (columns 96..111; both lane groups read them: rows 112..127 of GA are never stored), e = s2 here
+        ga3[e] = 1536u + 32u * (4 * half + q4) + 16u * ((pp >> 1) ^ e) + 8u * (pp & 1);
         // R image: item row j = 16 s + 8 half + 4 e + q4, persons 16 gl + 4 pp .. + 3 (8-byte piece 4 gl + pp, swizzled)
         rB[e] = 512u * half + 256u * e + 64u * q4 + 8u * (((4 * gl + pp) ^ (4 * e + q4) ^ half) & 7);
     }
-#pragma unroll
-    for (int sp2 = 0; sp2 < 2; ++sp2)                               // k-tile 3 (columns 96..111; both lane groups read them)
-        ga3[sp2] = 1536u + 32u * (4 * half + q4) + 16u * ((pp >> 1) ^ sp2) + 8u * (pp & 1);
-    // R image write: item row jl = 32 wave + l31, persons 8 g4 + 4 half + 0..3 = piece 2 g4 + half, swizzled
-    const int jl = 32 * wave + l31;
-    const uint32_t rW = (uint32_t)jl * 64u, rSw = (uint32_t)((jl & 7) ^ ((jl >> 3) & 1));
+    // R image write: item row jl, persons 8 g4 + 4 half + 0..3 = piece 2 g4 + half, swizzled
+    const uint32_t rSw = (uint32_t)((jl & 7) ^ ((jl >> 3) & 1));
+    lb_lds* const rWp = Rimg + jl * 64;
+    lb_lds* const rRp0 = Rimg + rB[0];
+    lb_lds* const rRp1 = Rimg + rB[1];
+    lb_lds* const yP0 = Yb + jl * 64;                               // this lane's item row: + 32 ph (+ buffer)
+    const int qc = l31 & 3;                                         // lane within its item quad: stores register 4 g4 + qc
+    lb_lds* const lpW = LPb + 4 * ((4 * half + qc) * 32 + 8 * wave + (l31 >> 2));    // + 128 * (32 ph + 8 g4)
+    lb_lds* const lpR = LPb + 4 * ((tid >> 3) * 32 + 4 * (tid & 7));                  // + 4096 * ph
+    // gx transposition slices: rows 0..15 / 16..31 of this wave's 32 latent rows sit in ITS OWN rows of planes 0 / 1 of the
+    // R image of the person half (2 KB each), which no other wave writes
+    lb_lds* const tW = Rimg + 2048 * wave + 128 * (4 * half) + 4 * l31;      // + 128 ((r & 3) + 8 ((r >> 2) & 1)) + 8192 (r >> 3)
+    lb_lds* const tR = Rimg + 2048 * wave + 128 * (lane >> 3) + 16 * (lane & 7);   // + 1024 (u & 1) + 8192 (u >> 1)
+    float* const gxw = gx_part + ((int64_t)g * LB_DP + 32 * wave + (lane >> 3)) * nbp + 4 * (lane & 7);
 
-    // ---- staging of one person tile: global -> LDS DMA.  x: the tile image, 42 linear 1 KB transfers; y: as k_irt_lik_r
-    const bool jfull = j0 + LB_JC <= J;                             // block-uniform: no item edge in this chunk
-    for (int e = tid; e < LB_P * (LB_YS / 4); e += LB_THREADS) ((uint32_t*)Yb)[e] = 0xFEFEFEFEu;
-    __syncthreads();
-    auto stage_x = [&](int64_t tile, int buf) {
-        const uint8_t* src = ximg + tile * LB_XT_BYTES + lane * 16;
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(xbuf_l + (uint32_t)buf * LB_XT_BYTES);
-#pragma unroll
-        for (int u = 0; u < 11; ++u) {
-            const int piece = wave + 4 * u;                         // wave-uniform
-            if (piece < LB_XT_BYTES / 1024) dma16(src + piece * 1024, dst + (uint32_t)piece * 1024u);
-        }
+    // ---- staging: global -> LDS DMA, ONE 1 KB transfer per call (the LDS-DMA path of a CU moves ~1 KB per ~100 cycles:
+    // the transfers of the next tile are issued one per step under the MFMAs).  x: piece wave + 4 u of the 42 of the tile
+    // image (u = 0..10; past the end: a repeat of the last).  y: 16 item rows x 64 persons per transfer, u = 0, 1.
+    auto stage_x_piece = [&](int64_t tile, int buf, int u) {
+        if constexpr (ABL & (4 | 64)) return;
+        int piece = wave + 4 * u;                                   // wave-uniform
+        piece = piece < LB_XT_BYTES / 1024 ? piece : LB_XT_BYTES / 1024 - 1;
+        dma16(ximg + tile * LB_XT_BYTES + lane * 16 + piece * 1024,
+              __builtin_amdgcn_readfirstlane(smem_l + (uint32_t)buf * LB_XT_BYTES + (uint32_t)piece * 1024u));
     };
-    auto stage_y = [&](int64_t tile) {
-        const int64_t i0 = tile * LB_P;
-        const int pv = (int)((dm.nb - i0) < LB_P ? (dm.nb - i0) : LB_P);
-        if (jfull) {
-            for (int r8 = wave; 8 * r8 < pv; r8 += 4) {
-                const int prow = 8 * r8 + (lane >> 3);
-                if (prow < pv) {
-                    const int64_t row = ROWS ? rows[i0 + prow] : i0 + prow;
-                    dma16(y + row * J + j0 + 16 * (lane & 7), __builtin_amdgcn_readfirstlane(Yb_l + (uint32_t)(r8 * 8 * LB_YS)));
-                }
-            }
-        } else {
-            for (int r2 = wave; 2 * r2 < pv; r2 += 4) {
-                const int prow = 2 * r2 + (lane >> 5), jj = j0 + 4 * (lane & 31);
-                if (prow < pv && jj < J) {
-                    const int64_t row = ROWS ? rows[i0 + prow] : i0 + prow;
-                    dma4(y + row * J + jj, __builtin_amdgcn_readfirstlane(Yb_l + (uint32_t)(r2 * 2 * LB_YS)));
-                }
-            }
-        }
-        if (pv < LB_P)                                              // the last tile: absent persons carry no cell
-            for (int e = tid; e < (LB_P - pv) * (LB_YS / 4); e += LB_THREADS) ((uint32_t*)Yb)[pv * (LB_YS / 4) + e] = 0xFEFEFEFEu;
+    auto stage_y_piece = [&](int64_t tile, int buf, int u) {
+        if constexpr (ABL & (4 | 128)) return;
+        const int piece = wave + 4 * u;                             // rows 16 piece .. + 15 of the chunk
+        int jr = j0 + 16 * piece + (lane >> 2);
+        jr = jr < J ? jr : J;                                       // items past J: the all-254 row
+        dma16(yT + (int64_t)jr * yT_stride + tile * LB_P + 16 * (lane & 3),
+              __builtin_amdgcn_readfirstlane(Yb_l + (uint32_t)buf * LB_YT_BYTES + (uint32_t)piece * 1024u));
     };
 
-    // gx of one person half: C layout of gx^T -- lane = person 32 ph + l31, register r = latent row 32 wave + crow32(r, half).
-    // - scale * x (the N(0, I) prior on x) is subtracted by ONE of the chunk workgroups per run of four rows.
-    auto store_gx = [&](int ph, f32x16 gxa, int64_t i0, const char* xb) {
-        const int p = 32 * ph + l31;
-        const int64_t i = i0 + p;
+    // gx of one person half: C layout of gx^T (lane = person, register r = latent row 32 wave + crow32(r, half)) -> rows of 32
+    // persons through the transposition slices -> four 16-byte stores per lane (128-byte rows; padded, no guards)
+    auto store_gx = [&](int ph, const f32x16& gxa, int64_t i0) {
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const int k0 = 32 * wave + 8 * g4 + 4 * half;
-            if ((g4 % dm.groups) == g && k0 < D) {                  // chunk 4 wave + g4 of the image row, its half `half`
-                const uint32_t o = lb_xoff(p, 4 * wave + g4) + 8u * half;
-                const lb_u32x2 vh = *(const lb_u32x2*)(xb + o), vm = *(const lb_u32x2*)(xb + LB_PLANE + o),
-                               vl = *(const lb_u32x2*)(xb + 2 * LB_PLANE + o);
+        for (int r = 0; r < 16; ++r)
+            *(__attribute__((address_space(3))) float*)(tW + ph * 3 * LB_RPLANE + 128 * ((r & 3) + 8 * ((r >> 2) & 1)) + 8192 * (r >> 3)) = gxa[r];
+        __builtin_amdgcn_wave_barrier();
+        if constexpr (!(ABL & 16)) {
+            float* dst = gxw + i0 + 32 * ph;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t wh = vh[e >> 1], wm = vm[e >> 1], wl = vl[e >> 1];
-                    const float xv = __builtin_bit_cast(float, (e & 1) ? (wh & 0xffff0000u) : (wh << 16)) +
-                                     (__builtin_bit_cast(float, (e & 1) ? (wm & 0xffff0000u) : (wm << 16)) +
-                                      __builtin_bit_cast(float, (e & 1) ? (wl & 0xffff0000u) : (wl << 16)));
-                    gxa[4 * g4 + e] = fmaf(-dm.scale, xv, gxa[4 * g4 + e]);
-                }
-            }
-        }
-        if (i < dm.nb) {
-            if (dm.gxt) {                                           // lanes = consecutive persons: 128-byte rows
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int k = 32 * wave + crow32(r, half);
-                    if (k < D) gx_part[((int64_t)g * D + k) * dm.nb + i] = gxa[r];
-                }
-            } else {
-                float* dst = gx_part + ((int64_t)g * dm.nb + i) * D;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int k = 32 * wave + crow32(r, half);
-                    if (k < D) dst[k] = gxa[r];
+            for (int u = 0; u < 4; ++u) {
+                if (32 * wave + 8 * u < D) {                        // uniform; rows D .. of the last run land in the row padding
+                    const f32x4 v = *(__attribute__((address_space(3))) const f32x4*)(tR + ph * 3 * LB_RPLANE + 1024 * (u & 1) + 8192 * (u >> 1));
+                    *(f32x4*)(dst + (int64_t)(8 * u) * nbp) = v;
                 }
             }
         }
     };
+    // per-person log-lik of this chunk, persons of one half: thread = (person, eighth of the 32 item quads); the eight lanes of
+    // a person end up with the same total and store it to the same word
+    auto ll_reduce = [&](int ph, int64_t i0) {
+        const f32x4 v = *(__attribute__((address_space(3))) const f32x4*)(lpR + 4096 * ph);
+        float sll = (v[0] + v[1]) + (v[2] + v[3]);
+        sll += dpp_mov0<0xB1, 0xF>(sll);
+        sll += dpp_mov0<0x4E, 0xF>(sll);
+        sll += dpp_mov0<0x141, 0xF>(sll);                           // row_half_mirror: the other quad of the eight lanes
+        if constexpr (!(ABL & 16)) ll_part[(int64_t)g * nbp + i0 + 32 * ph + (tid >> 3)] = sll;
+    };
 
-    int64_t tile = pr;
-    int buf = 0;
+    const float sdc = dm.scale * dm.Dc;
+    uint32_t Rp[2][3][8];                                           // [half][split][pair]: packed bf16 terms of R
+    float lpq[4];                                                   // log-lik terms of the current run of four registers
+    f32x16 z0 = zero16();                                           // Z of persons 0..31 of the CURRENT tile (made one tile early)
     f32x16 gx1 = zero16();                                          // gx of persons 32..63: stored one tile late
     int64_t i0_prev = -1;
-    if (tile < n_ptiles) { stage_x(tile, 0); stage_y(tile); }
-    const float sdc = dm.scale * dm.Dc;
-    const int par = l31 & 1;
+    int64_t tile = pr;
+    int buf = 0;
+
+    // ---- operand reads and products (xb: tile image base)
+    auto z_frags = [&](lb_lds* xb, int ph, int s, bf16x8& fh, bf16x8& fm, bf16x8& fl) {
+        lb_lds* o = xb + ((s == 6) ? z6[ph] : (((s & 1) ? zO[ph] : zE[ph]) + 512 * (s >> 1)));
+        fh = lb_read128(o);
+        fm = lb_read128(o + LB_PLANE);
+        fl = lb_read128(o + 2 * LB_PLANE);
+    };
+    auto z_mma = [&](int s, f32x16& z, const bf16x8& xh, const bf16x8& xm, const bf16x8& xl) {
+        z = mfma_bf16(xl, aZ[0][s], z);
+        z = mfma_bf16(xh, aZ[2][s], z);
+        z = mfma_bf16(xm, aZ[1][s], z);
+        z = mfma_bf16(xm, aZ[0][s], z);
+        z = mfma_bf16(xh, aZ[1][s], z);
+        z = mfma_bf16(xh, aZ[0][s], z);
+    };
+    // GA step u = (s2 = u >> 2: persons 16 s2 .. + 15 of the half, kt = u & 3: latent tile): A = x^T by transposed reads
+    auto ga_frags = [&](lb_lds* xb, int ph, int u, bf16x8& fh, bf16x8& fm, bf16x8& fl) {
+        const int s2 = u >> 2, kt = u & 3;
+        const int g0 = 256 * LB_NKS * (4 * ph + 2 * s2), g1 = g0 + 256 * LB_NKS;
+        lb_lds* o0 = xb + ((kt == 3) ? ga3[s2] + g0 : gaB[0] + g0 + 512 * kt);
+        lb_lds* o1 = xb + ((kt == 3) ? ga3[s2] + g1 : gaB[1] + g1 + 512 * kt);
+        fh = lb_frag(lb_tr_read(o0), lb_tr_read(o1));
+        fm = lb_frag(lb_tr_read(o0 + LB_PLANE), lb_tr_read(o1 + LB_PLANE));
+        fl = lb_frag(lb_tr_read(o0 + 2 * LB_PLANE), lb_tr_read(o1 + 2 * LB_PLANE));
+    };
+    auto rfrag = [&](int ph, int sp, int s2) -> bf16x8 {            // B fragment of k-step s2: registers 8 s2 .. 8 s2 + 7
+        const lb_u32x4 qv = {Rp[ph][sp][4 * s2], Rp[ph][sp][4 * s2 + 1], Rp[ph][sp][4 * s2 + 2], Rp[ph][sp][4 * s2 + 3]};
+        return __builtin_bit_cast(bf16x8, qv);
+    };
+    auto ga_mma = [&](int ph, int u, const bf16x8& xh, const bf16x8& xm, const bf16x8& xl) {
+        const int s2 = u >> 2, kt = u & 3;
+        const bf16x8 rh = rfrag(ph, 0, s2), rm = rfrag(ph, 1, s2), rl = rfrag(ph, 2, s2);
+        ga[kt] = mfma_bf16(xl, rh, ga[kt]);
+        ga[kt] = mfma_bf16(xh, rl, ga[kt]);
+        ga[kt] = mfma_bf16(xm, rm, ga[kt]);
+        ga[kt] = mfma_bf16(xm, rh, ga[kt]);
+        ga[kt] = mfma_bf16(xh, rm, ga[kt]);
+        ga[kt] = mfma_bf16(xh, rh, ga[kt]);
+    };
+    // gx step (person half ph, k-step s = items 16 s .. + 15 of the chunk): B = R^T by transposed reads of the R image
+    auto gx_frags = [&](int ph, int s, bf16x8& fh, bf16x8& fm, bf16x8& fl) {
+        const int o = ph * 3 * LB_RPLANE + 1024 * s;
+        fh = lb_frag(lb_tr_read(rRp0 + o), lb_tr_read(rRp1 + o));
+        fm = lb_frag(lb_tr_read(rRp0 + o + LB_RPLANE), lb_tr_read(rRp1 + o + LB_RPLANE));
+        fl = lb_frag(lb_tr_read(rRp0 + o + 2 * LB_RPLANE), lb_tr_read(rRp1 + o + 2 * LB_RPLANE));
+    };
+    auto gx_mma = [&](int s, f32x16& gx, const bf16x8& rh, const bf16x8& rm, const bf16x8& rl) {
+        gx = mfma_bf16(aG[2][s], rh, gx);
+        gx = mfma_bf16(aG[0][s], rl, gx);
+        gx = mfma_bf16(aG[1][s], rm, gx);
+        gx = mfma_bf16(aG[1][s], rh, gx);
+        gx = mfma_bf16(aG[0][s], rm, gx);
+        gx = mfma_bf16(aG[0][s], rh, gx);
+    };
+
+    // ---- the epilogue of one register PAIR (2 i, 2 i + 1) of a person half: cells, R split, R image, LP quad sums.
+    // yq: the 32 response bytes of (this lane's item, persons of the half) = two 16-byte reads; live: 0 for the phantom tile
+    // past the end (its cells are computed on stale data; only the 3PL / 4PL accumulators could see them)
+    auto cell_pair = [&](auto phc, auto ic, f32x16& z, const lb_u32x4& yq0, const lb_u32x4& yq1, float scale_live) {
+        constexpr int ph = decltype(phc)::value, i = decltype(ic)::value;
+        constexpr int g4 = i >> 1;                                  // run of four registers = persons 8 g4 + 4 half + 0..3
+        const uint32_t wlo = (g4 < 2 ? yq0 : yq1)[2 * (g4 & 1)], whi = (g4 < 2 ? yq0 : yq1)[2 * (g4 & 1) + 1];
+        const uint32_t yw = half ? whi : wlo;
+        float rv[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int r = 2 * i + e;
+            const float yf = (float)((yw >> (8 * (r & 3))) & 0xffu);
+            const float zz = z[r];
+            float lp, dz, dc, dd;
+            if constexpr (ABL & 1) {
+                lp = zz; dz = zz + yf; dc = 0.f; dd = 0.f;
+            } else if (GEN) {
+                if (dm.model == 4) irt_cell_f<4>(zz, yf, cj, dj, omdj, lp, dz, dc, dd);
+                else irt_cell_f<3>(zz, yf, cj, 1.0f, 0.f, lp, dz, dc, dd);
+                gc = fmaf(scale_live, dc, gc);
+                gd = fmaf(scale_live, dd, gd);
+            } else {
+                irt_cell_f<2>(zz, yf, 0.f, 1.f, 0.f, lp, dz, dc, dd);
+            }
+            rv[e] = sdc * dz;
+            const float l2 = lp + dpp_mov0<0xB1, 0xF>(lp);          // + the terms of the three other items of the quad
+            lpq[2 * (i & 1) + e] = l2 + dpp_mov0<0x4E, 0xF>(l2);
+        }
+        lb_split_pair(rv[0], rv[1], Rp[ph][0][i], Rp[ph][1][i], Rp[ph][2][i]);
+        if constexpr (i & 1) {                                      // registers 4 g4 .. 4 g4 + 3 are complete
+            // item quad (l31 >> 2): lane qc of the quad stores register 4 g4 + qc = person 32 ph + 8 g4 + 4 half + qc
+            const float t01 = (qc & 1) ? lpq[1] : lpq[0], t23 = (qc & 1) ? lpq[3] : lpq[2];
+            *(__attribute__((address_space(3))) float*)(lpW + 128 * (32 * ph + 8 * g4)) = (qc & 2) ? t23 : t01;
+            lb_lds* wb = rWp + ph * 3 * LB_RPLANE + 8u * (((2 * g4 + half) ^ rSw) & 7);
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) {
+                const lb_u32x2 w = {Rp[ph][sp][i - 1], Rp[ph][sp][i]};
+                *(__attribute__((address_space(3))) lb_u32x2*)(wb + sp * LB_RPLANE) = w;
+            }
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    constexpr bool HINT = !(ABL & 8);
+
+    // ---- prologue: stage the first tile, Z and cells of its persons 0..31 (no overlap: once per workgroup)
+    if (tile < n_ptiles) {
+#pragma unroll
+        for (int u = 0; u < 11; ++u) stage_x_piece(tile, 0, u);
+        stage_y_piece(tile, 0, 0);
+        stage_y_piece(tile, 0, 1);
+        vx_wait_vmem();
+        __syncthreads();
+        bf16x8 fh, fm, fl;
+        static_for<LB_NKS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            z_frags(smem, 0, s, fh, fm, fl);
+            z_mma(s, z0, fh, fm, fl);
+        });
+        const lb_u32x4 yq0 = *(__attribute__((address_space(3))) const lb_u32x4*)(yP0), yq1 = *(__attribute__((address_space(3))) const lb_u32x4*)(yP0 + 16);
+        static_for<8>([&](auto ic) { cell_pair(I0{}, ic, z0, yq0, yq1, dm.scale); });
+    }
+    if constexpr (ABL & 32) tlast = (long long)__builtin_amdgcn_s_memtime();
     for (; tile < n_ptiles; tile += dm.n_pr, buf ^= 1) {
-        vx_wait_vmem();                                             // this wave's DMA of the tile has landed
-        __syncthreads();                                            // S1: tile staged; R / LP of the previous tile consumed
-        const char* xb = xbuf + buf * LB_XT_BYTES;
-        const uint32_t xb_l = xbuf_l + (uint32_t)buf * LB_XT_BYTES;
-        if (i0_prev >= 0) store_gx(1, gx1, i0_prev, xbuf + (buf ^ 1) * LB_XT_BYTES);
-        gx1 = zero16();
+        if constexpr (!(ABL & 2)) __syncthreads();                  // TOP: R image / LP of persons 0..31 complete; the other
+        stamp(0);                                                   //      x / y buffers and the R image of persons 32..63 are free
+        lb_lds* const xb = smem + buf * LB_XT_BYTES;
+        lb_lds* const xn = smem + (buf ^ 1) * LB_XT_BYTES;
         const int64_t i0 = tile * LB_P;
         const int64_t next = tile + dm.n_pr;
         const bool has_next = next < n_ptiles;                      // block-uniform
+        const int64_t nx = has_next ? next : tile;                  // past the last tile: a harmless reload of this one
+        const float scale_next = has_next ? dm.scale : 0.f;
+        f32x16 z1 = zero16(), gx0 = zero16();
+        bf16x8 ch, cm, cl, nh, nm, nl;
 
-        // ---- operand reads
-        auto z_frags = [&](int ph, int s, bf16x8& fh, bf16x8& fm, bf16x8& fl) {
-            const uint32_t o = (s == 6) ? z6[ph] : (((s & 1) ? zO[ph] : zE[ph]) + 512u * (s >> 1));
-            fh = *(const bf16x8*)(xb + o);
-            fm = *(const bf16x8*)(xb + LB_PLANE + o);
-            fl = *(const bf16x8*)(xb + 2 * LB_PLANE + o);
-        };
-        auto z_mma = [&](int s, f32x16& z, const bf16x8& xh, const bf16x8& xm, const bf16x8& xl) {
-            z = mfma_bf16(xl, aZ[0][s], z);
-            z = mfma_bf16(xh, aZ[2][s], z);
-            z = mfma_bf16(xm, aZ[1][s], z);
-            z = mfma_bf16(xm, aZ[0][s], z);
-            z = mfma_bf16(xh, aZ[1][s], z);
-            z = mfma_bf16(xh, aZ[0][s], z);
-        };
-        // GA step (person half ph, k-step s2 = persons 16 s2 .. + 15 of the half, latent tile kt): A = x^T by transposed reads
-        auto ga_frags = [&](int ph, int s2, int kt, bf16x8& fh, bf16x8& fm, bf16x8& fl) {
-            const uint32_t g0 = 256u * LB_NKS * (4 * ph + 2 * s2), g1 = g0 + 256u * LB_NKS;
-            const uint32_t o0 = (kt == 3) ? g0 + ga3[s2] : g0 + gaB[0] + 512u * kt;
-            const uint32_t o1 = (kt == 3) ? g1 + ga3[s2] : g1 + gaB[1] + 512u * kt;
-            fh = lb_frag(lb_tr_read(xb_l + o0), lb_tr_read(xb_l + o1));
-            fm = lb_frag(lb_tr_read(xb_l + LB_PLANE + o0), lb_tr_read(xb_l + LB_PLANE + o1));
-            fl = lb_frag(lb_tr_read(xb_l + 2 * LB_PLANE + o0), lb_tr_read(xb_l + 2 * LB_PLANE + o1));
-        };
-        auto ga_mma = [&](int kt, const bf16x8& xh, const bf16x8& xm, const bf16x8& xl, const bf16x8& rh, const bf16x8& rm,
-                          const bf16x8& rl) {
-            ga[kt] = mfma_bf16(xl, rh, ga[kt]);
-            ga[kt] = mfma_bf16(xh, rl, ga[kt]);
-            ga[kt] = mfma_bf16(xm, rm, ga[kt]);
-            ga[kt] = mfma_bf16(xm, rh, ga[kt]);
-            ga[kt] = mfma_bf16(xh, rm, ga[kt]);
-            ga[kt] = mfma_bf16(xh, rh, ga[kt]);
-        };
-        // gx step (person half ph, k-step s = items 16 s .. + 15 of the chunk): B = R^T by transposed reads of the R image
-        auto gx_frags = [&](int ph, int s, bf16x8& fh, bf16x8& fm, bf16x8& fl) {
-            const uint32_t rb = Rimg_l + (uint32_t)(ph * 3 * LB_RPLANE + 1024 * s);
-            fh = lb_frag(lb_tr_read(rb + rB[0]), lb_tr_read(rb + rB[1]));
-            fm = lb_frag(lb_tr_read(rb + LB_RPLANE + rB[0]), lb_tr_read(rb + LB_RPLANE + rB[1]));
-            fl = lb_frag(lb_tr_read(rb + 2 * LB_RPLANE + rB[0]), lb_tr_read(rb + 2 * LB_RPLANE + rB[1]));
-        };
-        auto gx_mma = [&](int s, f32x16& gx, const bf16x8& rh, const bf16x8& rm, const bf16x8& rl) {
-            gx = mfma_bf16(aG[2][s], rh, gx);
-            gx = mfma_bf16(aG[0][s], rl, gx);
-            gx = mfma_bf16(aG[1][s], rm, gx);
-            gx = mfma_bf16(aG[1][s], rh, gx);
-            gx = mfma_bf16(aG[0][s], rm, gx);
-            gx = mfma_bf16(aG[0][s], rh, gx);
-        };
-
-        // ---- the epilogue of one register PAIR (2 i, 2 i + 1) of a person half: cells, R split, LP pair sums
-        uint32_t Rp[2][3][8];                                       // [half][split][pair]: packed bf16 terms of R
-        auto cell_pair = [&](auto phc, auto ic, f32x16& z) {
-            constexpr int ph = decltype(phc)::value, i = decltype(ic)::value;
-            float lpv[2], rv[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int r = 2 * i + e;
-                const int p = 32 * ph + crow32(r, half);
-                const unsigned yy = Yb[p * LB_YS + 32 * wave + l31];
-                const float zz = z[r];
-                float lp, dz, dc, dd;
-                if (GEN) {
-                    if (dm.model == 4) irt_cell<4>(zz, yy, cj, dj, omdj, lp, dz, dc, dd);
-                    else irt_cell<3>(zz, yy, cj, 1.0f, 0.f, lp, dz, dc, dd);
-                    gc = fmaf(dm.scale, dc, gc);
-                    gd = fmaf(dm.scale, dd, gd);
-                } else {
-                    irt_cell<2>(zz, yy, 0.f, 1.f, 0.f, lp, dz, dc, dd);
-                }
-                rv[e] = sdc * dz;
-                lpv[e] = lp + dpp_mov0<0xB1, 0xF>(lp);              // + the neighbouring item's term (quad_perm [1,0,3,2])
-            }
-            lb_split_pair(rv[0], rv[1], Rp[ph][0][i], Rp[ph][1][i], Rp[ph][2][i]);
-            // item pair (l31 >> 1): the even lane stores register 2 i, the odd lane register 2 i + 1
-            const int pw = 32 * ph + crow32(2 * i, half) + par;
-            LPp[pw * 64 + 16 * wave + (l31 >> 1)] = par ? lpv[1] : lpv[0];
-            if constexpr (i & 1) {                                  // registers 4 g4 .. 4 g4 + 3 are complete: 8 bytes per plane
-                constexpr int g4 = i >> 1;
-                char* wb = Rimg + ph * 3 * LB_RPLANE + rW + 8u * (((2 * g4 + half) ^ rSw) & 7);
-#pragma unroll
-                for (int sp = 0; sp < 3; ++sp) {
-                    const lb_u32x2 w = {Rp[ph][sp][i - 1], Rp[ph][sp][i]};
-                    *(lb_u32x2*)(wb + sp * LB_RPLANE) = w;
-                }
-            }
-        };
-        auto rfrag = [&](int ph, int sp, int s2) -> bf16x8 {        // B fragment of k-step s2: registers 8 s2 .. 8 s2 + 7
-            const lb_u32x4 qv = {Rp[ph][sp][4 * s2], Rp[ph][sp][4 * s2 + 1], Rp[ph][sp][4 * s2 + 2], Rp[ph][sp][4 * s2 + 3]};
-            return __builtin_bit_cast(bf16x8, qv);
-        };
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-
-        // ---- A: Z of persons 0..31
-        f32x16 z0 = zero16(), z1 = zero16();
+        // ---- phase 1: Z of persons 32..63 | deferred gx store of the previous tile, log-lik of persons 0..31
+        z_frags(xb, 1, 0, ch, cm, cl);
+        static_for<LB_NKS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if constexpr (s + 1 < LB_NKS) z_frags(xb, 1, s + 1, nh, nm, nl); else ga_frags(xb, 0, 0, nh, nm, nl);
+            z_mma(s, z1, ch, cm, cl);
+            ch = nh; cm = nm; cl = nl;
+            stage_x_piece(nx, buf ^ 1, s);
+            if constexpr (s == 1) { if (i0_prev >= 0) store_gx(1, gx1, i0_prev); }
+            if constexpr (s == 3) ll_reduce(0, i0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        gx1 = zero16();
+        stamp(1);
+        // ---- phase 2: GA and gx of persons 0..31 | the epilogue of persons 32..63
         {
-            bf16x8 ch, cm, cl, nh, nm, nl;
-            z_frags(0, 0, ch, cm, cl);
-            static_for<LB_NKS>([&](auto sc) {
-                constexpr int s = decltype(sc)::value;
-                if constexpr (s + 1 < LB_NKS) z_frags(0, s + 1, nh, nm, nl); else z_frags(1, 0, nh, nm, nl);
-                z_mma(s, z0, ch, cm, cl);
-                ch = nh; cm = nm; cl = nl;
+            lb_lds* const yP = yP0 + buf * LB_YT_BYTES + 32;
+            const lb_u32x4 yq0 = *(__attribute__((address_space(3))) const lb_u32x4*)(yP), yq1 = *(__attribute__((address_space(3))) const lb_u32x4*)(yP + 16);
+            static_for<4>([&](auto dc_) {                           // two GA steps + one cell pair per region
+                constexpr int d2 = decltype(dc_)::value, u = 2 * d2;
+                ga_frags(xb, 0, u + 1, nh, nm, nl);
+                ga_mma(0, u, ch, cm, cl);
+                if constexpr (u + 2 < 8) ga_frags(xb, 0, u + 2, ch, cm, cl); else gx_frags(0, 0, ch, cm, cl);
+                ga_mma(0, u + 1, nh, nm, nl);
+                cell_pair(I1{}, dc_, z1, yq0, yq1, dm.scale);
+                stage_x_piece(nx, buf ^ 1, 7 + d2);
+                if constexpr (HINT) lb_interleave<12, 7, 6>();
                 __builtin_amdgcn_sched_barrier(0);
             });
-            // ---- B: Z of persons 32..63 | the epilogue of persons 0..31
-            static_for<LB_NKS>([&](auto sc) {
-                constexpr int s = decltype(sc)::value;
-                if constexpr (s + 1 < LB_NKS) z_frags(1, s + 1, nh, nm, nl);
-                z_mma(s, z1, ch, cm, cl);
-                if constexpr (s + 1 < LB_NKS) { ch = nh; cm = nm; cl = nl; }
-                cell_pair(I0{}, sc, z0);
-                if constexpr (s == LB_NKS - 1) cell_pair(I0{}, std::integral_constant<int, 7>{}, z0);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        }
-        __syncthreads();                                            // S2: R image / LP of persons 0..31 complete
-        // ---- C: GA and gx of persons 0..31 | the epilogue of persons 32..63
-        f32x16 gx0 = zero16();
-        {
-            bf16x8 ch, cm, cl, nh, nm, nl;
-            ga_frags(0, 0, 0, ch, cm, cl);
-            static_for<8>([&](auto uc) {                            // (s2, kt) = (u >> 2, u & 3)
-                constexpr int u = decltype(uc)::value, s2 = u >> 2, kt = u & 3;
-                if constexpr (u + 1 < 8) ga_frags(0, (u + 1) >> 2, (u + 1) & 3, nh, nm, nl); else gx_frags(0, 0, nh, nm, nl);
-                ga_mma(kt, ch, cm, cl, rfrag(0, 0, s2), rfrag(0, 1, s2), rfrag(0, 2, s2));
-                ch = nh; cm = nm; cl = nl;
-                if constexpr ((u & 1) == 0) cell_pair(I1{}, std::integral_constant<int, u / 2>{}, z1);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            static_for<8>([&](auto sc) {
-                constexpr int s = decltype(sc)::value;
-                if constexpr (s + 1 < 8) gx_frags(0, s + 1, nh, nm, nl);
+            static_for<4>([&](auto dc_) {                           // two gx steps + one cell pair per region
+                constexpr int d2 = decltype(dc_)::value, s = 2 * d2;
+                gx_frags(0, s + 1, nh, nm, nl);
                 gx_mma(s, gx0, ch, cm, cl);
-                if constexpr (s + 1 < 8) { ch = nh; cm = nm; cl = nl; }
-                if constexpr ((s & 1) == 0) cell_pair(I1{}, std::integral_constant<int, 4 + s / 2>{}, z1);
+                if constexpr (s + 2 < 8) gx_frags(0, s + 2, ch, cm, cl);
+                gx_mma(s + 1, gx0, nh, nm, nl);
+                cell_pair(I1{}, std::integral_constant<int, 4 + d2>{}, z1, yq0, yq1, dm.scale);
+                if constexpr (d2 < 2) stage_y_piece(nx, buf ^ 1, d2);
+                if constexpr (HINT) lb_interleave<12, 7, 6>();
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
-        __syncthreads();                                            // S3: R image of persons 32..63 and all LP rows complete
-        if (has_next) { stage_x(next, buf ^ 1); stage_y(next); }    // DMA of the next tile flies under the 96 MFMAs of D
-        // ---- D: gx and GA of persons 32..63 | ll reduce, gx store of persons 0..31
+        stamp(2);
+        vx_wait_vmem();                                             // this wave's transfers of the next tile have landed
+        stamp(3);
+        if constexpr (!(ABL & 2)) __syncthreads();                  // MID: R image / LP of persons 32..63 complete; next tile staged
+        stamp(4);
+        // ---- phase 3: Z of persons 0..31 of the NEXT tile | log-lik of persons 32..63, gx store of persons 0..31
+        z0 = zero16();
+        z_frags(xn, 0, 0, ch, cm, cl);
+        static_for<LB_NKS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if constexpr (s + 1 < LB_NKS) z_frags(xn, 0, s + 1, nh, nm, nl); else gx_frags(1, 0, nh, nm, nl);
+            z_mma(s, z0, ch, cm, cl);
+            ch = nh; cm = nm; cl = nl;
+            if constexpr (s == 1) ll_reduce(1, i0);
+            if constexpr (s == 3) store_gx(0, gx0, i0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        stamp(5);
+        // ---- phase 4: gx and GA of persons 32..63 | the epilogue of persons 0..31 of the NEXT tile
         {
-            bf16x8 ch, cm, cl, nh, nm, nl;
-            gx_frags(1, 0, ch, cm, cl);
-            static_for<8>([&](auto sc) {
-                constexpr int s = decltype(sc)::value;
-                if constexpr (s + 1 < 8) gx_frags(1, s + 1, nh, nm, nl); else ga_frags(1, 0, 0, nh, nm, nl);
+            lb_lds* const yP = yP0 + (buf ^ 1) * LB_YT_BYTES;
+            const lb_u32x4 yq0 = *(__attribute__((address_space(3))) const lb_u32x4*)(yP), yq1 = *(__attribute__((address_space(3))) const lb_u32x4*)(yP + 16);
+            static_for<4>([&](auto dc_) {
+                constexpr int d2 = decltype(dc_)::value, s = 2 * d2;
+                gx_frags(1, s + 1, nh, nm, nl);
                 gx_mma(s, gx1, ch, cm, cl);
-                ch = nh; cm = nm; cl = nl;
-                if constexpr (s == 1) {
-                    // per-person log-lik of this chunk (+ the N(0, I) prior once, in chunk 0): thread = (person, quarter)
-                    const int p = tid >> 2, qq = tid & 3;
-                    float sll = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const f32x4 v = *(const f32x4*)(LPp + p * 64 + 16 * qq + 4 * ((e + p) & 3));
-                        sll += (v[0] + v[1]) + (v[2] + v[3]);
-                    }
-                    sll += dpp_mov0<0xB1, 0xF>(sll);
-                    sll += dpp_mov0<0x4E, 0xF>(sll);
-                    if (qq == 0 && i0 + p < dm.nb) {
-                        if (g == 0) sll = fmaf(-0.5f, xsq[i0 + p], sll);
-                        ll_part[(int64_t)g * dm.nb + i0 + p] = sll;
-                    }
-                }
-                if constexpr (s == 4) store_gx(0, gx0, i0, xb);
+                if constexpr (s + 2 < 8) gx_frags(1, s + 2, ch, cm, cl); else ga_frags(xb, 1, 0, ch, cm, cl);
+                gx_mma(s + 1, gx1, nh, nm, nl);
+                cell_pair(I0{}, dc_, z0, yq0, yq1, scale_next);
+                if constexpr (HINT) lb_interleave<12, 7, 6>();
                 __builtin_amdgcn_sched_barrier(0);
             });
-            static_for<8>([&](auto uc) {
-                constexpr int u = decltype(uc)::value, s2 = u >> 2, kt = u & 3;
-                if constexpr (u + 1 < 8) ga_frags(1, (u + 1) >> 2, (u + 1) & 3, nh, nm, nl);
-                ga_mma(kt, ch, cm, cl, rfrag(1, 0, s2), rfrag(1, 1, s2), rfrag(1, 2, s2));
-                if constexpr (u + 1 < 8) { ch = nh; cm = nm; cl = nl; }
+            static_for<4>([&](auto dc_) {
+                constexpr int d2 = decltype(dc_)::value, u = 2 * d2;
+                ga_frags(xb, 1, u + 1, nh, nm, nl);
+                ga_mma(1, u, ch, cm, cl);
+                if constexpr (u + 2 < 8) ga_frags(xb, 1, u + 2, ch, cm, cl);
+                ga_mma(1, u + 1, nh, nm, nl);
+                cell_pair(I0{}, std::integral_constant<int, 4 + d2>{}, z0, yq0, yq1, scale_next);
+                if constexpr (HINT) lb_interleave<12, 7, 6>();
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
         i0_prev = i0;
+        stamp(6);
     }
-    if (i0_prev >= 0) store_gx(1, gx1, i0_prev, xbuf + (buf ^ 1) * LB_XT_BYTES);
+    if constexpr (ABL & 32) {
+        if (stamps && tid == 0 && blockIdx.x < 1024)
+            for (int q = 0; q < 8; ++q) stamps[blockIdx.x * 8 + q] = tacc[q];
+    }
+    if constexpr (!(ABL & 2)) __syncthreads();                      // every wave is done reading the R image of persons 32..63
+    if (i0_prev >= 0) store_gx(1, gx1, i0_prev);
     // ---- item-gradient slab of this person range: GA C layout = rows k = 32 kt + crow32(r, half), column = this lane's item
     float* slab = slabs + (int64_t)pr * dm.slab_len;
     if (jv) {
@@ -510,6 +563,35 @@ __global__ __launch_bounds__(LB_THREADS, 1) void k_irt_lik_b(
         if (jv && half == 0) {
             slab[(int64_t)(D + 1) * J + jw] = gc;
             slab[(int64_t)(D + 2) * J + jw] = gd;
+        }
+    }
+}
+
+// gxT[k][i] = sum_g gx_part[g][k][i] - scale x[i][k],  ll[i] = sum_g ll_part[g][i] - 0.5 |x_i|^2  (the N(0, I) prior on
+// x, vi.py:607-613): one block per 64 persons; x rows are read coalesced and turned through LDS
+__global__ __launch_bounds__(256) void k_lik_reduce_parts(const float* __restrict__ gx_part, const float* __restrict__ ll_part,
+                                                         const float* __restrict__ x, int groups, int D, int64_t nb, int64_t nbp,
+                                                         float scale, float* __restrict__ gxT, float* __restrict__ ll) {
+    __shared__ float xs[64 * 129];
+    const int64_t i0 = (int64_t)blockIdx.x * 64;
+    const int pv = (int)((nb - i0) < 64 ? (nb - i0) : 64);
+    for (int e = threadIdx.x; e < pv * D; e += 256) {
+        const int p = e / D, k = e - p * D;
+        xs[p * 129 + k] = x[(i0 + p) * D + k];
+    }
+    __syncthreads();
+    const int p = threadIdx.x & 63;
+    if (p < pv) {
+        for (int k = threadIdx.x >> 6; k < D; k += 4) {
+            float acc = 0.f;
+            for (int gq = 0; gq < groups; ++gq) acc += gx_part[((int64_t)gq * LB_DP + k) * nbp + i0 + p];
+            gxT[(int64_t)k * nb + i0 + p] = fmaf(-scale, xs[p * 129 + k], acc);
+        }
+        if (threadIdx.x < 64) {
+            float acc = 0.f, sq = 0.f;
+            for (int gq = 0; gq < groups; ++gq) acc += ll_part[(int64_t)gq * nbp + i0 + p];
+            for (int k = 0; k < D; ++k) { const float t = xs[p * 129 + k]; sq = fmaf(t, t, sq); }
+            ll[i0 + p] = fmaf(-0.5f, sq, acc);
         }
     }
 }

@@ -617,7 +617,8 @@ __global__ __launch_bounds__(F1_THREADS, 1) void k_fc1_bwd_t(
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const uint32_t lo = m ? yc[t].z : yc[t].x, hi = m ? yc[t].w : yc[t].y;
-                    const int w = (int)(half ? hi : lo);               // bytes of persons 16c + 8m + 4half + 0..3
+                    const uint32_t wu = half ? hi : lo;                // bytes of persons 16c + 8m + 4half + 0..3
+                    const int w = (int)(wu & ((wu & 0x01010101u) * 0xFFu));   // 254 (pad byte: even) -> 0; 0 / 1 / 255 unchanged
                     const float y0 = (float)((w << 24) >> 24), y1 = (float)((w << 16) >> 24);
                     const float y2 = (float)((w << 8) >> 24), y3 = (float)(w >> 24);
                     acc[t][0] = mfma32(g0[0], y0, acc[t][0]); acc[t][1] = mfma32(g1[0], y0, acc[t][1]);

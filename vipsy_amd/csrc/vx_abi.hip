@@ -9,6 +9,7 @@
 #include "k_mvn_enc_bwd_fast.hip"
 #include "k_irt_lik.hip"
 #include "k_irt_lik_r.hip"
+#include "k_irt_lik_b.hip"
 #include "k_irt1d.hip"
 #include "k_irt1d_sparse.hip"
 #include "k_hodina.hip"
@@ -380,6 +381,32 @@ static void lik_r_plan(const vx_irt_cfg* cfg, int64_t nb, int& groups, int& n_pr
     n_pr = (int)(want < 1 ? 1 : want);
 }
 
+// bf16x3 variant (k_irt_lik_b.hip): D + 1 in (96, 112], full batch, item-major responses supplied
+static bool lik_b_shape(const vx_irt_cfg* cfg) { return !force_generic() && cfg->D >= 96 && cfg->D <= 16 * LB_NKS - 1; }
+static bool lik_b_ok(const vx_irt_cfg* cfg, const int64_t* rows, int64_t nb, const uint8_t* yT, int64_t yT_stride,
+                     const float* gxT) {
+    const int64_t nbp = (nb + LB_P - 1) / LB_P * LB_P;
+    return lik_b_shape(cfg) && !rows && yT && gxT && yT_stride % 64 == 0 && yT_stride >= nbp && aligned16(yT) && nb > 0;
+}
+static void lik_b_plan(const vx_irt_cfg* cfg, int64_t nb, int& groups, int& n_pr) {
+    groups = (cfg->J + LB_JC - 1) / LB_JC;
+    const int64_t n_ptiles = (nb + LB_P - 1) / LB_P;
+    int64_t want = num_cu() / groups;
+    if (want < 1) want = 1;
+    if (want > n_ptiles) want = n_ptiles;
+    if (want >= 8) want &= ~7LL;                          // whole XCD rounds (see the kernel's block decode)
+    n_pr = (int)(want < 1 ? 1 : want);
+}
+// workspace of the bf16x3 path, in floats: slabs | x image | gx partials | ll partials
+static int64_t lik_b_ws_floats(const vx_irt_cfg* cfg, int64_t nb) {
+    int groups, n_pr;
+    lik_b_plan(cfg, nb, groups, n_pr);
+    const int64_t n_ptiles = (nb + LB_P - 1) / LB_P, nbp = n_ptiles * LB_P;
+    const int64_t slab_len = (int64_t)cfg->D * cfg->J + 3 * (int64_t)cfg->J;
+    return (((int64_t)n_pr * slab_len + 3) & ~(int64_t)3) + n_ptiles * (LB_XT_BYTES / 4) + (int64_t)groups * LB_DP * nbp +
+           (int64_t)groups * nbp;
+}
+
 static bool lik_cfg_ok(const vx_irt_cfg* cfg) {
     return cfg && cfg->D >= 2 && cfg->D <= 127 && cfg->J >= 1 && cfg->model >= VX_IRT_2PL &&
            cfg->model <= VX_IRT_4PL;
@@ -394,16 +421,62 @@ int64_t vx_irt_lik_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
     int64_t w = (int64_t)n_pr * slab_len;
     if (groups > 1) w += (int64_t)groups * nb * (cfg->D + 1);
     if (!lik_r_shape(cfg)) w += nb * cfg->D + 4;          // person-major gx when only gxT is asked for
+    if (lik_b_shape(cfg)) {                               // whichever of the two D >= 64 paths the call takes
+        const int64_t wb = lik_b_ws_floats(cfg, nb);
+        if (wb > w) w = wb;
+    }
     return w;
 }
 
 int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* x,
                     const float* a, const float* b, const float* c_un, const float* d_un, float* gx, float* gxT,
-                    float* ll, float* gitem, float* workspace, void* hs) {
+                    float* ll, float* gitem, float* workspace, const uint8_t* yT, int64_t yT_stride, void* hs) {
     if (!lik_cfg_ok(cfg) || !y || !x || !a || !b || (!gx && !gxT) || !ll || !gitem || !workspace || nb < 0)
         return VX_EINVAL;
     if (cfg->model >= VX_IRT_3PL && !c_un) return VX_EINVAL;
     if (cfg->model == VX_IRT_4PL && !d_un) return VX_EINVAL;
+    if (lik_b_ok(cfg, rows, nb, yT, yT_stride, gxT) && aligned16(workspace) && aligned16(gxT)) {
+        int groups, n_pr;
+        lik_b_plan(cfg, nb, groups, n_pr);
+        const int64_t n_ptiles = (nb + LB_P - 1) / LB_P, nbp = n_ptiles * LB_P;
+        LikBDims dm;
+        dm.D = cfg->D; dm.J = cfg->J; dm.model = cfg->model; dm.groups = groups; dm.n_pr = n_pr; dm.gxt = 1;
+        dm.Dc = cfg->Dc; dm.scale = cfg->scale; dm.nb = nb;
+        dm.slab_len = (int64_t)cfg->D * cfg->J + 3 * (int64_t)cfg->J;
+        float* slabs = workspace;
+        uint8_t* ximg = (uint8_t*)(workspace + (((int64_t)n_pr * dm.slab_len + 3) & ~(int64_t)3));
+        float* gx_part = (float*)(ximg + n_ptiles * LB_XT_BYTES);
+        float* ll_part = gx_part + (int64_t)groups * LB_DP * nbp;
+        hipStream_t st = (hipStream_t)hs;
+        hipError_t he = hipMemsetAsync(slabs, 0, sizeof(float) * (size_t)n_pr * dm.slab_len, st);
+        if (he != hipSuccess) return (int)he;
+        hipLaunchKernelGGL(k_lik_ximg, dim3((unsigned)n_ptiles), dim3(256), 0, st, (int)cfg->D, nb, x, ximg);
+        VX_CHECK_LAUNCH();
+        int rc;
+        const dim3 grid((unsigned)(groups * n_pr));
+        if (cfg->model >= VX_IRT_3PL) {
+            rc = set_lds(k_irt_lik_b<1>, LB_LDS_BYTES);
+            if (rc) return rc;
+            ProfScope ps("k_irt_lik_b", st);
+            hipLaunchKernelGGL((k_irt_lik_b<1>), grid, dim3(LB_THREADS), LB_LDS_BYTES, st, dm, yT, yT_stride, (const uint8_t*)ximg,
+                               a, b, c_un, d_un, gx_part, ll_part, slabs, (long long*)nullptr);
+        } else {
+            rc = set_lds(k_irt_lik_b<0>, LB_LDS_BYTES);
+            if (rc) return rc;
+            ProfScope ps("k_irt_lik_b", st);
+            hipLaunchKernelGGL((k_irt_lik_b<0>), grid, dim3(LB_THREADS), LB_LDS_BYTES, st, dm, yT, yT_stride, (const uint8_t*)ximg,
+                               a, b, c_un, d_un, gx_part, ll_part, slabs, (long long*)nullptr);
+        }
+        VX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_lik_reduce_parts, dim3((unsigned)n_ptiles), dim3(256), 0, st, (const float*)gx_part, (const float*)ll_part,
+                           x, groups, (int)cfg->D, nb, nbp, cfg->scale, gxT, ll);
+        VX_CHECK_LAUNCH();
+        if (gx) {                                          // both orders requested: gx[nb][D] = transpose(gxT[D][nb])
+            hipLaunchKernelGGL(k_transpose, dim3(num_cu() * 8), dim3(256), 0, st, gxT, gx, (int64_t)cfg->D, nb);
+            VX_CHECK_LAUNCH();
+        }
+        return vx_reduce_slabs(slabs, n_pr, dm.slab_len, -1.0f, gitem, hs);
+    }
     if (lik_r_shape(cfg)) {
         int groups, n_pr;
         lik_r_plan(cfg, nb, groups, n_pr);

@@ -153,6 +153,48 @@ __device__ __forceinline__ void irt_cell(float z, unsigned y, float c, float d, 
     }
 }
 
+// The same cell with the response handed over as a float (0, 1, 254 = outside the problem, 255 = missing): the byte comes
+// out of a packed word by v_cvt_f32_ubyteN, no integer copy of it is needed.
+template <int MODEL>
+__device__ __forceinline__ void irt_cell_f(float z, float yf, float c, float d, float omd, float& lp, float& dz, float& dc,
+                                           float& dd) {
+    const bool obs = yf < 1.5f;
+    if (MODEL <= 2) {
+        const float ZL = 15.942384719848633f;       // logit(1 - eps32)
+        const float zc = __builtin_amdgcn_fmed3f(z, -ZL, ZL);
+        const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(zc));   // exp(-|zc|) in (1e-7, 1]
+        const float t = 1.0f + e;
+        const float r = fast_rcp(t);
+        const float sp = fmaf(__builtin_amdgcn_logf(t), 0.6931471805599453f, fmaxf(zc, 0.f));   // softplus(zc)
+        const float sg = (zc >= 0.f) ? r : e * r;
+        const float mval = fmaf(yf, VX_LOGP_MISSING, -254.0f * VX_LOGP_MISSING);
+        float lp0 = fmaf(yf, zc, -sp), d0 = yf - sg;
+        asm("" : "+v"(lp0), "+v"(d0));
+        lp = obs ? lp0 : mval;
+        dz = (obs && zc == z) ? d0 : 0.f;
+        dc = 0.f; dd = 0.f;
+    } else {
+        const bool one = yf == 1.0f;
+        const float e = __expf(-fabsf(z));
+        const float r = fast_rcp(1.0f + e);
+        const float sg = (z >= 0.f) ? r : e * r;
+        const float sn = (z >= 0.f) ? e * r : r;
+        const float dmc = d - c;
+        const float P = c + dmc * sg;
+        const float Q = omd + dmc * sn;
+        const bool inside = obs && (P >= VX_EPS32) && (Q >= VX_EPS32);
+        const float Pc = fminf(fmaxf(P, VX_EPS32), 1.0f - VX_EPS32);
+        const float Qc = fminf(fmaxf(Q, VX_EPS32), 1.0f - VX_EPS32);
+        const float sel = one ? Pc : Qc;
+        lp = obs ? __logf(sel) : (yf > 254.5f ? VX_LOGP_MISSING : 0.f);
+        const float inv = fast_rcp(sel);
+        const float dP = inside ? (one ? inv : -inv) : 0.f;
+        dz = dP * dmc * sg * sn;
+        dc = dP * sn * c * (1.0f - c);
+        dd = (MODEL == 4) ? dP * sg * d * omd : 0.f;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // wave / block reductions
 // ---------------------------------------------------------------------------------------------

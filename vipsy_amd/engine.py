@@ -61,10 +61,11 @@ class HipBackend(object):
             raise _hip.VxError("vx_irt_lik_workspace_floats: unsupported configuration (code %d)" % n)
         return n
 
-    def lik_grad(self, cfg, y, rows, nb, x, a, b, c_un, d_un, gx, ll, gitem, ws, gxT=None):
+    def lik_grad(self, cfg, y, rows, nb, x, a, b, c_un, d_un, gx, ll, gitem, ws, gxT=None, yT=None):
         rc = self.L.vx_irt_lik_grad(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb, _hip.ptr(x), _hip.ptr(a),
                                     _hip.ptr(b), _hip.ptr(c_un), _hip.ptr(d_un), _hip.ptr(gx), _hip.ptr(gxT),
-                                    _hip.ptr(ll), _hip.ptr(gitem), _hip.ptr(ws), _hip.stream_ptr())
+                                    _hip.ptr(ll), _hip.ptr(gitem), _hip.ptr(ws), _hip.ptr(yT),
+                                    int(yT.shape[1]) if yT is not None else 0, _hip.stream_ptr())
         _hip.check(rc, "vx_irt_lik_grad")
 
     def mvn_enc_bwd_workspace(self, cfg, nb):
@@ -282,14 +283,15 @@ class _EngineBase(object):
         return {k: self.view("encoder$$$" + k) for k in ENC_KEYS}
 
     def _item_major_y(self, rows):
-        """Item-major copy of the responses ([J][stride] bytes, stride = n_local rounded up to 16, zero padded) for the
-        dimension-major fc1 gradient kernel: made once (the responses never change); full batches only."""
+        """Item-major copy of the responses ([J + 1][stride] bytes, stride = n_local rounded up to 64; row J and the
+        columns past n_local hold 254 = "outside the problem") for the dimension-major fc1 gradient kernel and the bf16-MFMA
+        likelihood kernel (include/vipsy_amd.h, vx_irt_lik_grad): made once (the responses never change); full batches only."""
         if rows is not None or self.n_local == 0:
             return None
         if getattr(self, "_yT", None) is None:
-            stride = (self.n_local + 15) // 16 * 16
-            yT = torch.zeros((self.J, stride), dtype=torch.uint8, device=self.dev)
-            yT[:, :self.n_local] = self.y.t()
+            stride = (self.n_local + 63) // 64 * 64
+            yT = torch.full((self.J + 1, stride), 254, dtype=torch.uint8, device=self.dev)
+            yT[:self.J, :self.n_local] = self.y.t()
             self._yT = yT
         return self._yT
 
@@ -574,7 +576,7 @@ class IrtEngine(_EngineBase):
                 be.mvn_enc_forward(cfg, self.y, rows, nb, self.gid0, enc, eps, fw)
             with self._phase("likelihood"):
                 be.lik_grad(cfg, self.y, rows, nb, fw["x"], a, self.view("b"), c_un, d_un, gx, ll, gitem, lik_ws,
-                            gxT=gxT)
+                            gxT=gxT, yT=yT)
             with self._phase("guide_backward"):
                 be.mvn_enc_backward(cfg, self.y, rows, nb, enc, fw, gx,
                                     self.G[self.enc_off0:self.enc_off0 + self.n_enc], encb_ws, gxT=gxT)
