@@ -86,7 +86,10 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y /*[n_local][J]*/,
                        const float* eps_in, float* h /*[nb][H]*/, float* x /*[nb][D]*/,
                        float* eps /*[nb][D]*/, float* ldT /*[D][nb]*/, float* ent /*[nb]*/,
                        float* hT /*[H][nb] or NULL*/, float* epsT /*[D][nb] or NULL*/,
-                       float* packws /*vx_mvn_pack_floats(cfg) floats or NULL*/, void* hip_stream);
+                       float* packws /*vx_mvn_pack_floats(cfg) floats or NULL*/,
+                       uint8_t* ximg /*vx_irt_lik_ximg_bytes(cfg, nb) bytes or NULL*/, void* hip_stream);
+/* ximg (optional): x once more, as the pre-split operand image of the bf16-MFMA likelihood kernel (three bf16 terms per
+ * value in that kernel's LDS tile order); hand the same buffer to vx_irt_lik_grad, which otherwise makes it itself. */
 /* hT / epsT: optional dimension-major copies of h and eps (person-contiguous rows) for the weight-gradient kernel
  * of vx_mvn_enc_backward; written only by the packed fast path (H == 64, D % 4 == 0, J % 4 == 0). */
 /* `packws` holds this step's packed copy of the head weights (a re-ordering of fc22 | fc21 rows that the
@@ -102,12 +105,15 @@ int64_t vx_mvn_pack_floats(const vx_irt_cfg* cfg);
  *                  zero for models without them); summed over this rank's batch only.
  * `workspace`: vx_irt_lik_workspace_floats(cfg, nb) floats of scratch (partial slabs). */
 int64_t vx_irt_lik_workspace_floats(const vx_irt_cfg* cfg, int64_t nb);
+/* size of the optional x operand image (0: this shape does not use one) */
+int64_t vx_irt_lik_ximg_bytes(const vx_irt_cfg* cfg, int64_t nb);
 int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
                     const float* x /*[nb][D]*/, const float* a /*[D][J]*/, const float* b /*[J]*/,
                     const float* c_un /*[J] or NULL*/, const float* d_un /*[J] or NULL*/,
                     float* gx /*[nb][D] or NULL*/, float* gxT /*[D][nb] or NULL*/, float* ll /*[nb]*/,
                     float* gitem /*[D*J + 3*J]*/, float* workspace,
-                    const uint8_t* yT /*[J + 1][yT_stride] or NULL*/, int64_t yT_stride, void* hip_stream);
+                    const uint8_t* yT /*[J + 1][yT_stride] or NULL*/, int64_t yT_stride,
+                    const uint8_t* ximg /*as written by vx_mvn_enc_forward, or NULL*/, void* hip_stream);
 /* gx and gxT are the same gradient in person-major / dimension-major order; at least one must be given.
  * yT (optional, full batches only: rows == NULL): the responses item-major -- row j = item j over the batch rows, row J
  * and every column past nb filled with 254 ("outside the problem"), yT_stride % 64 == 0 and >= nb rounded up to 64.

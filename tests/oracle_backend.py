@@ -98,13 +98,16 @@ class OracleBackend(object):
     def mvn_pack_floats(self, cfg):
         return 1
 
+    def lik_ximg_bytes(self, cfg, nb):
+        return 0
+
     def mvn_enc_bwd_layout(self, cfg, nb):
         return 0                                            # person-major gx is what this backend's backward reads
 
     def lik_workspace(self, cfg, nb):
         return 1
 
-    def lik_grad(self, cfg, y, rows, nb, x, a, b, c_un, d_un, gx, ll, gitem, ws, gxT=None, yT=None):
+    def lik_grad(self, cfg, y, rows, nb, x, a, b, c_un, d_un, gx, ll, gitem, ws, gxT=None, yT=None, ximg=None):
         model, D, J = CODE_MODEL[cfg.model], cfg.D, cfg.J
         r = self._rows(rows, nb)
         yy = y.cpu().numpy()[r]

@@ -568,30 +568,46 @@ __global__ __launch_bounds__(LB_THREADS, 1) void k_irt_lik_b(
 }
 
 // gxT[k][i] = sum_g gx_part[g][k][i] - scale x[i][k],  ll[i] = sum_g ll_part[g][i] - 0.5 |x_i|^2  (the N(0, I) prior on
-// x, vi.py:607-613): one block per 64 persons; x rows are read coalesced and turned through LDS
+// x, vi.py:607-613).  One block per 64 persons: x rows are read coalesced and turned through LDS; a thread owns four
+// consecutive persons (16-byte accesses of the partial rows) and every 16th latent row: 4 groups x 7 rows of independent loads.
 __global__ __launch_bounds__(256) void k_lik_reduce_parts(const float* __restrict__ gx_part, const float* __restrict__ ll_part,
                                                          const float* __restrict__ x, int groups, int D, int64_t nb, int64_t nbp,
                                                          float scale, float* __restrict__ gxT, float* __restrict__ ll) {
     __shared__ float xs[64 * 129];
     const int64_t i0 = (int64_t)blockIdx.x * 64;
     const int pv = (int)((nb - i0) < 64 ? (nb - i0) : 64);
-    for (int e = threadIdx.x; e < pv * D; e += 256) {
-        const int p = e / D, k = e - p * D;
-        xs[p * 129 + k] = x[(i0 + p) * D + k];
+    const int tid = threadIdx.x;
+    if (D % 4 == 0) {                                               // whole 16-byte pieces of the x rows (aligned: i0 D % 4 == 0)
+        const int c4 = D >> 2;
+        for (int e = tid; e < pv * c4; e += 256) {
+            const int p = e / c4, c = e - p * c4;
+            const f32x4 v = *(const f32x4*)(x + (i0 + p) * D + 4 * c);
+            xs[p * 129 + 4 * c] = v[0]; xs[p * 129 + 4 * c + 1] = v[1]; xs[p * 129 + 4 * c + 2] = v[2]; xs[p * 129 + 4 * c + 3] = v[3];
+        }
+    } else {
+        for (int e = tid; e < pv * D; e += 256) {
+            const int p = e / D, k = e - p * D;
+            xs[p * 129 + k] = x[(i0 + p) * D + k];
+        }
     }
     __syncthreads();
-    const int p = threadIdx.x & 63;
-    if (p < pv) {
-        for (int k = threadIdx.x >> 6; k < D; k += 4) {
-            float acc = 0.f;
-            for (int gq = 0; gq < groups; ++gq) acc += gx_part[((int64_t)gq * LB_DP + k) * nbp + i0 + p];
-            gxT[(int64_t)k * nb + i0 + p] = fmaf(-scale, xs[p * 129 + k], acc);
-        }
-        if (threadIdx.x < 64) {
-            float acc = 0.f, sq = 0.f;
-            for (int gq = 0; gq < groups; ++gq) acc += ll_part[(int64_t)gq * nbp + i0 + p];
-            for (int k = 0; k < D; ++k) { const float t = xs[p * 129 + k]; sq = fmaf(t, t, sq); }
-            ll[i0 + p] = fmaf(-0.5f, sq, acc);
-        }
+    const int pq = tid & 15, kq = tid >> 4;                          // persons 4 pq .. 4 pq + 3, latent rows kq, kq + 16, ...
+    const bool vec = (nb & 3) == 0 && 4 * pq + 4 <= pv;             // aligned full quad
+    for (int k = kq; k < D; k += 16) {
+        const float* src = gx_part + (int64_t)k * nbp + i0 + 4 * pq;
+        f32x4 acc = *(const f32x4*)src;                              // nbp % 64 == 0: always in bounds and aligned
+        for (int gq = 1; gq < groups; ++gq) acc += *(const f32x4*)(src + (int64_t)gq * LB_DP * nbp);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = fmaf(-scale, xs[(4 * pq + c) * 129 + k], acc[c]);
+        float* dst = gxT + (int64_t)k * nb + i0 + 4 * pq;
+        if (vec) *(f32x4*)dst = acc;
+        else
+            for (int c = 0; c < 4; ++c) if (4 * pq + c < pv) dst[c] = acc[c];
+    }
+    if (tid < pv) {
+        float acc = 0.f, sq = 0.f;
+        for (int gq = 0; gq < groups; ++gq) acc += ll_part[(int64_t)gq * nbp + i0 + tid];
+        for (int k = 0; k < D; ++k) { const float t = xs[tid * 129 + k]; sq = fmaf(t, t, sq); }
+        ll[i0 + tid] = fmaf(-0.5f, sq, acc);
     }
 }

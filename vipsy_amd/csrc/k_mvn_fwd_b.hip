@@ -131,6 +131,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     const uint32_t* __restrict__ gt2, const float* __restrict__ eps_in, uint64_t seed, uint32_t step, uint32_t stream, float* __restrict__ h_out,
     float* __restrict__ x_out, float* __restrict__ eps_out, float* __restrict__ ldT, float* __restrict__ ent_out,
     float* __restrict__ hT_out /*[64][nb] or null*/, float* __restrict__ epsT_out /*[D][nb] or null*/,
+    uint8_t* __restrict__ ximg_out /*bf16x3 tile images of x for k_irt_lik_b (k_irt_lik_b.hip), or null*/,
     long long* __restrict__ stamps /*timing experiments only, normally null*/) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
@@ -506,6 +507,39 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     __builtin_amdgcn_wave_barrier();
     stamp(5);
     // ---------------------------------------------------------------- write x, entropy part
+    if (ximg_out && i0 < (dm.nb + 63) / 64 * 64) {
+        // the likelihood kernel's operand: x_aug = [x, 1, 0..] as three bf16 terms, in its LDS tile order (lb_xoff): this
+        // wave's 32 persons are one half of a 64-person tile (absent persons: all-zero rows); 14 chunks of 8 columns each
+        const int pvi = (int)((dm.nb - i0) < FB_WP ? (dm.nb - i0) : FB_WP);       // may be <= 0
+        uint8_t* out = ximg_out + (i0 >> 6) * LB_XT_BYTES;
+        const int pbase = (int)(i0 & 63);
+        for (int e = lane; e < FB_WP * 2 * LB_NKS; e += 64) {
+            // order of the image bytes: 32 consecutive lanes fill one 512-byte subtile (8 persons x 4 chunks), then the
+            // 256-byte half subtiles (8 persons x 2 chunks): whole contiguous runs per store instruction
+            int pp, ch;
+            if (e < 4 * 3 * 32) {
+                const int blk = e >> 5, r = e & 31;                   // blk = person group * 3 + subtile
+                pp = 8 * (blk / 3) + (r >> 2);
+                ch = 4 * (blk % 3) + (r & 3);
+            } else {
+                const int r = e - 4 * 3 * 32;                         // 4 person groups x 8 persons x 2 chunks
+                pp = 8 * (r >> 4) + ((r >> 1) & 7);
+                ch = 12 + (r & 1);
+            }
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 8 * ch + j;
+                v[j] = (pp < pvi) ? (k < D ? x_lds[pp * DX + k] : (k == D ? 1.0f : 0.f)) : 0.f;
+            }
+            bf16x8 fh, fm, fl;
+            split3_frag(v, fh, fm, fl);
+            const uint32_t o = lb_xoff(pbase + pp, ch);
+            *(bf16x8*)(out + o) = fh;
+            *(bf16x8*)(out + LB_PLANE + o) = fm;
+            *(bf16x8*)(out + 2 * LB_PLANE + o) = fl;
+        }
+    }
     if (wave_live) {
         const int pv = (int)((dm.nb - i0) < FB_WP ? (dm.nb - i0) : FB_WP);
         const int c4 = D >> 2;

@@ -263,14 +263,23 @@ int vx_adam_step(float* p, const float* g, float* m, float* v, const float* free
 int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, int64_t gid0,
                        const float* W1, const float* b1, const float* W21, const float* b21, const float* W22,
                        const float* b22, const float* eps_in, float* h, float* x, float* eps, float* ldT,
-                       float* ent, float* hT, float* epsT, float* packws, void* hs) {
+                       float* ent, float* hT, float* epsT, float* packws, uint8_t* ximg, void* hs) {
     if (!enc_cfg_ok(cfg) || !y || !W1 || !b1 || !W21 || !b21 || !W22 || !b22 || !h || !x || !eps || !ldT || !ent ||
         nb < 0)
         return VX_EINVAL;
     if (nb == 0) return VX_OK;
+    if (ximg && !(cfg->D >= 96 && cfg->D <= 16 * LB_NKS - 1 && aligned16(ximg))) return VX_EINVAL;
     EncDims dm = make_enc_dims(cfg, nb);
     const dim3 grid((unsigned)((nb + ENC_P - 1) / ENC_P));
     int rc;
+    // every forward kernel but k_mvn_enc_fwd_b leaves the likelihood operand image to this pass over x
+    struct XimgAfter {
+        uint8_t* img; const vx_irt_cfg* cfg; int64_t nb; const float* x; hipStream_t st; bool done;
+        ~XimgAfter() {
+            if (img && !done)
+                hipLaunchKernelGGL(k_lik_ximg, dim3((unsigned)((nb + LB_P - 1) / LB_P)), dim3(256), 0, st, (int)cfg->D, nb, x, img);
+        }
+    } ximg_after{ximg, cfg, nb, x, (hipStream_t)hs, false};
     if (packed_ok(cfg) && packws && aligned16(packws) && aligned16(y) && aligned16(W1) && aligned16(b1) &&
         aligned16(W21) && aligned16(W22) && aligned16(h)) {
         const int Rp = pk_rows(cfg->D);
@@ -297,9 +306,10 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
             const dim3 gridb((unsigned)((nb + FB_WAVES * FB_WP - 1) / (FB_WAVES * FB_WP)));
             long long* stamps = stamps_alloc();
             ProfScope ps("k_mvn_enc_fwd_b", (hipStream_t)hs);
+            ximg_after.done = true;
             hipLaunchKernelGGL(k_mvn_enc_fwd_b, gridb, dim3(FB_THREADS), ldsb, (hipStream_t)hs, dm, y, rows, gid0,
                                (const uint8_t*)w1img, b1, (const uint8_t*)img, (const uint32_t*)gt2, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT,
-                               stamps);
+                               ximg, stamps);
             VX_CHECK_LAUNCH();
             stamps_report(stamps, "fwd_b", gridb.x);
             return VX_OK;
@@ -412,6 +422,11 @@ static bool lik_cfg_ok(const vx_irt_cfg* cfg) {
            cfg->model <= VX_IRT_4PL;
 }
 
+int64_t vx_irt_lik_ximg_bytes(const vx_irt_cfg* cfg, int64_t nb) {
+    if (!lik_cfg_ok(cfg) || nb < 0) return VX_EINVAL;
+    return lik_b_shape(cfg) ? ((nb + LB_P - 1) / LB_P) * (int64_t)LB_XT_BYTES : 0;
+}
+
 int64_t vx_irt_lik_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
     if (!lik_cfg_ok(cfg) || nb < 0) return VX_EINVAL;
     int kt, nch, groups, n_pr;
@@ -430,7 +445,8 @@ int64_t vx_irt_lik_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
 
 int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* x,
                     const float* a, const float* b, const float* c_un, const float* d_un, float* gx, float* gxT,
-                    float* ll, float* gitem, float* workspace, const uint8_t* yT, int64_t yT_stride, void* hs) {
+                    float* ll, float* gitem, float* workspace, const uint8_t* yT, int64_t yT_stride, const uint8_t* ximg_in,
+                    void* hs) {
     if (!lik_cfg_ok(cfg) || !y || !x || !a || !b || (!gx && !gxT) || !ll || !gitem || !workspace || nb < 0)
         return VX_EINVAL;
     if (cfg->model >= VX_IRT_3PL && !c_un) return VX_EINVAL;
@@ -444,27 +460,30 @@ int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows
         dm.Dc = cfg->Dc; dm.scale = cfg->scale; dm.nb = nb;
         dm.slab_len = (int64_t)cfg->D * cfg->J + 3 * (int64_t)cfg->J;
         float* slabs = workspace;
-        uint8_t* ximg = (uint8_t*)(workspace + (((int64_t)n_pr * dm.slab_len + 3) & ~(int64_t)3));
-        float* gx_part = (float*)(ximg + n_ptiles * LB_XT_BYTES);
+        uint8_t* ximg_ws = (uint8_t*)(workspace + (((int64_t)n_pr * dm.slab_len + 3) & ~(int64_t)3));
+        float* gx_part = (float*)(ximg_ws + n_ptiles * LB_XT_BYTES);
+        const uint8_t* ximg = (ximg_in && aligned16(ximg_in)) ? ximg_in : ximg_ws;
         float* ll_part = gx_part + (int64_t)groups * LB_DP * nbp;
         hipStream_t st = (hipStream_t)hs;
         hipError_t he = hipMemsetAsync(slabs, 0, sizeof(float) * (size_t)n_pr * dm.slab_len, st);
         if (he != hipSuccess) return (int)he;
-        hipLaunchKernelGGL(k_lik_ximg, dim3((unsigned)n_ptiles), dim3(256), 0, st, (int)cfg->D, nb, x, ximg);
-        VX_CHECK_LAUNCH();
+        if (ximg == ximg_ws) {
+            hipLaunchKernelGGL(k_lik_ximg, dim3((unsigned)n_ptiles), dim3(256), 0, st, (int)cfg->D, nb, x, ximg_ws);
+            VX_CHECK_LAUNCH();
+        }
         int rc;
         const dim3 grid((unsigned)(groups * n_pr));
         if (cfg->model >= VX_IRT_3PL) {
             rc = set_lds(k_irt_lik_b<1>, LB_LDS_BYTES);
             if (rc) return rc;
             ProfScope ps("k_irt_lik_b", st);
-            hipLaunchKernelGGL((k_irt_lik_b<1>), grid, dim3(LB_THREADS), LB_LDS_BYTES, st, dm, yT, yT_stride, (const uint8_t*)ximg,
+            hipLaunchKernelGGL((k_irt_lik_b<1>), grid, dim3(LB_THREADS), LB_LDS_BYTES, st, dm, yT, yT_stride, ximg,
                                a, b, c_un, d_un, gx_part, ll_part, slabs, (long long*)nullptr);
         } else {
             rc = set_lds(k_irt_lik_b<0>, LB_LDS_BYTES);
             if (rc) return rc;
             ProfScope ps("k_irt_lik_b", st);
-            hipLaunchKernelGGL((k_irt_lik_b<0>), grid, dim3(LB_THREADS), LB_LDS_BYTES, st, dm, yT, yT_stride, (const uint8_t*)ximg,
+            hipLaunchKernelGGL((k_irt_lik_b<0>), grid, dim3(LB_THREADS), LB_LDS_BYTES, st, dm, yT, yT_stride, ximg,
                                a, b, c_un, d_un, gx_part, ll_part, slabs, (long long*)nullptr);
         }
         VX_CHECK_LAUNCH();

@@ -46,7 +46,7 @@ class HipBackend(object):
                                        _hip.ptr(eps_in), _hip.ptr(out["h"]), _hip.ptr(out["x"]),
                                        _hip.ptr(out["eps"]), _hip.ptr(out["ldT"]), _hip.ptr(out["ent"]),
                                        _hip.ptr(out.get("hT")), _hip.ptr(out.get("epsT")),
-                                       _hip.ptr(out.get("packws")), _hip.stream_ptr())
+                                       _hip.ptr(out.get("packws")), _hip.ptr(out.get("ximg")), _hip.stream_ptr())
         _hip.check(rc, "vx_mvn_enc_forward")
 
     def mvn_pack_floats(self, cfg):
@@ -55,17 +55,23 @@ class HipBackend(object):
             raise _hip.VxError("vx_mvn_pack_floats: unsupported configuration (code %d)" % n)
         return n
 
+    def lik_ximg_bytes(self, cfg, nb):
+        n = self.L.vx_irt_lik_ximg_bytes(ctypes.byref(cfg), nb)
+        if n < 0:
+            raise _hip.VxError("vx_irt_lik_ximg_bytes: unsupported configuration (code %d)" % n)
+        return n
+
     def lik_workspace(self, cfg, nb):
         n = self.L.vx_irt_lik_workspace_floats(ctypes.byref(cfg), nb)
         if n < 0:
             raise _hip.VxError("vx_irt_lik_workspace_floats: unsupported configuration (code %d)" % n)
         return n
 
-    def lik_grad(self, cfg, y, rows, nb, x, a, b, c_un, d_un, gx, ll, gitem, ws, gxT=None, yT=None):
+    def lik_grad(self, cfg, y, rows, nb, x, a, b, c_un, d_un, gx, ll, gitem, ws, gxT=None, yT=None, ximg=None):
         rc = self.L.vx_irt_lik_grad(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb, _hip.ptr(x), _hip.ptr(a),
                                     _hip.ptr(b), _hip.ptr(c_un), _hip.ptr(d_un), _hip.ptr(gx), _hip.ptr(gxT),
                                     _hip.ptr(ll), _hip.ptr(gitem), _hip.ptr(ws), _hip.ptr(yT),
-                                    int(yT.shape[1]) if yT is not None else 0, _hip.stream_ptr())
+                                    int(yT.shape[1]) if yT is not None else 0, _hip.ptr(ximg), _hip.stream_ptr())
         _hip.check(rc, "vx_irt_lik_grad")
 
     def mvn_enc_bwd_workspace(self, cfg, nb):
@@ -566,6 +572,9 @@ class IrtEngine(_EngineBase):
             yT = self._item_major_y(rows)
             if yT is not None:
                 fw["yT"] = yT
+                n_img = be.lik_ximg_bytes(cfg, nb)        # x once more as the likelihood kernel's operand image
+                if n_img > 0:
+                    fw["ximg"] = self._buf("ximg", (n_img + 3) // 4)
             gx, ll = self._buf("gx", nb * D), self._buf("ll", nb)
             if be.mvn_enc_bwd_layout(cfg, nb) == 1:
                 gx = None                                  # the backward kernels read gxT only
@@ -576,7 +585,7 @@ class IrtEngine(_EngineBase):
                 be.mvn_enc_forward(cfg, self.y, rows, nb, self.gid0, enc, eps, fw)
             with self._phase("likelihood"):
                 be.lik_grad(cfg, self.y, rows, nb, fw["x"], a, self.view("b"), c_un, d_un, gx, ll, gitem, lik_ws,
-                            gxT=gxT, yT=yT)
+                            gxT=gxT, yT=yT, ximg=fw.get("ximg"))
             with self._phase("guide_backward"):
                 be.mvn_enc_backward(cfg, self.y, rows, nb, enc, fw, gx,
                                     self.G[self.enc_off0:self.enc_off0 + self.n_enc], encb_ws, gxT=gxT)
