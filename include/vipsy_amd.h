@@ -113,8 +113,13 @@ int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows
                     float* gx /*[nb][D] or NULL*/, float* gxT /*[D][nb] or NULL*/, float* ll /*[nb]*/,
                     float* gitem /*[D*J + 3*J]*/, float* workspace,
                     const uint8_t* yT /*[J + 1][yT_stride] or NULL*/, int64_t yT_stride,
-                    const uint8_t* ximg /*as written by vx_mvn_enc_forward, or NULL*/, void* hip_stream);
+                    const uint8_t* ximg /*as written by vx_mvn_enc_forward, or NULL*/,
+                    const float* epsT /*[D][nb] or NULL*/, const float* ldT /*[D][nb] or NULL*/,
+                    float* gdT /*[D][nb] or NULL: fused output gxT * epsT * ldT + scale*/, void* hip_stream);
 /* gx and gxT are the same gradient in person-major / dimension-major order; at least one must be given.
+ * gdT (optional, with gxT, epsT, ldT; nb * D % 4 == 0): the DIAG-row operand of the dimension-major guide-backward kernels,
+ * written in the same pass over gxT -- point it at workspace + vx_mvn_enc_bwd_gd_offset(cfg, nb) of the backward call and
+ * hand that call gd_ready = 1.
  * yT (optional, full batches only: rows == NULL): the responses item-major -- row j = item j over the batch rows, row J
  * and every column past nb filled with 254 ("outside the problem"), yT_stride % 64 == 0 and >= nb rounded up to 64.
  * With it, 96 <= D <= 111 runs on the bf16-MFMA kernel (k_irt_lik_b.hip: fp32 results by three-term operand
@@ -133,7 +138,10 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                         const float* h, const float* eps, const float* ldT, const float* gx,
                         const float* hT /*or NULL*/, const float* epsT /*or NULL*/, const float* gxT /*or NULL*/,
                         const uint8_t* yT /*[>= J][yT_stride] item-major copy of y (pad bytes 0 or 254), or NULL*/, int64_t yT_stride,
-                        float* genc, float* workspace, const float* packws, void* hip_stream);
+                        float* genc, float* workspace, const float* packws,
+                        int32_t gd_ready /*1: vx_irt_lik_grad already wrote gdT into the workspace*/, void* hip_stream);
+/* float offset of gdT[D][nb] inside the backward workspace, or -1 when this (cfg, nb) has no such operand */
+int64_t vx_mvn_enc_bwd_gd_offset(const vx_irt_cfg* cfg, int64_t nb);
 /* With hT, epsT and gxT (the dimension-major copies made by the forward / likelihood calls) the head weight
  * gradients run on the DMA-staged kernel of k_mvn_bwd_t.hip; without them on the person-major one.
  * yT (full batch only, rows == NULL, yT_stride % 16 == 0): the responses item-major, which lets the fc1 weight

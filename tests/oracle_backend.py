@@ -107,7 +107,8 @@ class OracleBackend(object):
     def lik_workspace(self, cfg, nb):
         return 1
 
-    def lik_grad(self, cfg, y, rows, nb, x, a, b, c_un, d_un, gx, ll, gitem, ws, gxT=None, yT=None, ximg=None):
+    def lik_grad(self, cfg, y, rows, nb, x, a, b, c_un, d_un, gx, ll, gitem, ws, gxT=None, yT=None, ximg=None, epsT=None,
+                 ldT=None, gdT=None):
         model, D, J = CODE_MODEL[cfg.model], cfg.D, cfg.J
         r = self._rows(rows, nb)
         yy = y.cpu().numpy()[r]
@@ -131,7 +132,10 @@ class OracleBackend(object):
     def mvn_enc_bwd_workspace(self, cfg, nb):
         return 1
 
-    def mvn_enc_backward(self, cfg, y, rows, nb, enc, fw, gx, genc, ws, gxT=None):
+    def mvn_enc_bwd_gd_offset(self, cfg, nb):
+        return -1
+
+    def mvn_enc_backward(self, cfg, y, rows, nb, enc, fw, gx, genc, ws, gxT=None, gd_ready=False):
         D, J, H = cfg.D, cfg.J, cfg.H
         T = D * (D + 1) // 2
         r = self._rows(rows, nb)

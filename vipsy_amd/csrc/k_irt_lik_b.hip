@@ -572,7 +572,9 @@ __global__ __launch_bounds__(LB_THREADS, 1) void k_irt_lik_b(
 // consecutive persons (16-byte accesses of the partial rows) and every 16th latent row: 4 groups x 7 rows of independent loads.
 __global__ __launch_bounds__(256) void k_lik_reduce_parts(const float* __restrict__ gx_part, const float* __restrict__ ll_part,
                                                          const float* __restrict__ x, int groups, int D, int64_t nb, int64_t nbp,
-                                                         float scale, float* __restrict__ gxT, float* __restrict__ ll) {
+                                                         float scale, float* __restrict__ gxT, float* __restrict__ ll,
+                                                         const float* __restrict__ epsT = nullptr, const float* __restrict__ ldT = nullptr,
+                                                         float* __restrict__ gdT = nullptr /*fused: gxT epsT ldT + scale*/) {
     __shared__ float xs[64 * 129];
     const int64_t i0 = (int64_t)blockIdx.x * 64;
     const int pv = (int)((nb - i0) < 64 ? (nb - i0) : 64);
@@ -599,10 +601,24 @@ __global__ __launch_bounds__(256) void k_lik_reduce_parts(const float* __restric
         for (int gq = 1; gq < groups; ++gq) acc += *(const f32x4*)(src + (int64_t)gq * LB_DP * nbp);
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = fmaf(-scale, xs[(4 * pq + c) * 129 + k], acc[c]);
-        float* dst = gxT + (int64_t)k * nb + i0 + 4 * pq;
-        if (vec) *(f32x4*)dst = acc;
-        else
-            for (int c = 0; c < 4; ++c) if (4 * pq + c < pv) dst[c] = acc[c];
+        const int64_t o = (int64_t)k * nb + i0 + 4 * pq;
+        float* dst = gxT + o;
+        if (vec) {
+            *(f32x4*)dst = acc;
+            if (gdT) {                                               // the DIAG-row operand of the guide backward (k_mvn_gd)
+                const f32x4 e = *(const f32x4*)(epsT + o), l = *(const f32x4*)(ldT + o);
+                f32x4 gdv;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) gdv[c] = fmaf(acc[c] * e[c], l[c], scale);
+                *(f32x4*)(gdT + o) = gdv;
+            }
+        } else {
+            for (int c = 0; c < 4; ++c)
+                if (4 * pq + c < pv) {
+                    dst[c] = acc[c];
+                    if (gdT) gdT[o + c] = fmaf(acc[c] * epsT[o + c], ldT[o + c], scale);
+                }
+        }
     }
     if (tid < pv) {
         float acc = 0.f, sq = 0.f;

@@ -446,7 +446,19 @@ int64_t vx_irt_lik_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
 int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* x,
                     const float* a, const float* b, const float* c_un, const float* d_un, float* gx, float* gxT,
                     float* ll, float* gitem, float* workspace, const uint8_t* yT, int64_t yT_stride, const uint8_t* ximg_in,
-                    void* hs) {
+                    const float* epsT, const float* ldT, float* gdT, void* hs) {
+    if (gdT && (!gxT || !epsT || !ldT || (nb * (int64_t)(cfg ? cfg->D : 0)) % 4 != 0 || !aligned16(gdT) || !aligned16(gxT) ||
+                !aligned16(epsT) || !aligned16(ldT)))
+        return VX_EINVAL;
+    // the fused DIAG-row operand of the guide backward, for the paths that do not make it themselves
+    struct GdAfter {
+        const vx_irt_cfg* cfg; int64_t nb; const float *gxT, *epsT, *ldT; float* gdT; hipStream_t st; bool done;
+        ~GdAfter() {
+            if (gdT && !done && nb > 0)
+                hipLaunchKernelGGL(k_mvn_gd, dim3(num_cu() * 8), dim3(256), 0, st, (const float4*)gxT, (const float4*)epsT,
+                                   (const float4*)ldT, cfg->scale, nb * cfg->D / 4, (float4*)gdT);
+        }
+    } gd_after{cfg, nb, gxT, epsT, ldT, gdT, (hipStream_t)hs, false};
     if (!lik_cfg_ok(cfg) || !y || !x || !a || !b || (!gx && !gxT) || !ll || !gitem || !workspace || nb < 0)
         return VX_EINVAL;
     if (cfg->model >= VX_IRT_3PL && !c_un) return VX_EINVAL;
@@ -487,8 +499,9 @@ int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows
                                a, b, c_un, d_un, gx_part, ll_part, slabs, (long long*)nullptr);
         }
         VX_CHECK_LAUNCH();
+        gd_after.done = true;
         hipLaunchKernelGGL(k_lik_reduce_parts, dim3((unsigned)n_ptiles), dim3(256), 0, st, (const float*)gx_part, (const float*)ll_part,
-                           x, groups, (int)cfg->D, nb, nbp, cfg->scale, gxT, ll);
+                           x, groups, (int)cfg->D, nb, nbp, cfg->scale, gxT, ll, epsT, ldT, gdT);
         VX_CHECK_LAUNCH();
         if (gx) {                                          // both orders requested: gx[nb][D] = transpose(gxT[D][nb])
             hipLaunchKernelGGL(k_transpose, dim3(num_cu() * 8), dim3(256), 0, st, gxT, gx, (int64_t)cfg->D, nb);
@@ -660,6 +673,26 @@ int vx_mvn_enc_bwd_layout(const vx_irt_cfg* cfg, int64_t nb) {
     return (bwt_shape(cfg, nb) && !oldh && nb >= 4 && bh_lds_bytes(cfg->D) <= 160 * 1024) ? 1 : 0;
 }
 
+// float offset, inside the workspace of vx_mvn_enc_backward, of gdT[D][nb] (the DIAG-row operand of the dimension-major
+// kernels); -1 when this (cfg, nb) does not run on them
+static int64_t encb_gd_offset(const vx_irt_cfg* cfg, int64_t nb) {
+    if (!bwt_shape(cfg, nb)) return -1;
+    int ns0, np0, nj0, nf0, ns1, np1;
+    encb_plan(cfg, nb, ns0, np0, nj0, nf0);
+    bwt_plan(cfg, nb, ns1, np1);
+    const int64_t D = cfg->D, J = cfg->J, H = cfg->H, T = tril_len(cfg->D);
+    const int64_t lenw_ref = D * H + D + T * H + T, lenf = H * J + H, Rp = pk_rows(cfg->D);
+    const int64_t lenw = Rp * (H + 1) > lenw_ref ? Rp * (H + 1) : lenw_ref;
+    const int n_prw_ws = np0 > np1 ? np0 : np1;
+    return nb * H + (int64_t)n_prw_ws * lenw + (int64_t)nf0 * lenf;
+}
+
+int64_t vx_mvn_enc_bwd_gd_offset(const vx_irt_cfg* cfg, int64_t nb) {
+    if (!enc_cfg_ok(cfg) || nb < 0) return VX_EINVAL;
+    const int64_t o = encb_gd_offset(cfg, nb);
+    return (o >= 0 && o % 4 == 0 && (nb * cfg->D) % 4 == 0) ? o : -1;
+}
+
 int64_t vx_mvn_pack_floats(const vx_irt_cfg* cfg) {
     if (!enc_cfg_ok(cfg)) return VX_EINVAL;
     const int64_t Rp = pk_rows(cfg->D);
@@ -693,7 +726,7 @@ int64_t vx_mvn_enc_bwd_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
 int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
                         const float* W21, const float* W22, const float* h, const float* eps, const float* ldT,
                         const float* gx, const float* hT, const float* epsT, const float* gxT, const uint8_t* yT,
-                        int64_t yT_stride, float* genc, float* workspace, const float* packws, void* hs) {
+                        int64_t yT_stride, float* genc, float* workspace, const float* packws, int32_t gd_ready, void* hs) {
     if (!enc_cfg_ok(cfg) || !y || !W21 || !W22 || !h || !eps || !ldT || (!gx && !gxT) || !genc || !workspace || nb < 0)
         return VX_EINVAL;
     int n_rowslabs, n_prw, n_jg, n_prf;
@@ -727,8 +760,8 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
         const uint32_t* gtab = (const uint32_t*)(packws + Rp * 64 + Rp);
         static int oldh = -1;
         if (oldh < 0) { const char* e = getenv("VX_BWDH"); oldh = (e && e[0] == 'o') ? 1 : 0; }
-        if (use_t) {                                        // DIAG-row operand of both dimension-major kernels
-            float* gdT0 = slabs_f + (int64_t)n_prf * lenf;
+        if (use_t && !(gd_ready && (slabs_f + (int64_t)n_prf * lenf) == workspace + encb_gd_offset(cfg, nb))) {
+            float* gdT0 = slabs_f + (int64_t)n_prf * lenf;      // DIAG-row operand of both dimension-major kernels
             hipLaunchKernelGGL(k_mvn_gd, dim3(num_cu() * 8), dim3(256), 0, st, (const float4*)gxT, (const float4*)epsT,
                                (const float4*)ldT, cfg->scale, nb * D / 4, (float4*)gdT0);
             VX_CHECK_LAUNCH();

@@ -67,11 +67,13 @@ class HipBackend(object):
             raise _hip.VxError("vx_irt_lik_workspace_floats: unsupported configuration (code %d)" % n)
         return n
 
-    def lik_grad(self, cfg, y, rows, nb, x, a, b, c_un, d_un, gx, ll, gitem, ws, gxT=None, yT=None, ximg=None):
+    def lik_grad(self, cfg, y, rows, nb, x, a, b, c_un, d_un, gx, ll, gitem, ws, gxT=None, yT=None, ximg=None,
+                 epsT=None, ldT=None, gdT=None):
         rc = self.L.vx_irt_lik_grad(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb, _hip.ptr(x), _hip.ptr(a),
                                     _hip.ptr(b), _hip.ptr(c_un), _hip.ptr(d_un), _hip.ptr(gx), _hip.ptr(gxT),
                                     _hip.ptr(ll), _hip.ptr(gitem), _hip.ptr(ws), _hip.ptr(yT),
-                                    int(yT.shape[1]) if yT is not None else 0, _hip.ptr(ximg), _hip.stream_ptr())
+                                    int(yT.shape[1]) if yT is not None else 0, _hip.ptr(ximg), _hip.ptr(epsT),
+                                    _hip.ptr(ldT), _hip.ptr(gdT), _hip.stream_ptr())
         _hip.check(rc, "vx_irt_lik_grad")
 
     def mvn_enc_bwd_workspace(self, cfg, nb):
@@ -83,13 +85,17 @@ class HipBackend(object):
     def mvn_enc_bwd_layout(self, cfg, nb):
         return int(self.L.vx_mvn_enc_bwd_layout(ctypes.byref(cfg), nb))
 
-    def mvn_enc_backward(self, cfg, y, rows, nb, enc, fw, gx, genc, ws, gxT=None):
+    def mvn_enc_bwd_gd_offset(self, cfg, nb):
+        return int(self.L.vx_mvn_enc_bwd_gd_offset(ctypes.byref(cfg), nb))
+
+    def mvn_enc_backward(self, cfg, y, rows, nb, enc, fw, gx, genc, ws, gxT=None, gd_ready=False):
         rc = self.L.vx_mvn_enc_backward(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb,
                                         _hip.ptr(enc["fc21.weight"]), _hip.ptr(enc["fc22.weight"]),
                                         _hip.ptr(fw["h"]), _hip.ptr(fw["eps"]), _hip.ptr(fw["ldT"]), _hip.ptr(gx),
                                         _hip.ptr(fw.get("hT")), _hip.ptr(fw.get("epsT")), _hip.ptr(gxT),
                                         _hip.ptr(fw.get("yT")), int(fw["yT"].shape[1]) if fw.get("yT") is not None else 0,
-                                        _hip.ptr(genc), _hip.ptr(ws), _hip.ptr(fw.get("packws")), _hip.stream_ptr())
+                                        _hip.ptr(genc), _hip.ptr(ws), _hip.ptr(fw.get("packws")), int(bool(gd_ready)),
+                                        _hip.stream_ptr())
         _hip.check(rc, "vx_mvn_enc_backward")
 
     def irt1d_workspace(self, cfg, nb):
@@ -583,12 +589,16 @@ class IrtEngine(_EngineBase):
             encb_ws = self._buf("encb_ws", be.mvn_enc_bwd_workspace(cfg, nb))
             with self._phase("guide_forward"):
                 be.mvn_enc_forward(cfg, self.y, rows, nb, self.gid0, enc, eps, fw)
+            gd_off = be.mvn_enc_bwd_gd_offset(cfg, nb)     # the backward's DIAG-row operand, made in the likelihood's last pass
+            gdT = encb_ws[gd_off:gd_off + nb * D] if gd_off >= 0 else None
             with self._phase("likelihood"):
                 be.lik_grad(cfg, self.y, rows, nb, fw["x"], a, self.view("b"), c_un, d_un, gx, ll, gitem, lik_ws,
-                            gxT=gxT, yT=yT, ximg=fw.get("ximg"))
+                            gxT=gxT, yT=yT, ximg=fw.get("ximg"), epsT=fw["epsT"] if gdT is not None else None,
+                            ldT=fw["ldT"] if gdT is not None else None, gdT=gdT)
             with self._phase("guide_backward"):
                 be.mvn_enc_backward(cfg, self.y, rows, nb, enc, fw, gx,
-                                    self.G[self.enc_off0:self.enc_off0 + self.n_enc], encb_ws, gxT=gxT)
+                                    self.G[self.enc_off0:self.enc_off0 + self.n_enc], encb_ws, gxT=gxT,
+                                    gd_ready=gdT is not None)
             # loss = -scale * sum_i (ll_i + ent_i)
             tmp = self._buf("loss2", 2)
             be.sum_into(ll, nb, -scale, tmp[0:1], self.sum_ws)
