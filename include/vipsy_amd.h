@@ -229,6 +229,36 @@ int vx_ccdm_grad(const vx_hodina_cfg* cfg, int32_t dino, const uint8_t* y, const
                  const float* q /*[K][J]*/, const float* g_un, const float* s_un, float* elbo, float* gitem,
                  float* workspace, void* hip_stream);
 
+/* ---- VCDM / VaeCDM: Bernoulli-guide DINA / DINO with the score-function (REINFORCE) estimator (vi.py:726-816),
+ * as pyro's Trace_ELBO treats a non-reparameterised guide site; cfg: K, J, scale, seed, step, stream.
+ *   u[nb][K]        guide logits in batch order (rows of the `attr_p` leaf gathered by the host, or the encoder output);
+ *                   clamp_t = 1 when they come from a unit_interval leaf (SigmoidTransform clamps the probability)
+ *   attr_in[nb][K]  the 0/1 draws to replay, or NULL: drawn in the kernel (Philox block k >> 2, word k & 3 of the person)
+ *   prior_p         probability of attr = 1 under the model prior BEFORE clamping -- 1.5 reproduces vi.py:753
+ *   baseline        control variate subtracted from log_r in the score term, or NULL (pyro's Trace_ELBO: none); indexed
+ *                   by the local person row (base_by_row = 1) or the batch position; base_beta >= 0 turns it into a per-person
+ *                   decaying average: baseline <- beta baseline + (1 - beta) log_r after use (any baseline that does not
+ *                   depend on the person's own draw keeps the estimator unbiased)
+ * Outputs: log_r[nb] = scale (log prior + log lik - log q) per person; gu[nb][K] = d LOSS / d u (one particle, unaveraged);
+ *   attr_out (optional) the draws; gitem = d LOSS / d [g_un: J | s_un: J].  Responses must be complete (0 / 1): the
+ *   reference passes them unmasked (vi.py:756).  Item gradients come from integer (eta, y) counts: order-independent. */
+int64_t vx_cdm_sf_workspace_floats(const vx_hodina_cfg* cfg, int64_t nb);
+int vx_cdm_sf_grad(const vx_hodina_cfg* cfg, int32_t dino, int32_t clamp_t, float prior_p, const uint8_t* y,
+                   const int64_t* rows, int64_t nb, int64_t gid0, const float* q /*[K][J]*/, const float* g_un,
+                   const float* s_un, const float* u, const uint8_t* attr_in, float* baseline, float base_beta,
+                   int32_t base_by_row, float* gu, float* log_r, uint8_t* attr_out, float* gitem, float* workspace,
+                   void* hip_stream);
+/* leave-one-out control variate over the S >= 2 particles of a step: out[i] = mean_{s' != s} lr_all[s'][i] */
+int vx_loo_baseline(const float* lr_all /*[S][nb]*/, int32_t S, int64_t nb, int32_t s, float* out, void* hip_stream);
+/* BinEncoder of VaeCDM (vi.py:458-470): h[nb][H] = softplus(W1 yin + b1), u[nb][K] = W2 h + b2 (logits; H <= 64).
+ * genc = d LOSS / d [W1: H*J | b1: H | W2: K*H | b2: K] from gu = d LOSS / d u. */
+int64_t vx_bin_enc_param_floats(const vx_hodina_cfg* cfg);
+int vx_bin_enc_forward(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* W1,
+                       const float* b1, const float* W2, const float* b2, float* h, float* u, void* hip_stream);
+int64_t vx_bin_enc_bwd_workspace_floats(const vx_hodina_cfg* cfg, int64_t nb);
+int vx_bin_enc_backward(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* W2,
+                        const float* h, const float* gu, float* genc, float* workspace, void* hip_stream);
+
 /* ---- slab reduction: out[i] = alpha * sum_s slabs[s][i]  (fixed order -> deterministic) */
 int vx_reduce_slabs(const float* slabs, int64_t n_slabs, int64_t len, float alpha, float* out,
                     void* hip_stream);

@@ -98,6 +98,22 @@ def philox_normals(seed, step, stream, gids, D):
     return out[:, :D]
 
 
+def philox_uniforms(seed, step, stream, gids, K):
+    """u[i, k] in (0, 1) for global person ids `gids`: word k % 4 of Philox block k // 4 (the draw rule of the
+    Bernoulli-guide kernel, vipsy_amd/csrc/k_cdm_sf.hip: attr_ik = u_ik < p_ik) -- float32 [len(gids), K]."""
+    gids = np.asarray(gids, dtype=np.int64)
+    nb = (K + 3) // 4
+    blocks = np.arange(nb, dtype=np.uint32)[None, :]
+    g_lo = (gids & 0xFFFFFFFF).astype(np.uint32)[:, None]
+    g_hi = ((gids >> 32) & 0xFFFFFFFF).astype(np.uint32)[:, None]
+    c3 = (np.uint32(stream) << np.uint32(16)) | blocks
+    w = philox4x32_10(g_lo, g_hi, np.uint32(step), c3, np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF))
+    out = np.empty((len(gids), nb * 4), dtype=np.float32)
+    for k in range(4):
+        out[:, k::4] = _u01(w[k])
+    return out[:, :K]
+
+
 # ------------------------------------------------------------------------------------------------
 # small math helpers
 # ------------------------------------------------------------------------------------------------
@@ -354,6 +370,110 @@ def ccdm_particle(spec, params, y_u8_full, idx, eps=None):
     return -elbo, grads
 
 
+# ------------------------------------------------------------------------------------------------
+# Bernoulli-guide CDMs: the score-function (REINFORCE) estimator (VCDM / VaeCDM, vi.py:726-816; BinEncoder :458-470)
+# ------------------------------------------------------------------------------------------------
+TINY32 = float(np.finfo(np.float32).tiny)
+CDM_REF_PRIOR = 1.5         # vi.py:753: Bernoulli(torch.ones(..) + 0.5), i.e. probs = 1.5 (validation is off in pyro 1.4)
+
+
+def cdm_eta_rows(attr, q, cdm):
+    """eta[i, j] for explicit attribute rows (vi.py:69-100), the DINO variant with the reference's in-place sequencing
+    (see dino_eta)."""
+    aa = np.broadcast_to((q ** 2).sum(axis=0), (attr.shape[0], q.shape[1]))
+    if cdm == "dino":
+        yita = (1 - attr) @ q
+        yita[yita < aa] = 1
+        yita[yita == aa] = 0
+        return yita
+    yita = attr @ q
+    return (yita == aa).astype(q.dtype)
+
+
+def bin_enc_forward(W, yin):
+    """BinEncoder (vi.py:458-470): softplus(fc1) -> sigmoid(fc2); returns (logits of the attribute probabilities, cache)."""
+    pre = yin @ W["fc1.weight"].T + W["fc1.bias"]
+    h = softplus(pre)
+    u = h @ W["fc2.weight"].T + W["fc2.bias"]
+    return u, (yin, pre, h)
+
+
+def bin_enc_backward(W, cache, g_u):
+    yin, pre, h = cache
+    g_h = g_u @ W["fc2.weight"]
+    g_pre = g_h * sigmoid(pre)
+    return {"fc2.weight": g_u.T @ h, "fc2.bias": g_u.sum(0), "fc1.weight": g_pre.T @ yin, "fc1.bias": g_pre.sum(0)}
+
+
+def cdm_sf_particle(spec, params, y_u8_full, idx, attr, baseline=None):
+    """One Trace_ELBO particle of VCDM / VaeCDM with the score-function estimator:
+
+        log_r_i = scale [ log p(attr_i) + log p(y_i | attr_i) - log q(attr_i) ]          (kept per plate index, detached)
+        loss    = - sum_i log_r_i
+        d loss / d (item leaves)  : pathwise through scale log p(y_i | attr_i)
+        d loss / d (guide logits) = - (log_r_i - baseline_i) d log q(attr_i) / d logits    (score term UNSCALED)
+
+    attr: the (B, K) 0/1 draws of the guide (so that reference, oracle and HIP replay the same sample); baseline: (B,)
+    control variate or None (pyro's Trace_ELBO has none).  spec["attr_prior"]: None = the reference's Bernoulli(1.5).
+    Returns (loss, grads, log_r)."""
+    K, N = spec["K"], spec["N"]
+    dt = params["g"].dtype
+    q = spec["q"].astype(dt)
+    B = len(idx)
+    scale = dt.type(N) / dt.type(B)
+    y = y_u8_full[idx]
+    if (y == 255).any():
+        raise ValueError("VCDM / VaeCDM pass the responses unmasked (vi.py:756): a NaN cell makes the reference's loss NaN")
+    attr = np.asarray(attr, dt).reshape(B, K)
+    amort = spec["amortized"]
+    if amort:
+        W = {k.split("$$$")[1]: v for k, v in params.items() if k.startswith("encoder$$$")}
+        u, cache = bin_enc_forward(W, y.astype(dt))                  # vi.py:800: data[idx] as it is (0 / 1)
+        p = sigmoid(u)
+        inside_t = np.ones_like(p, dtype=bool)
+    else:
+        u = params["attr_p"][idx]
+        ps = sigmoid(u)                                            # constraints.unit_interval -> SigmoidTransform, clamped
+        p = np.clip(ps, TINY32, 1.0 - EPS32)
+        inside_t = (ps >= TINY32) & (ps <= 1.0 - EPS32)
+    pc = np.clip(p, EPS32, 1.0 - EPS32)                            # Bernoulli(probs).log_prob: clamp_probs
+    inside = inside_t & (p >= EPS32) & (p <= 1.0 - EPS32)
+    lq = (attr * np.log(pc) + (1 - attr) * np.log1p(-pc)).sum(1)
+    prior = CDM_REF_PRIOR if spec.get("attr_prior") is None else spec["attr_prior"]
+    pp = np.clip(dt.type(prior), EPS32, 1.0 - EPS32)
+    lpa = (attr * np.log(pp) + (1 - attr) * np.log1p(-pp)).sum(1)
+    eta = cdm_eta_rows(attr, q, spec.get("cdm", "dina"))
+    g_, s_ = sigmoid(params["g"]), sigmoid(params["s"])
+    P = (1 - s_) ** eta * g_ ** (1 - eta)
+    lp, dlp = bernoulli_logprob_probs(P.astype(dt), y)
+    ll = lp.sum(1)
+    log_r = scale * (lpa + ll - lq)
+    loss = -log_r.sum()
+    f = log_r - (0.0 if baseline is None else np.asarray(baseline, dt))
+    g_u = -(f[:, None]) * np.where(inside, attr - pc, 0.0)           # d log q / d logit = attr - p inside the clamps
+    grads = {"g": -scale * (dlp * (1 - eta)).sum(0, keepdims=True) * g_ * (1 - g_),
+             "s": -scale * (-(dlp * eta)).sum(0, keepdims=True) * s_ * (1 - s_)}
+    if amort:
+        for k, v in bin_enc_backward(W, cache, g_u).items():
+            grads["encoder$$$" + k] = v
+    else:
+        ga = np.zeros_like(params["attr_p"])
+        np.add.at(ga, idx, g_u)
+        grads["attr_p"] = ga
+    return loss, grads, log_r
+
+
+def init_cdm_sf_params(spec, J, dtype=np.float32, encoder=None):
+    K, N = spec["K"], spec["N"]
+    p = {"g": np.full((1, J), logit(np.asarray(0.1, dtype)), dtype), "s": np.full((1, J), logit(np.asarray(0.1, dtype)), dtype)}
+    if spec["amortized"]:
+        for k, v in encoder.items():
+            p["encoder$$$" + k] = np.asarray(v, dtype)
+    else:
+        p["attr_p"] = np.zeros((N, K), dtype)                        # unit_interval^-1 (0.5) = 0 (vi.py:811)
+    return p
+
+
 def hodina_particle(spec, params, y_u8_full, idx, eps):
     K, N = spec["K"], spec["N"]
     dt = params["g"].dtype
@@ -424,7 +544,10 @@ def hodina_particle(spec, params, y_u8_full, idx, eps):
 # loss_and_grads over particles + optimiser
 # ------------------------------------------------------------------------------------------------
 def loss_and_grads(spec, params, y_u8, idx_list, eps_list):
-    fn = {"hodina": hodina_particle, "ccdm": ccdm_particle}.get(spec.get("family"), irt_particle)
+    if spec.get("family") == "cdm_sf":                      # eps_list carries the guide's attribute draws
+        fn = lambda sp, pa, yy, ii, at: cdm_sf_particle(sp, pa, yy, ii, at)[:2]      # noqa: E731
+    else:
+        fn = {"hodina": hodina_particle, "ccdm": ccdm_particle}.get(spec.get("family"), irt_particle)
     S = len(idx_list)
     loss, grads = 0.0, None
     for idx, eps in zip(idx_list, eps_list):
@@ -538,6 +661,8 @@ def constrained(name, value):
     base = name.split("$$$")[-1]
     if name in ("c", "d", "g", "s"):
         return sigmoid(value)
+    if name == "attr_p":
+        return np.clip(sigmoid(value), np.finfo(np.float32).tiny, 1.0 - EPS32)
     if name in ("lam1", "theta_scale") or (name == "x_scale" and value.ndim == 2 and value.shape[1] == 1):
         return np.exp(value)
     if name == "x_scale":

@@ -4,6 +4,7 @@ import torch
 _STACK = []
 EPS_LOG = []      # every reparameterised noise draw, in program order (captured into fixtures)
 IDX_LOG = []      # every subsample index draw
+DISC_LOG = []     # every draw of a non-reparameterised (discrete) site that was actually sampled (guide sites)
 
 
 def apply_stack(msg):
@@ -16,6 +17,7 @@ def apply_stack(msg):
             msg["value"] = fn.rsample()
         else:
             msg["value"] = fn.sample()
+            DISC_LOG.append(msg["value"].detach().clone())
     elif msg["type"] == "subsample" and msg["value"] is None:
         size, ss = msg["size"], msg["subsample_size"]
         if ss is None or ss >= size:

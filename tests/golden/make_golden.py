@@ -71,6 +71,7 @@ def snapshot_params():
 def run_case(tag, model_obj, data, optim, loss, steps, extra):
     rt.EPS_LOG.clear()
     rt.IDX_LOG.clear()
+    rt.DISC_LOG.clear()
     cap = CapOptim(optim)
     svi = vi.SVI(model_obj.model, model_obj.guide, optim=cap, loss=loss)
     rec = dict(extra)
@@ -80,7 +81,7 @@ def run_case(tag, model_obj, data, optim, loss, steps, extra):
         for k, v in model_obj.encoder.state_dict().items():
             rec["enc0/" + k] = v.detach().clone().numpy()
     for t in range(steps):
-        n_eps0, n_idx0 = len(rt.EPS_LOG), len(rt.IDX_LOG)
+        n_eps0, n_idx0, n_disc0 = len(rt.EPS_LOG), len(rt.IDX_LOG), len(rt.DISC_LOG)
         lossv = svi.step(data)
         if isinstance(optim, PyroLRScheduler):
             optim.step()               # vi.py:639-640: scheduler advances every iteration
@@ -92,6 +93,8 @@ def run_case(tag, model_obj, data, optim, loss, steps, extra):
             rec["s%d/eps%d" % (t, k)] = e.numpy()
         for k, i in enumerate(idx):
             rec["s%d/idx%d" % (t, k)] = i.numpy().astype(np.int64)
+        for k, a in enumerate(rt.DISC_LOG[n_disc0:]):              # draws of non-reparameterised guide sites
+            rec["s%d/attr%d" % (t, k)] = a.numpy().astype(np.uint8)
         for name, g in cap.grads.items():
             rec["s%d/grad/%s" % (t, name)] = g
         for name, p in snapshot_params().items():
@@ -298,6 +301,33 @@ def gen_round2_cases():
              {"cls": "VCHoDina", "N": 48, "J": 130, "K": 3, "B": 48, "lr": 1e-1, "q": ri.q.numpy()})
 
 
+def gen_score_function_cases():
+    """Bernoulli-guide CDMs with the score-function estimator (VCDM / VaeCDM, vi.py:726-816), incl. the reference's
+    Bernoulli(1.5) prior (vi.py:753) and the DINO in-place quirk; complete data (the model does not mask NaN)."""
+    torch.manual_seed(300)
+    ri = vi.RandomDina(sample_size=26, item_size=9, q_size=3)
+    y = ri.y
+    m = vi.VCDM(data=y, q=ri.q, model="dina", subsample_size=26)
+    run_case("vcdm_dina_k3", m, y, Adam({"lr": 5e-2}), Trace_ELBO(num_particles=1), 3,
+             {"cls": "VCDM", "cdm": "dina", "N": 26, "J": 9, "K": 3, "B": 26, "lr": 5e-2, "q": ri.q.numpy()})
+    torch.manual_seed(301)
+    ri = vi.RandomDino(sample_size=30, item_size=11, q_size=4)
+    y = ri.y
+    m = vi.VCDM(data=y, q=ri.q, model="dino", subsample_size=12)
+    run_case("vcdm_dino_k4_sub_particles2", m, y, Adam({"lr": 5e-2}), Trace_ELBO(num_particles=2), 3,
+             {"cls": "VCDM", "cdm": "dino", "N": 30, "J": 11, "K": 4, "B": 12, "lr": 5e-2, "S": 2, "q": ri.q.numpy()})
+    torch.manual_seed(302)
+    ri = vi.RandomDina(sample_size=24, item_size=10, q_size=3)
+    y = ri.y
+    m = vi.VaeCDM(data=y, q=ri.q, model="dina", subsample_size=10, hidden_dim=8)
+
+    def lr_cdm(module_name, param_name):
+        return {"lr": 1e-1 if param_name in ("g", "s") else 1e-2}
+    run_case("vaecdm_dina_k3", m, y, Adam(lr_cdm), Trace_ELBO(num_particles=1), 3,
+             {"cls": "VaeCDM", "cdm": "dina", "N": 24, "J": 10, "K": 3, "B": 10, "H": 8, "q": ri.q.numpy(),
+              "lr_item": 1e-1, "lr_other": 1e-2})
+
+
 def gen_function_cases():
     """G1-G5 of SURVEY.md section 8c: pure-torch pieces of vi.py imported and evaluated."""
     rec = {}
@@ -386,6 +416,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "r2":       # only the round-2 additions
         gen_round2_cases()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "sf":
+        gen_score_function_cases()
         sys.exit(0)
     gen_function_cases()
     gen_elbo_cases()

@@ -35,6 +35,12 @@ def _lr_ho(item, other):
     return fn
 
 
+def _lr_cdm(item, other):
+    def fn(module, name):
+        return {"lr": item if name in ("g", "s") else other}
+    return fn
+
+
 def build(tag, dtype=np.float32):
     f = load(tag)
     cls = str(f["cls"])
@@ -49,6 +55,11 @@ def build(tag, dtype=np.float32):
         params = vo.init_irt_params(spec, J, dtype, encoder=enc if amort else None,
                                     b0=f["b0"] if "b0" in f else None, a0=f["a0"] if "a0" in f else None)
         lr = _lr_irt(float(f["lr_item"]), float(f["lr_other"])) if "lr_item" in f else float(f["lr"])
+    elif cls in ("VCDM", "VaeCDM"):
+        spec = {"family": "cdm_sf", "cdm": str(f["cdm"]), "K": int(f["K"]), "N": N, "amortized": amort, "q": f["q"],
+                "attr_prior": None}
+        params = vo.init_cdm_sf_params(spec, J, dtype, encoder=enc if amort else None)
+        lr = _lr_cdm(float(f["lr_item"]), float(f["lr_other"])) if "lr_item" in f else float(f["lr"])
     elif cls == "VCCDM":
         spec = {"family": "ccdm", "cdm": str(f["cdm"]), "K": int(f["K"]), "N": N, "amortized": False, "q": f["q"]}
         params = vo.init_ccdm_params(spec, J, dtype)
@@ -70,7 +81,8 @@ def build(tag, dtype=np.float32):
             S = sum(1 for k in f if k.startswith("s%d/idx" % t))
         rec = {"loss": float(f["s%d/loss" % t]),
                "idx": [f["s%d/idx%d" % (t, k)] for k in range(S)],
-               "eps": [f["s%d/eps%d" % (t, k)] if k < n_eps else None for k in range(S)],
+               "eps": [f["s%d/eps%d" % (t, k)] if k < n_eps else
+                       (f["s%d/attr%d" % (t, k)] if ("s%d/attr%d" % (t, k)) in f else None) for k in range(S)],
                "grad": {k.split("/grad/")[1]: f[k] for k in f if k.startswith("s%d/grad/" % t)},
                "param": {k.split("/param/")[1]: f[k] for k in f if k.startswith("s%d/param/" % t)}}
         steps.append(rec)

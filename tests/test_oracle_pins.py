@@ -78,3 +78,33 @@ def test_elbo_gradient_is_unbiased_direction_check():
             lm, _ = vo.loss_and_grads(spec, params, y, [idx], [eps])
             flat[pos] = old
             assert g[name].reshape(-1)[pos] == pytest.approx((lp - lm) / 2e-6, rel=1e-5, abs=1e-6), (name, pos)
+
+
+def test_score_function_baselines_keep_the_estimator_unbiased_and_cut_its_variance():
+    """north_star: REINFORCE with a control-variate baseline.  On a small VCDM problem the mean of the guide-logit gradient
+    over many draws is the same with and without a baseline that does not depend on the person's own draw (here: the
+    leave-one-out mean of log_r over the particles), and its variance is smaller."""
+    from oracle import vi_oracle as vo
+    rng = np.random.RandomState(4)
+    N, J, K, S, reps = 12, 8, 2, 4, 600
+    q = (rng.rand(K, J) < 0.6).astype(np.float64)
+    q[0, q.sum(0) == 0] = 1
+    y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+    spec = {"family": "cdm_sf", "cdm": "dina", "K": K, "N": N, "amortized": False, "q": q, "attr_prior": 0.5}
+    params = vo.init_cdm_sf_params(spec, J, np.float64)
+    params["attr_p"] = 0.3 * rng.randn(N, K)
+    idx = np.arange(N)
+    p = vo.sigmoid(params["attr_p"])
+    plain, loo = [], []
+    for _ in range(reps):
+        attrs = [(rng.rand(N, K) < p).astype(np.float64) for _ in range(S)]
+        lrs = [vo.cdm_sf_particle(spec, params, y, idx, a)[2] for a in attrs]
+        g0 = np.mean([vo.cdm_sf_particle(spec, params, y, idx, a)[1]["attr_p"] for a in attrs], axis=0)
+        g1 = np.mean([vo.cdm_sf_particle(spec, params, y, idx, a, baseline=(sum(lrs) - lrs[s]) / (S - 1))[1]["attr_p"]
+                      for s, a in enumerate(attrs)], axis=0)
+        plain.append(g0)
+        loo.append(g1)
+    plain, loo = np.array(plain), np.array(loo)
+    se = plain.std(0) / np.sqrt(reps)
+    assert np.all(np.abs(plain.mean(0) - loo.mean(0)) < 6 * se + 1e-9)          # same expectation
+    assert loo.var(0).mean() < 0.5 * plain.var(0).mean()                        # the control variate pays

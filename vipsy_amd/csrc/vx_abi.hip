@@ -20,6 +20,7 @@
 #include "k_mvn_fwd_b.hip"
 #include "k_mvn_bwd_hb.hip"
 #include "k_fc1_bwd_b.hip"
+#include "k_cdm_sf.hip"
 
 #include <cstdlib>
 #include <cstring>
@@ -1279,6 +1280,129 @@ int vx_ccdm_grad(const vx_hodina_cfg* cfg, int32_t dino, const uint8_t* y, const
                        (int64_t)len, (int64_t)(2 * cfg->J), -1.0f, gitem);
     VX_CHECK_LAUNCH();
     return VX_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Bernoulli-guide DINA / DINO with the score-function estimator (VCDM / VaeCDM, vi.py:726-816): k_cdm_sf.hip
+static bool cdm_sf_cfg_ok(const vx_hodina_cfg* cfg) { return cfg && cfg->K >= 1 && cfg->K <= CS_MAXK && cfg->J >= 1 && cfg->J <= 4096; }
+static int cdm_sf_blocks(int64_t nb) {
+    const int64_t n_groups = (nb + 63) / 64;
+    int64_t blocks = (n_groups + CS_THREADS / 64 - 1) / (CS_THREADS / 64);
+    const int64_t cap = (int64_t)num_cu() * 4;
+    if (blocks > cap) blocks = cap;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+int64_t vx_cdm_sf_workspace_floats(const vx_hodina_cfg* cfg, int64_t nb) {
+    if (!cdm_sf_cfg_ok(cfg) || nb < 0) return VX_EINVAL;
+    return (int64_t)cdm_sf_blocks(nb) * 4 * cfg->J;
+}
+
+int vx_cdm_sf_grad(const vx_hodina_cfg* cfg, int32_t dino, int32_t clamp_t, float prior_p, const uint8_t* y,
+                   const int64_t* rows, int64_t nb, int64_t gid0, const float* q, const float* g_un, const float* s_un,
+                   const float* u, const uint8_t* attr_in, float* baseline, float base_beta, int32_t base_by_row, float* gu,
+                   float* log_r, uint8_t* attr_out, float* gitem, float* workspace, void* hs) {
+    if (!cdm_sf_cfg_ok(cfg) || !y || !q || !g_un || !s_un || !u || !gu || !log_r || !gitem || !workspace || nb < 0)
+        return VX_EINVAL;
+    const int blocks = cdm_sf_blocks(nb);
+    CdmSfDims dm;
+    dm.K = cfg->K; dm.J = cfg->J; dm.dino = dino ? 1 : 0; dm.clamp_t = clamp_t ? 1 : 0; dm.scale = cfg->scale; dm.nb = nb;
+    const float pc = fminf(fmaxf(prior_p, VX_EPS32), 1.0f - VX_EPS32);        // Bernoulli(probs).log_prob clamps (vi.py:753: 1.5)
+    dm.lp1 = logf(pc); dm.lp0 = log1pf(-pc);
+    dm.base_beta = base_beta; dm.base_by_row = base_by_row ? 1 : 0;
+    hipStream_t st = (hipStream_t)hs;
+    const size_t lds = (size_t)cfg->J * (4 * sizeof(float) + 4 * sizeof(int) + sizeof(uint32_t));
+    int rc = set_lds(k_cdm_sf, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cdm_sf, dim3(blocks), dim3(CS_THREADS), lds, st, dm, y, rows, gid0, u, attr_in, cfg->seed, cfg->step,
+                       cfg->stream, q, g_un, s_un, baseline, gu, log_r, attr_out, (int*)workspace);
+    VX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_cdm_sf_items, dim3((cfg->J + 127) / 128), dim3(128), 0, st, (int)cfg->J, blocks, cfg->scale,
+                       (const int*)workspace, g_un, s_un, gitem);
+    VX_CHECK_LAUNCH();
+    return VX_OK;
+}
+
+int vx_loo_baseline(const float* lr_all, int32_t S, int64_t nb, int32_t s, float* out, void* hs) {
+    if (!lr_all || !out || S < 2 || s < 0 || s >= S || nb < 0) return VX_EINVAL;
+    if (nb == 0) return VX_OK;
+    hipLaunchKernelGGL(k_loo_baseline, dim3(grid_1d(nb, 256)), dim3(256), 0, (hipStream_t)hs, lr_all, (int)S, nb, (int)s, out);
+    VX_CHECK_LAUNCH();
+    return VX_OK;
+}
+
+static bool bin_enc_cfg_ok(const vx_hodina_cfg* cfg) {
+    return cfg && cfg->K >= 1 && cfg->K <= CS_MAXK && cfg->H >= 1 && cfg->H <= 64 && cfg->J >= 1;
+}
+static void bin_enc_plan(const vx_hodina_cfg* cfg, int64_t nb, int& nblk, int& n_jg, int& n_prf) {
+    int64_t b = (nb + 3) / 4;
+    if (b > 1024) b = 1024;
+    nblk = (int)(b < 1 ? 1 : b);
+    n_jg = (cfg->J + FC1_JG - 1) / FC1_JG;
+    const int64_t n_ptiles = (nb + ENC_P - 1) / ENC_P;
+    int64_t f = num_cu() / n_jg; if (f < 1) f = 1;
+    n_prf = (int)(n_ptiles < f ? n_ptiles : f); if (n_prf < 1) n_prf = 1;
+}
+
+int64_t vx_bin_enc_param_floats(const vx_hodina_cfg* cfg) {
+    if (!bin_enc_cfg_ok(cfg)) return VX_EINVAL;
+    return (int64_t)cfg->H * cfg->J + cfg->H + (int64_t)cfg->K * cfg->H + cfg->K;
+}
+
+int vx_bin_enc_forward(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* W1,
+                       const float* b1, const float* W2, const float* b2, float* h, float* u, void* hs) {
+    if (!bin_enc_cfg_ok(cfg) || !y || !W1 || !b1 || !W2 || !b2 || !h || !u || nb < 0) return VX_EINVAL;
+    if (nb == 0) return VX_OK;
+    int64_t blocks = (nb + 3) / 4;
+    if (blocks > (int64_t)num_cu() * 8) blocks = (int64_t)num_cu() * 8;
+    hipLaunchKernelGGL(k_bin_enc_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hs, (int)cfg->K, (int)cfg->J, (int)cfg->H,
+                       nb, y, rows, W1, b1, W2, b2, h, u);
+    VX_CHECK_LAUNCH();
+    return VX_OK;
+}
+
+int64_t vx_bin_enc_bwd_workspace_floats(const vx_hodina_cfg* cfg, int64_t nb) {
+    if (!bin_enc_cfg_ok(cfg) || nb < 0) return VX_EINVAL;
+    int nblk, n_jg, n_prf;
+    bin_enc_plan(cfg, nb, nblk, n_jg, n_prf);
+    const int64_t H = cfg->H, J = cfg->J, K = cfg->K;
+    return nb * H + (int64_t)nblk * (K * H + K) + (int64_t)n_prf * (H * J + H) + 8;          // ghpre | head slabs | fc1 slabs
+}
+
+int vx_bin_enc_backward(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* W2,
+                        const float* h, const float* gu, float* genc, float* workspace, void* hs) {
+    if (!bin_enc_cfg_ok(cfg) || !y || !W2 || !h || !gu || !genc || !workspace || nb < 0) return VX_EINVAL;
+    int nblk, n_jg, n_prf;
+    bin_enc_plan(cfg, nb, nblk, n_jg, n_prf);
+    const int64_t H = cfg->H, J = cfg->J, K = cfg->K;
+    const int64_t lenh = K * H + K, lenf = H * J + H;
+    float* ghpre = workspace;
+    float* slabs_h = ghpre + nb * H;
+    float* slabs_f = slabs_h + (int64_t)nblk * lenh;
+    hipStream_t st = (hipStream_t)hs;
+    hipError_t he = hipMemsetAsync(slabs_h, 0, sizeof(float) * (size_t)(nblk * lenh + n_prf * lenf), st);
+    if (he != hipSuccess) return (int)he;
+    if (nb > 0) {
+        hipLaunchKernelGGL(k_bin_enc_bwd_small, dim3(nblk), dim3(256), 0, st, (int)K, (int)H, nb, W2, h, gu, ghpre, slabs_h);
+        VX_CHECK_LAUNCH();
+        EncDims dm;
+        dm.D = 1; dm.J = cfg->J; dm.H = cfg->H; dm.Hp = (cfg->H + 31) / 32 * 32; dm.DS = 3; dm.T = 1; dm.nb = nb;
+        const size_t lds = fc1_bwd_lds_floats(dm.Hp) * sizeof(float);
+        const dim3 grid((unsigned)n_jg, (unsigned)n_prf);
+        int rc;
+#define LAUNCH_F1(HT)                                                                                        \
+    rc = set_lds(k_fc1_bwd<HT>, lds);                                                                        \
+    if (rc) return rc;                                                                                       \
+    hipLaunchKernelGGL(k_fc1_bwd<HT>, grid, dim3(ENC_THREADS), lds, st, dm, y, rows, ghpre, slabs_f, lenf, 0)
+        if (dm.Hp == 32) { LAUNCH_F1(1); } else { LAUNCH_F1(2); }
+#undef LAUNCH_F1
+        VX_CHECK_LAUNCH();
+    }
+    // flat layout = nn.Linear order of BinEncoder (vi.py:462-463): [W1 | b1 | W2 | b2]; ghpre already is d LOSS
+    int rc2 = vx_reduce_slabs(slabs_f, n_prf, lenf, 1.0f, genc, hs);
+    if (rc2) return rc2;
+    return vx_reduce_slabs(slabs_h, nblk, lenh, 1.0f, genc + lenf, hs);
 }
 
 }  // extern "C"

@@ -187,6 +187,41 @@ class HipBackend(object):
                                  _hip.ptr(s_), _hip.ptr(elbo), _hip.ptr(gitem), _hip.ptr(ws), _hip.stream_ptr())
         _hip.check(rc, "vx_ccdm_grad")
 
+    def cdm_sf_workspace(self, cfg, nb):
+        n = self.L.vx_cdm_sf_workspace_floats(ctypes.byref(cfg), nb)
+        if n < 0:
+            raise _hip.VxError("vx_cdm_sf_workspace_floats: unsupported configuration (code %d)" % n)
+        return n
+
+    def cdm_sf_grad(self, cfg, dino, clamp_t, prior_p, y, rows, nb, gid0, q, g, s_, u, attr_in, baseline, base_beta,
+                    base_by_row, gu, log_r, attr_out, gitem, ws):
+        rc = self.L.vx_cdm_sf_grad(ctypes.byref(cfg), int(dino), int(clamp_t), float(prior_p), _hip.ptr(y), _hip.ptr(rows), nb,
+                                   gid0, _hip.ptr(q), _hip.ptr(g), _hip.ptr(s_), _hip.ptr(u), _hip.ptr(attr_in),
+                                   _hip.ptr(baseline), float(base_beta), int(base_by_row), _hip.ptr(gu), _hip.ptr(log_r),
+                                   _hip.ptr(attr_out), _hip.ptr(gitem), _hip.ptr(ws), _hip.stream_ptr())
+        _hip.check(rc, "vx_cdm_sf_grad")
+
+    def loo_baseline(self, lr_all, S, nb, s, out):
+        _hip.check(self.L.vx_loo_baseline(_hip.ptr(lr_all), int(S), nb, int(s), _hip.ptr(out), _hip.stream_ptr()),
+                   "vx_loo_baseline")
+
+    def bin_enc_forward(self, cfg, y, rows, nb, enc, h, u):
+        rc = self.L.vx_bin_enc_forward(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb, _hip.ptr(enc["fc1.weight"]),
+                                       _hip.ptr(enc["fc1.bias"]), _hip.ptr(enc["fc2.weight"]), _hip.ptr(enc["fc2.bias"]),
+                                       _hip.ptr(h), _hip.ptr(u), _hip.stream_ptr())
+        _hip.check(rc, "vx_bin_enc_forward")
+
+    def bin_enc_bwd_workspace(self, cfg, nb):
+        n = self.L.vx_bin_enc_bwd_workspace_floats(ctypes.byref(cfg), nb)
+        if n < 0:
+            raise _hip.VxError("vx_bin_enc_bwd_workspace_floats: unsupported configuration (code %d)" % n)
+        return n
+
+    def bin_enc_backward(self, cfg, y, rows, nb, enc, h, gu, genc, ws):
+        rc = self.L.vx_bin_enc_backward(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb, _hip.ptr(enc["fc2.weight"]),
+                                        _hip.ptr(h), _hip.ptr(gu), _hip.ptr(genc), _hip.ptr(ws), _hip.stream_ptr())
+        _hip.check(rc, "vx_bin_enc_backward")
+
     def sum_into(self, v, n, alpha, out, ws):
         rc = self.L.vx_sum(_hip.ptr(v), n, alpha, _hip.ptr(out), _hip.ptr(ws), _hip.stream_ptr())
         _hip.check(rc, "vx_sum")
@@ -799,6 +834,172 @@ class CcdmEngine(_EngineBase):
                          self.G[:self.n_item], ws)
         be.sum_into(elbo, nb, -scale, self.G[self.n_params:self.n_params + 1], self.sum_ws)
         self.last = {"elbo": elbo, "nb": nb}
+
+
+BIN_ENC_KEYS = ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias")
+CDM_REF_PRIOR = 1.5          # vi.py:753: Bernoulli(torch.ones(..) + 0.5) -- probability 1.5, clamped by log_prob
+
+
+class CdmSfEngine(_EngineBase):
+    """Bernoulli-guide DINA / DINO with the score-function (REINFORCE) estimator: VCDM / VaeCDM (vi.py:726-816).
+
+    Flat parameter buffer: [g_un: J | s_un: J | BinEncoder (amortized only)]; per-person rows `attr_p` (n, K) logits of the
+    guide probabilities for VCDM (vi.py:811).  baseline: 'none' = pyro's Trace_ELBO; 'avg' = per-person decaying average
+    of log_r (rate `baseline_beta`); 'loo' = leave-one-out mean over the particles of a step (all particles then share the
+    step's subsample).  attr_prior: probability of mastering an attribute under the model prior; None reproduces the
+    reference's Bernoulli(1.5)."""
+
+    pp_names = ("attr_p",)
+
+    def __init__(self, y_u8, q, cdm="dina", n_global=None, gid0=0, amortized=False, H=64, encoder_init=None, seed=1234,
+                 group=None, backend=None, attr_prior=None, baseline="none", baseline_beta=0.9):
+        if cdm not in ("dina", "dino"):
+            raise ValueError("model must be 'dina' or 'dino' (BaseCDM.CDM_FUN, vi.py:728-731)")
+        if baseline not in ("none", "avg", "loo"):
+            raise ValueError("baseline must be 'none', 'avg' or 'loo'")
+        self.be = backend if backend is not None else HipBackend()
+        self.y = y_u8.contiguous()
+        assert self.y.dtype == torch.uint8 and self.y.dim() == 2
+        if bool((self.y > 1).any()):
+            raise ValueError("VCDM / VaeCDM need complete 0/1 responses: the reference hands them to the likelihood "
+                             "unmasked (vi.py:756), a missing cell makes its loss NaN")
+        self.dev = self.y.device
+        self.n_local, self.J = self.y.shape
+        self.N = int(n_global) if n_global is not None else self.n_local
+        self.gid0 = int(gid0)
+        q = torch.as_tensor(q, dtype=torch.float32)
+        assert q.dim() == 2 and q.shape[1] == self.J
+        if not bool(((q == 0) | (q == 1)).all()):
+            raise ValueError("the Q-matrix must be binary (the subset tests of vi.py:78-81, 96-100 assume it)")
+        self.K = int(q.shape[0])
+        self.q = q.to(self.dev).contiguous()
+        self.cdm, self.amortized, self.H = cdm, bool(amortized), int(H) if amortized else 0
+        self.seed, self.group = int(seed), group
+        self.attr_prior = CDM_REF_PRIOR if attr_prior is None else float(attr_prior)
+        self.baseline, self.baseline_beta = baseline, float(baseline_beta)
+        J, K = self.J, self.K
+        self.off = {"g": 0, "s": J}
+        self.shape = {"g": (1, J), "s": (1, J)}
+        self.n_item = 2 * J
+        o = self.n_item
+        if self.amortized:
+            o = (self.n_item + 63) // 64 * 64
+            self.enc_shapes = {"fc1.weight": (self.H, J), "fc1.bias": (self.H,), "fc2.weight": (K, self.H), "fc2.bias": (K,)}
+            self.enc_off0 = o
+            for k in BIN_ENC_KEYS:
+                self.off["encoder$$$" + k] = o
+                self.shape["encoder$$$" + k] = self.enc_shapes[k]
+                o += int(np.prod(self.enc_shapes[k]))
+            self.n_enc = o - self.enc_off0
+        self.pp_shape = {"attr_p": (self.n_local, K)}
+        self._alloc(o, self.n_local, per_person=not self.amortized)
+        self.view("g").fill_(float(np.float32(_logit(np.float32(0.1)))))      # vi.py:748-749: g = s = 0.1
+        self.view("s").fill_(float(np.float32(_logit(np.float32(0.1)))))
+        if self.amortized:
+            if encoder_init is None:
+                encoder_init = default_bin_encoder_init(J, K, self.H, seed)
+            for k in BIN_ENC_KEYS:
+                self.view("encoder$$$" + k).copy_(torch.as_tensor(encoder_init[k], dtype=torch.float32).reshape(-1))
+        self.base = torch.zeros(max(self.n_local, 1), dtype=torch.float32, device=self.dev) if baseline == "avg" else None
+
+    def names(self):
+        return ["g", "s"] + (["encoder$$$" + k for k in BIN_ENC_KEYS] if self.amortized else [])
+
+    def all_names(self):
+        return self.names() + (list(self.pp_names) if self.per_person else [])
+
+    def param(self, name):
+        u = self.unconstrained(name)
+        if name in ("g", "s"):
+            return torch.sigmoid(u)
+        if name == "attr_p":                                                   # unit_interval: clamped sigmoid
+            return torch.clamp(torch.sigmoid(u), min=float(np.finfo(np.float32).tiny), max=1.0 - float(np.finfo(np.float32).eps))
+        return u.clone()
+
+    def loss_and_grads(self, rows=None, b_global=None, eps=None, stream_id=0, baseline_buf=None, grads=True):
+        """One particle.  `eps`: uint8 (nb, K) attribute draws to replay, or None (drawn in the kernel from Philox, keyed
+        by the global person id).  baseline_buf: explicit control variate in batch order (the 'loo' mode of step())."""
+        be = self.be
+        nb = self.n_local if rows is None else int(rows.numel())
+        Bg = int(b_global) if b_global is not None else (self.N if rows is None else nb)
+        scale = float(self.N) / float(Bg)
+        K = self.K
+        cfg = be.hodina_cfg(K, self.J, self.H, scale, self.seed, self.t, stream_id)
+        ws = self._buf("cs_ws", be.cdm_sf_workspace(cfg, nb))
+        gu, log_r = self._buf("cs_gu", nb * K), self._buf("cs_lr%d" % stream_id if not grads else "cs_lr", nb)
+        if self.amortized:
+            enc = {k: self.view("encoder$$$" + k) for k in BIN_ENC_KEYS}
+            h, u = self._buf("cs_h", nb * self.H), self._buf("cs_u", nb * K)
+            with self._phase("guide_forward"):
+                be.bin_enc_forward(cfg, self.y, rows, nb, enc, h, u)
+        else:
+            u = self.PP if rows is None else self.PP.reshape(self.n_local, K)[rows].contiguous().reshape(-1)
+        if baseline_buf is not None:
+            base, beta, by_row = baseline_buf, -1.0, 0
+        elif self.baseline == "avg":
+            base, beta, by_row = self.base, (self.baseline_beta if grads else -1.0), 1
+        else:
+            base, beta, by_row = None, -1.0, 0
+        with self._phase("cdm_sf"):
+            be.cdm_sf_grad(cfg, self.cdm == "dino", not self.amortized, self.attr_prior, self.y, rows, nb, self.gid0, self.q,
+                           self.view("g"), self.view("s"), u, eps, base, beta, by_row, gu, log_r, None,
+                           self.G[:self.n_item], ws)
+        if grads:
+            if self.amortized:
+                with self._phase("guide_backward"):
+                    bw = self._buf("cs_bws", be.bin_enc_bwd_workspace(cfg, nb))
+                    be.bin_enc_backward(cfg, self.y, rows, nb, enc, h, gu,
+                                        self.G[self.enc_off0:self.enc_off0 + self.n_enc], bw)
+            elif rows is None:
+                self.GP.copy_(gu[:nb * K])
+            else:                                              # dense per-person gradient: zero off the batch (vi.py:811)
+                self.GP.zero_()
+                self.GP.reshape(self.n_local, K).index_add_(0, rows, gu[:nb * K].reshape(nb, K))
+        be.sum_into(log_r, nb, -1.0, self.G[self.n_params:self.n_params + 1], self.sum_ws)
+        self.last = {"log_r": log_r, "gu": gu, "nb": nb}
+
+    def step(self, lrs, rows=None, b_global=None, eps=None, num_particles=1):
+        S = int(num_particles)
+        if self.baseline != "loo" or S < 2:
+            return super().step(lrs, rows=rows, b_global=b_global, eps=eps, num_particles=S)
+        # leave-one-out control variate: a first pass records log_r of every particle (same subsample, the same Philox
+        # draws as the second pass: the particle index is the Philox stream), the second pass uses the means
+        r = rows[0] if isinstance(rows, (list, tuple)) else rows
+        nb = self.n_local if r is None else int(r.numel())
+        lr_all = self._buf("cs_lr_all", S * nb)
+        for sidx in range(S):
+            e = eps[sidx] if isinstance(eps, (list, tuple)) else eps
+            self.loss_and_grads(r, b_global, e, sidx, grads=False)
+            lr_all[sidx * nb:(sidx + 1) * nb].copy_(self.last["log_r"][:nb])
+        accG = torch.zeros_like(self.G)
+        accP = torch.zeros_like(self.GP) if self.per_person else None
+        loo = self._buf("cs_loo", nb)
+        for sidx in range(S):
+            e = eps[sidx] if isinstance(eps, (list, tuple)) else eps
+            self.be.loo_baseline(lr_all, S, nb, sidx, loo)
+            self.loss_and_grads(r, b_global, e, sidx, baseline_buf=loo)
+            accG.add_(self.G, alpha=1.0 / S)
+            if accP is not None:
+                accP.add_(self.GP, alpha=1.0 / S)
+        self.G.copy_(accG)
+        if accP is not None:
+            self.GP.copy_(accP)
+        self.allreduce()
+        loss = self.G[self.n_params].clone()
+        self.apply_optim(lrs)
+        return loss
+
+
+def default_bin_encoder_init(J, K, H, seed):
+    """nn.Linear default initialisation for BinEncoder (vi.py:458-470), drawn on the host."""
+    g = torch.Generator().manual_seed(int(seed) + 7919)
+
+    def lin(out_f, in_f):
+        k = 1.0 / math.sqrt(in_f)
+        return (torch.rand(out_f, in_f, generator=g) * 2 - 1) * k, (torch.rand(out_f, generator=g) * 2 - 1) * k
+    w1, b1 = lin(H, J)
+    w2, b2 = lin(K, H)
+    return {"fc1.weight": w1, "fc1.bias": b1, "fc2.weight": w2, "fc2.bias": b2}
 
 
 class _Phase(object):

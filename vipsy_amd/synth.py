@@ -121,5 +121,41 @@ def simulate_hodina(n, gid0, prm, device, seed, missing=0.0, chunk=262144):
     return y
 
 
+def dina_params(J, K, seed, q_p=0.5):
+    """RandomDina / RandomDino item side (vi.py:134-156): q ~ Bern(q_p) with the zero-column fix-up, g, s ~ U(0, .3)."""
+    prm = hodina_params(J, K, seed)
+    if q_p != 0.5:
+        g = torch.Generator().manual_seed(seed + 1)
+        q = (torch.rand(K, J, generator=g) < q_p).float()
+        empty = q.sum(0) == 0
+        if bool(empty.any()):
+            q[:, empty] = torch.eye(K)[torch.randint(0, K, (int(empty.sum()),), generator=g)].T
+        prm["q"] = q
+    return {"q": prm["q"], "g": prm["g"], "s": prm["s"]}
+
+
+def simulate_dina(n, gid0, prm, device, seed, cdm="dina", attr_p=0.5, missing=0.0, chunk=262144):
+    """attr_k ~ Bern(attr_p); DINA / DINO response (vi.py:69-100, 158-172; DINO without the reference's in-place quirk of
+    dino(): this is the data-generating model, eta = 1 iff at least one required attribute is mastered)."""
+    q = prm["q"].to(device)
+    K, J = q.shape
+    need = (q ** 2).sum(0)
+    y = torch.empty(n, J, dtype=torch.uint8, device=device)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        g = torch.Generator(device=device).manual_seed(seed * 1000003 + (gid0 + s))
+        attr = (torch.rand(e - s, K, generator=g, device=device) < attr_p).float()
+        if cdm == "dino":
+            eta = (((1 - attr) @ q) < need).float()
+        else:
+            eta = ((attr @ q) == need).float()
+        p = eta * (1 - prm["s"].to(device)) + (1 - eta) * prm["g"].to(device)
+        yy = (torch.rand(e - s, J, generator=g, device=device) < p).to(torch.uint8)
+        if missing > 0:
+            yy[torch.rand(e - s, J, generator=g, device=device) < missing] = 255
+        y[s:e] = yy
+    return y
+
+
 def np_u8(y):
     return y.detach().cpu().numpy().astype(np.uint8)

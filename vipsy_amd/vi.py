@@ -17,7 +17,7 @@ import math
 import numpy as np
 import torch
 
-from .engine import CcdmEngine, IrtEngine, HoDinaEngine, LrSpec
+from .engine import CcdmEngine, CdmSfEngine, IrtEngine, HoDinaEngine, LrSpec
 
 _STORE = {}          # name -> engine that owns the parameter (the process-global store of the reference)
 
@@ -264,8 +264,61 @@ def _out_of_scope(name, cite):
     return _C
 
 
-VCDM = _out_of_scope("VCDM", "vi.py:807-816")
-VaeCDM = _out_of_scope("VaeCDM", "vi.py:785-804")
+class _CdmSfBase(BasePsy):
+    """BaseCDM (vi.py:726-782) with a Bernoulli guide: the score-function (REINFORCE) estimator of pyro's Trace_ELBO.
+    Extra keyword arguments of this build: attr_prior (None = the reference's Bernoulli(1.5) prior, vi.py:753; a float
+    p = Bernoulli(p)), baseline ('none' = pyro; 'avg' = per-person decaying average; 'loo' = leave-one-out over the
+    particles), baseline_beta."""
+
+    amortized = False
+
+    def __init__(self, q=None, model="dina", hidden_dim=64, *args, **kwargs):
+        if q is None or kwargs.get("data") is None:
+            raise NotImplementedError("%s needs q and data (vi.py:733-743)" % type(self).__name__)
+        super().__init__(*args, **kwargs)
+        self.q, self._model = q, model
+        self.attr_size = int(q.shape[0])
+        self.engine = CdmSfEngine(self.data, q, cdm=model, amortized=self.amortized, H=hidden_dim,
+                                  encoder_init=self.kwargs.get("encoder_init"), attr_prior=self.kwargs.get("attr_prior"),
+                                  baseline=self.kwargs.get("baseline", "none"),
+                                  baseline_beta=self.kwargs.get("baseline_beta", 0.9), **self._eng_kw)
+        self._register()
+        self._ri = None
+
+    def fit(self, optim=None, loss=None, max_iter=5000, random_instance=None, progress=True):
+        """vi.py:758-782 (defaults Adam lr 1e-3, Trace_ELBO(1), 5000 iterations).  The reference evaluates the loss a
+        second time per iteration only to display it (vi.py:770); the step's own loss is shown."""
+        optim = optim if optim is not None else Adam({"lr": 1e-3})
+        loss = loss if loss is not None else Trace_ELBO(num_particles=1)
+        self._ri = random_instance
+        self._S, self._loo_left = max(1, getattr(loss, "num_particles", 1)), 0
+        return self._loop(optim, loss, max_iter, progress)
+
+    def _subsample(self):
+        if self.engine.baseline == "loo":                 # the particles of a step share one subsample
+            if self._loo_left == 0:
+                self._loo_cache, self._loo_left = super()._subsample(), self._S
+            self._loo_left -= 1
+            return self._loo_cache
+        return super()._subsample()
+
+    def _postfix(self):
+        ri, out = self._ri, {}
+        if ri is None:
+            return out
+        for n in ("g", "s"):
+            out[n] = "{0:.4f}".format(float((param(n) - getattr(ri, n).to(self.device)).abs().mean()))   # vi.py:775-779
+        return out
+
+
+class VCDM(_CdmSfBase):
+    """Black-box VI for DINA / DINO with per-person Bernoulli guide rows `attr_p` (vi.py:807-816)."""
+    amortized = False
+
+
+class VaeCDM(_CdmSfBase):
+    """Amortized VI for DINA / DINO with the BinEncoder guide (vi.py:785-804, 458-470)."""
+    amortized = True
 
 
 class VCCDM(BasePsy):
