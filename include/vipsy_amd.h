@@ -259,6 +259,19 @@ int64_t vx_bin_enc_bwd_workspace_floats(const vx_hodina_cfg* cfg, int64_t nb);
 int vx_bin_enc_backward(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* W2,
                         const float* h, const float* gu, float* genc, float* workspace, void* hip_stream);
 
+/* ---- synthetic response matrices with the distributions of the reference's Random* generators (vi.py:120-412), written
+ * straight into the uint8 storage contract; benchmark / test INPUT (never in a timed region).  Every draw is a Philox word
+ * keyed by the GLOBAL person id (gid0 + row): a data set does not depend on the sharding.  cfg->seed keys the draws.
+ *   vx_synth_irt: y ~ Bern(c + (d - c) sigmoid(Dc (x.a + b))); x = x_in or N(0, 1) drawn here (x_out optional);
+ *                 `missing` = MCAR rate of 255 cells.  a [D][J], b / c / d [J] are the CONSTRAINED item parameters.
+ *   vx_synth_cdm: DINA / DINO (the reference's dino(), vi.py:86-101) / HO-DINA responses; attributes ~ Bern(attr_p) or
+ *                 Bern(sigmoid(theta lam1 + lam0)), theta ~ N(0, 1) (hodina = 1); attr_out [nb][K], theta_out [nb] optional. */
+int vx_synth_irt(const vx_irt_cfg* cfg, int64_t nb, int64_t gid0, const float* x_in, const float* a, const float* b,
+                 const float* c, const float* d, float missing, uint8_t* y, float* x_out, void* hip_stream);
+int vx_synth_cdm(const vx_hodina_cfg* cfg, int32_t dino, int32_t hodina, float attr_p, int64_t nb, int64_t gid0,
+                 const float* q, const float* g, const float* s, const float* lam0, const float* lam1, float missing,
+                 uint8_t* y, uint8_t* attr_out, float* theta_out, void* hip_stream);
+
 /* ---- slab reduction: out[i] = alpha * sum_s slabs[s][i]  (fixed order -> deterministic) */
 int vx_reduce_slabs(const float* slabs, int64_t n_slabs, int64_t len, float alpha, float* out,
                     void* hip_stream);

@@ -114,6 +114,37 @@ def philox_uniforms(seed, step, stream, gids, K):
     return out[:, :K]
 
 
+def _philox_word_uniform(seed, stream, gids, idx):
+    """u01 of word idx % 4 of Philox block idx // 4 (step 0, given stream) for every (person, idx): [len(gids), len(idx)]."""
+    gids = np.asarray(gids, dtype=np.int64)
+    idx = np.asarray(idx, dtype=np.int64)
+    g_lo = (gids & 0xFFFFFFFF).astype(np.uint32)[:, None]
+    g_hi = ((gids >> 32) & 0xFFFFFFFF).astype(np.uint32)[:, None]
+    c3 = (np.uint32(stream) << np.uint32(16)) | (idx >> 2).astype(np.uint32)[None, :]
+    w = philox4x32_10(g_lo, g_hi, np.uint32(0), c3, np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF))
+    sel = (idx & 3)[None, :]
+    word = np.where(sel == 0, w[0], np.where(sel == 1, w[1], np.where(sel == 2, w[2], w[3])))
+    return _u01(word)
+
+
+def synth_irt(model, seed, gids, a, b, c, d, Dc=1.0, missing=0.0, x=None):
+    """Restatement of vipsy_amd/csrc/k_synth.hip::k_synth_irt (streams 0xE0 latent, 0xD1 response, 0xD2 missing)."""
+    J = b.shape[-1]
+    D = 1 if a is None else a.shape[0]
+    if x is None:
+        x = philox_normals(seed, 0, 0xE0, gids, D).astype(np.float64)
+    z = x @ a if a is not None else np.repeat(x[:, :1], J, axis=1)
+    P = sigmoid(Dc * (z + b.reshape(1, J)))
+    cc = 0.0 if c is None else c.reshape(1, J)
+    dd = 1.0 if d is None else d.reshape(1, J)
+    P = cc + (dd - cc) * P
+    u = _philox_word_uniform(seed, 0xD1, gids, np.arange(J))
+    y = (u < P).astype(np.uint8)
+    if missing > 0:
+        y[_philox_word_uniform(seed, 0xD2, gids, np.arange(J)) < missing] = 255
+    return y, x, P, u
+
+
 # ------------------------------------------------------------------------------------------------
 # small math helpers
 # ------------------------------------------------------------------------------------------------

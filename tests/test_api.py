@@ -9,8 +9,11 @@ def test_surface_matches_reference_names():
     from vipsy_amd import vi
     for n in ("VIRT", "VaeIRT", "VCHoDina", "VaeCHoDina", "VCDM", "VaeCDM", "VCCDM", "VaeCCDM", "Adam", "MultiStepLR",
               "Trace_ELBO", "TraceEnum_ELBO", "param", "clear_param_store", "rmse_", "Irt2PL", "Irt4PL", "IrtMultiDim",
-              "HoDina"):
+              "HoDina", "RandomIrt1PL", "RandomIrt2PL", "RandomIrt3PL", "RandomIrt4PL", "RandomMilIrt2PL", "RandomMilIrt3PL",
+              "RandomMilIrt4PL", "RandomDina", "RandomDino", "RandomHoDina"):
         assert hasattr(vi, n), n
+    spec2 = vi.Adam(lambda m, n: {"lr": 1e-2, "betas": (0.8, 0.9), "eps": 1e-6} if n == "a" else {"lr": 1e-3}).spec()
+    assert spec2.hyper_of("a") == ((0.8, 0.9), 1e-6) and spec2.hyper_of("b") == ((0.9, 0.999), 1e-8)
     with pytest.raises(NotImplementedError):
         vi.VaeCCDM(q=None, data=None)
     spec = vi.MultiStepLR({"optimizer": torch.optim.Adam, "optim_args": lambda m, n: {"lr": 1e-2 if n == "a" else 1e-3},

@@ -83,6 +83,8 @@ SIGNATURES = {
     "vx_bin_enc_forward": (ctypes.c_int, [ctypes.POINTER(HoDinaCfg), _P, _P, _I64] + [_P] * 4 + [_P, _P, _P]),
     "vx_bin_enc_bwd_workspace_floats": (_I64, [ctypes.POINTER(HoDinaCfg), _I64]),
     "vx_bin_enc_backward": (ctypes.c_int, [ctypes.POINTER(HoDinaCfg), _P, _P, _I64] + [_P] * 3 + [_P, _P, _P]),
+    "vx_synth_irt": (ctypes.c_int, [_CFG, _I64, _I64] + [_P] * 5 + [_F, _P, _P, _P]),
+    "vx_synth_cdm": (ctypes.c_int, [ctypes.POINTER(HoDinaCfg), _I32, _I32, _F, _I64, _I64] + [_P] * 5 + [_F, _P, _P, _P, _P]),
     "vx_reduce_slabs": (ctypes.c_int, [_P, _I64, _I64, _F, _P, _P]),
     "vx_sum_workspace_floats": (_I64, []),
     "vx_sum": (ctypes.c_int, [_P, _I64, _F, _P, _P, _P]),

@@ -21,6 +21,7 @@
 #include "k_mvn_bwd_hb.hip"
 #include "k_fc1_bwd_b.hip"
 #include "k_cdm_sf.hip"
+#include "k_synth.hip"
 
 #include <cstdlib>
 #include <cstring>
@@ -1403,6 +1404,47 @@ int vx_bin_enc_backward(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_
     int rc2 = vx_reduce_slabs(slabs_f, n_prf, lenf, 1.0f, genc, hs);
     if (rc2) return rc2;
     return vx_reduce_slabs(slabs_h, nblk, lenh, 1.0f, genc + lenf, hs);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// synthetic response matrices (k_synth.hip): benchmark / test input with the reference generators' distributions
+int vx_synth_irt(const vx_irt_cfg* cfg, int64_t nb, int64_t gid0, const float* x_in, const float* a, const float* b,
+                 const float* c, const float* d, float missing, uint8_t* y, float* x_out, void* hs) {
+    if (!cfg || cfg->D < 1 || cfg->D > 128 || cfg->J < 1 || cfg->model < VX_IRT_1PL || cfg->model > VX_IRT_4PL || !b || !y ||
+        nb < 0 || missing < 0.f || missing >= 1.f)
+        return VX_EINVAL;
+    if (cfg->model >= VX_IRT_2PL && !a) return VX_EINVAL;
+    if (cfg->model >= VX_IRT_3PL && !c) return VX_EINVAL;
+    if (cfg->model == VX_IRT_4PL && !d) return VX_EINVAL;
+    if (cfg->model == VX_IRT_1PL && cfg->D != 1) return VX_EINVAL;
+    if (nb == 0) return VX_OK;
+    int64_t blocks = (nb + SY_P - 1) / SY_P;
+    if (blocks > (int64_t)num_cu() * 8) blocks = (int64_t)num_cu() * 8;
+    const size_t lds = sizeof(float) * SY_P * (size_t)cfg->D;
+    int rc = set_lds(k_synth_irt, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_synth_irt, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)hs, (int)cfg->model, (int)cfg->D,
+                       (int)cfg->J, cfg->Dc, nb, gid0, x_in, a, b, c, d, missing, cfg->seed, y, x_out);
+    VX_CHECK_LAUNCH();
+    return VX_OK;
+}
+
+int vx_synth_cdm(const vx_hodina_cfg* cfg, int32_t dino, int32_t hodina, float attr_p, int64_t nb, int64_t gid0, const float* q,
+                 const float* g, const float* s, const float* lam0, const float* lam1, float missing, uint8_t* y,
+                 uint8_t* attr_out, float* theta_out, void* hs) {
+    if (!cfg || cfg->K < 1 || cfg->K > 16 || cfg->J < 1 || !q || !g || !s || !y || nb < 0 || missing < 0.f || missing >= 1.f)
+        return VX_EINVAL;
+    if (hodina && (!lam0 || !lam1)) return VX_EINVAL;
+    if (nb == 0) return VX_OK;
+    const size_t lds = sizeof(uint32_t) * (size_t)cfg->J;
+    int rc = set_lds(k_synth_cdm, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_synth_cdm, dim3(grid_1d(nb, 256)), dim3(256), lds, (hipStream_t)hs, (int)cfg->K, (int)cfg->J,
+                       dino ? 1 : 0, hodina ? 1 : 0, attr_p, nb, gid0, q, g, s, lam0, lam1, missing, cfg->seed, y, attr_out,
+                       theta_out);
+    VX_CHECK_LAUNCH();
+    return VX_OK;
 }
 
 }  // extern "C"

@@ -18,6 +18,8 @@ import numpy as np
 import torch
 
 from .engine import CcdmEngine, CdmSfEngine, IrtEngine, HoDinaEngine, LrSpec
+from .random_data import (RandomPsyData, RandomIrt1PL, RandomIrt2PL, RandomIrt3PL, RandomIrt4PL, RandomMilIrt2PL,    # noqa: F401
+                          RandomMilIrt3PL, RandomMilIrt4PL, RandomDina, RandomDino, RandomHoDina)  # vi.py:120-412 live in vi too
 
 _STORE = {}          # name -> engine that owns the parameter (the process-global store of the reference)
 
