@@ -272,6 +272,31 @@ int vx_synth_cdm(const vx_hodina_cfg* cfg, int32_t dino, int32_t hodina, float a
                  const float* q, const float* g, const float* s, const float* lam0, const float* lam1, float missing,
                  uint8_t* y, uint8_t* attr_out, float* theta_out, void* hip_stream);
 
+/* ---- VaeCCDM (vi.py:866-891): enumerated DINA / DINO whose pattern prior is Categorical(attr_p[i]), attr_p =
+ * softmax(fc2(relu(fc1(data_))), dim = 0) -- the SoftmaxEncoder (vi.py:473-485) normalises over the BATCH -- and whose missing
+ * responses stay in the observation as -1 (no mask, vi.py:882-891).  C = 2^K patterns; cfg: K, J, H, scale.  One step =
+ *   vx_sm_enc_forward                      h[nb][H] = relu(..), z[nb][C] = fc2 scores
+ *   vx_col_reduce(0, z) -> m[C]            column maximum over the batch          [+ all-reduce MAX over the ranks]
+ *   vx_col_reduce(1, z, shift = m) -> Z[C] column sum of exp(z - m)               [+ all-reduce SUM]; off = m + log Z (host)
+ *   vx_vaeccdm_grad                        elbo[nb], gitem, gla[nb][C] = d ELBO / d log attr_p (scaled)
+ *   vx_col_reduce(2, gla) -> T[C]          column sums                            [+ all-reduce SUM]
+ *   vx_sm_enc_backward                     genc = d LOSS / d [W1: H*J | b1: H | W2: C*H | b2: C]  (overwrites gla) */
+int64_t vx_sm_enc_param_floats(const vx_hodina_cfg* cfg);
+int vx_sm_enc_forward(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* W1,
+                      const float* b1, const float* W2, const float* b2, float* h, float* z, void* hip_stream);
+int64_t vx_col_reduce_workspace_floats(int64_t nb, int32_t C);
+int vx_col_reduce(int32_t mode /*0 max, 1 sum exp(v - shift), 2 sum*/, const float* v /*[nb][C]*/, int64_t nb, int32_t C,
+                  const float* shift /*[C], mode 1*/, float* out /*[C]*/, float* workspace, void* hip_stream);
+int64_t vx_vaeccdm_workspace_floats(const vx_hodina_cfg* cfg, int64_t nb);
+int vx_vaeccdm_grad(const vx_hodina_cfg* cfg, int32_t dino, const uint8_t* y, const int64_t* rows, int64_t nb,
+                    const float* q, const float* g_un, const float* s_un, const float* z /*[nb][C]*/,
+                    const float* off /*[C]*/, float* elbo, float* gla /*[nb][C]*/, float* gitem, float* workspace,
+                    void* hip_stream);
+int64_t vx_sm_enc_bwd_workspace_floats(const vx_hodina_cfg* cfg, int64_t nb);
+int vx_sm_enc_backward(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* W2,
+                       const float* h, const float* z, const float* off, const float* T, float* gla, float* genc,
+                       float* workspace, void* hip_stream);
+
 /* ---- slab reduction: out[i] = alpha * sum_s slabs[s][i]  (fixed order -> deterministic) */
 int vx_reduce_slabs(const float* slabs, int64_t n_slabs, int64_t len, float alpha, float* out,
                     void* hip_stream);

@@ -505,6 +505,64 @@ def init_cdm_sf_params(spec, J, dtype=np.float32, encoder=None):
     return p
 
 
+def vaeccdm_particle(spec, params, y_u8_full, idx, eps=None):
+    """VaeCCDM (vi.py:866-891, SoftmaxEncoder vi.py:473-485), TraceEnum_ELBO, as the reference computes it:
+      * the pattern prior of person i is Categorical(attr_p[i]) with attr_p = softmax(fc2(relu(fc1(data_))), dim=0) --
+        the softmax runs over the BATCH (vi.py:478,483), so every column of attr_p sums to one over the persons of the
+        subsample; Categorical renormalises each row and clamps it to [eps, 1 - eps] before the log;
+      * missing responses are replaced by -1 for the encoder AND stay -1 in `obs` (vi.py:882-891: no mask), so a missing cell
+        contributes Bernoulli(p).log_prob(-1) = -logit(p) - softplus(logit(p)).
+    ELBO = scale sum_i log sum_c pi_ic prod_j exp(lp_icj)."""
+    K, N = spec["K"], spec["N"]
+    dt = params["g"].dtype
+    q = spec["q"].astype(dt)
+    B = len(idx)
+    scale = dt.type(N) / dt.type(B)
+    y = y_u8_full[idx]
+    v = np.where(y == 255, -1.0, y.astype(dt)).astype(dt)          # encoder input and observation alike
+    W = {k.split("$$$")[1]: p for k, p in params.items() if k.startswith("encoder$$$")}
+    pre = v @ W["fc1.weight"].T + W["fc1.bias"]
+    h = np.maximum(pre, 0)
+    z = h @ W["fc2.weight"].T + W["fc2.bias"]                       # (B, C)
+    zm = z.max(axis=0, keepdims=True)
+    ez = np.exp(z - zm)
+    a = ez / ez.sum(axis=0, keepdims=True)                          # softmax over the batch
+    R = a.sum(axis=1, keepdims=True)
+    pi = a / R
+    ins = (pi >= EPS32) & (pi <= 1 - EPS32)
+    lg = np.log(np.clip(pi, EPS32, 1 - EPS32))
+    eta, _ = (dino_eta if spec.get("cdm", "dina") == "dino" else dina_eta)(K, q)      # (C, J)
+    g_, s_ = sigmoid(params["g"]), sigmoid(params["s"])
+
+    def lp_const(P):
+        Pc = np.clip(P, EPS32, 1 - EPS32)
+        l = np.log(Pc) - np.log1p(-Pc)
+        lp = v * l - softplus(l)
+        inside = (P >= EPS32) & (P <= 1 - EPS32)
+        return lp, np.where(inside, (v - Pc) / (Pc * (1 - Pc)), 0.0)
+    lp0, d0 = lp_const(np.broadcast_to(g_, v.shape).astype(dt))
+    lp1, d1 = lp_const(np.broadcast_to(1 - s_, v.shape).astype(dt))
+    Bc = lp0.sum(1, keepdims=True) + (lp1 - lp0) @ eta.T
+    f = lg + Bc
+    fmax = f.max(axis=1, keepdims=True)
+    lse = fmax[:, 0] + np.log(np.exp(f - fmax).sum(axis=1))
+    elbo = scale * lse.sum()
+    r = np.exp(f - lse[:, None])
+    E = r @ eta
+    grads = {"g": -scale * ((1 - E) * d0).sum(0, keepdims=True) * g_ * (1 - g_),
+             "s": -scale * (-(E * d1)).sum(0, keepdims=True) * s_ * (1 - s_)}
+    G = scale * np.where(ins, r, 0.0)                               # d ELBO / d log pi
+    H = G - pi * G.sum(axis=1, keepdims=True)                       # d ELBO / d log a   (row normalisation)
+    gz = H - a * H.sum(axis=0, keepdims=True)                       # d ELBO / d z       (softmax over the batch)
+    g_h = gz @ W["fc2.weight"]
+    g_pre = g_h * (pre > 0)
+    grads["encoder$$$fc2.weight"] = -(gz.T @ h)
+    grads["encoder$$$fc2.bias"] = -gz.sum(0)
+    grads["encoder$$$fc1.weight"] = -(g_pre.T @ v)
+    grads["encoder$$$fc1.bias"] = -g_pre.sum(0)
+    return -elbo, grads
+
+
 def hodina_particle(spec, params, y_u8_full, idx, eps):
     K, N = spec["K"], spec["N"]
     dt = params["g"].dtype
@@ -578,7 +636,7 @@ def loss_and_grads(spec, params, y_u8, idx_list, eps_list):
     if spec.get("family") == "cdm_sf":                      # eps_list carries the guide's attribute draws
         fn = lambda sp, pa, yy, ii, at: cdm_sf_particle(sp, pa, yy, ii, at)[:2]      # noqa: E731
     else:
-        fn = {"hodina": hodina_particle, "ccdm": ccdm_particle}.get(spec.get("family"), irt_particle)
+        fn = {"hodina": hodina_particle, "ccdm": ccdm_particle, "vaeccdm": vaeccdm_particle}.get(spec.get("family"), irt_particle)
     S = len(idx_list)
     loss, grads = 0.0, None
     for idx, eps in zip(idx_list, eps_list):
@@ -682,9 +740,12 @@ def init_hodina_params(spec, J, dtype=np.float32, encoder=None):
     return p
 
 
-def init_ccdm_params(spec, J, dtype=np.float32):
-    return {"g": np.full((1, J), logit(np.asarray(0.1, dtype)), dtype),
-            "s": np.full((1, J), logit(np.asarray(0.1, dtype)), dtype)}
+def init_ccdm_params(spec, J, dtype=np.float32, encoder=None):
+    p = {"g": np.full((1, J), logit(np.asarray(0.1, dtype)), dtype),
+         "s": np.full((1, J), logit(np.asarray(0.1, dtype)), dtype)}
+    for k, v in (encoder or {}).items():
+        p["encoder$$$" + k] = np.asarray(v, dtype)
+    return p
 
 
 def constrained(name, value):

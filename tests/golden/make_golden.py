@@ -328,6 +328,28 @@ def gen_score_function_cases():
               "lr_item": 1e-1, "lr_other": 1e-2})
 
 
+def gen_vaeccdm_cases():
+    """VaeCCDM (vi.py:866-891): pattern prior from the SoftmaxEncoder (softmax over the batch), missing responses as -1."""
+    g = torch.Generator().manual_seed(377)
+    torch.manual_seed(310)
+    ri = vi.RandomDina(sample_size=22, item_size=9, q_size=3)
+    y = add_missing(ri.y, 0.15, g)
+    m = vi.VaeCCDM(data=y, q=ri.q, model="dina", subsample_size=10, hidden_dim=8)
+
+    def lr_cc(module_name, param_name):
+        return {"lr": 1e-1 if param_name in ("g", "s") else 1e-2}
+    run_case("vaeccdm_dina_k3", m, y, Adam(lr_cc), TraceEnum_ELBO(num_particles=1), 3,
+             {"cls": "VaeCCDM", "cdm": "dina", "N": 22, "J": 9, "K": 3, "B": 10, "H": 8, "q": ri.q.numpy(),
+              "lr_item": 1e-1, "lr_other": 1e-2})
+    torch.manual_seed(311)
+    ri = vi.RandomDino(sample_size=20, item_size=8, q_size=2)
+    y = ri.y
+    m = vi.VaeCCDM(data=y, q=ri.q, model="dino", subsample_size=20, hidden_dim=8)
+    run_case("vaeccdm_dino_k2", m, y, Adam(lr_cc), TraceEnum_ELBO(num_particles=1), 2,
+             {"cls": "VaeCCDM", "cdm": "dino", "N": 20, "J": 8, "K": 2, "B": 20, "H": 8, "q": ri.q.numpy(),
+              "lr_item": 1e-1, "lr_other": 1e-2})
+
+
 def gen_function_cases():
     """G1-G5 of SURVEY.md section 8c: pure-torch pieces of vi.py imported and evaluated."""
     rec = {}
@@ -416,6 +438,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "r2":       # only the round-2 additions
         gen_round2_cases()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "vaeccdm":
+        gen_vaeccdm_cases()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sf":
         gen_score_function_cases()

@@ -60,6 +60,10 @@ def build(tag, dtype=np.float32):
                 "attr_prior": None}
         params = vo.init_cdm_sf_params(spec, J, dtype, encoder=enc if amort else None)
         lr = _lr_cdm(float(f["lr_item"]), float(f["lr_other"])) if "lr_item" in f else float(f["lr"])
+    elif cls == "VaeCCDM":
+        spec = {"family": "vaeccdm", "cdm": str(f["cdm"]), "K": int(f["K"]), "N": N, "amortized": True, "q": f["q"]}
+        params = vo.init_ccdm_params(spec, J, dtype, encoder=enc)
+        lr = _lr_cdm(float(f["lr_item"]), float(f["lr_other"]))
     elif cls == "VCCDM":
         spec = {"family": "ccdm", "cdm": str(f["cdm"]), "K": int(f["K"]), "N": N, "amortized": False, "q": f["q"]}
         params = vo.init_ccdm_params(spec, J, dtype)
@@ -97,6 +101,19 @@ def adam_conditioned(steps, t, name, rel=1e-4):
     ok = None
     for u in range(t + 1):
         g = np.abs(steps[u]["grad"][name])
-        m = (g == 0) | (g >= rel * max(float(g.max()), 1e-30))      # exact zeros (frozen / off-batch entries) are exact
+        # a whole tensor can be noise: the fc2 bias of the SoftmaxEncoder has an exactly zero gradient (its softmax runs over
+        # the batch, vi.py:478) -- so the floor also looks at the largest gradient of the step
+        top = max(float(np.abs(v).max()) for v in steps[u]["grad"].values())
+        floor = rel * max(float(g.max()), 1e-2 * top, 1e-30)
+        m = (g == 0) | (g >= floor)                                  # exact zeros (frozen / off-batch entries) are exact
+        if float(g.max()) < floor:                                   # ... unless the whole tensor is rounding noise
+            m = np.zeros(g.shape, bool)
         ok = m if ok is None else (ok & m)
     return ok
+
+
+def grad_scale(rec, name):
+    """Scale a gradient tensor is compared on: its own largest entry, but not below 1e-3 of the step's largest gradient (a
+    tensor whose true gradient is zero -- the SoftmaxEncoder's fc2 bias -- holds only rounding noise of the others)."""
+    top = max(float(np.abs(v).max()) for v in rec["grad"].values())
+    return max(1e-3, float(np.abs(rec["grad"][name]).max()), 1e-3 * top)

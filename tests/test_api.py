@@ -15,7 +15,7 @@ def test_surface_matches_reference_names():
     spec2 = vi.Adam(lambda m, n: {"lr": 1e-2, "betas": (0.8, 0.9), "eps": 1e-6} if n == "a" else {"lr": 1e-3}).spec()
     assert spec2.hyper_of("a") == ((0.8, 0.9), 1e-6) and spec2.hyper_of("b") == ((0.9, 0.999), 1e-8)
     with pytest.raises(NotImplementedError):
-        vi.VaeCCDM(q=None, data=None)
+        vi.VaeCCDM(q=None, data=None)                   # needs q and data, like every BaseCDM (vi.py:733-743)
     spec = vi.MultiStepLR({"optimizer": torch.optim.Adam, "optim_args": lambda m, n: {"lr": 1e-2 if n == "a" else 1e-3},
                            "milestones": [2], "gamma": 0.1}).spec()
     assert spec.lr_of("a") == 1e-2 and spec.lr_of("encoder$$$fc1.weight") == 1e-3

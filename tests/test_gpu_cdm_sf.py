@@ -170,3 +170,93 @@ def test_vcdm_class_surface_recovers_guess_and_slip():
     m2 = vi.VaeCDM(data=y, q=prm["q"], model="dino", subsample_size=500, hidden_dim=32)
     assert np.isfinite(m2.fit(max_iter=5, progress=False))
     vi.clear_param_store()
+
+
+# ---- VaeCCDM (vi.py:866-891): SoftmaxEncoder prior over the patterns, softmax over the batch, -1 for missing -------------
+def _vaeccdm_engine(tag):
+    from vipsy_amd.engine import VaeCcdmEngine, LrSpec
+    spec, params, opt, y, steps, B = gu.build(tag, np.float64)
+    enc = {k.split("$$$")[1]: v for k, v in params.items() if k.startswith("encoder$$$")}
+    eng = VaeCcdmEngine(torch.from_numpy(y).to(_dev()), spec["q"], cdm=spec["cdm"], H=enc["fc1.weight"].shape[0],
+                        encoder_init=enc, seed=1)
+    return eng, LrSpec(opt["lr"], milestones=opt["milestones"], gamma=opt["gamma"]), spec, params, opt, y, steps
+
+
+@pytest.mark.parametrize("tag", ["vaeccdm_dina_k3", "vaeccdm_dino_k2"])
+def test_hip_replays_reference_vaeccdm_steps(tag):
+    eng, lrs, spec, params, opt, y, steps = _vaeccdm_engine(tag)
+    adam = vo.Adam(opt["lr"], milestones=opt["milestones"], gamma=opt["gamma"])
+    for t, rec in enumerate(steps):
+        idx = rec["idx"][0]
+        full = len(idx) == spec["N"] and (idx == np.arange(spec["N"])).all()
+        eng.loss_and_grads(None if full else torch.from_numpy(idx).to(_dev()), len(idx))
+        torch.cuda.synchronize()
+        loss_o, g_o = vo.loss_and_grads(spec, params, y, [idx], [None])
+        loss_h = float(eng.G[eng.n_params].item())
+        assert loss_h == pytest.approx(loss_o, rel=2e-5), (tag, t)
+        assert loss_h == pytest.approx(rec["loss"], rel=2e-4), (tag, t)
+        for name, go in g_o.items():
+            gh = eng.unconstrained(name, eng.G).cpu().numpy()
+            sc = gu.grad_scale(rec, name)
+            if name == "encoder$$$fc2.bias":            # exactly zero in exact arithmetic (the softmax over the batch is shift
+                sc = max(sc, float(np.abs(g_o["encoder$$$fc2.weight"]).max()))   # invariant): float32 leaves the rounding of its terms
+            np.testing.assert_allclose(gh / sc, go / sc, atol=3e-5, err_msg="%s step %d grad %s" % (tag, t, name))
+            np.testing.assert_allclose(gh / sc, rec["grad"][name] / sc, atol=1e-3, err_msg="golden %s %s" % (tag, name))
+        eng.allreduce()
+        eng.apply_optim(lrs)
+        lrs.scheduler_step()
+        adam.step(params, g_o)
+        adam.scheduler_step()
+        torch.cuda.synchronize()
+        for name, p in rec["param"].items():
+            ok = gu.adam_conditioned(steps, t, name)
+            ph = eng.unconstrained(name).cpu().numpy()
+            np.testing.assert_allclose(ph[ok], params[name][ok], atol=2e-5, rtol=1e-4, err_msg="%s step %d param %s" % (tag, t, name))
+            np.testing.assert_allclose(ph[ok], p[ok], atol=2e-4, rtol=1e-3, err_msg="golden %s step %d %s" % (tag, t, name))
+            if not ok.all():
+                params[name][~ok] = p[~ok]
+                ph[~ok] = p[~ok]
+                eng.unconstrained(name).copy_(torch.from_numpy(ph).to(eng.dev))
+
+
+@pytest.mark.parametrize("N,J,K,cdm,miss,B,H", [(600, 30, 8, "dina", 0.1, None, 64), (257, 70, 5, "dino", 0.0, 100, 24),
+                                                (130, 12, 2, "dina", 0.3, None, 8), (300, 140, 9, "dina", 0.05, 77, 32)])
+def test_vaeccdm_step_vs_oracle(N, J, K, cdm, miss, B, H):
+    from vipsy_amd.engine import VaeCcdmEngine
+    rng = np.random.RandomState(N + J + K)
+    q = (rng.rand(K, J) < 0.4).astype(np.float32)
+    q[rng.randint(0, K, size=J), np.arange(J)] = 1.0
+    y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+    y[rng.rand(N, J) < miss] = 255
+    eng = VaeCcdmEngine(torch.from_numpy(y).to(_dev()), q, cdm=cdm, H=H, seed=4)
+    eng.unconstrained("g").copy_(torch.from_numpy(vo.logit(0.05 + 0.3 * rng.rand(1, J))).float())
+    eng.unconstrained("s").copy_(torch.from_numpy(vo.logit(0.05 + 0.3 * rng.rand(1, J))).float())
+    eng.unconstrained("encoder$$$fc2.weight").mul_(3.0)             # spread the pattern priors
+    idx = np.arange(N) if B is None else np.sort(rng.permutation(N)[:B])
+    eng.loss_and_grads(None if B is None else torch.from_numpy(idx).to(_dev()), len(idx))
+    torch.cuda.synchronize()
+    spec = {"family": "vaeccdm", "cdm": cdm, "K": K, "N": N, "amortized": True, "q": q.astype(np.float64)}
+    params = {n: eng.unconstrained(n).cpu().numpy().astype(np.float64) for n in eng.names()}
+    loss_o, g_o = vo.loss_and_grads(spec, params, y, [idx], [None])
+    assert float(eng.G[eng.n_params].item()) == pytest.approx(loss_o, rel=3e-5)
+    top = max(float(np.abs(v).max()) for v in g_o.values())
+    for name, go in g_o.items():
+        gh = eng.unconstrained(name, eng.G).cpu().numpy()
+        sc = max(1e-6, float(np.abs(go).max()), 1e-3 * top)
+        if name == "encoder$$$fc2.bias":
+            sc = max(sc, float(np.abs(g_o["encoder$$$fc2.weight"]).max()))
+        assert np.abs(gh - go).max() / sc < 3e-4, (name, np.abs(gh - go).max() / sc)
+
+
+def test_vaeccdm_class_surface():
+    from vipsy_amd import vi, synth
+    dev = _dev()
+    prm = synth.dina_params(16, 3, seed=21)
+    y = synth.simulate_dina(3000, 0, prm, dev, seed=22, missing=0.05)
+    vi.clear_param_store()
+    m = vi.VaeCCDM(data=y, q=prm["q"], model="dina", subsample_size=500, hidden_dim=32)
+    err0 = float((torch.sigmoid(m.engine.unconstrained("g")) - prm["g"].to(dev)).abs().mean())
+    m.fit(optim=vi.Adam({"lr": 2e-2}), max_iter=300, progress=False)
+    err1 = float((vi.param("g") - prm["g"].to(dev)).abs().mean())
+    assert np.isfinite(err1) and err1 < err0
+    vi.clear_param_store()

@@ -85,6 +85,14 @@ SIGNATURES = {
     "vx_bin_enc_backward": (ctypes.c_int, [ctypes.POINTER(HoDinaCfg), _P, _P, _I64] + [_P] * 3 + [_P, _P, _P]),
     "vx_synth_irt": (ctypes.c_int, [_CFG, _I64, _I64] + [_P] * 5 + [_F, _P, _P, _P]),
     "vx_synth_cdm": (ctypes.c_int, [ctypes.POINTER(HoDinaCfg), _I32, _I32, _F, _I64, _I64] + [_P] * 5 + [_F, _P, _P, _P, _P]),
+    "vx_sm_enc_param_floats": (_I64, [ctypes.POINTER(HoDinaCfg)]),
+    "vx_sm_enc_forward": (ctypes.c_int, [ctypes.POINTER(HoDinaCfg), _P, _P, _I64] + [_P] * 4 + [_P, _P, _P]),
+    "vx_col_reduce_workspace_floats": (_I64, [_I64, _I32]),
+    "vx_col_reduce": (ctypes.c_int, [_I32, _P, _I64, _I32, _P, _P, _P, _P]),
+    "vx_vaeccdm_workspace_floats": (_I64, [ctypes.POINTER(HoDinaCfg), _I64]),
+    "vx_vaeccdm_grad": (ctypes.c_int, [ctypes.POINTER(HoDinaCfg), _I32, _P, _P, _I64] + [_P] * 3 + [_P, _P] + [_P, _P, _P, _P, _P]),
+    "vx_sm_enc_bwd_workspace_floats": (_I64, [ctypes.POINTER(HoDinaCfg), _I64]),
+    "vx_sm_enc_backward": (ctypes.c_int, [ctypes.POINTER(HoDinaCfg), _P, _P, _I64] + [_P] * 5 + [_P, _P, _P, _P]),
     "vx_reduce_slabs": (ctypes.c_int, [_P, _I64, _I64, _F, _P, _P]),
     "vx_sum_workspace_floats": (_I64, []),
     "vx_sum": (ctypes.c_int, [_P, _I64, _F, _P, _P, _P]),

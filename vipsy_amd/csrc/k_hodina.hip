@@ -20,7 +20,8 @@ struct HoDinaDims {
     int64_t nb;
     // VCCDM (vi.py:819-865): uniform prior over the patterns, no theta / lambda; dino = the reference's dino()
     // (vi.py:86-101) INCLUDING its in-place sequencing: eta = [item needs >= 2 attributes] * [c masters one of them]
-    int uniform_prior, dino;
+    int uniform_prior, dino;       // uniform_prior: 0 HO-DINA prior, 1 uniform (VCCDM), 2 per-person row of pattern scores (VaeCCDM)
+    int unmasked;                  // VaeCCDM (vi.py:882-891): a missing response stays in `obs` as -1 (no mask)
 };
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -55,11 +56,18 @@ __device__ __forceinline__ void zeta(float (&v)[1 << LOGCPL], int K, int lane) {
 
 // Bernoulli log-prob of y under a CONSTANT success probability P (clamped like torch clamp_probs):
 // returns lp and dlp/dP (0 when P is outside [eps, 1-eps]); y == 255 -> missing cell.
-__device__ __forceinline__ void bern_const(float P, float Q /* = 1 - P, accurate */, unsigned y, float& lp, float& dP) {
-    if (y == 255u) { lp = VX_LOGP_MISSING; dP = 0.f; return; }
+__device__ __forceinline__ void bern_const(float P, float Q /* = 1 - P, accurate */, unsigned y, float& lp, float& dP,
+                                           bool unmasked = false) {
     const bool inside = (P >= VX_EPS32) && (Q >= VX_EPS32);
     const float Pc = fminf(fmaxf(P, VX_EPS32), 1.0f - VX_EPS32);
     const float Qc = fminf(fmaxf(Q, VX_EPS32), 1.0f - VX_EPS32);
+    if (y == 255u) {
+        if (!unmasked) { lp = VX_LOGP_MISSING; dP = 0.f; return; }
+        // Bernoulli(p).log_prob(-1) = -logit - softplus(logit) = 2 log(1 - p) - log p;  d/dP = (-1 - p) / (p (1 - p))
+        lp = 2.0f * logf(Qc) - logf(Pc);
+        dP = inside ? (-1.0f - Pc) / (Pc * Qc) : 0.f;
+        return;
+    }
     lp = (y != 0u) ? logf(Pc) : logf(Qc);
     dP = inside ? ((y != 0u) ? 1.0f / Pc : -1.0f / Qc) : 0.f;
 }
@@ -71,7 +79,10 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
     const float* __restrict__ loc, const float* __restrict__ raw, const float* __restrict__ eps_in,
     uint64_t seed, uint32_t step, uint32_t stream, const float* __restrict__ q, const float* __restrict__ lam0,
     const float* __restrict__ lam1_un, const float* __restrict__ g_un, const float* __restrict__ s_un,
-    float* __restrict__ gloc, float* __restrict__ graw, float* __restrict__ elbo, float* __restrict__ slabs) {
+    float* __restrict__ gloc, float* __restrict__ graw, float* __restrict__ elbo, float* __restrict__ slabs,
+    const float* __restrict__ zrow = nullptr /*[nb][C] pattern scores (uniform_prior == 2)*/,
+    const float* __restrict__ zoff = nullptr /*[C] column offsets: prior weight = exp(z - off)*/,
+    float* __restrict__ gla = nullptr /*[nb][C] out: d ELBO / d log(prior weight), scaled*/) {
     constexpr int CPL = 1 << LOGCPL;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // per wave: [C] scatter/gather table; then block reduce
     const int K = dm.K, J = dm.J, C = dm.C;
@@ -133,8 +144,8 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
                 if (j < J) {
                     const unsigned yy = yr[j];
                     float lp0, lp1;
-                    bern_const(gj[u], og[u], yy, lp0, d0[u]);
-                    bern_const(os[u], sj[u], yy, lp1, d1[u]);
+                    bern_const(gj[u], og[u], yy, lp0, d0[u], dm.unmasked != 0);
+                    bern_const(os[u], sj[u], yy, lp1, d1[u], dm.unmasked != 0);
                     base += lp0;
                     if (!dm.dino || __popc(qpat[u]) >= 2)
                         atomicAdd(&tab[qpat[u]], lp1 - lp0);           // f(S) = sum of delta_j over items with q_j = S
@@ -177,7 +188,9 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
 #pragma unroll
             for (int ii = 0; ii < CPL; ++ii) {
                 const int c = CPL * lane + ii;
-                pr[ii] = (c < C) ? (dm.uniform_prior ? 1.0f : __expf(Ac[ii])) : 0.f;       // Categorical(1 / C): vi.py:849
+                const int64_t ip = grp * 64 + pp;
+                pr[ii] = (c < C) ? (dm.uniform_prior == 2 ? __expf(zrow[ip * C + c] - zoff[c])
+                                    : dm.uniform_prior ? 1.0f : __expf(Ac[ii])) : 0.f;       // Categorical(1 / C): vi.py:849
                 psum += pr[ii];
             }
             psum = wave_sum_dpp(psum);
@@ -205,6 +218,13 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
             float rho[CPL];
 #pragma unroll
             for (int ii = 0; ii < CPL; ++ii) rho[ii] = (ins[ii] ? rc[ii] : 0.f) - pr[ii] * rins;
+            if (gla) {                                                    // d ELBO / d log a_ic (through the row normalisation)
+#pragma unroll
+                for (int ii = 0; ii < CPL; ++ii) {
+                    const int c = CPL * lane + ii;
+                    if (c < C) gla[(grp * 64 + pp) * C + c] = dm.scale * rho[ii];
+                }
+            }
             // -- E_j = sum_c r_c eta_cj.  DINA: superset sums gathered at q_j.  DINO: 1 - (subset sum at ~q_j), and 0
             //    for items that need fewer than two attributes.
             if (dm.dino) zeta<LOGCPL, false>(rc, K, lane);

@@ -22,6 +22,7 @@
 #include "k_fc1_bwd_b.hip"
 #include "k_cdm_sf.hip"
 #include "k_synth.hip"
+#include "k_vaeccdm.hip"
 
 #include <cstdlib>
 #include <cstring>
@@ -1219,7 +1220,7 @@ int vx_hodina_grad(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t* ro
     const int blocks = hodina_blocks(nb);
     HoDinaDims dm;
     dm.K = cfg->K; dm.J = cfg->J; dm.C = 1 << cfg->K; dm.scale = cfg->scale; dm.nb = nb;
-    dm.uniform_prior = 0; dm.dino = 0;
+    dm.uniform_prior = 0; dm.dino = 0; dm.unmasked = 0;
     const int len = 2 * cfg->J + 2 * cfg->K;
     const int tabf = HD_WAVES * dm.C;
     const size_t lds = sizeof(float) * (size_t)(tabf > len ? tabf : len);
@@ -1254,7 +1255,7 @@ int vx_ccdm_grad(const vx_hodina_cfg* cfg, int32_t dino, const uint8_t* y, const
     const int blocks = hodina_blocks(nb);
     HoDinaDims dm;
     dm.K = cfg->K; dm.J = cfg->J; dm.C = 1 << cfg->K; dm.scale = cfg->scale; dm.nb = nb;
-    dm.uniform_prior = 1; dm.dino = dino ? 1 : 0;
+    dm.uniform_prior = 1; dm.dino = dino ? 1 : 0; dm.unmasked = 0;
     const int len = 2 * cfg->J + 2 * cfg->K;                  // slab layout of k_hodina; the lambda tail stays zero
     const int tabf = HD_WAVES * dm.C;
     const size_t lds = sizeof(float) * (size_t)(tabf > len ? tabf : len);
@@ -1445,6 +1446,149 @@ int vx_synth_cdm(const vx_hodina_cfg* cfg, int32_t dino, int32_t hodina, float a
                        theta_out);
     VX_CHECK_LAUNCH();
     return VX_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// VaeCCDM (vi.py:866-891): SoftmaxEncoder prior over the patterns (k_vaeccdm.hip) + the enumeration of k_hodina.hip
+static bool sm_enc_cfg_ok(const vx_hodina_cfg* cfg) {
+    return cfg && cfg->K >= 1 && cfg->K <= 10 && cfg->H >= 1 && cfg->H <= 64 && cfg->J >= 1 && cfg->J <= 1024;
+}
+static int col_parts(int64_t nb) {
+    int64_t p = (nb + 255) / 256;
+    if (p > 256) p = 256;
+    return (int)(p < 1 ? 1 : p);
+}
+
+int64_t vx_sm_enc_param_floats(const vx_hodina_cfg* cfg) {
+    if (!sm_enc_cfg_ok(cfg)) return VX_EINVAL;
+    const int64_t C = (int64_t)1 << cfg->K;
+    return (int64_t)cfg->H * cfg->J + cfg->H + C * cfg->H + C;
+}
+
+int vx_sm_enc_forward(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* W1,
+                      const float* b1, const float* W2, const float* b2, float* h, float* z, void* hs) {
+    if (!sm_enc_cfg_ok(cfg) || !y || !W1 || !b1 || !W2 || !b2 || !h || !z || nb < 0) return VX_EINVAL;
+    if (nb == 0) return VX_OK;
+    int64_t blocks = (nb + 3) / 4;
+    if (blocks > (int64_t)num_cu() * 8) blocks = (int64_t)num_cu() * 8;
+    hipLaunchKernelGGL(k_sm_enc_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hs, 1 << cfg->K, (int)cfg->J, (int)cfg->H,
+                       nb, y, rows, W1, b1, W2, b2, h, z);
+    VX_CHECK_LAUNCH();
+    return VX_OK;
+}
+
+int64_t vx_col_reduce_workspace_floats(int64_t nb, int32_t C) { return (nb < 0 || C < 1) ? VX_EINVAL : (int64_t)col_parts(nb) * C; }
+
+int vx_col_reduce(int32_t mode, const float* v, int64_t nb, int32_t C, const float* shift, float* out, float* workspace,
+                  void* hs) {
+    if (mode < 0 || mode > 2 || !v || !out || !workspace || nb < 1 || C < 1 || (mode == 1 && !shift)) return VX_EINVAL;
+    const int np = col_parts(nb);
+    hipLaunchKernelGGL(k_col_part, dim3(np), dim3(256), 0, (hipStream_t)hs, (int)mode, v, nb, (int)C, shift, workspace);
+    VX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_col_final, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)hs, (int)mode, (const float*)workspace, np,
+                       (int)C, out);
+    VX_CHECK_LAUNCH();
+    return VX_OK;
+}
+
+int64_t vx_vaeccdm_workspace_floats(const vx_hodina_cfg* cfg, int64_t nb) { return vx_hodina_workspace_floats(cfg, nb); }
+
+int vx_vaeccdm_grad(const vx_hodina_cfg* cfg, int32_t dino, const uint8_t* y, const int64_t* rows, int64_t nb, const float* q,
+                    const float* g_un, const float* s_un, const float* z, const float* off, float* elbo, float* gla,
+                    float* gitem, float* workspace, void* hs) {
+    if (!hodina_cfg_ok(cfg) || !y || !q || !g_un || !s_un || !z || !off || !elbo || !gla || !gitem || !workspace || nb < 0)
+        return VX_EINVAL;
+    const int blocks = hodina_blocks(nb);
+    HoDinaDims dm;
+    dm.K = cfg->K; dm.J = cfg->J; dm.C = 1 << cfg->K; dm.scale = cfg->scale; dm.nb = nb;
+    dm.uniform_prior = 2; dm.dino = dino ? 1 : 0; dm.unmasked = 1;
+    const int len = 2 * cfg->J + 2 * cfg->K;
+    const int tabf = HD_WAVES * dm.C;
+    const size_t lds = sizeof(float) * (size_t)(tabf > len ? tabf : len);
+    hipStream_t st = (hipStream_t)hs;
+    const int logcpl = cfg->K <= 8 ? 2 : (cfg->K == 9 ? 3 : 4);
+    const int jpl = (cfg->J + 63) / 64;
+    const float* nul = nullptr;
+    float* fnul = nullptr;
+#define LAUNCH_VC(L, JP)                                                                                      \
+    hipLaunchKernelGGL((k_hodina<L, JP>), dim3(blocks), dim3(HD_THREADS), lds, st, dm, y, rows, (int64_t)0, nul, nul, \
+                       nul, (uint64_t)0, 0u, 0u, q, nul, nul, g_un, s_un, fnul, fnul, elbo, workspace, z, off, gla)
+#define DISPATCH_VC(L)                               \
+    if (jpl <= 1) { LAUNCH_VC(L, 1); }               \
+    else if (jpl <= 2) { LAUNCH_VC(L, 2); }          \
+    else if (jpl <= 4) { LAUNCH_VC(L, 4); }          \
+    else if (jpl <= 8) { LAUNCH_VC(L, 8); }          \
+    else { LAUNCH_VC(L, 16); }
+    if (logcpl == 2) { DISPATCH_VC(2) } else if (logcpl == 3) { DISPATCH_VC(3) } else { DISPATCH_VC(4) }
+#undef DISPATCH_VC
+#undef LAUNCH_VC
+    VX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(grid_1d(2 * cfg->J, 64)), dim3(256), 0, st, workspace, (int64_t)blocks,
+                       (int64_t)len, (int64_t)(2 * cfg->J), -1.0f, gitem);
+    VX_CHECK_LAUNCH();
+    return VX_OK;
+}
+
+static void sm_bwd_plan(const vx_hodina_cfg* cfg, int64_t nb, int& n_rs, int& n_jg, int& n_prf) {
+    int64_t r = (nb + 511) / 512;
+    if (r > 32) r = 32;
+    n_rs = (int)(r < 1 ? 1 : r);
+    n_jg = (cfg->J + FC1_JG - 1) / FC1_JG;
+    const int64_t n_ptiles = (nb + ENC_P - 1) / ENC_P;
+    int64_t f = num_cu() / n_jg; if (f < 1) f = 1;
+    n_prf = (int)(n_ptiles < f ? n_ptiles : f); if (n_prf < 1) n_prf = 1;
+}
+
+int64_t vx_sm_enc_bwd_workspace_floats(const vx_hodina_cfg* cfg, int64_t nb) {
+    if (!sm_enc_cfg_ok(cfg) || nb < 0) return VX_EINVAL;
+    int n_rs, n_jg, n_prf;
+    sm_bwd_plan(cfg, nb, n_rs, n_jg, n_prf);
+    const int64_t H = cfg->H, J = cfg->J, C = (int64_t)1 << cfg->K;
+    return nb * H + (int64_t)n_rs * (C * H + C) + (int64_t)n_prf * (H * J + H) + 8;
+}
+
+int vx_sm_enc_backward(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* W2,
+                       const float* h, const float* z, const float* off, const float* T, float* gla, float* genc,
+                       float* workspace, void* hs) {
+    if (!sm_enc_cfg_ok(cfg) || !y || !W2 || !h || !z || !off || !T || !gla || !genc || !workspace || nb < 0) return VX_EINVAL;
+    int n_rs, n_jg, n_prf;
+    sm_bwd_plan(cfg, nb, n_rs, n_jg, n_prf);
+    const int64_t H = cfg->H, J = cfg->J, C = (int64_t)1 << cfg->K;
+    const int64_t lenh = C * H + C, lenf = H * J + H;
+    float* ghpre = workspace;
+    float* slabs_h = ghpre + nb * H;
+    float* slabs_f = slabs_h + (int64_t)n_rs * lenh;
+    hipStream_t st = (hipStream_t)hs;
+    hipError_t he = hipMemsetAsync(slabs_h, 0, sizeof(float) * (size_t)(n_rs * lenh + n_prf * lenf), st);
+    if (he != hipSuccess) return (int)he;
+    if (nb > 0) {
+        hipLaunchKernelGGL(k_vaeccdm_gz, dim3(grid_1d(nb * C, 256)), dim3(256), 0, st, z, off, T, nb, (int)C, gla);
+        VX_CHECK_LAUNCH();
+        int64_t blocks = (nb + 3) / 4;
+        if (blocks > (int64_t)num_cu() * 8) blocks = (int64_t)num_cu() * 8;
+        hipLaunchKernelGGL(k_sm_enc_bwd_h, dim3((unsigned)blocks), dim3(256), 0, st, (int)C, (int)H, nb, W2, h, (const float*)gla, ghpre);
+        VX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_sm_enc_bwd_w, dim3((unsigned)((C + 63) / 64), (unsigned)n_rs), dim3(256), 0, st, (int)C, (int)H, nb, h,
+                           (const float*)gla, slabs_h);
+        VX_CHECK_LAUNCH();
+        EncDims dm;
+        dm.D = 1; dm.J = cfg->J; dm.H = cfg->H; dm.Hp = (cfg->H + 31) / 32 * 32; dm.DS = 3; dm.T = 1; dm.nb = nb;
+        const size_t lds = fc1_bwd_lds_floats(dm.Hp) * sizeof(float);
+        const dim3 grid((unsigned)n_jg, (unsigned)n_prf);
+        int rc;
+#define LAUNCH_F1(HT)                                                                                        \
+    rc = set_lds(k_fc1_bwd<HT>, lds);                                                                        \
+    if (rc) return rc;                                                                                       \
+    hipLaunchKernelGGL(k_fc1_bwd<HT>, grid, dim3(ENC_THREADS), lds, st, dm, y, rows, ghpre, slabs_f, lenf, 0)
+        if (dm.Hp == 32) { LAUNCH_F1(1); } else { LAUNCH_F1(2); }
+#undef LAUNCH_F1
+        VX_CHECK_LAUNCH();
+    }
+    // gz / ghpre are d ELBO: loss gradients = -(.)   flat layout [W1 | b1 | W2 | b2] (SoftmaxEncoder, vi.py:477-478)
+    int rc2 = vx_reduce_slabs(slabs_f, n_prf, lenf, -1.0f, genc, hs);
+    if (rc2) return rc2;
+    return vx_reduce_slabs(slabs_h, n_rs, lenh, -1.0f, genc + lenf, hs);
 }
 
 }  // extern "C"

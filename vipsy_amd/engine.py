@@ -222,6 +222,43 @@ class HipBackend(object):
                                         _hip.ptr(h), _hip.ptr(gu), _hip.ptr(genc), _hip.ptr(ws), _hip.stream_ptr())
         _hip.check(rc, "vx_bin_enc_backward")
 
+    def sm_enc_forward(self, cfg, y, rows, nb, enc, h, z):
+        rc = self.L.vx_sm_enc_forward(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb, _hip.ptr(enc["fc1.weight"]),
+                                      _hip.ptr(enc["fc1.bias"]), _hip.ptr(enc["fc2.weight"]), _hip.ptr(enc["fc2.bias"]),
+                                      _hip.ptr(h), _hip.ptr(z), _hip.stream_ptr())
+        _hip.check(rc, "vx_sm_enc_forward")
+
+    def col_reduce(self, mode, v, nb, C, shift, out, ws):
+        _hip.check(self.L.vx_col_reduce(int(mode), _hip.ptr(v), nb, int(C), _hip.ptr(shift), _hip.ptr(out), _hip.ptr(ws),
+                                        _hip.stream_ptr()), "vx_col_reduce")
+
+    def col_reduce_workspace(self, nb, C):
+        return int(self.L.vx_col_reduce_workspace_floats(nb, int(C)))
+
+    def vaeccdm_workspace(self, cfg, nb):
+        n = self.L.vx_vaeccdm_workspace_floats(ctypes.byref(cfg), nb)
+        if n < 0:
+            raise _hip.VxError("vx_vaeccdm_workspace_floats: unsupported configuration (code %d)" % n)
+        return n
+
+    def vaeccdm_grad(self, cfg, dino, y, rows, nb, q, g, s_, z, off, elbo, gla, gitem, ws):
+        rc = self.L.vx_vaeccdm_grad(ctypes.byref(cfg), int(dino), _hip.ptr(y), _hip.ptr(rows), nb, _hip.ptr(q), _hip.ptr(g),
+                                    _hip.ptr(s_), _hip.ptr(z), _hip.ptr(off), _hip.ptr(elbo), _hip.ptr(gla), _hip.ptr(gitem),
+                                    _hip.ptr(ws), _hip.stream_ptr())
+        _hip.check(rc, "vx_vaeccdm_grad")
+
+    def sm_enc_bwd_workspace(self, cfg, nb):
+        n = self.L.vx_sm_enc_bwd_workspace_floats(ctypes.byref(cfg), nb)
+        if n < 0:
+            raise _hip.VxError("vx_sm_enc_bwd_workspace_floats: unsupported configuration (code %d)" % n)
+        return n
+
+    def sm_enc_backward(self, cfg, y, rows, nb, enc, h, z, off, T, gla, genc, ws):
+        rc = self.L.vx_sm_enc_backward(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb, _hip.ptr(enc["fc2.weight"]),
+                                       _hip.ptr(h), _hip.ptr(z), _hip.ptr(off), _hip.ptr(T), _hip.ptr(gla), _hip.ptr(genc),
+                                       _hip.ptr(ws), _hip.stream_ptr())
+        _hip.check(rc, "vx_sm_enc_backward")
+
     def sum_into(self, v, n, alpha, out, ws):
         rc = self.L.vx_sum(_hip.ptr(v), n, alpha, _hip.ptr(out), _hip.ptr(ws), _hip.stream_ptr())
         _hip.check(rc, "vx_sum")
@@ -832,6 +869,107 @@ class CcdmEngine(_EngineBase):
         with self._phase("ccdm"):
             be.ccdm_grad(cfg, self.cdm == "dino", self.y, rows, nb, self.q, self.view("g"), self.view("s"), elbo,
                          self.G[:self.n_item], ws)
+        be.sum_into(elbo, nb, -scale, self.G[self.n_params:self.n_params + 1], self.sum_ws)
+        self.last = {"elbo": elbo, "nb": nb}
+
+
+class VaeCcdmEngine(_EngineBase):
+    """VaeCCDM (vi.py:866-891): pattern-enumerated DINA / DINO with the SoftmaxEncoder prior (vi.py:473-485).  The encoder's
+    softmax runs over the BATCH (dim = 0), so a step needs three batch-wide reductions of C = 2^K floats (column max, column
+    sum of exponentials, column sum of the prior gradients) -- all-reduced over the ranks when the persons are sharded.
+    Missing responses stay in the observation as -1, as in the reference.  Flat buffer: [g_un: J | s_un: J | encoder]."""
+
+    pp_names = ()
+
+    def __init__(self, y_u8, q, cdm="dina", n_global=None, gid0=0, H=64, encoder_init=None, seed=1234, group=None,
+                 backend=None):
+        if cdm not in ("dina", "dino"):
+            raise ValueError("model must be 'dina' or 'dino' (BaseCDM.CDM_FUN, vi.py:728-731)")
+        self.be = backend if backend is not None else HipBackend()
+        self.y = y_u8.contiguous()
+        assert self.y.dtype == torch.uint8 and self.y.dim() == 2
+        self.dev = self.y.device
+        self.n_local, self.J = self.y.shape
+        self.N = int(n_global) if n_global is not None else self.n_local
+        self.gid0 = int(gid0)
+        q = torch.as_tensor(q, dtype=torch.float32)
+        assert q.dim() == 2 and q.shape[1] == self.J
+        if not bool(((q == 0) | (q == 1)).all()):
+            raise ValueError("the Q-matrix must be binary (the subset tests of vi.py:78-81, 96-100 assume it)")
+        self.K = int(q.shape[0])
+        self.C = 1 << self.K
+        self.q = q.to(self.dev).contiguous()
+        self.cdm, self.amortized, self.H = cdm, True, int(H)
+        self.seed, self.group = int(seed), group
+        J, C = self.J, self.C
+        self.off = {"g": 0, "s": J}
+        self.shape = {"g": (1, J), "s": (1, J)}
+        self.n_item = 2 * J
+        o = (self.n_item + 63) // 64 * 64
+        self.enc_shapes = {"fc1.weight": (self.H, J), "fc1.bias": (self.H,), "fc2.weight": (C, self.H), "fc2.bias": (C,)}
+        self.enc_off0 = o
+        for k in BIN_ENC_KEYS:
+            self.off["encoder$$$" + k] = o
+            self.shape["encoder$$$" + k] = self.enc_shapes[k]
+            o += int(np.prod(self.enc_shapes[k]))
+        self.n_enc = o - self.enc_off0
+        self._alloc(o, self.n_local, per_person=False)
+        self.view("g").fill_(float(np.float32(_logit(np.float32(0.1)))))      # vi.py:875-876
+        self.view("s").fill_(float(np.float32(_logit(np.float32(0.1)))))
+        if encoder_init is None:
+            encoder_init = default_bin_encoder_init(J, C, self.H, seed)       # same nn.Linear shapes with C outputs
+        for k in BIN_ENC_KEYS:
+            self.view("encoder$$$" + k).copy_(torch.as_tensor(encoder_init[k], dtype=torch.float32).reshape(-1))
+
+    def names(self):
+        return ["g", "s"] + ["encoder$$$" + k for k in BIN_ENC_KEYS]
+
+    def all_names(self):
+        return self.names()
+
+    def param(self, name):
+        u = self.unconstrained(name)
+        return torch.sigmoid(u) if name in ("g", "s") else u.clone()
+
+    def _allreduce_small(self, t, op):
+        if self.group is not None:
+            if t.is_cuda and torch.distributed.get_backend(self.group) == "gloo":
+                host = t.cpu()
+                torch.distributed.all_reduce(host, op=op, group=self.group)
+                t.copy_(host)
+            else:
+                torch.distributed.all_reduce(t, op=op, group=self.group)
+
+    def loss_and_grads(self, rows=None, b_global=None, eps=None, stream_id=0):
+        be = self.be
+        nb = self.n_local if rows is None else int(rows.numel())
+        Bg = int(b_global) if b_global is not None else (self.N if rows is None else nb)
+        scale = float(self.N) / float(Bg)
+        C, H = self.C, self.H
+        cfg = be.hodina_cfg(self.K, self.J, H, scale, self.seed, self.t, stream_id)
+        enc = {k: self.view("encoder$$$" + k) for k in BIN_ENC_KEYS}
+        h, z, gla = self._buf("vc_h", nb * H), self._buf("vc_z", nb * C), self._buf("vc_gla", nb * C)
+        m, Z, T = self._buf("vc_m", C), self._buf("vc_Z", C), self._buf("vc_T", C)
+        cws = self._buf("vc_cws", be.col_reduce_workspace(max(nb, 1), C))
+        elbo = self._buf("elbo", nb)
+        ws = self._buf("vc_ws", be.vaeccdm_workspace(cfg, nb))
+        with self._phase("guide_forward"):
+            be.sm_enc_forward(cfg, self.y, rows, nb, enc, h, z)
+            be.col_reduce(0, z, nb, C, None, m, cws)                      # column maximum over the batch ...
+            self._allreduce_small(m[:C], torch.distributed.ReduceOp.MAX)  # ... of every rank
+            be.col_reduce(1, z, nb, C, m, Z, cws)
+            self._allreduce_small(Z[:C], torch.distributed.ReduceOp.SUM)
+            off = self._buf("vc_off", C)
+            torch.add(m[:C], torch.log(Z[:C]), out=off[:C])               # attr_p = exp(z - off)
+        with self._phase("vaeccdm"):
+            be.vaeccdm_grad(cfg, self.cdm == "dino", self.y, rows, nb, self.q, self.view("g"), self.view("s"), z, off, elbo,
+                            gla, self.G[:self.n_item], ws)
+        with self._phase("guide_backward"):
+            be.col_reduce(2, gla, nb, C, None, T, cws)
+            self._allreduce_small(T[:C], torch.distributed.ReduceOp.SUM)
+            bws = self._buf("vc_bws", be.sm_enc_bwd_workspace(cfg, nb))
+            be.sm_enc_backward(cfg, self.y, rows, nb, enc, h, z, off, T, gla,
+                               self.G[self.enc_off0:self.enc_off0 + self.n_enc], bws)
         be.sum_into(elbo, nb, -scale, self.G[self.n_params:self.n_params + 1], self.sum_ws)
         self.last = {"elbo": elbo, "nb": nb}
 

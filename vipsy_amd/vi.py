@@ -17,7 +17,7 @@ import math
 import numpy as np
 import torch
 
-from .engine import CcdmEngine, CdmSfEngine, IrtEngine, HoDinaEngine, LrSpec
+from .engine import CcdmEngine, CdmSfEngine, IrtEngine, HoDinaEngine, LrSpec, VaeCcdmEngine
 from .random_data import (RandomPsyData, RandomIrt1PL, RandomIrt2PL, RandomIrt3PL, RandomIrt4PL, RandomMilIrt2PL,    # noqa: F401
                           RandomMilIrt3PL, RandomMilIrt4PL, RandomDina, RandomDino, RandomHoDina)  # vi.py:120-412 live in vi too
 
@@ -352,7 +352,20 @@ class VCCDM(BasePsy):
         return out
 
 
-VaeCCDM = _out_of_scope("VaeCCDM", "vi.py:866-891")
+class VaeCCDM(VCCDM):
+    """Pattern-enumerated DINA / DINO with the SoftmaxEncoder prior inside the model (vi.py:866-891, 473-485); as in the
+    reference the encoder's softmax normalises over the persons of the batch and missing responses enter the likelihood as -1."""
+
+    def __init__(self, hidden_dim=64, q=None, model="dina", *args, **kwargs):
+        if q is None or kwargs.get("data") is None:
+            raise NotImplementedError("VaeCCDM needs q and data (vi.py:733-743)")
+        BasePsy.__init__(self, *args, **kwargs)
+        self.q, self._model = q, model
+        self.attr_size = int(q.shape[0])
+        self.engine = VaeCcdmEngine(self.data, q, cdm=model, H=hidden_dim, encoder_init=self.kwargs.get("encoder_init"),
+                                    **self._eng_kw)
+        self._register()
+        self._ri = None
 
 
 def rmse_(item_size, model_name, r, x_feature):
