@@ -170,8 +170,11 @@ int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, 
 int vx_mvn_bbvi_forward(const vx_irt_cfg* cfg, int64_t nb, const int64_t* rows, int64_t gid0, const float* loc,
                         const float* M, int32_t shared, const float* eps_in, float* x, float* eps, float* ent,
                         void* hip_stream);
+int64_t vx_mvn_bbvi_bwd_workspace_floats(const vx_irt_cfg* cfg, int64_t nb, int32_t shared);
 int vx_mvn_bbvi_backward(const vx_irt_cfg* cfg, int64_t nb, const int64_t* rows, const float* M, int32_t shared,
-                         const float* gx, const float* eps, float* gloc, float* gM, void* hip_stream);
+                         const float* gx, const float* eps, float* gloc, float* gM,
+                         float* workspace /*shared == 1: per-block slabs, summed in fixed order into gM (overwritten)*/,
+                         void* hip_stream);
 
 /* ---- amortized Normal guide for ONE latent dimension (NormEncoder, vi.py:417-435; VaeIRT with
  * x_feature == 1, vi.py:677-684, and VaeCHoDina, vi.py:968-981).  cfg->J, cfg->H are used.

@@ -78,6 +78,9 @@ def test_cfg4_bbvi_missing90_sharding_additivity():
     torch.cuda.synchronize()
     g_full = _flat(full)
     gp_full = full.GP.double().cpu().numpy()
+    full.loss_and_grads()                                   # determinism: a repeated step is bit-identical
+    torch.cuda.synchronize()
+    assert np.array_equal(_flat(full), g_full) and np.array_equal(full.GP.double().cpu().numpy(), gp_full)
     acc = np.zeros_like(g_full)
     for s in range(2):
         lo, hi = s * (N // 2), (s + 1) * (N // 2)
@@ -105,6 +108,9 @@ def test_cfg5_hodina_sharding_additivity():
     torch.cuda.synchronize()
     g_full = _flat(full)
     assert np.isfinite(g_full).all()
+    full.loss_and_grads()                                   # determinism (fixed-point pattern table, per-wave reduce slots)
+    torch.cuda.synchronize()
+    assert np.array_equal(_flat(full), g_full)
     acc = np.zeros_like(g_full)
     for s in range(2):
         lo, hi = s * (N // 2), (s + 1) * (N // 2)
@@ -116,3 +122,38 @@ def test_cfg5_hodina_sharding_additivity():
         del sh
     assert np.abs(acc[:-1] - g_full[:-1]).max() <= 2e-4 * np.abs(g_full[:-1]).max()
     assert acc[-1] == pytest.approx(g_full[-1], rel=2e-5)
+
+
+@pytest.mark.parametrize("case", ["cfg2_4pl_dense", "cfg4_dense_kernel", "virt_d8_share_cov", "generic_mvn"])
+def test_repeated_step_is_bit_identical(case):
+    """Every block reduction is a fixed-order tree or an integer (fixed-point) sum: no float atomics anywhere, so a repeated
+    step reproduces every gradient bit for bit -- also on the dense D = 1 kernel (BASELINE config 2), the shared-covariance
+    BBVI guide and the shape-generic amortized kernels (odd D, H = 40)."""
+    from vipsy_amd import synth
+    from vipsy_amd.engine import IrtEngine
+    dev = _dev()
+    if case == "cfg2_4pl_dense":
+        items = synth.irt_item_params(100, "irt_4pl", seed=20242)
+        y = synth.simulate_responses(100000, 0, items, "irt_4pl", dev, seed=20240)
+        eng = IrtEngine(y, model="irt_4pl", D=1, seed=1234)
+    elif case == "cfg4_dense_kernel":
+        items = synth.irt_item_params(500, "irt_2pl", seed=20242)
+        y = synth.simulate_responses(200000, 0, items, "irt_2pl", dev, seed=20240, missing=0.3)    # < 50 % missing: dense kernel
+        eng = IrtEngine(y, model="irt_2pl", D=1, seed=1234)
+    elif case == "virt_d8_share_cov":
+        items = synth.irt_item_params(60, "irt_2pl", seed=20242, D=8)
+        y = synth.simulate_responses(20000, 0, items, "irt_2pl", dev, seed=20240)
+        eng = IrtEngine(y, model="irt_2pl", D=8, share_cov=True, seed=1234)
+    else:
+        a, b = synth.mirt_item_params(70, 7, seed=20243)
+        y = synth.simulate_responses(5000, 0, {"a": a, "b": b}, "irt_3pl" if False else "irt_2pl", dev, seed=20240)
+        eng = IrtEngine(y, model="irt_2pl", D=7, amortized=True, H=40, seed=1234)
+    outs = []
+    for _ in range(2):
+        eng.loss_and_grads()
+        torch.cuda.synchronize()
+        outs.append((_flat(eng), eng.GP.double().cpu().numpy() if eng.per_person else None))
+    assert np.isfinite(outs[0][0]).all()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    if outs[0][1] is not None:
+        assert np.array_equal(outs[0][1], outs[1][1])

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
     extern __shared__ __attribute__((aligned(16))) float smem[];   // per wave: [C] scatter/gather table; then block reduce
     const int K = dm.K, J = dm.J, C = dm.C;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* tab = smem + wave * C;
+    long long* tabx = (long long*)smem + (size_t)wave * C;          // per wave: [C] fixed-point sums / float table (aliased)
+    float* tab = (float*)tabx;
     const int64_t n_waves = (int64_t)gridDim.x * HD_WAVES;
     const int64_t wg = (int64_t)blockIdx.x * HD_WAVES + wave;
     const int64_t n_groups = (dm.nb + 63) / 64;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
             // -- item side: lp0 = log Bern(y; g), lp1 = log Bern(y; 1 - s)   (p_cj in {g_j, 1 - s_j}, vi.py:82)
             float d0[JPL], d1[JPL], base = 0.f;
 #pragma unroll
-            for (int c4 = lane; c4 < CPL * 64; c4 += 64) if (c4 < C) tab[c4] = 0.f;
+            for (int c4 = lane; c4 < CPL * 64; c4 += 64) if (c4 < C) tabx[c4] = 0;
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int u = 0; u < JPL; ++u) {
@@ -148,14 +149,16 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
                     bern_const(os[u], sj[u], yy, lp1, d1[u], dm.unmasked != 0);
                     base += lp0;
                     if (!dm.dino || __popc(qpat[u]) >= 2)
-                        atomicAdd(&tab[qpat[u]], lp1 - lp0);           // f(S) = sum of delta_j over items with q_j = S
+                        fx_add(&tabx[qpat[u]], lp1 - lp0);             // f(S) = sum of delta_j over items with q_j = S
+                                                                       // (fixed point: the order of the adds does not matter)
                 }
             }
             base = wave_sum_dpp(base);
             __builtin_amdgcn_wave_barrier();
             float Bc[CPL];
 #pragma unroll
-            for (int ii = 0; ii < CPL; ++ii) { const int c = CPL * lane + ii; Bc[ii] = (c < C) ? tab[c] : 0.f; }
+            for (int ii = 0; ii < CPL; ++ii) { const int c = CPL * lane + ii; Bc[ii] = (c < C) ? fx_get(tabx[c]) : 0.f; }
+            __builtin_amdgcn_wave_barrier();                              // the table is reused as floats below
             zeta<LOGCPL, false>(Bc, K, lane);
             if (dm.dino) {
                 // eta_cj = [c meets q_j]: B_c = sum_j delta_j - sum_{q_j disjoint from c} delta_j = Z[full] - Z[~c]
@@ -272,24 +275,29 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
             }
         }
     }
-    // ---- block reduction of item / attribute gradients -> one slab per block
+    // ---- block reduction of item / attribute gradients -> one slab per block: a slot per wave (every wave holds one
+    // partial per item / attribute in the same lane), summed in fixed order: bit-reproducible, no float atomics
     __syncthreads();
-    float* red = smem;                                                    // [2J + 2K]
-    for (int e2 = tid; e2 < 2 * J + 2 * K; e2 += HD_THREADS) red[e2] = 0.f;
-    __syncthreads();
+    const int len = 2 * J + 2 * K;
+    float* red = smem + (size_t)wave * len;                               // [waves][2J + 2K]
 #pragma unroll
     for (int u = 0; u < JPL; ++u) {
         const int j = lane + 64 * u;
         if (j < J) {
-            atomicAdd(&red[j], gg[u] * gj[u] * og[u]);                     // chain through sigmoid: g (1 - g)
-            atomicAdd(&red[J + j], gs[u] * sj[u] * os[u]);
+            red[j] = gg[u] * gj[u] * og[u];                                // chain through sigmoid: g (1 - g)
+            red[J + j] = gs[u] * sj[u] * os[u];
         }
     }
     if (lane < K) {
-        atomicAdd(&red[2 * J + lane], gl0);
-        atomicAdd(&red[2 * J + K + lane], gl1 * l1);                       // chain through exp
+        red[2 * J + lane] = gl0;
+        red[2 * J + K + lane] = gl1 * l1;                                  // chain through exp
     }
     __syncthreads();
-    float* slab = slabs + (int64_t)blockIdx.x * (2 * J + 2 * K);
-    for (int e2 = tid; e2 < 2 * J + 2 * K; e2 += HD_THREADS) slab[e2] = dm.scale * red[e2];
+    float* slab = slabs + (int64_t)blockIdx.x * len;
+    for (int e2 = tid; e2 < len; e2 += HD_THREADS) {
+        float acc = smem[e2];
+#pragma unroll
+        for (int w = 1; w < HD_WAVES; ++w) acc += smem[(size_t)w * len + e2];
+        slab[e2] = dm.scale * acc;
+    }
 }

@@ -119,20 +119,28 @@ __global__ __launch_bounds__(I1_THREADS) void k_irt1d(
             elbo[i] = my_ll - 0.5f * xv * xv + 0.5f * e * e + r;        // log p(y|x) + log p(x) - log q(x)
         }
     }
-    // block-level reduction of the item gradients, one slab per block: [a: J | b: J | c: J | d: J]
-    for (int e = tid; e < 4 * J; e += I1_THREADS) smem[e] = 0.f;
+    // block-level reduction of the item gradients, one slab per block: [a: J | b: J | c: J | d: J].  Every wave holds one
+    // partial per item in the same lane: a slot per wave, then a sum in fixed order (bit-reproducible, no float atomics)
     __syncthreads();
+    float* wslot = smem + (size_t)(tid >> 6) * 4 * J;
+    for (int e = lane; e < 4 * J; e += 64) wslot[e] = 0.f;
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int q = 0; q < IPL; ++q) {
         const int j = 256 * (q >> 2) + 4 * lane + (q & 3);
         if (j < J) {
-            if (MODEL >= 2) atomicAdd(&smem[j], ga[q]);
-            atomicAdd(&smem[J + j], gb[q]);
-            if (MODEL >= 3) atomicAdd(&smem[2 * J + j], gc[q]);
-            if (MODEL >= 4) atomicAdd(&smem[3 * J + j], gd[q]);
+            if (MODEL >= 2) wslot[j] = ga[q];
+            wslot[J + j] = gb[q];
+            if (MODEL >= 3) wslot[2 * J + j] = gc[q];
+            if (MODEL >= 4) wslot[3 * J + j] = gd[q];
         }
     }
     __syncthreads();
     float* slab = slabs + (int64_t)blockIdx.x * 4 * J;
-    for (int e = tid; e < 4 * J; e += I1_THREADS) slab[e] = dm.scale * smem[e];
+    for (int e = tid; e < 4 * J; e += I1_THREADS) {
+        float acc = smem[e];
+#pragma unroll
+        for (int w = 1; w < I1_THREADS / 64; ++w) acc += smem[(size_t)w * 4 * J + e];
+        slab[e] = dm.scale * acc;
+    }
 }

@@ -23,8 +23,9 @@ struct LikDims {
 __host__ __device__ inline int lik_ds(int D) { return (D + 2) | 1; }
 __host__ __device__ inline size_t lik_lds_floats(int D, int nch, int gen) {
     const size_t DS = lik_ds(D), Dk2 = (D + 2) & ~1;
-    return (size_t)LIK_P * DS + Dk2 * (LIK_JC + 1) + (size_t)LIK_JC * (LIK_P + 1) + LIK_P * 33 + LIK_P +
-           (gen ? (size_t)(3 * LIK_JC + 2 * nch * LIK_JC) : 0);
+    // ll / gc / gd accumulate as 64-bit fixed point (fx_add): two floats of space each
+    return (size_t)LIK_P * DS + Dk2 * (LIK_JC + 1) + (size_t)LIK_JC * (LIK_P + 1) + LIK_P * 33 + 2 * LIK_P + 2 +
+           (gen ? (size_t)(3 * LIK_JC + 4 * nch * LIK_JC + 2) : 0);
 }
 
 template <int KT, int NCH, int GEN>
@@ -40,12 +41,13 @@ __global__ __launch_bounds__(LIK_THREADS) void k_irt_lik(
     float* a_lds = x_lds + LIK_P * DS;                // [Dk2][AS] a_aug chunk
     float* R_lds = a_lds + Dk2 * AS;                  // [JC][RS]
     uint8_t* Yb = (uint8_t*)(R_lds + LIK_JC * RS);    // [P][132] bytes
-    float* ll_lds = R_lds + LIK_JC * RS + LIK_P * 33; // [P]
-    float* cs = ll_lds + LIK_P;                       // GEN: c[JC], d[JC], gc[NCH*JC], gd[NCH*JC]
+    float* after_y = R_lds + LIK_JC * RS + LIK_P * 33;
+    long long* ll_lds = (long long*)(after_y + (((size_t)(after_y - smem)) & 1));   // [P] fixed point (8-byte aligned)
+    float* cs = (float*)(ll_lds + LIK_P);             // GEN: c[JC], d[JC], 1-d[JC], gc[NCH*JC], gd[NCH*JC] (fixed point)
     float* dsv = cs + LIK_JC;
     float* omds = dsv + LIK_JC;
-    float* gc_acc = omds + LIK_JC;
-    float* gd_acc = gc_acc + NCH * LIK_JC;
+    long long* gc_acc = (long long*)(omds + LIK_JC + (((size_t)(omds + LIK_JC - smem)) & 1));
+    long long* gd_acc = gc_acc + NCH * LIK_JC;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int g = blockIdx.x;
     const int jbase = g * NCH * LIK_JC;
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(LIK_THREADS) void k_irt_lik(
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) ga[c][kt] = zero16();
     if (GEN) {
-        for (int e = tid; e < 2 * NCH * LIK_JC; e += LIK_THREADS) gc_acc[e] = 0.f;
+        for (int e = tid; e < 2 * NCH * LIK_JC; e += LIK_THREADS) gc_acc[e] = 0;
     }
 
     for (int64_t tile = blockIdx.y; tile < n_ptiles; tile += gridDim.y) {
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(LIK_THREADS) void k_irt_lik(
                 x_lds[e] = v;
             }
         }
-        if (tid < LIK_P) ll_lds[tid] = 0.f;
+        if (tid < LIK_P) ll_lds[tid] = 0;
         f32x16 gxa[GXT];
 #pragma unroll
         for (int t = 0; t < GXT; ++t) gxa[t] = zero16();
@@ -214,12 +216,12 @@ __global__ __launch_bounds__(LIK_THREADS) void k_irt_lik(
 #pragma unroll
                             for (int o = 16; o > 0; o >>= 1) { vc += __shfl_xor(vc, o, 64); vd += __shfl_xor(vd, o, 64); }
                             if (l31 == 0) {
-                                atomicAdd(&gc_acc[c * LIK_JC + jj], vc);
-                                atomicAdd(&gd_acc[c * LIK_JC + jj], vd);
+                                fx_add(&gc_acc[c * LIK_JC + jj], vc);
+                                fx_add(&gd_acc[c * LIK_JC + jj], vd);
                             }
                         }
                     }
-                    atomicAdd(&ll_lds[p], llp);
+                    fx_add(&ll_lds[p], llp);
                 }
                 __syncthreads();
                 // ---- gx^T tiles (rows = dims, cols = persons), contraction over the chunk's items
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(LIK_THREADS) void k_irt_lik(
                 float s2 = 0.f;
                 if (g == 0)
                     for (int k = 0; k < D; ++k) { const float xv = x_lds[tid * DS + k]; s2 += xv * xv; }
-                ll_part[(int64_t)g * dm.nb + i] = ll_lds[tid] - 0.5f * s2;
+                ll_part[(int64_t)g * dm.nb + i] = fx_get(ll_lds[tid]) - 0.5f * s2;
             }
         }
         __syncthreads();
@@ -321,8 +323,8 @@ __global__ __launch_bounds__(LIK_THREADS) void k_irt_lik(
         for (int e = tid; e < NCH * LIK_JC; e += LIK_THREADS) {
             const int j = jbase + e;
             if (j < J) {
-                slab[(int64_t)(D + 1) * J + j] = gc_acc[e];
-                slab[(int64_t)(D + 2) * J + j] = gd_acc[e];
+                slab[(int64_t)(D + 1) * J + j] = fx_get(gc_acc[e]);
+                slab[(int64_t)(D + 2) * J + j] = fx_get(gd_acc[e]);
             }
         }
     } else if (tid < 0) {

@@ -52,14 +52,16 @@ __global__ __launch_bounds__(BB_THREADS) void k_mvn_bbvi_fwd(
 }
 
 // gloc: dense [n_local][D] (rows of the batch are written, the caller zeroed the rest);
-// gM  : dense [n_local][D][D] (shared == 0) or [D][D] accumulated with atomics (shared == 1, caller zeroed)
+// gM  : dense [n_local][D][D] (shared == 0), or one [D][D] slab PER BLOCK (shared == 1) that the host sums in fixed
+//       order: inside the block the waves accumulate in 64-bit fixed point (fx_add), so neither level depends on the order
+//       in which the hardware retires atomics -- the shared-covariance gradient is bit-reproducible
 __global__ __launch_bounds__(BB_THREADS) void k_mvn_bbvi_bwd(
     int D, int64_t nb, float scale, const int64_t* __restrict__ rows, const float* __restrict__ M, int shared,
     const float* __restrict__ gx, const float* __restrict__ eps, float* __restrict__ gloc, float* __restrict__ gM) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // shared == 1: [D][D] block accumulator
+    extern __shared__ __attribute__((aligned(16))) long long smem_fx[];   // shared == 1: [D][D] block accumulator
     const int lane = threadIdx.x & 63;
     if (shared) {
-        for (int e = threadIdx.x; e < D * D; e += BB_THREADS) smem[e] = 0.f;
+        for (int e = threadIdx.x; e < D * D; e += BB_THREADS) smem_fx[e] = 0;
         __syncthreads();
     }
     const int64_t nw = (int64_t)gridDim.x * (BB_THREADS / 64);
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(BB_THREADS) void k_mvn_bbvi_bwd(
                     float v = 0.f;
                     if (l < k) v = gk * (h ? e1 : e0);
                     else if (l == k) v = gk * (h ? e1 : e0) * __expf(Mi[k * D + k]) + scale;
-                    if (shared) { if (l <= k) atomicAdd(&smem[k * D + l], -v); }
+                    if (shared) { if (l <= k) fx_add(&smem_fx[k * D + l], -v); }
                     else gM[(prow * D + k) * D + l] = -v;
                 }
             }
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(BB_THREADS) void k_mvn_bbvi_bwd(
     }
     if (shared) {
         __syncthreads();
-        for (int e = threadIdx.x; e < D * D; e += BB_THREADS)
-            if (smem[e] != 0.f) atomicAdd(&gM[e], smem[e]);
+        float* slab = gM + (int64_t)blockIdx.x * D * D;
+        for (int e = threadIdx.x; e < D * D; e += BB_THREADS) slab[e] = fx_get(smem_fx[e]);
     }
 }

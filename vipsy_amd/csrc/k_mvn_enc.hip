@@ -40,7 +40,10 @@ __host__ __device__ inline size_t enc_fwd_lds_floats(int D, int Hp) {
     const size_t h = (size_t)ENC_P * (Hp + 1);
     const size_t ua = (size_t)ENC_P * (ENC_JC + 1) + (size_t)Hp * (ENC_JC + 1);
     const size_t ub = (size_t)ENC_ROWS * (Hp + 1) + 2 * ENC_ROWS;
-    return h + 2 * ENC_P * DS + ENC_P + (ua > ub ? ua : ub);
+    // eps [P][DS] floats | U.  x [P][DS] and ent [P] accumulate as 64-bit fixed point (fx_add: order-independent sums);
+    // they exist in the head phase only and sit in U behind its head-phase part
+    const size_t ubx = ub + 2 + 2 * ENC_P * DS + 2 * ENC_P;
+    return h + ENC_P * DS + 2 + (ua > ubx ? ua : ubx);
 }
 
 template <int HT>   // HT = Hp / 32 hidden tiles
@@ -56,9 +59,10 @@ __global__ __launch_bounds__(ENC_THREADS) void k_mvn_enc_fwd(
     const int HS = Hp + 1;
     float* h_lds = smem;                                   // [P][HS]
     float* eps_lds = h_lds + ENC_P * HS;                   // [P][DS]
-    float* x_lds = eps_lds + ENC_P * DS;                   // [P][DS]
-    float* ent_lds = x_lds + ENC_P * DS;                   // [P]
-    float* U = ent_lds + ENC_P;
+    float* U = eps_lds + ENC_P * DS;
+    U += ((size_t)(U - smem)) & 1;                         // 8-byte aligned
+    long long* x_lds = (long long*)(U + (((size_t)ENC_ROWS * (Hp + 1) + 2 * ENC_ROWS + 1) & ~(size_t)1));   // [P][DS] fixed point
+    long long* ent_lds = x_lds + ENC_P * DS;               // [P]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int64_t i0 = (int64_t)blockIdx.x * ENC_P;
 
@@ -120,6 +124,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_mvn_enc_fwd(
         }
     }
     // ------------------------------------------------------------------ eps, x := 0
+    __syncthreads();                                       // every wave is done with the fc1 staging area (x overlays it)
     {
         const int nblk = (D + 3) >> 2;
         for (int e = tid; e < ENC_P * nblk; e += ENC_THREADS) {
@@ -143,8 +148,8 @@ __global__ __launch_bounds__(ENC_THREADS) void k_mvn_enc_fwd(
                     if (i < dm.nb) eps_out[i * D + 4 * blk + q] = z[q];
                 }
         }
-        for (int e = tid; e < ENC_P * DS; e += ENC_THREADS) x_lds[e] = 0.f;
-        if (tid < ENC_P) ent_lds[tid] = 0.f;
+        for (int e = tid; e < ENC_P * DS; e += ENC_THREADS) x_lds[e] = 0;
+        if (tid < ENC_P) ent_lds[tid] = 0;
     }
     __syncthreads();
     // ------------------------------------------------------------------ phase B: head rows
@@ -195,15 +200,15 @@ __global__ __launch_bounds__(ENC_THREADS) void k_mvn_enc_fwd(
                     if (code == ROW_NONE) continue;
                     const float v = (uu == 0 ? a0[r] : a1[r]) + biasl[rl];
                     if (code & ROW_LOC) {
-                        atomicAdd(&x_lds[p * DS + (int)(code & 0xFFFFu)], v);          // loc head (vi.py:450)
+                        fx_add(&x_lds[p * DS + (int)(code & 0xFFFFu)], v);             // loc head (vi.py:450)
                     } else {
                         const int k = (int)(code >> 16), l = (int)(code & 0xFFFFu);
                         if (l < k) {
-                            atomicAdd(&x_lds[p * DS + k], v * eps_lds[p * DS + l]);     // tril(M,-1) eps
+                            fx_add(&x_lds[p * DS + k], v * eps_lds[p * DS + l]);        // tril(M,-1) eps
                         } else {
                             const float ld = __expf(v);                                // exp(diag M): vi.py:686
-                            atomicAdd(&x_lds[p * DS + k], ld * eps_lds[p * DS + k]);
-                            atomicAdd(&ent_lds[p], v);
+                            fx_add(&x_lds[p * DS + k], ld * eps_lds[p * DS + k]);
+                            fx_add(&ent_lds[p], v);
                             if (i < dm.nb) ldT[(int64_t)k * dm.nb + i] = ld;
                         }
                     }
@@ -216,14 +221,14 @@ __global__ __launch_bounds__(ENC_THREADS) void k_mvn_enc_fwd(
     for (int e = tid; e < ENC_P * D; e += ENC_THREADS) {
         const int p = e / D, k = e - p * D;
         const int64_t i = i0 + p;
-        if (i < dm.nb) x_out[i * D + k] = x_lds[p * DS + k];
+        if (i < dm.nb) x_out[i * D + k] = fx_get(x_lds[p * DS + k]);
     }
     if (tid < ENC_P) {
         const int64_t i = i0 + tid;
         if (i < dm.nb) {
             float s = 0.f;
             for (int k = 0; k < D; ++k) { const float e = eps_lds[tid * DS + k]; s += e * e; }
-            ent_out[i] = 0.5f * s + ent_lds[tid];        // -log q + const = 0.5|eps|^2 + sum_k M_kk
+            ent_out[i] = 0.5f * s + fx_get(ent_lds[tid]);        // -log q + const = 0.5|eps|^2 + sum_k M_kk
         }
     }
 }

@@ -972,7 +972,7 @@ int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, 
     const int blocks = irt1d_blocks(nb);
     Irt1dDims dm;
     dm.J = cfg->J; dm.model = cfg->model; dm.Dc = cfg->Dc; dm.scale = cfg->scale; dm.nb = nb;
-    const size_t lds = sizeof(float) * 4 * (size_t)cfg->J;
+    const size_t lds = sizeof(float) * 4 * (size_t)cfg->J * (I1_THREADS / 64);       // one partial slot per wave
     hipStream_t st = (hipStream_t)hs;
     const int wpl_need = (cfg->J + 255) / 256;
     const int words_ok = (cfg->J % 4 == 0 && aligned16(y)) ? 1 : 0;     // 4-byte response loads need aligned rows
@@ -1056,19 +1056,32 @@ int vx_mvn_bbvi_forward(const vx_irt_cfg* cfg, int64_t nb, const int64_t* rows, 
     return VX_OK;
 }
 
+static int bbvi_shared_blocks(int64_t nb) {
+    int64_t blocks = (nb + 3) / 4;
+    if (blocks > 64) blocks = 64;                           // one [D][D] slab each
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+int64_t vx_mvn_bbvi_bwd_workspace_floats(const vx_irt_cfg* cfg, int64_t nb, int32_t shared) {
+    if (!cfg || cfg->D < 2 || cfg->D > 128 || nb < 0) return VX_EINVAL;
+    return shared ? (int64_t)bbvi_shared_blocks(nb) * cfg->D * cfg->D : 1;
+}
+
 int vx_mvn_bbvi_backward(const vx_irt_cfg* cfg, int64_t nb, const int64_t* rows, const float* M, int32_t shared,
-                         const float* gx, const float* eps, float* gloc, float* gM, void* hs) {
-    if (!cfg || cfg->D < 2 || cfg->D > 128 || !M || !gx || !eps || !gloc || !gM || nb < 0) return VX_EINVAL;
+                         const float* gx, const float* eps, float* gloc, float* gM, float* workspace, void* hs) {
+    if (!cfg || cfg->D < 2 || cfg->D > 128 || !M || !gx || !eps || !gloc || !gM || nb < 0 || (shared && !workspace))
+        return VX_EINVAL;
     if (nb == 0) return VX_OK;
     int64_t blocks = (nb + 3) / 4;
-    const int64_t cap = shared ? (int64_t)num_cu() : (int64_t)num_cu() * 8;
+    const int64_t cap = shared ? (int64_t)bbvi_shared_blocks(nb) : (int64_t)num_cu() * 8;
     if (blocks > cap) blocks = cap;
-    const size_t lds = shared ? sizeof(float) * (size_t)cfg->D * cfg->D : 0;
+    const size_t lds = shared ? sizeof(long long) * (size_t)cfg->D * cfg->D : 0;
     int rc = set_lds(k_mvn_bbvi_bwd, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(k_mvn_bbvi_bwd, dim3((unsigned)blocks), dim3(BB_THREADS), lds, (hipStream_t)hs, (int)cfg->D, nb,
-                       cfg->scale, rows, M, (int)shared, gx, eps, gloc, gM);
+                       cfg->scale, rows, M, (int)shared, gx, eps, gloc, shared ? workspace : gM);
     VX_CHECK_LAUNCH();
+    if (shared) return vx_reduce_slabs(workspace, blocks, (int64_t)cfg->D * cfg->D, 1.0f, gM, hs);   // fixed-order sum of the slabs
     return VX_OK;
 }
 
@@ -1197,6 +1210,11 @@ static bool hodina_cfg_ok(const vx_hodina_cfg* cfg) {
     return cfg && cfg->K >= 1 && cfg->K <= 10 && cfg->J >= 1 && cfg->J <= 1024;
 }
 
+// per wave a [C] table of 64-bit fixed-point sums (also used as a float table); the block reduce needs [waves][len] floats
+static size_t hodina_lds_bytes(int C, int len) {
+    const size_t tab = (size_t)HD_WAVES * C * sizeof(long long), red = (size_t)HD_WAVES * len * sizeof(float);
+    return tab > red ? tab : red;
+}
 static int hodina_blocks(int64_t nb) {
     const int64_t n_groups = (nb + 63) / 64;
     int64_t blocks = (n_groups + HD_WAVES - 1) / HD_WAVES;
@@ -1222,8 +1240,7 @@ int vx_hodina_grad(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t* ro
     dm.K = cfg->K; dm.J = cfg->J; dm.C = 1 << cfg->K; dm.scale = cfg->scale; dm.nb = nb;
     dm.uniform_prior = 0; dm.dino = 0; dm.unmasked = 0;
     const int len = 2 * cfg->J + 2 * cfg->K;
-    const int tabf = HD_WAVES * dm.C;
-    const size_t lds = sizeof(float) * (size_t)(tabf > len ? tabf : len);
+    const size_t lds = hodina_lds_bytes(dm.C, len);
     hipStream_t st = (hipStream_t)hs;
     const int logcpl = cfg->K <= 8 ? 2 : (cfg->K == 9 ? 3 : 4);
     const int jpl = (cfg->J + 63) / 64;
@@ -1257,8 +1274,7 @@ int vx_ccdm_grad(const vx_hodina_cfg* cfg, int32_t dino, const uint8_t* y, const
     dm.K = cfg->K; dm.J = cfg->J; dm.C = 1 << cfg->K; dm.scale = cfg->scale; dm.nb = nb;
     dm.uniform_prior = 1; dm.dino = dino ? 1 : 0; dm.unmasked = 0;
     const int len = 2 * cfg->J + 2 * cfg->K;                  // slab layout of k_hodina; the lambda tail stays zero
-    const int tabf = HD_WAVES * dm.C;
-    const size_t lds = sizeof(float) * (size_t)(tabf > len ? tabf : len);
+    const size_t lds = hodina_lds_bytes(dm.C, len);
     hipStream_t st = (hipStream_t)hs;
     const int logcpl = cfg->K <= 8 ? 2 : (cfg->K == 9 ? 3 : 4);
     const int jpl = (cfg->J + 63) / 64;
@@ -1504,8 +1520,7 @@ int vx_vaeccdm_grad(const vx_hodina_cfg* cfg, int32_t dino, const uint8_t* y, co
     dm.K = cfg->K; dm.J = cfg->J; dm.C = 1 << cfg->K; dm.scale = cfg->scale; dm.nb = nb;
     dm.uniform_prior = 2; dm.dino = dino ? 1 : 0; dm.unmasked = 1;
     const int len = 2 * cfg->J + 2 * cfg->K;
-    const int tabf = HD_WAVES * dm.C;
-    const size_t lds = sizeof(float) * (size_t)(tabf > len ? tabf : len);
+    const size_t lds = hodina_lds_bytes(dm.C, len);
     hipStream_t st = (hipStream_t)hs;
     const int logcpl = cfg->K <= 8 ? 2 : (cfg->K == 9 ? 3 : 4);
     const int jpl = (cfg->J + 63) / 64;

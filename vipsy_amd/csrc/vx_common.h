@@ -196,6 +196,16 @@ __device__ __forceinline__ void irt_cell_f(float z, float yf, float c, float d, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Order-independent accumulation in LDS: a float is added as a 64-bit fixed-point integer (2^-32 resolution, +-2^31
+// range).  Integer adds commute, so the sum does not depend on the order in which the hardware retires the atomics --
+// block reductions stay bit-reproducible from run to run at the cost of a float atomic.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fx_add(long long* slot, float v) {
+    atomicAdd((unsigned long long*)slot, (unsigned long long)(long long)(v * 4294967296.0f));
+}
+__device__ __forceinline__ float fx_get(long long s) { return (float)((double)s * 2.3283064365386963e-10); }
+
+// ---------------------------------------------------------------------------------------------
 // wave / block reductions
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

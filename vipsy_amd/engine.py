@@ -131,9 +131,12 @@ class HipBackend(object):
                                         _hip.stream_ptr())
         _hip.check(rc, "vx_mvn_bbvi_forward")
 
-    def mvn_bbvi_backward(self, cfg, nb, rows, M, shared, gx, eps, gloc, gM):
+    def mvn_bbvi_bwd_workspace(self, cfg, nb, shared):
+        return max(1, int(self.L.vx_mvn_bbvi_bwd_workspace_floats(ctypes.byref(cfg), nb, int(shared))))
+
+    def mvn_bbvi_backward(self, cfg, nb, rows, M, shared, gx, eps, gloc, gM, ws=None):
         rc = self.L.vx_mvn_bbvi_backward(ctypes.byref(cfg), nb, _hip.ptr(rows), _hip.ptr(M), int(shared), _hip.ptr(gx),
-                                         _hip.ptr(eps), _hip.ptr(gloc), _hip.ptr(gM), _hip.stream_ptr())
+                                         _hip.ptr(eps), _hip.ptr(gloc), _hip.ptr(gM), _hip.ptr(ws), _hip.stream_ptr())
         _hip.check(rc, "vx_mvn_bbvi_backward")
 
     def norm_enc_forward(self, cfg, y, rows, nb, enc, out):
@@ -633,7 +636,8 @@ class IrtEngine(_EngineBase):
                 self.GP.zero_()                                       # dense per-person grads: zero off the batch
                 if self.share_cov:
                     gM.zero_()
-                be.mvn_bbvi_backward(cfg, nb, rows, Mq, self.share_cov, gx, fw["eps"], self.GP[:n * D], gM)
+                be.mvn_bbvi_backward(cfg, nb, rows, Mq, self.share_cov, gx, fw["eps"], self.GP[:n * D], gM,
+                                     self._buf("bbvi_ws", be.mvn_bbvi_bwd_workspace(cfg, nb, self.share_cov)))
             tmp = self._buf("loss2", 2)
             be.sum_into(ll, nb, -scale, tmp[0:1], self.sum_ws)
             be.sum_into(fw["ent"], nb, -scale, tmp[1:2], self.sum_ws)
