@@ -193,17 +193,19 @@ int vx_norm_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t*
                          float* genc, float* workspace, void* hip_stream);
 
 /* ---- D = 1 models on OBSERVED cells only (full batch; for heavily masked data, BASELINE config 4).  The responses
- * never change, so the host compacts them once (vipsy_amd/engine.py::_sparse_lists):
- *   pent [n_groups][L][64] uint16: entry e of person 64 g + lane = item | y << 15, 0xFFFF = padding;
- *   glen [n_groups]: longest list in the group;  ient [nnz] uint32: person | y << 31 grouped by item,
- *   ioff [J + 1]: item j owns ient[ioff[j] .. ioff[j+1]).
- * Same outputs as vx_irt1d_grad.  workspace: vx_irt1d_sparse_workspace_floats(cfg, nb) floats.  J <= 1024. */
-int64_t vx_irt1d_sparse_workspace_floats(const vx_irt_cfg* cfg, int64_t nb);
-int vx_irt1d_sparse_grad(const vx_irt_cfg* cfg, const uint16_t* pent, const int32_t* glen, int32_t L,
-                         const uint32_t* ient, const int64_t* ioff, int64_t nb, int64_t gid0, const float* loc,
-                         const float* raw, const float* eps_in, const float* a, const float* b, const float* c_un,
-                         const float* d_un, float* gloc, float* graw, float* elbo, float* gitem, float* workspace,
-                         void* hip_stream);
+ * never change, so the host compacts them once (vipsy_amd/engine.py::_sparse_lists) into groups of 64 person SLOTS:
+ *   pidx [n_groups][64] int32: the person (row of loc / raw / gloc / graw / elbo) in the slot, -1 = empty.  Any order
+ *        works; lists of similar length in one group waste no lanes (the host sorts windows of persons by length);
+ *   pent [n_groups][Lq][64][4] uint16: the slot's list in quads, entry = item | y << 15, 0xFFFF past its end
+ *        (an empty slot's list is all 0xFFFF);
+ *   glen [n_groups] int32: quads in the longest list of the group (<= Lq).
+ * Same outputs as vx_irt1d_grad, one pass; item gradients are summed with integer atomics (bit-reproducible).
+ * workspace: vx_irt1d_sparse_workspace_floats(cfg, n_groups) floats.  J <= 1024. */
+int64_t vx_irt1d_sparse_workspace_floats(const vx_irt_cfg* cfg, int64_t n_groups);
+int vx_irt1d_sparse_grad(const vx_irt_cfg* cfg, const uint16_t* pent, const int32_t* glen, int32_t Lq,
+                         const int32_t* pidx, int64_t n_groups, int64_t gid0, const float* loc, const float* raw,
+                         const float* eps_in, const float* a, const float* b, const float* c_un, const float* d_un,
+                         float* gloc, float* graw, float* elbo, float* gitem, float* workspace, void* hip_stream);
 
 /* ---- HO-DINA with exact enumeration of the 2^K attribute patterns (VCHoDina / VaeCHoDina model,
  * vi.py:897-923, under TraceEnum_ELBO; guide theta ~ Normal(loc, exp(raw)), vi.py:925-934 / 968-981).

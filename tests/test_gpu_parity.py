@@ -237,6 +237,7 @@ def test_mvn_amortized_step_vs_oracle(N, J, D, H, model, miss, B):
     (777, 130, "irt_4pl", 0.7, None),
     (300, 37, "irt_1pl", 0.6, None),
     (640, 200, "irt_3pl", 0.95, None),
+    (4500, 60, "irt_2pl", 0.8, None),                # two sort windows; a few |x| > 8 (full-range slots of the list kernel)
 ])
 def test_irt1d_step_vs_oracle(N, J, model, miss, B):
     from vipsy_amd.engine import IrtEngine
@@ -249,7 +250,10 @@ def test_irt1d_step_vs_oracle(N, J, model, miss, B):
         eng.unconstrained("a").copy_(torch.from_numpy(0.5 + 2 * rng.rand(1, J)).float())
     if model in ("irt_3pl", "irt_4pl"):
         eng.unconstrained("c").add_(torch.from_numpy(0.3 * rng.randn(1, J)).float().to(_dev()))
-    eng.PP.copy_(torch.from_numpy(np.concatenate([rng.randn(N), 0.3 * rng.randn(N)])).float())
+    loc0 = rng.randn(N)
+    if N == 4500:
+        loc0[::500] = 11.0 * np.sign(loc0[::500])
+    eng.PP.copy_(torch.from_numpy(np.concatenate([loc0, 0.3 * rng.randn(N)])).float())
     idx = np.arange(N) if B is None else np.sort(rng.permutation(N)[:B])
     rows = None if B is None else torch.from_numpy(idx).to(_dev())
     eps = vo.philox_normals(5, 0, 0, idx, 1)

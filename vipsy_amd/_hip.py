@@ -65,7 +65,7 @@ SIGNATURES = {
     "vx_irt1d_workspace_floats": (_I64, [_CFG, _I64]),
     "vx_irt1d_grad": (ctypes.c_int, [_CFG, _P, _P, _I64, _I64] + [_P] * 3 + [_P] * 4 + [_P] * 4 + [_P, _P]),
     "vx_irt1d_sparse_workspace_floats": (_I64, [_CFG, _I64]),
-    "vx_irt1d_sparse_grad": (ctypes.c_int, [_CFG, _P, _P, _I32, _P, _P, _I64, _I64] + [_P] * 3 + [_P] * 4 + [_P] * 4 + [_P, _P]),
+    "vx_irt1d_sparse_grad": (ctypes.c_int, [_CFG, _P, _P, _I32, _P, _I64, _I64] + [_P] * 3 + [_P] * 4 + [_P] * 4 + [_P, _P]),
     "vx_mvn_bbvi_forward": (ctypes.c_int, [_CFG, _I64, _P, _I64, _P, _P, _I32, _P, _P, _P, _P, _P]),
     "vx_mvn_bbvi_bwd_workspace_floats": (_I64, [_CFG, _I64, _I32]),
     "vx_mvn_bbvi_backward": (ctypes.c_int, [_CFG, _I64, _P, _P, _I32, _P, _P, _P, _P, _P, _P]),

@@ -1,54 +1,76 @@
 // D = 1 IRT on OBSERVED cells only (BASELINE config 4: 90 % of the responses missing).
 //
 // The dense kernel (k_irt1d.hip) evaluates every cell, and with one latent dimension the cell math (exp2 / rcp / log2
-// + ~20 VALU) is the bound, not HBM.  The responses never change between steps, so the host compacts them once into
-// two lists and each step touches the observed ~10 % only, with no atomics and fixed summation orders:
+// + ~20 VALU) is the bound, not HBM.  The responses never change between steps, so the host compacts them once
+// (vipsy_amd/engine.py::_sparse_lists) and each step touches the observed ~10 % only, in ONE pass:
 //
-//   pass 1, person-major  (k_irt1d_sp_person): lane = person, a wave = 64 persons; entry e of the wave's group is one
-//           coalesced 128-byte row of uint16 codes  item | y << 15  (0xFFFF = padding); item parameters are gathered
-//           from LDS.  Produces x, the per-person ELBO term and d/dx -> gloc, graw.
-//   pass 2, item-major    (k_irt1d_sp_item): workgroup = (item j, chunk c of its person list); entries are
-//           person | y << 31; x is gathered (4 MB, L2 / MALL resident), the cell is evaluated again and the four item
-//           gradients are reduced over the chunk in a fixed order -> slab c, summed by k_reduce_slabs.
+//   slot    lane = one person slot, a wave = a group of 64 slots.  pidx[slot] names the person (-1 = empty): the host
+//           orders the persons of a window by their number of observed cells, so the 64 lists of a group have (almost)
+//           the same length and no lane idles through another lane's tail.
+//   lists   pent [n_groups][Lq][64] of 8-byte quads: four uint16 codes  item | y << 15  (0xFFFF = past the end of the
+//           list), so a wave reads 512 contiguous bytes per four cells and the next quad is in flight while the current
+//           one is evaluated.
+//   items   (Dc a_j, Dc b_j) gathered from LDS as one 8-byte read.
+//   d/d item  accumulated per block in LDS with INTEGER atomics, so the sums do not depend on the order the hardware
+//           retires them (run-to-run bit-reproducible).  For a cell t = dlp/dz with |t| <= 1 always, so the pair
+//           (t x, t) is quantised to two 32-bit integers with scales the host derives from the persons a block can see
+//           (no overflow by construction) and added as ONE 64-bit atomic  q_a 2^32 + q_b.  A person with |x| > SP_XB
+//           (8 prior standard deviations) takes a separate full-range 64-bit fixed-point slot for t x instead.  The
+//           3PL / 4PL asymptote gradients are unbounded (1 / P) and use full-range slots as well.
+//           One slab [a | b | c | d][J] per block, summed by k_reduce_slabs.
 //
-// A missing cell contributes the reference's constant log Bern(0 | clamp 0) (vi.py:621-624) and no gradient: pass 1
-// adds it as (J - observed) * constant.
+// A missing cell contributes the reference's constant log Bern(0 | clamp 0) (vi.py:621-624) and no gradient: added as
+// (J - observed) * constant per person.
 #pragma once
 #include "vx_common.h"
 
-#define SP_THREADS 256
-#define SP_NC 32                                                       // chunks per item in pass 2
+#define SP_THREADS 512
+#define SP_XB 8.0f
 
 struct Irt1dSpDims {
-    int J, model, L;
+    int J, model, Lq;
     float Dc, scale;
-    int64_t nb;
+    float sb, inv_sb;                 // quantisation of t  (power of two); t x uses sb / SP_XB
+    int64_t n_groups;
 };
 
+__device__ __forceinline__ int sp_rint(float v) { return (int)__builtin_rintf(v); }
+
 template <int MODEL>
-__global__ __launch_bounds__(SP_THREADS) void k_irt1d_sp_person(
-    Irt1dSpDims dm, const uint16_t* __restrict__ pent /*[n_groups][L][64]*/, const int32_t* __restrict__ glen,
-    int64_t gid0, const float* __restrict__ loc, const float* __restrict__ raw, const float* __restrict__ eps_in,
-    uint64_t seed, uint32_t step, uint32_t stream, const float* __restrict__ a, const float* __restrict__ b,
-    const float* __restrict__ c_un, const float* __restrict__ d_un, float* __restrict__ gloc,
-    float* __restrict__ graw, float* __restrict__ elbo, float* __restrict__ xout) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // [5][J]: a, b, c, d, 1 - d
+__global__ __launch_bounds__(SP_THREADS) void k_irt1d_sp(
+    Irt1dSpDims dm, const uint2* __restrict__ pent /*[n_groups][Lq][64]*/, const int32_t* __restrict__ glen,
+    const int32_t* __restrict__ pidx, int64_t gid0, const float* __restrict__ loc, const float* __restrict__ raw,
+    const float* __restrict__ eps_in, uint64_t seed, uint32_t step, uint32_t stream, const float* __restrict__ a,
+    const float* __restrict__ b, const float* __restrict__ c_un, const float* __restrict__ d_un,
+    float* __restrict__ gloc, float* __restrict__ graw, float* __restrict__ elbo, float* __restrict__ slabs) {
+    // LDS: ab [J] float2 | acc [J] packed (t x, t) | big [J] fixed point t x | (3PL+) accc, accd [J], cs, ds, os [J] floats
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int J = dm.J;
-    float* as = smem; float* bs = as + J; float* cs = bs + J; float* ds = cs + J; float* os = ds + J;
+    float2* ab = (float2*)smem_raw;
+    long long* acc = (long long*)(ab + J);
+    long long* big = acc + J;
+    long long* accc = big + J;
+    long long* accd = accc + J;
+    float* cs = (float*)(accd + J);
+    float* ds = cs + J;
+    float* os = ds + J;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int j = tid; j < J; j += SP_THREADS) {
-        as[j] = (MODEL >= 2) ? a[j] : 1.0f;
-        bs[j] = b[j];
-        cs[j] = (MODEL >= 3) ? fminf(sigmoidf_(c_un[j]), 1.0f - VX_EPS32) : 0.f;
-        ds[j] = (MODEL >= 4) ? fminf(sigmoidf_(d_un[j]), 1.0f - VX_EPS32) : 1.0f;
-        os[j] = (MODEL >= 4) ? fmaxf(sigmoidf_(-d_un[j]), VX_EPS32) : 0.f;
+        ab[j] = make_float2(dm.Dc * ((MODEL >= 2) ? a[j] : 1.0f), dm.Dc * b[j]);
+        acc[j] = 0; big[j] = 0;
+        if (MODEL >= 3) {
+            accc[j] = 0; accd[j] = 0;
+            cs[j] = fminf(sigmoidf_(c_un[j]), 1.0f - VX_EPS32);
+            ds[j] = (MODEL >= 4) ? fminf(sigmoidf_(d_un[j]), 1.0f - VX_EPS32) : 1.0f;
+            os[j] = (MODEL >= 4) ? fmaxf(sigmoidf_(-d_un[j]), VX_EPS32) : 0.f;
+        }
     }
     __syncthreads();
-    const int64_t n_groups = (dm.nb + 63) / 64;
+    const float sb = dm.sb, sa = dm.sb * (1.0f / SP_XB);
     const int64_t n_waves = (int64_t)gridDim.x * (SP_THREADS / 64);
-    for (int64_t grp = (int64_t)blockIdx.x * (SP_THREADS / 64) + wave; grp < n_groups; grp += n_waves) {
-        const int64_t i = grp * 64 + lane;
-        const bool valid = i < dm.nb;
+    for (int64_t grp = (int64_t)blockIdx.x * (SP_THREADS / 64) + wave; grp < dm.n_groups; grp += n_waves) {
+        const int i = pidx[grp * 64 + lane];
+        const bool valid = i >= 0;
         float l = 0.f, r = 0.f, e = 0.f;
         if (valid) {
             l = loc[i]; r = raw[i];
@@ -56,24 +78,58 @@ __global__ __launch_bounds__(SP_THREADS) void k_irt1d_sp_person(
         }
         const float sig = __expf(r);
         const float x = l + sig * e;
-        const int len = glen[grp];                                     // longest list of the group (wave-uniform)
-        const uint16_t* ent = pent + grp * (int64_t)dm.L * 64 + lane;
+        const bool far = fabsf(x) > SP_XB;                             // practically never: full-range slot for t x
+        const float xs = far ? 0.f : x * sa;
+        const int nq = __builtin_amdgcn_readfirstlane(glen[grp]);      // quads in the longest list of the group
+        const uint2* ent = pent + grp * (int64_t)dm.Lq * 64 + lane;
         float ll = 0.f, gx = 0.f;
         int nobs = 0;
-        uint32_t code = len > 0 ? ent[0] : 0xFFFFu;
-        for (int t = 0; t < len; ++t) {
-            const uint32_t nxt = (t + 1 < len) ? ent[(int64_t)(t + 1) * 64] : 0xFFFFu;       // one entry ahead
-            const bool ok = code != 0xFFFFu;
-            const int j = ok ? (int)(code & 0x7FFFu) : 0;
-            const unsigned yy = ok ? (code >> 15) : 254u;              // 254: outside the problem -> no contribution
-            const float aj = as[j];
-            const float z = dm.Dc * fmaf(x, aj, bs[j]);
-            float lp, dz, dc, dd;
-            irt_cell<MODEL>(z, yy, cs[j], ds[j], os[j], lp, dz, dc, dd);
-            ll += lp;
-            gx = fmaf(dm.Dc * dz, aj, gx);
-            nobs += ok ? 1 : 0;
-            code = nxt;
+        uint2 cur = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (nq > 0) cur = ent[0];
+        for (int q = 0; q < nq; ++q) {
+            uint2 nxt = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+            if (q + 1 < nq) nxt = ent[(int64_t)(q + 1) * 64];          // wave-uniform: the next quad is in flight
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t word = (k < 2) ? cur.x : cur.y;
+                const uint32_t code = (k & 1) ? (word >> 16) : (word & 0xFFFFu);
+                if (code != 0xFFFFu) {                                 // lists of a group end together (sorted): rare
+                    const int j = (int)(code & 0x7FFFu);
+                    const bool y1 = (code & 0x8000u) != 0;
+                    const float2 p = ab[j];
+                    const float z = fmaf(x, p.x, p.y);                 // Dc (a x + b)
+                    float t;                                           // dlp/dz
+                    if (MODEL <= 2) {
+                        // Bernoulli(logit z) with the reference's clamp of the probability to [eps, 1 - eps]:
+                        // with w = -z for y = 1 and z for y = 0,  lp = -softplus(w),  dlp/dz = +-sigmoid(w)
+                        const float ZL = 15.942384719848633f;          // logit(1 - eps32)
+                        const float w = y1 ? -z : z;
+                        const float wc = __builtin_amdgcn_fmed3f(w, -ZL, ZL);
+                        const float ex = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(wc));
+                        const float u = 1.0f + ex;
+                        const float rc = fast_rcp(u);
+                        ll -= fmaf(__builtin_amdgcn_logf(u), 0.6931471805599453f, fmaxf(wc, 0.f));
+                        const float sg = (wc >= 0.f) ? rc : ex * rc;   // sigmoid(wc)
+                        const float s0 = (wc == w) ? sg : 0.f;         // zero gradient where the clamp is active
+                        t = y1 ? s0 : -s0;
+                    } else {
+                        float lp, dz, dc, dd;
+                        irt_cell<MODEL>(z, y1 ? 1u : 0u, cs[j], ds[j], os[j], lp, dz, dc, dd);
+                        ll += lp;
+                        t = dz;
+                        fx_add(&accc[j], dc);
+                        if (MODEL >= 4) fx_add(&accd[j], dd);
+                    }
+                    gx = fmaf(t, p.x, gx);
+                    nobs += 1;
+                    // (t x, t) as one 64-bit integer add: q_a 2^32 + q_b
+                    const int qb = sp_rint(t * sb), qa = sp_rint(t * xs);
+                    const unsigned long long pk = ((unsigned long long)(unsigned)(qa + (qb >> 31)) << 32) | (unsigned)qb;
+                    atomicAdd((unsigned long long*)&acc[j], pk);
+                    if (far) fx_add(&big[j], t * x);
+                }
+            }
+            cur = nxt;
         }
         if (valid) {
             ll += (float)(J - nobs) * VX_LOGP_MISSING;
@@ -81,47 +137,18 @@ __global__ __launch_bounds__(SP_THREADS) void k_irt1d_sp_person(
             gloc[i] = -gxt;
             graw[i] = -(gxt * sig * e + dm.scale);
             elbo[i] = ll - 0.5f * x * x + 0.5f * e * e + r;
-            xout[i] = x;
         }
     }
-}
-
-// slabs: [SP_NC][4 J] = per chunk [a: J | b: J | c: J | d: J] (d ELBO, scaled); every entry is written
-template <int MODEL>
-__global__ __launch_bounds__(SP_THREADS) void k_irt1d_sp_item(
-    Irt1dSpDims dm, const uint32_t* __restrict__ ient, const int64_t* __restrict__ ioff, const float* __restrict__ xin,
-    const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c_un,
-    const float* __restrict__ d_un, float* __restrict__ slabs) {
-    __shared__ float red[4][SP_THREADS / 64];
-    const int J = dm.J, j = blockIdx.x, c = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float aj = (MODEL >= 2) ? a[j] : 1.0f, bj = b[j];
-    const float cj = (MODEL >= 3) ? fminf(sigmoidf_(c_un[j]), 1.0f - VX_EPS32) : 0.f;
-    const float dj = (MODEL >= 4) ? fminf(sigmoidf_(d_un[j]), 1.0f - VX_EPS32) : 1.0f;
-    const float oj = (MODEL >= 4) ? fmaxf(sigmoidf_(-d_un[j]), VX_EPS32) : 0.f;
-    const int64_t lo = ioff[j], n = ioff[j + 1] - lo;
-    const int64_t per = (n + SP_NC - 1) / SP_NC;
-    const int64_t e0 = lo + c * per, e1 = (e0 + per < lo + n) ? e0 + per : lo + n;
-    float ga = 0.f, gb = 0.f, gc = 0.f, gd = 0.f;
-    for (int64_t e = e0 + tid; e < e1; e += SP_THREADS) {
-        const uint32_t v = ient[e];
-        const float x = xin[v & 0x7FFFFFFFu];
-        const float z = dm.Dc * fmaf(x, aj, bj);
-        float lp, dz, dc, dd;
-        irt_cell<MODEL>(z, v >> 31, cj, dj, oj, lp, dz, dc, dd);
-        const float t = dm.Dc * dz;
-        gb += t;
-        ga = fmaf(t, x, ga);
-        gc += dc;
-        gd += dd;
-    }
-    ga = wave_sum_dpp(ga); gb = wave_sum_dpp(gb); gc = wave_sum_dpp(gc); gd = wave_sum_dpp(gd);
-    if (lane == 0) { red[0][wave] = ga; red[1][wave] = gb; red[2][wave] = gc; red[3][wave] = gd; }
     __syncthreads();
-    if (tid < 4) {
-        float s = 0.f;
-        for (int w = 0; w < SP_THREADS / 64; ++w) s += red[tid][w];
-        const bool has = (tid == 0 && MODEL >= 2) || tid == 1 || (tid == 2 && MODEL >= 3) || (tid == 3 && MODEL >= 4);
-        slabs[(int64_t)c * 4 * J + (int64_t)tid * J + j] = has ? dm.scale * s : 0.f;
+    float* slab = slabs + (int64_t)blockIdx.x * 4 * J;
+    const float ua = dm.Dc * dm.scale * dm.inv_sb * SP_XB, ub = dm.Dc * dm.scale * dm.inv_sb;
+    for (int j = tid; j < J; j += SP_THREADS) {
+        const long long s = acc[j];
+        const int qb = (int)(s & 0xFFFFFFFFll);
+        const int qa = (int)((s - (long long)qb) >> 32);
+        slab[j] = (MODEL >= 2) ? fmaf((float)qa, ua, dm.Dc * dm.scale * fx_get(big[j])) : 0.f;
+        slab[J + j] = (float)qb * ub;
+        slab[2 * J + j] = (MODEL >= 3) ? dm.scale * fx_get(accc[j]) : 0.f;
+        slab[3 * J + j] = (MODEL >= 4) ? dm.scale * fx_get(accd[j]) : 0.f;
     }
 }

@@ -999,38 +999,45 @@ int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, 
 }
 
 // ---- D = 1 on the host-compacted lists of observed cells (k_irt1d_sparse.hip); full batch only
-int64_t vx_irt1d_sparse_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
-    if (!irt1d_cfg_ok(cfg) || nb < 0) return VX_EINVAL;
-    return ((nb + 3) & ~(int64_t)3) + (int64_t)SP_NC * 4 * cfg->J;      // x | slabs
+static int irt1d_sp_blocks(int64_t n_groups) {
+    int64_t blocks = (n_groups + SP_THREADS / 64 - 1) / (SP_THREADS / 64);
+    if (blocks > (int64_t)num_cu() * 4) blocks = (int64_t)num_cu() * 4;
+    return (int)(blocks < 1 ? 1 : blocks);
 }
 
-int vx_irt1d_sparse_grad(const vx_irt_cfg* cfg, const uint16_t* pent, const int32_t* glen, int32_t L,
-                         const uint32_t* ient, const int64_t* ioff, int64_t nb, int64_t gid0, const float* loc,
-                         const float* raw, const float* eps_in, const float* a, const float* b, const float* c_un,
-                         const float* d_un, float* gloc, float* graw, float* elbo, float* gitem, float* workspace,
-                         void* hs) {
-    if (!irt1d_cfg_ok(cfg) || !pent || !glen || !ient || !ioff || L < 0 || !loc || !raw || !b || !gloc || !graw || !elbo ||
-        !gitem || !workspace || nb < 0 || cfg->J > 32767)
+int64_t vx_irt1d_sparse_workspace_floats(const vx_irt_cfg* cfg, int64_t n_groups) {
+    if (!irt1d_cfg_ok(cfg) || n_groups < 0) return VX_EINVAL;
+    return (int64_t)irt1d_sp_blocks(n_groups) * 4 * cfg->J;                                // one slab per block
+}
+
+int vx_irt1d_sparse_grad(const vx_irt_cfg* cfg, const uint16_t* pent, const int32_t* glen, int32_t Lq,
+                         const int32_t* pidx, int64_t n_groups, int64_t gid0, const float* loc, const float* raw,
+                         const float* eps_in, const float* a, const float* b, const float* c_un, const float* d_un,
+                         float* gloc, float* graw, float* elbo, float* gitem, float* workspace, void* hs) {
+    if (!irt1d_cfg_ok(cfg) || !pent || !glen || !pidx || Lq < 0 || !loc || !raw || !b || !gloc || !graw || !elbo ||
+        !gitem || !workspace || n_groups < 0 || cfg->J > 32767)
         return VX_EINVAL;
     if (cfg->model >= VX_IRT_2PL && !a) return VX_EINVAL;
     if (cfg->model >= VX_IRT_3PL && !c_un) return VX_EINVAL;
     if (cfg->model == VX_IRT_4PL && !d_un) return VX_EINVAL;
+    const int blocks = irt1d_sp_blocks(n_groups);
+    // every |t| <= 1, so a block's integer sums stay below 2^30 whatever the data: persons a block can see x scale
+    const int64_t n_waves = (int64_t)blocks * (SP_THREADS / 64);
+    const int64_t per_block = ((n_groups + n_waves - 1) / n_waves) * SP_THREADS;
+    float sb = 1048576.0f;                                                                 // 2^20
+    while (sb * (float)(per_block > 0 ? per_block : 1) > 1073741824.0f) sb *= 0.5f;
     Irt1dSpDims dm;
-    dm.J = cfg->J; dm.model = cfg->model; dm.L = L; dm.Dc = cfg->Dc; dm.scale = cfg->scale; dm.nb = nb;
-    float* xbuf = workspace;
-    float* slabs = workspace + ((nb + 3) & ~(int64_t)3);
+    dm.J = cfg->J; dm.model = cfg->model; dm.Lq = Lq; dm.Dc = cfg->Dc; dm.scale = cfg->scale;
+    dm.sb = sb; dm.inv_sb = 1.0f / sb; dm.n_groups = n_groups;
     hipStream_t st = (hipStream_t)hs;
-    const int64_t n_groups = (nb + 63) / 64;
-    int64_t blocks1 = (n_groups + 3) / 4;
-    if (blocks1 > (int64_t)num_cu() * 8) blocks1 = (int64_t)num_cu() * 8;
-    if (blocks1 < 1) blocks1 = 1;
-    const size_t lds = sizeof(float) * 5 * (size_t)cfg->J;
+    const size_t lds = (size_t)cfg->J * (cfg->model >= VX_IRT_3PL ? 52 : 24);
+    int rc = VX_EINVAL;
 #define LAUNCH_SP(MODEL)                                                                                      \
-    hipLaunchKernelGGL((k_irt1d_sp_person<MODEL>), dim3((unsigned)blocks1), dim3(SP_THREADS), lds, st, dm, pent, glen,  \
-                       gid0, loc, raw, eps_in, cfg->seed, cfg->step, cfg->stream, a, b, c_un, d_un, gloc, graw, elbo,   \
-                       xbuf);                                                                                 \
-    hipLaunchKernelGGL((k_irt1d_sp_item<MODEL>), dim3((unsigned)cfg->J, SP_NC), dim3(SP_THREADS), 0, st, dm, ient, ioff, \
-                       xbuf, a, b, c_un, d_un, slabs)
+    rc = set_lds(k_irt1d_sp<MODEL>, lds);                                                                     \
+    if (rc) return rc;                                                                                        \
+    hipLaunchKernelGGL((k_irt1d_sp<MODEL>), dim3((unsigned)blocks), dim3(SP_THREADS), lds, st, dm, (const uint2*)pent, glen, \
+                       pidx, gid0, loc, raw, eps_in, cfg->seed, cfg->step, cfg->stream, a, b, c_un, d_un, gloc, graw,   \
+                       elbo, workspace)
     switch (cfg->model) {
         case VX_IRT_1PL: LAUNCH_SP(1); break;
         case VX_IRT_2PL: LAUNCH_SP(2); break;
@@ -1039,7 +1046,7 @@ int vx_irt1d_sparse_grad(const vx_irt_cfg* cfg, const uint16_t* pent, const int3
     }
 #undef LAUNCH_SP
     VX_CHECK_LAUNCH();
-    return vx_reduce_slabs(slabs, SP_NC, 4 * (int64_t)cfg->J, -1.0f, gitem, hs);
+    return vx_reduce_slabs(workspace, blocks, 4 * (int64_t)cfg->J, -1.0f, gitem, hs);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -111,15 +111,15 @@ class HipBackend(object):
                                   _hip.ptr(ws), _hip.stream_ptr())
         _hip.check(rc, "vx_irt1d_grad")
 
-    def irt1d_sparse_workspace(self, cfg, nb):
-        n = self.L.vx_irt1d_sparse_workspace_floats(ctypes.byref(cfg), nb)
+    def irt1d_sparse_workspace(self, cfg, n_groups):
+        n = self.L.vx_irt1d_sparse_workspace_floats(ctypes.byref(cfg), n_groups)
         if n < 0:
             raise _hip.VxError("vx_irt1d_sparse_workspace_floats: unsupported configuration (code %d)" % n)
         return n
 
-    def irt1d_sparse_grad(self, cfg, lists, nb, gid0, loc, raw, eps_in, a, b, c_un, d_un, gloc, graw, elbo, gitem, ws):
+    def irt1d_sparse_grad(self, cfg, lists, gid0, loc, raw, eps_in, a, b, c_un, d_un, gloc, graw, elbo, gitem, ws):
         rc = self.L.vx_irt1d_sparse_grad(ctypes.byref(cfg), _hip.ptr(lists["pent"]), _hip.ptr(lists["glen"]),
-                                         int(lists["L"]), _hip.ptr(lists["ient"]), _hip.ptr(lists["ioff"]), nb, gid0,
+                                         int(lists["Lq"]), _hip.ptr(lists["pidx"]), int(lists["n_groups"]), gid0,
                                          _hip.ptr(loc), _hip.ptr(raw), _hip.ptr(eps_in), _hip.ptr(a), _hip.ptr(b),
                                          _hip.ptr(c_un), _hip.ptr(d_un), _hip.ptr(gloc), _hip.ptr(graw), _hip.ptr(elbo),
                                          _hip.ptr(gitem), _hip.ptr(ws), _hip.stream_ptr())
@@ -383,8 +383,9 @@ class _EngineBase(object):
         return self._yT
 
     def _sparse_lists(self, rows):
-        """Observed-cell lists for the D = 1 kernels (include/vipsy_amd.h, vx_irt1d_sparse_grad): built once -- the
-        responses never change -- and only when most cells are missing and the batch is the whole shard."""
+        """Observed-cell lists for the D = 1 kernel (include/vipsy_amd.h, vx_irt1d_sparse_grad): built once -- the
+        responses never change -- and only when most cells are missing and the batch is the whole shard.  Persons are
+        placed in slots sorted by list length inside windows of 4096, so the 64 lists a wave walks end together."""
         if rows is not None or self.n_local == 0 or self.J > 1024 or not self.observed_lists:
             return None
         if getattr(self, "_sp", None) is None:
@@ -394,26 +395,26 @@ class _EngineBase(object):
                 self._sp = False
             else:
                 ng = (n + 63) // 64
-                cnt = torch.zeros(ng * 64, dtype=torch.int64, device=self.dev)
+                cnt = torch.full((ng * 64,), -1, dtype=torch.int64, device=self.dev)             # -1: empty slot, sorts last
                 cnt[:n] = (y != 255).sum(1)
-                L = max(1, int(cnt.max().item()))
-                pent = torch.full((ng * 64, L), -1, dtype=torch.int16, device=self.dev)          # 0xFFFF = padding
-                ar = torch.arange(L, device=self.dev)[None, :]
-                for lo in range(0, n, 65536):                                                     # bounded temporaries
-                    hi = min(n, lo + 65536)
-                    yc = y[lo:hi]
-                    order = torch.argsort((yc == 255).to(torch.uint8), dim=1, stable=True)[:, :L]  # observed items first
+                slot = torch.arange(ng * 64, device=self.dev)
+                perm = torch.argsort((slot // 4096) * (J + 2) + (J - cnt), stable=True)           # slot -> person
+                cnt_s = cnt[perm].clamp_(min=0)
+                pidx = torch.where(perm < n, perm, torch.full_like(perm, -1)).to(torch.int32).contiguous()
+                Lq = max(1, (int(cnt_s.max().item()) + 3) // 4)
+                W = min(J, 4 * Lq)
+                pent = torch.full((ng * 64, 4 * Lq), -1, dtype=torch.int16, device=self.dev)      # 0xFFFF = past the end
+                ar = torch.arange(W, device=self.dev)[None, :]
+                for lo in range(0, ng * 64, 65536):                                               # bounded temporaries
+                    hi = min(ng * 64, lo + 65536)
+                    yc = y[perm[lo:hi].clamp(max=n - 1)]
+                    order = torch.argsort((yc == 255).to(torch.uint8), dim=1, stable=True)[:, :W]  # observed items first
                     code = order.to(torch.int32) | ((torch.gather(yc, 1, order) == 1).to(torch.int32) << 15)
-                    code = torch.where(ar < cnt[lo:hi, None], code, torch.full_like(code, 0xFFFF))
-                    pent[lo:hi] = code.to(torch.int16)                                            # wraps: bit pattern kept
-                pent = pent.reshape(ng, 64, L).permute(0, 2, 1).contiguous()
-                glen = cnt.reshape(ng, 64).max(1).values.to(torch.int32).contiguous()
-                nz = (y != 255).t().nonzero()                                                     # (item, person), sorted
-                yb = (y.t()[nz[:, 0], nz[:, 1]] == 1).to(torch.int64)
-                ient = (nz[:, 1] | (yb << 31)).to(torch.int32).contiguous()                       # wraps: bit 31 = y
-                ioff = torch.zeros(J + 1, dtype=torch.int64, device=self.dev)
-                ioff[1:] = torch.cumsum(torch.bincount(nz[:, 0], minlength=J), 0)
-                self._sp = {"pent": pent, "glen": glen, "L": L, "ient": ient, "ioff": ioff, "missing": frac}
+                    code = torch.where(ar < cnt_s[lo:hi, None], code, torch.full_like(code, 0xFFFF))
+                    pent[lo:hi, :W] = code.to(torch.int16)                                        # wraps: bit pattern kept
+                pent = pent.reshape(ng, 64, Lq, 4).permute(0, 2, 1, 3).contiguous()
+                glen = ((cnt_s.reshape(ng, 64).max(1).values + 3) // 4).to(torch.int32).contiguous()
+                self._sp = {"pent": pent, "glen": glen, "Lq": Lq, "pidx": pidx, "n_groups": ng, "missing": frac}
         return self._sp or None
 
     def _buf(self, key, n):
@@ -698,8 +699,8 @@ class IrtEngine(_EngineBase):
             lists = self._sparse_lists(rows)
             with self._phase("irt1d"):
                 if lists is not None:                      # mostly-missing responses: observed cells only
-                    sp_ws = self._buf("i1d_sp_ws", be.irt1d_sparse_workspace(cfg, nb))
-                    be.irt1d_sparse_grad(cfg, lists, nb, self.gid0, loc, raw, eps, a, self.view("b"), c_un, d_un,
+                    sp_ws = self._buf("i1d_sp_ws", be.irt1d_sparse_workspace(cfg, lists["n_groups"]))
+                    be.irt1d_sparse_grad(cfg, lists, self.gid0, loc, raw, eps, a, self.view("b"), c_un, d_un,
                                          gloc, graw, elbo, g1d, sp_ws)
                 else:
                     be.irt1d_grad(cfg, self.y, rows, nb, self.gid0, loc, raw, eps, a, self.view("b"), c_un, d_un,
