@@ -154,13 +154,17 @@ int64_t vx_mvn_enc_bwd_gd_offset(const vx_irt_cfg* cfg, int64_t nb);
  *   outputs: gloc[nb], graw[nb] = d LOSS / d loc, d raw;  elbo[nb] = per-person
  *            log p(y|x) + log p(x) - log q(x) (unscaled);
  *   gitem:   d LOSS / d [a: J | b: J | c_un: J | d_un: J] for this rank's batch (a = 0 for 1PL).
- * J <= 1024.  workspace: vx_irt1d_workspace_floats(cfg, nb) floats. */
+ * J <= 1024.  workspace: vx_irt1d_workspace_floats(cfg, nb) floats.
+ * loss (or NULL): receives d LOSS itself, -scale * sum(elbo), summed in a fixed order.
+ * step_dev (or NULL): the step counter in DEVICE memory -- the kernel reads the Philox step from it instead of cfg->step,
+ * and the call ADVANCES it by one when the gradients are done (so vx_adam_step's t_dev may point at the same word: Adam's
+ * count is the step + 1).  Lets a whole step be captured once in a HIP graph and replayed. */
 int64_t vx_irt1d_workspace_floats(const vx_irt_cfg* cfg, int64_t nb);
 int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, int64_t gid0,
                   const float* loc, const float* raw, const float* eps_in,
                   const float* a, const float* b, const float* c_un, const float* d_un,
-                  float* gloc, float* graw, float* elbo, float* gitem, float* workspace,
-                  void* hip_stream);
+                  float* gloc, float* graw, float* elbo, float* gitem, float* loss, uint32_t* step_dev,
+                  float* workspace, void* hip_stream);
 
 /* ---- black-box MVN guide with per-person or shared Cholesky rows (VIRT.guide, x_feature > 1, vi.py:706-723).
  *   loc: [n_local][D];  M: [n_local][D][D] unconstrained (shared == 0) or [D][D] (shared == 1, share_cov=True)
@@ -205,7 +209,8 @@ int64_t vx_irt1d_sparse_workspace_floats(const vx_irt_cfg* cfg, int64_t n_groups
 int vx_irt1d_sparse_grad(const vx_irt_cfg* cfg, const uint16_t* pent, const int32_t* glen, int32_t Lq,
                          const int32_t* pidx, int64_t n_groups, int64_t gid0, const float* loc, const float* raw,
                          const float* eps_in, const float* a, const float* b, const float* c_un, const float* d_un,
-                         float* gloc, float* graw, float* elbo, float* gitem, float* workspace, void* hip_stream);
+                         float* gloc, float* graw, float* elbo, float* gitem, float* loss /*or NULL*/,
+                         uint32_t* step_dev /*or NULL*/, float* workspace, void* hip_stream);
 
 /* ---- HO-DINA with exact enumeration of the 2^K attribute patterns (VCHoDina / VaeCHoDina model,
  * vi.py:897-923, under TraceEnum_ELBO; guide theta ~ Normal(loc, exp(raw)), vi.py:925-934 / 968-981).
@@ -312,11 +317,14 @@ int vx_sum(const float* v, int64_t n, float alpha, float* out, float* workspace,
 
 /* ---- optimiser: torch.optim.Adam on a flat float32 buffer split into segments with their own
  * learning rate (pyro.optim.Adam with callable optim_args; vi.py:514, test.py:345-350), optional
- * 0/1 `free` mask multiplied into the gradient first (vi.py:511-512). */
+ * 0/1 `free` mask multiplied into the gradient first (vi.py:511-512).
+ * t: the 1-based step count of the bias corrections; t_dev (or NULL): the same count in DEVICE memory, read by the
+ * kernel instead of t (captured steps, see vx_irt1d_grad). */
 typedef struct vx_adam_seg { int64_t begin, end; float lr; float _pad; } vx_adam_seg;
 int vx_adam_step(float* p, const float* g, float* m, float* v, const float* free_mask /*or NULL*/,
-                 int64_t n, const vx_adam_seg* segs /*host*/, int32_t n_segs, int32_t t,
+                 int64_t n, const vx_adam_seg* segs /*host*/, int32_t n_segs, int32_t t, const uint32_t* t_dev,
                  float beta1, float beta2, float eps, void* hip_stream);
+
 
 #ifdef __cplusplus
 }

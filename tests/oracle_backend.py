@@ -37,7 +37,8 @@ class OracleBackend(object):
     def irt1d_workspace(self, cfg, nb):
         return 1
 
-    def irt1d_grad(self, cfg, y, rows, nb, gid0, loc, raw, eps_in, a, b, c_un, d_un, gloc, graw, elbo, gitem, ws):
+    def irt1d_grad(self, cfg, y, rows, nb, gid0, loc, raw, eps_in, a, b, c_un, d_un, gloc, graw, elbo, gitem, ws,
+                   loss=None):
         model, J = CODE_MODEL[cfg.model], cfg.J
         r = self._rows(rows, nb)
         yy = y.cpu().numpy()[r]
@@ -51,7 +52,10 @@ class OracleBackend(object):
         gxt = cfg.scale * (g["x"] - x)
         _put(gloc, -gxt)
         _put(graw, -(gxt * sig * eps + cfg.scale))
-        _put(elbo, ll + (-0.5 * x ** 2 + 0.5 * eps ** 2 + rw)[:, 0])
+        el = ll + (-0.5 * x ** 2 + 0.5 * eps ** 2 + rw)[:, 0]
+        _put(elbo, el)
+        if loss is not None:
+            loss[0] = -cfg.scale * float(el.sum())
         out = np.zeros(4 * J)
         if "a" in g:
             out[0:J] = -cfg.scale * g["a"].reshape(-1)

@@ -492,3 +492,29 @@ def test_trained_item_parameters_within_1e3_of_cpu_reference(amortized, D, model
         rmse = float(np.sqrt(np.mean((ph - po) ** 2)))
         assert rmse < 1e-3, (name, rmse)
         assert float(np.abs(po - (1.0 if name == "a" else 0.0)).max()) > 0.05     # the parameters did move
+
+
+@pytest.mark.parametrize("miss,model", [(0.0, "irt_4pl"), (0.9, "irt_2pl")])
+def test_captured_step_equals_eager_step(miss, model):
+    """The D = 1 full-batch step replayed from a HIP graph (step counters in device memory) against the same step
+    launched kernel by kernel: same bits, across a scheduler milestone (which captures again)."""
+    from vipsy_amd.engine import IrtEngine, LrSpec
+    rng = np.random.RandomState(3)
+    N, J = 3000, 40
+    y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+    y[rng.rand(N, J) < miss] = 255
+    out = []
+    for graph in (True, False):
+        eng = IrtEngine(torch.from_numpy(y).to(_dev()), model=model, D=1, seed=11)
+        eng.use_graph = graph
+        lrs = LrSpec(lambda m, p: {"lr": 1e-2 if p in ("a", "b") else 1e-3}, milestones=(3,), gamma=0.5)
+        losses = []
+        for _ in range(7):
+            losses.append(eng.step(lrs))
+            lrs.scheduler_step()
+        torch.cuda.synchronize()
+        assert eng.t == 7
+        assert (getattr(eng, "_graph", None) or {}).get("graph") is not None if graph else getattr(eng, "_graph", None) is None
+        out.append((torch.stack(losses).cpu().numpy(), eng.P.cpu().numpy().copy(), eng.PP.cpu().numpy().copy()))
+    for u, v in zip(out[0], out[1]):
+        assert np.array_equal(u, v)

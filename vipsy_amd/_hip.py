@@ -63,9 +63,9 @@ SIGNATURES = {
     "vx_mvn_enc_backward": (ctypes.c_int, [_CFG, _P, _P, _I64] + [_P] * 6 + [_P] * 3 + [_P, _I64] + [_P, _P, _P, _I32, _P]),
     "vx_mvn_enc_bwd_gd_offset": (_I64, [_CFG, _I64]),
     "vx_irt1d_workspace_floats": (_I64, [_CFG, _I64]),
-    "vx_irt1d_grad": (ctypes.c_int, [_CFG, _P, _P, _I64, _I64] + [_P] * 3 + [_P] * 4 + [_P] * 4 + [_P, _P]),
+    "vx_irt1d_grad": (ctypes.c_int, [_CFG, _P, _P, _I64, _I64] + [_P] * 3 + [_P] * 4 + [_P] * 4 + [_P, _P, _P, _P]),
     "vx_irt1d_sparse_workspace_floats": (_I64, [_CFG, _I64]),
-    "vx_irt1d_sparse_grad": (ctypes.c_int, [_CFG, _P, _P, _I32, _P, _I64, _I64] + [_P] * 3 + [_P] * 4 + [_P] * 4 + [_P, _P]),
+    "vx_irt1d_sparse_grad": (ctypes.c_int, [_CFG, _P, _P, _I32, _P, _I64, _I64] + [_P] * 3 + [_P] * 4 + [_P] * 4 + [_P, _P, _P, _P]),
     "vx_mvn_bbvi_forward": (ctypes.c_int, [_CFG, _I64, _P, _I64, _P, _P, _I32, _P, _P, _P, _P, _P]),
     "vx_mvn_bbvi_bwd_workspace_floats": (_I64, [_CFG, _I64, _I32]),
     "vx_mvn_bbvi_backward": (ctypes.c_int, [_CFG, _I64, _P, _P, _I32, _P, _P, _P, _P, _P, _P]),
@@ -97,7 +97,7 @@ SIGNATURES = {
     "vx_reduce_slabs": (ctypes.c_int, [_P, _I64, _I64, _F, _P, _P]),
     "vx_sum_workspace_floats": (_I64, []),
     "vx_sum": (ctypes.c_int, [_P, _I64, _F, _P, _P, _P]),
-    "vx_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, ctypes.POINTER(AdamSeg), _I32, _I32, _F, _F, _F, _P]),
+    "vx_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, ctypes.POINTER(AdamSeg), _I32, _I32, _P, _F, _F, _F, _P]),
 }
 
 _lib = None

@@ -22,10 +22,13 @@ template <int MODEL, int WPL, bool WORDS>
 __global__ __launch_bounds__(I1_THREADS) void k_irt1d(
     Irt1dDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, int64_t gid0,
     const float* __restrict__ loc, const float* __restrict__ raw, const float* __restrict__ eps_in,
-    uint64_t seed, uint32_t step, uint32_t stream, const float* __restrict__ a, const float* __restrict__ b,
-    const float* __restrict__ c_un, const float* __restrict__ d_un, float* __restrict__ gloc,
-    float* __restrict__ graw, float* __restrict__ elbo, float* __restrict__ slabs) {
+    uint64_t seed, uint32_t step, const uint32_t* __restrict__ step_dev, uint32_t stream, const float* __restrict__ a,
+    const float* __restrict__ b, const float* __restrict__ c_un, const float* __restrict__ d_un,
+    float* __restrict__ gloc, float* __restrict__ graw, float* __restrict__ elbo, float* __restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [4*J] block-level item-grad reduction
+    __shared__ float el_w[I1_THREADS / 64];
+    float el_acc = 0.f;
+    if (step_dev) step = *step_dev;                                // replayed from a HIP graph: the counter lives on the device
     constexpr int IPL = 4 * WPL;
     const int J = dm.J;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -116,11 +119,15 @@ __global__ __launch_bounds__(I1_THREADS) void k_irt1d(
             const float gxt = dm.scale * (my_gx - xv);                 // d ELBO / d x (likelihood + prior)
             gloc[i] = -gxt;
             graw[i] = -(gxt * sig * e + dm.scale);                      // + scale from the entropy term
-            elbo[i] = my_ll - 0.5f * xv * xv + 0.5f * e * e + r;        // log p(y|x) + log p(x) - log q(x)
+            const float el = my_ll - 0.5f * xv * xv + 0.5f * e * e + r; // log p(y|x) + log p(x) - log q(x)
+            elbo[i] = el;
+            el_acc += el;
         }
     }
     // block-level reduction of the item gradients, one slab per block: [a: J | b: J | c: J | d: J].  Every wave holds one
     // partial per item in the same lane: a slot per wave, then a sum in fixed order (bit-reproducible, no float atomics)
+    el_acc = wave_sum_dpp(el_acc);
+    if (lane == 0) el_w[wave] = el_acc;
     __syncthreads();
     float* wslot = smem + (size_t)(tid >> 6) * 4 * J;
     for (int e = lane; e < 4 * J; e += 64) wslot[e] = 0.f;
@@ -136,11 +143,17 @@ __global__ __launch_bounds__(I1_THREADS) void k_irt1d(
         }
     }
     __syncthreads();
-    float* slab = slabs + (int64_t)blockIdx.x * 4 * J;
+    float* slab = slabs + (int64_t)blockIdx.x * (4 * J + 1);
     for (int e = tid; e < 4 * J; e += I1_THREADS) {
         float acc = smem[e];
 #pragma unroll
         for (int w = 1; w < I1_THREADS / 64; ++w) acc += smem[(size_t)w * 4 * J + e];
         slab[e] = dm.scale * acc;
+    }
+    if (tid == 0) {                                                    // column 4 J: this block's share of the ELBO
+        float acc = el_w[0];
+#pragma unroll
+        for (int w = 1; w < I1_THREADS / 64; ++w) acc += el_w[w];
+        slab[4 * J] = dm.scale * acc;
     }
 }

@@ -17,7 +17,7 @@
 //           (no overflow by construction) and added as ONE 64-bit atomic  q_a 2^32 + q_b.  A person with |x| > SP_XB
 //           (8 prior standard deviations) takes a separate full-range 64-bit fixed-point slot for t x instead.  The
 //           3PL / 4PL asymptote gradients are unbounded (1 / P) and use full-range slots as well.
-//           One slab [a | b | c | d][J] per block, summed by k_reduce_slabs.
+//           One slab [a | b | c | d][J] (+ the block's ELBO share) per block, summed by k_reduce_wide.
 //
 // A missing cell contributes the reference's constant log Bern(0 | clamp 0) (vi.py:621-624) and no gradient: added as
 // (J - observed) * constant per person.
@@ -40,9 +40,13 @@ template <int MODEL>
 __global__ __launch_bounds__(SP_THREADS) void k_irt1d_sp(
     Irt1dSpDims dm, const uint2* __restrict__ pent /*[n_groups][Lq][64]*/, const int32_t* __restrict__ glen,
     const int32_t* __restrict__ pidx, int64_t gid0, const float* __restrict__ loc, const float* __restrict__ raw,
-    const float* __restrict__ eps_in, uint64_t seed, uint32_t step, uint32_t stream, const float* __restrict__ a,
-    const float* __restrict__ b, const float* __restrict__ c_un, const float* __restrict__ d_un,
-    float* __restrict__ gloc, float* __restrict__ graw, float* __restrict__ elbo, float* __restrict__ slabs) {
+    const float* __restrict__ eps_in, uint64_t seed, uint32_t step, const uint32_t* __restrict__ step_dev,
+    uint32_t stream, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c_un,
+    const float* __restrict__ d_un, float* __restrict__ gloc, float* __restrict__ graw, float* __restrict__ elbo,
+    float* __restrict__ slabs) {
+    if (step_dev) step = *step_dev;                                    // replayed from a HIP graph: the counter lives on the device
+    __shared__ float el_w[SP_THREADS / 64];
+    float el_acc = 0.f;
     // LDS: ab [J] float2 | acc [J] packed (t x, t) | big [J] fixed point t x | (3PL+) accc, accd [J], cs, ds, os [J] floats
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int J = dm.J;
@@ -136,11 +140,21 @@ __global__ __launch_bounds__(SP_THREADS) void k_irt1d_sp(
             const float gxt = dm.scale * (gx - x);                     // d ELBO / d x (likelihood + prior)
             gloc[i] = -gxt;
             graw[i] = -(gxt * sig * e + dm.scale);
-            elbo[i] = ll - 0.5f * x * x + 0.5f * e * e + r;
+            const float el = ll - 0.5f * x * x + 0.5f * e * e + r;
+            elbo[i] = el;
+            el_acc += el;
         }
     }
+    el_acc = wave_sum_dpp(el_acc);
+    if (lane == 0) el_w[wave] = el_acc;
     __syncthreads();
-    float* slab = slabs + (int64_t)blockIdx.x * 4 * J;
+    float* slab = slabs + (int64_t)blockIdx.x * (4 * J + 1);
+    if (tid == 0) {                                                    // column 4 J: this block's share of the ELBO
+        float acc = el_w[0];
+#pragma unroll
+        for (int w = 1; w < SP_THREADS / 64; ++w) acc += el_w[w];
+        slab[4 * J] = dm.scale * acc;
+    }
     const float ua = dm.Dc * dm.scale * dm.inv_sb * SP_XB, ub = dm.Dc * dm.scale * dm.inv_sb;
     for (int j = tid; j < J; j += SP_THREADS) {
         const long long s = acc[j];

@@ -49,6 +49,35 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ 
     }
 }
 
+// Many slabs, few columns, and the tail of a D = 1 step folded in: block = 32 columns x 32 slab groups (group g sums
+// slabs g, g + 32, ... in ascending order; the 32 group sums are added in ascending order) -> deterministic.  The last
+// column may go to its own address (the loss slot), and the step counter of a captured step advances here.
+__global__ __launch_bounds__(1024) void k_reduce_wide(const float* __restrict__ slabs, int64_t n_slabs, int64_t stride,
+                                                      int64_t len, float alpha, float* __restrict__ out,
+                                                      float* __restrict__ last_out, uint32_t* __restrict__ tick) {
+    __shared__ float part[32][33];
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    if (tick && blockIdx.x == 0 && threadIdx.x == 0) *tick += 1u;
+    for (int64_t c0 = (int64_t)blockIdx.x * 32; c0 < len; c0 += (int64_t)gridDim.x * 32) {
+        const int64_t i = c0 + col;
+        float acc = 0.f;
+        if (i < len) {
+#pragma unroll 4
+            for (int64_t s = grp; s < n_slabs; s += 32) acc += slabs[s * stride + i];
+        }
+        part[grp][col] = acc;
+        __syncthreads();
+        if (grp == 0 && i < len) {
+            float t = part[0][col];
+#pragma unroll
+            for (int g = 1; g < 32; ++g) t += part[g][col];
+            if (last_out && i == len - 1) last_out[0] = alpha * t;
+            else out[i] = alpha * t;
+        }
+        __syncthreads();
+    }
+}
+
 // few slabs, long rows (the 4 item-chunk partials of gx at 1M persons: 2 GB): 16-byte streaming loads, slabs added in
 // ascending order -> deterministic; HBM-bound
 __global__ __launch_bounds__(256) void k_reduce_few(const float4* __restrict__ slabs, int n_slabs, int64_t stride4,
@@ -100,7 +129,20 @@ struct AdamSegs { int64_t begin[VX_MAX_SEGS]; int64_t end[VX_MAX_SEGS]; float lr
 // torch.optim.Adam: p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                        float* __restrict__ v, const float* __restrict__ free_mask, int64_t n, AdamSegs segs,
-                       float beta1, float beta2, float eps, float bc1, float bc2_sqrt) {
+                       float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
+                       const uint32_t* __restrict__ t_dev) {
+    if (t_dev) {
+        // replayed from a HIP graph: the step count lives in device memory; the bias corrections are made here, in
+        // double like the host makes them, once per block
+        __shared__ float bc[2];
+        if (threadIdx.x == 0) {
+            const double t = (double)*t_dev;
+            bc[0] = (float)(1.0 - pow((double)beta1, t));
+            bc[1] = (float)sqrt(1.0 - pow((double)beta2, t));
+        }
+        __syncthreads();
+        bc1 = bc[0]; bc2_sqrt = bc[1];
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float lr = 0.f;
         bool found = false;

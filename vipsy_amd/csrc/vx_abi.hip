@@ -24,6 +24,8 @@
 #include "k_synth.hip"
 #include "k_vaeccdm.hip"
 
+#include <unordered_map>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -44,13 +46,21 @@ int num_cu() {
     return g_num_cu;
 }
 
-template <typename K>
-int set_lds(K kernel, size_t bytes) {
+// the attribute is raised once per kernel and size (not per launch: nothing but launches inside a stream capture)
+inline int set_lds_ptr(const void* kernel, size_t bytes) {
     if (bytes > 160 * 1024) return VX_EINVAL;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    return e == hipSuccess ? VX_OK : (int)e;
+    static std::mutex mu;
+    static std::unordered_map<const void*, size_t> have;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = have.find(kernel);
+    if (it != have.end() && it->second >= bytes) return VX_OK;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    have[kernel] = bytes;
+    return VX_OK;
 }
+template <typename K>
+int set_lds(K kernel, size_t bytes) { return set_lds_ptr(reinterpret_cast<const void*>(kernel), bytes); }
 
 inline int grid_1d(int64_t n, int block) {
     int64_t g = (n + block - 1) / block;
@@ -230,6 +240,16 @@ int vx_reduce_slabs(const float* slabs, int64_t n_slabs, int64_t len, float alph
     return VX_OK;
 }
 
+// the tail of a D = 1 step: slabs of [4 J item gradients | ELBO share] -> gitem, loss; the device step counter advances
+static int reduce_step_slabs(const float* slabs, int64_t n_slabs, int J, float* gitem, float* loss, uint32_t* tick,
+                             void* hs) {
+    const int64_t len = 4 * (int64_t)J + (loss ? 1 : 0);
+    hipLaunchKernelGGL(k_reduce_wide, dim3(grid_1d(len, 32)), dim3(1024), 0, (hipStream_t)hs, slabs, n_slabs,
+                       4 * (int64_t)J + 1, len, -1.0f, gitem, loss, tick);
+    VX_CHECK_LAUNCH();
+    return VX_OK;
+}
+
 int64_t vx_sum_workspace_floats(void) { return 1024; }
 
 int vx_sum(const float* v, int64_t n, float alpha, float* out, float* workspace, void* hs) {
@@ -245,19 +265,19 @@ int vx_sum(const float* v, int64_t n, float alpha, float* out, float* workspace,
 }
 
 int vx_adam_step(float* p, const float* g, float* m, float* v, const float* free_mask, int64_t n,
-                 const vx_adam_seg* segs, int32_t n_segs, int32_t t, float beta1, float beta2, float eps,
-                 void* hs) {
-    if (!p || !g || !m || !v || !segs || n_segs < 1 || n_segs > VX_MAX_SEGS || t < 1) return VX_EINVAL;
+                 const vx_adam_seg* segs, int32_t n_segs, int32_t t, const uint32_t* t_dev, float beta1, float beta2,
+                 float eps, void* hs) {
+    if (!p || !g || !m || !v || !segs || n_segs < 1 || n_segs > VX_MAX_SEGS || (t < 1 && !t_dev)) return VX_EINVAL;
     AdamSegs s;
     s.n = n_segs;
     for (int i = 0; i < n_segs; ++i) {
         if (segs[i].begin < 0 || segs[i].end > n || segs[i].begin > segs[i].end) return VX_EINVAL;
         s.begin[i] = segs[i].begin; s.end[i] = segs[i].end; s.lr[i] = segs[i].lr;
     }
-    const double bc1 = 1.0 - pow((double)beta1, (double)t);
-    const double bc2 = 1.0 - pow((double)beta2, (double)t);
+    const double bc1 = 1.0 - pow((double)beta1, (double)(t_dev ? 1 : t));
+    const double bc2 = 1.0 - pow((double)beta2, (double)(t_dev ? 1 : t));
     hipLaunchKernelGGL(k_adam, dim3(grid_1d(n, 256)), dim3(256), 0, (hipStream_t)hs, p, g, m, v, free_mask, n, s,
-                       beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+                       beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), t_dev);
     VX_CHECK_LAUNCH();
     return VX_OK;
 }
@@ -957,13 +977,13 @@ static bool irt1d_cfg_ok(const vx_irt_cfg* cfg) {
 
 int64_t vx_irt1d_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
     if (!irt1d_cfg_ok(cfg) || nb < 0) return VX_EINVAL;
-    return (int64_t)irt1d_blocks(nb) * 4 * cfg->J;
+    return (int64_t)irt1d_blocks(nb) * (4 * cfg->J + 1);
 }
 
 int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, int64_t gid0,
                   const float* loc, const float* raw, const float* eps_in, const float* a, const float* b,
                   const float* c_un, const float* d_un, float* gloc, float* graw, float* elbo, float* gitem,
-                  float* workspace, void* hs) {
+                  float* loss, uint32_t* step_dev, float* workspace, void* hs) {
     if (!irt1d_cfg_ok(cfg) || !y || !loc || !raw || !b || !gloc || !graw || !elbo || !gitem || !workspace || nb < 0)
         return VX_EINVAL;
     if (cfg->model >= VX_IRT_2PL && !a) return VX_EINVAL;
@@ -978,7 +998,7 @@ int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, 
     const int words_ok = (cfg->J % 4 == 0 && aligned16(y)) ? 1 : 0;     // 4-byte response loads need aligned rows
 #define LAUNCH_1DW(MODEL, WPL, WORDS)                                                                         \
     hipLaunchKernelGGL((k_irt1d<MODEL, WPL, WORDS>), dim3(blocks), dim3(I1_THREADS), lds, st, dm, y, rows, gid0, loc, \
-                       raw, eps_in, cfg->seed, cfg->step, cfg->stream, a, b, c_un, d_un, gloc, graw, elbo, workspace)
+                       raw, eps_in, cfg->seed, cfg->step, step_dev, cfg->stream, a, b, c_un, d_un, gloc, graw, elbo, workspace)
 #define LAUNCH_1D(MODEL, WPL)                                      \
     if (words_ok) { LAUNCH_1DW(MODEL, WPL, true); } else { LAUNCH_1DW(MODEL, WPL, false); }
 #define DISPATCH_IPL(MODEL)                                        \
@@ -995,7 +1015,7 @@ int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, 
 #undef LAUNCH_1D
 #undef LAUNCH_1DW
     VX_CHECK_LAUNCH();
-    return vx_reduce_slabs(workspace, blocks, 4 * (int64_t)cfg->J, -1.0f, gitem, hs);
+    return reduce_step_slabs(workspace, blocks, cfg->J, gitem, loss, step_dev, hs);
 }
 
 // ---- D = 1 on the host-compacted lists of observed cells (k_irt1d_sparse.hip); full batch only
@@ -1007,13 +1027,14 @@ static int irt1d_sp_blocks(int64_t n_groups) {
 
 int64_t vx_irt1d_sparse_workspace_floats(const vx_irt_cfg* cfg, int64_t n_groups) {
     if (!irt1d_cfg_ok(cfg) || n_groups < 0) return VX_EINVAL;
-    return (int64_t)irt1d_sp_blocks(n_groups) * 4 * cfg->J;                                // one slab per block
+    return (int64_t)irt1d_sp_blocks(n_groups) * (4 * cfg->J + 1);                          // one slab per block
 }
 
 int vx_irt1d_sparse_grad(const vx_irt_cfg* cfg, const uint16_t* pent, const int32_t* glen, int32_t Lq,
                          const int32_t* pidx, int64_t n_groups, int64_t gid0, const float* loc, const float* raw,
                          const float* eps_in, const float* a, const float* b, const float* c_un, const float* d_un,
-                         float* gloc, float* graw, float* elbo, float* gitem, float* workspace, void* hs) {
+                         float* gloc, float* graw, float* elbo, float* gitem, float* loss, uint32_t* step_dev,
+                         float* workspace, void* hs) {
     if (!irt1d_cfg_ok(cfg) || !pent || !glen || !pidx || Lq < 0 || !loc || !raw || !b || !gloc || !graw || !elbo ||
         !gitem || !workspace || n_groups < 0 || cfg->J > 32767)
         return VX_EINVAL;
@@ -1036,8 +1057,8 @@ int vx_irt1d_sparse_grad(const vx_irt_cfg* cfg, const uint16_t* pent, const int3
     rc = set_lds(k_irt1d_sp<MODEL>, lds);                                                                     \
     if (rc) return rc;                                                                                        \
     hipLaunchKernelGGL((k_irt1d_sp<MODEL>), dim3((unsigned)blocks), dim3(SP_THREADS), lds, st, dm, (const uint2*)pent, glen, \
-                       pidx, gid0, loc, raw, eps_in, cfg->seed, cfg->step, cfg->stream, a, b, c_un, d_un, gloc, graw,   \
-                       elbo, workspace)
+                       pidx, gid0, loc, raw, eps_in, cfg->seed, cfg->step, step_dev, cfg->stream, a, b, c_un, d_un, gloc,   \
+                       graw, elbo, workspace)
     switch (cfg->model) {
         case VX_IRT_1PL: LAUNCH_SP(1); break;
         case VX_IRT_2PL: LAUNCH_SP(2); break;
@@ -1046,7 +1067,7 @@ int vx_irt1d_sparse_grad(const vx_irt_cfg* cfg, const uint16_t* pent, const int3
     }
 #undef LAUNCH_SP
     VX_CHECK_LAUNCH();
-    return vx_reduce_slabs(workspace, blocks, 4 * (int64_t)cfg->J, -1.0f, gitem, hs);
+    return reduce_step_slabs(workspace, blocks, cfg->J, gitem, loss, step_dev, hs);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -104,11 +104,12 @@ class HipBackend(object):
             raise _hip.VxError("vx_irt1d_workspace_floats: unsupported configuration (code %d)" % n)
         return n
 
-    def irt1d_grad(self, cfg, y, rows, nb, gid0, loc, raw, eps_in, a, b, c_un, d_un, gloc, graw, elbo, gitem, ws):
+    def irt1d_grad(self, cfg, y, rows, nb, gid0, loc, raw, eps_in, a, b, c_un, d_un, gloc, graw, elbo, gitem, ws,
+                   loss=None, step_dev=None):
         rc = self.L.vx_irt1d_grad(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb, gid0, _hip.ptr(loc),
                                   _hip.ptr(raw), _hip.ptr(eps_in), _hip.ptr(a), _hip.ptr(b), _hip.ptr(c_un),
                                   _hip.ptr(d_un), _hip.ptr(gloc), _hip.ptr(graw), _hip.ptr(elbo), _hip.ptr(gitem),
-                                  _hip.ptr(ws), _hip.stream_ptr())
+                                  _hip.ptr(loss), _hip.ptr(step_dev), _hip.ptr(ws), _hip.stream_ptr())
         _hip.check(rc, "vx_irt1d_grad")
 
     def irt1d_sparse_workspace(self, cfg, n_groups):
@@ -117,12 +118,14 @@ class HipBackend(object):
             raise _hip.VxError("vx_irt1d_sparse_workspace_floats: unsupported configuration (code %d)" % n)
         return n
 
-    def irt1d_sparse_grad(self, cfg, lists, gid0, loc, raw, eps_in, a, b, c_un, d_un, gloc, graw, elbo, gitem, ws):
+    def irt1d_sparse_grad(self, cfg, lists, gid0, loc, raw, eps_in, a, b, c_un, d_un, gloc, graw, elbo, gitem, ws,
+                          loss=None, step_dev=None):
         rc = self.L.vx_irt1d_sparse_grad(ctypes.byref(cfg), _hip.ptr(lists["pent"]), _hip.ptr(lists["glen"]),
                                          int(lists["Lq"]), _hip.ptr(lists["pidx"]), int(lists["n_groups"]), gid0,
                                          _hip.ptr(loc), _hip.ptr(raw), _hip.ptr(eps_in), _hip.ptr(a), _hip.ptr(b),
                                          _hip.ptr(c_un), _hip.ptr(d_un), _hip.ptr(gloc), _hip.ptr(graw), _hip.ptr(elbo),
-                                         _hip.ptr(gitem), _hip.ptr(ws), _hip.stream_ptr())
+                                         _hip.ptr(gitem), _hip.ptr(loss), _hip.ptr(step_dev), _hip.ptr(ws),
+                                         _hip.stream_ptr())
         _hip.check(rc, "vx_irt1d_sparse_grad")
 
     def mvn_bbvi_forward(self, cfg, nb, rows, gid0, loc, M, shared, eps_in, x, eps, ent):
@@ -266,10 +269,10 @@ class HipBackend(object):
         rc = self.L.vx_sum(_hip.ptr(v), n, alpha, _hip.ptr(out), _hip.ptr(ws), _hip.stream_ptr())
         _hip.check(rc, "vx_sum")
 
-    def adam(self, p, g, m, v, free, n, segs, t, betas=(0.9, 0.999), eps=1e-8):
+    def adam(self, p, g, m, v, free, n, segs, t, betas=(0.9, 0.999), eps=1e-8, t_dev=None):
         arr = (_hip.AdamSeg * len(segs))(*[_hip.AdamSeg(b, e, lr, 0.0) for (b, e, lr) in segs])
         rc = self.L.vx_adam_step(_hip.ptr(p), _hip.ptr(g), _hip.ptr(m), _hip.ptr(v), _hip.ptr(free), n, arr,
-                                 len(segs), t, betas[0], betas[1], eps, _hip.stream_ptr())
+                                 len(segs), t, _hip.ptr(t_dev), betas[0], betas[1], eps, _hip.stream_ptr())
         _hip.check(rc, "vx_adam_step")
 
     def philox_normals(self, out, gids, gid0, n, D, seed, step, stream):
@@ -464,21 +467,63 @@ class _EngineBase(object):
             o = self.off[name]
             by_hyper.setdefault(lrs.hyper_of(name), []).append(
                 (o, o + int(np.prod(self.shape[name])), float(lrs.lr_of(name))))
+        sd = getattr(self, "_step_dev", None)
+        kw = {"t_dev": sd} if sd is not None else {}         # captured step: Adam's t = the (already advanced) device counter
         for (betas, eps), segs in by_hyper.items():         # one launch per distinct (betas, eps): normally one
-            self.be.adam(self.P, self.G, self.M, self.V, self.free, self.n_params, _merge_segments(segs), self.t, betas, eps)
+            self.be.adam(self.P, self.G, self.M, self.V, self.free, self.n_params, _merge_segments(segs), self.t, betas, eps, **kw)
         if self.per_person:
             by_hyper = {}
             for nme, o in self.pp_off.items():
                 by_hyper.setdefault(lrs.hyper_of(nme), []).append(
                     (o, o + int(np.prod(self.pp_shape[nme])), float(lrs.lr_of(nme))))
             for (betas, eps), segs in by_hyper.items():
-                self.be.adam(self.PP, self.GP, self.MP, self.VP, None, self.pp_len, _merge_segments(segs), self.t, betas, eps)
+                self.be.adam(self.PP, self.GP, self.MP, self.VP, None, self.pp_len, _merge_segments(segs), self.t, betas, eps, **kw)
+
+    # -- the whole step as one HIP graph ---------------------------------------------------------
+    # A D = 1 full-batch step is a handful of 10-100 us kernels: launched one by one the host (Python + ctypes, ~10 us a
+    # launch) is slower than the GPU.  Nothing in such a step changes from call to call except the step count (Philox
+    # counter, Adam bias corrections), which the kernels can read from device memory -- so the step is captured once
+    # and replayed.  A new learning rate (scheduler milestone) captures again.
+    use_graph = True
+
+    def _graphable(self):
+        return (self.use_graph and getattr(self, "D", 0) == 1 and not getattr(self, "amortized", True)
+                and self.group is None and self.events is None and isinstance(self.be, HipBackend))
+
+    def _step_graph(self, lrs):
+        st = self._graph
+        key = (id(lrs), sum(1 for m in lrs.milestones if m <= lrs.epoch))
+        if st["graph"] is None or st["key"] != key:
+            ctr = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            t0 = self.t
+            self._step_dev = ctr
+            try:
+                with torch.cuda.graph(g):
+                    self.loss_and_grads(None, None, None, 0)  # reads the counter as the Philox step, then advances it
+                    self.apply_optim(lrs)                     # reads it as Adam's t
+            finally:
+                self._step_dev = None
+                self.t = t0                                  # capture records, it does not run
+            st.update(graph=g, key=key, ctr=ctr, ctr_t=None)
+        if st["ctr_t"] != self.t:                            # (re)seed the device counter
+            st["ctr"].fill_(self.t)
+        st["graph"].replay()
+        self.t += 1
+        st["ctr_t"] = self.t
+        return self.G[self.n_params].clone()                 # the optimiser does not touch the loss slot
 
     def step(self, lrs, rows=None, b_global=None, eps=None, num_particles=1):
         """loss_and_grads + optimiser, the body of SVI.step (vi.py:505-516).  `rows` (and `eps`) may be
         lists with one entry per particle: every particle draws its own subsample.
         Returns the loss as a 0-d device tensor (no host sync)."""
         S = int(num_particles)
+        if (S == 1 and rows is None and eps is None and (b_global is None or int(b_global) == self.N)
+                and self._graphable()):
+            if getattr(self, "_graph", None) is not None:
+                return self._step_graph(lrs)
+            self._graph = {"graph": None}                    # the first step runs eagerly: workspaces and lists get built
         if S == 1:
             self.loss_and_grads(rows[0] if isinstance(rows, (list, tuple)) else rows, b_global,
                                 eps[0] if isinstance(eps, (list, tuple)) else eps, 0)
@@ -683,7 +728,8 @@ class IrtEngine(_EngineBase):
             torch.add(tmp[0:1], tmp[1:2], out=lossslot)
             self.last = {"fw": fw, "gx": gx, "gxT": gxT, "ll": ll, "nb": nb}
         else:
-            g1d, i1d_ws = self._buf("g1d", 4 * self.J), self._buf("i1d_ws", be.irt1d_workspace(cfg, nb))
+            # D = 1: the flat item layout [a: J | b: J | c: J | d: J] IS the kernels' gradient layout -> written in place
+            g1d, i1d_ws = gitem, self._buf("i1d_ws", be.irt1d_workspace(cfg, nb))
             elbo = self._buf("elbo", nb)
             if self.amortized:
                 H = self.H
@@ -697,18 +743,16 @@ class IrtEngine(_EngineBase):
             else:
                 loc, raw, gloc, graw = self._gather_pp(rows, nb)
             lists = self._sparse_lists(rows)
+            sd = getattr(self, "_step_dev", None)
+            sdk = {"step_dev": sd} if sd is not None else {}          # captured step: the step count lives in device memory
             with self._phase("irt1d"):
                 if lists is not None:                      # mostly-missing responses: observed cells only
                     sp_ws = self._buf("i1d_sp_ws", be.irt1d_sparse_workspace(cfg, lists["n_groups"]))
                     be.irt1d_sparse_grad(cfg, lists, self.gid0, loc, raw, eps, a, self.view("b"), c_un, d_un,
-                                         gloc, graw, elbo, g1d, sp_ws)
+                                         gloc, graw, elbo, g1d, sp_ws, loss=lossslot, **sdk)
                 else:
                     be.irt1d_grad(cfg, self.y, rows, nb, self.gid0, loc, raw, eps, a, self.view("b"), c_un, d_un,
-                                  gloc, graw, elbo, g1d, i1d_ws)
-            J = self.J
-            gitem.zero_()
-            gitem[self.off["a"]:self.off["a"] + J].copy_(g1d[0:J])
-            gitem[self.off["b"]:self.off["b"] + 3 * J].copy_(g1d[J:4 * J])
+                                  gloc, graw, elbo, g1d, i1d_ws, loss=lossslot, **sdk)
             if self.amortized:
                 with self._phase("guide_backward"):
                     be.norm_enc_backward(cfg, self.y, rows, nb, enc, fw["h"], gloc, graw,
@@ -716,8 +760,7 @@ class IrtEngine(_EngineBase):
                                          yT=self._item_major_y(rows))
             else:
                 self._scatter_pp(rows, nb, gloc, graw)
-            be.sum_into(elbo, nb, -scale, lossslot, self.sum_ws)
-            self.last = {"elbo": elbo, "nb": nb}
+            self.last = {"elbo": elbo, "nb": nb}                # the loss itself came out of the kernel's reduction
 
 
 class HoDinaEngine(_EngineBase):
