@@ -330,6 +330,9 @@ print("RESULT" + json.dumps(out))
     (200, 70, 9, 0.1, None, False),                  # 512 patterns: 8 per lane
     (150, 40, 10, 0.0, 50, True),                    # 1024 patterns, amortized guide
     (100, 9, 1, 0.3, None, True),
+    (333, 32, 5, 0.2, 77, False),                    # 5 <= K <= 8, J <= 32: the MFMA kernel (k_hodina_m.hip), one pattern tile
+    (260, 17, 6, 0.3, None, True),                   # ... two tiles, amortized guide
+    (131, 25, 7, 0.1, None, False),                  # ... four tiles; large lambda: clamped prior probabilities
 ])
 def test_hodina_step_vs_oracle(N, J, K, miss, B, amort):
     from vipsy_amd.engine import HoDinaEngine, ENC_KEYS
@@ -339,7 +342,8 @@ def test_hodina_step_vs_oracle(N, J, K, miss, B, amort):
     y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
     y[rng.rand(N, J) < miss] = 255
     eng = HoDinaEngine(torch.from_numpy(y).to(_dev()), q, amortized=amort, H=64, seed=9)
-    eng.unconstrained("lam0").copy_(torch.from_numpy(0.5 * rng.randn(1, K)).float())
+    lam_sc = 4.0 if K == 7 else 1.0
+    eng.unconstrained("lam0").copy_(torch.from_numpy(lam_sc * 0.5 * rng.randn(1, K)).float())
     eng.unconstrained("lam1").copy_(torch.from_numpy(0.4 * rng.randn(1, K)).float())
     eng.unconstrained("g").add_(torch.from_numpy(0.5 * rng.randn(1, J)).float().to(_dev()))
     eng.unconstrained("s").add_(torch.from_numpy(0.5 * rng.randn(1, J)).float().to(_dev()))

@@ -13,6 +13,7 @@
 #include "k_irt1d.hip"
 #include "k_irt1d_sparse.hip"
 #include "k_hodina.hip"
+#include "k_hodina_m.hip"
 #include "k_norm_enc.hip"
 #include "k_mvn_bbvi.hip"
 #include "k_mvn_bwd_t.hip"
@@ -1268,8 +1269,24 @@ int vx_hodina_grad(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t* ro
     dm.K = cfg->K; dm.J = cfg->J; dm.C = 1 << cfg->K; dm.scale = cfg->scale; dm.nb = nb;
     dm.uniform_prior = 0; dm.dino = 0; dm.unmasked = 0;
     const int len = 2 * cfg->J + 2 * cfg->K;
-    const size_t lds = hodina_lds_bytes(dm.C, len);
     hipStream_t st = (hipStream_t)hs;
+    if (cfg->K >= 5 && cfg->K <= 8 && cfg->J <= 32) {
+        // the pattern contractions on the bf16 MFMA, 32 persons per wave (k_hodina_m.hip); same slab layout
+        const int NT = dm.C / 32;
+        const size_t ldsm = hm_lds_bytes(NT);
+        const int blocks_m = blocks < 2 * num_cu() ? blocks : 2 * num_cu();   // persistent (two blocks a CU): the operand images are built per block
+        int rc = VX_EINVAL;
+#define LAUNCH_HM(N)                                                                                          \
+    rc = set_lds(k_hodina_m<N>, ldsm);                                                                        \
+    if (rc) return rc;                                                                                        \
+    hipLaunchKernelGGL((k_hodina_m<N>), dim3(blocks_m), dim3(HM_THREADS), ldsm, st, dm, y, rows, gid0, loc, raw, eps_in, \
+                       cfg->seed, cfg->step, cfg->stream, q, lam0, lam1_un, g_un, s_un, gloc, graw, elbo, workspace)
+        if (NT == 1) { LAUNCH_HM(1); } else if (NT == 2) { LAUNCH_HM(2); } else if (NT == 4) { LAUNCH_HM(4); } else { LAUNCH_HM(8); }
+#undef LAUNCH_HM
+        VX_CHECK_LAUNCH();
+        return vx_reduce_slabs(workspace, blocks_m, len, -1.0f, gitem, hs);
+    }
+    const size_t lds = hodina_lds_bytes(dm.C, len);
     const int logcpl = cfg->K <= 8 ? 2 : (cfg->K == 9 ? 3 : 4);
     const int jpl = (cfg->J + 63) / 64;
 #define LAUNCH_HD(L, JP)                                                                                      \
