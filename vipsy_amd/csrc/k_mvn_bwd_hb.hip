@@ -92,7 +92,7 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
     const int64_t i0 = ((int64_t)blockIdx.x * HB_WAVES + wave) * 32;
     const int64_t i = i0 + l31;
     const int64_t ic = i < nb ? i : nb - 1;                            // absent persons: a valid one, never stored
-    const int n_units = hb_units(D), n_pairs = (n_units + 1) / 2;
+    const int n_units = hb_units(D);
     const int ns = (D + 15) / 16;
 
     // ---- weight ring: pair q = units 2q, 2q + 1 -> slots (2q) % 8, (2q + 1) % 8; this wave moves pieces w, w + 4, w + 8

@@ -301,13 +301,8 @@ __global__ __launch_bounds__(BH_THREADS, 1) void k_mvn_enc_bwd_h_t(
     const float* __restrict__ h_in, const float* __restrict__ eps_in, const float* __restrict__ ldT,
     const float* __restrict__ gxT, const float* __restrict__ gdT /*DIAG-row operand [D][nb]*/,
     float* __restrict__ ghpre_out /*[nb][64] or null*/,
-    const float* __restrict__ hT /*[64][nb], with ghpreT_out*/, float* __restrict__ ghpreT_out /*[64][nb] or null*/,
-    long long* __restrict__ stamps /*timing experiments only, normally null*/) {
+    const float* __restrict__ hT /*[64][nb], with ghpreT_out*/, float* __restrict__ ghpreT_out /*[64][nb] or null*/) {
     extern __shared__ __attribute__((aligned(16))) char smem_bh[];
-    auto stamp = [&](int idx) {
-        if (stamps && threadIdx.x == 0 && blockIdx.x < 2048) stamps[blockIdx.x * 8 + idx] = (long long)__builtin_amdgcn_s_memtime();
-    };
-    stamp(0);
     constexpr int H = 64;
     const int D = dm.D, ES = bh_es(D);
     const int64_t nb = dm.nb;
@@ -461,7 +456,6 @@ __global__ __launch_bounds__(BH_THREADS, 1) void k_mvn_enc_bwd_h_t(
         __syncthreads();
         if (tile + 2 < n_tiles) stage_w(tile + 2, (tile + 2) % BH_NBUF);
     };
-    stamp(1);
     int tile = 0;
     for (; tile + 2 < n_off; tile += 3) {
         wait_tile(tile);
@@ -471,7 +465,6 @@ __global__ __launch_bounds__(BH_THREADS, 1) void k_mvn_enc_bwd_h_t(
         wait_tile(tile + 2);
         off_tile(std::integral_constant<int, 2>{}, tile + 2);
     }
-    stamp(2);
     __syncthreads();                                                   // every wave is done with eps
     stage_gd();
     for (; tile < n_tiles; ++tile) {
@@ -484,7 +477,6 @@ __global__ __launch_bounds__(BH_THREADS, 1) void k_mvn_enc_bwd_h_t(
         }
         tail_tile(tile % BH_NBUF, tile);
     }
-    stamp(3);
     // ---- ghpre = gh * softplus'(pre) = gh * (1 - exp(-h));  C layout: rows hh = crow32(r, half), cols p
     if (ghpreT_out) {                                                  // dimension-major: 128-byte rows per half-wave
         if (i < nb) {
@@ -511,7 +503,6 @@ __global__ __launch_bounds__(BH_THREADS, 1) void k_mvn_enc_bwd_h_t(
                 *(float4*)(ghpre_out + i * H + hh0) = o;
             }
     }
-    stamp(4);
 }
 
 // ------------------------------------------------------------------------------------------------------------

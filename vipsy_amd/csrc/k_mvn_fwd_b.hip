@@ -131,8 +131,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     const uint32_t* __restrict__ gt2, const float* __restrict__ eps_in, uint64_t seed, uint32_t step, uint32_t stream, float* __restrict__ h_out,
     float* __restrict__ x_out, float* __restrict__ eps_out, float* __restrict__ ldT, float* __restrict__ ent_out,
     float* __restrict__ hT_out /*[64][nb] or null*/, float* __restrict__ epsT_out /*[D][nb] or null*/,
-    uint8_t* __restrict__ ximg_out /*bf16x3 tile images of x for k_irt_lik_b (k_irt_lik_b.hip), or null*/,
-    long long* __restrict__ stamps /*timing experiments only, normally null*/) {
+    uint8_t* __restrict__ ximg_out /*bf16x3 tile images of x for k_irt_lik_b (k_irt_lik_b.hip), or null*/) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
     constexpr int H = 64;
@@ -140,10 +139,6 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     const int DS = pk_dse(D), DX = (D + 3) & ~3;
     const int YS = ef_ys(J);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    auto stamp = [&](int idx) {
-        if (stamps && tid == 0 && blockIdx.x < 2048) stamps[blockIdx.x * 8 + idx] = (long long)__builtin_amdgcn_s_memtime();
-    };
-    stamp(0);
     const int half = lane >> 5, l31 = lane & 31;
     float* R1 = smem + wave * enc_p_wave_floats(D, J);
     int8_t* Yi = (int8_t*)R1;                                 // phase A
@@ -238,7 +233,6 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         }
     }
     __builtin_amdgcn_wave_barrier();
-    stamp(1);
     // ---------------------------------------------------------------- phase A: fc1 (+ softplus), both hidden tiles
     bf16x8 hb[3][4];                                          // [split][k-step]: B fragments of every head tile
     {
@@ -315,7 +309,6 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         }
     }
     __builtin_amdgcn_wave_barrier();                          // response bytes no longer needed
-    stamp(2);
     // ---------------------------------------------------------------- eps (zero padded to DS), x := 0
     {
         for (int e = lane; e < FB_WP * (DS + DX); e += 64) R1[e] = 0.f;
@@ -402,7 +395,6 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     // completion latency of the output stores above (h, hT, eps, epsT; measured: no difference either way).  Stores
     // still outstanding only make the counted waits of the first iterations stricter.
     __syncthreads();
-    stamp(3);
     TileRegs RA, RB;
     pull(RA, 0);
     f32x16 accP = zero16();                                    // accumulator of the tile before the current one
@@ -461,7 +453,6 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         epi_group(accP, E.e4[2], codeP.z, 2);
         epi_group(accP, E.e4[3], codeP.w, 3);
     }
-    stamp(4);
     // ---- DIAG section (exp(M_kk) eps_k, entropy, ldT) and LOC section (the loc head): 2 * n_sec tiles; RA holds the
     // first of them.  The 16 x entries a lane updates are read together, updated and written together.
     auto tile_sec = [&](const f32x16& a, int t2) __attribute__((always_inline)) {
@@ -505,7 +496,6 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     }
     vx_wait_vmem();                                            // no DMA may still be in flight when the LDS is released
     __builtin_amdgcn_wave_barrier();
-    stamp(5);
     // ---------------------------------------------------------------- write x, entropy part
     if (ximg_out && i0 < (dm.nb + 63) / 64 * 64) {
         // the likelihood kernel's operand: x_aug = [x, 1, 0..] as three bf16 terms, in its LDS tile order (lb_xoff): this
@@ -554,5 +544,4 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
             ent_out[i] = 0.5f * s + ent_acc;                  // -log q + const = 0.5|eps|^2 + sum_k M_kk
         }
     }
-    stamp(6);
 }

@@ -38,8 +38,7 @@ __global__ __launch_bounds__(EP_THREADS, 1) void k_mvn_enc_fwd_p(
     const float* __restrict__ bp, const uint32_t* __restrict__ gtab, const float* __restrict__ eps_in,
     uint64_t seed, uint32_t step, uint32_t stream, float* __restrict__ h_out, float* __restrict__ x_out,
     float* __restrict__ eps_out, float* __restrict__ ldT, float* __restrict__ ent_out,
-    float* __restrict__ hT_out /*[64][nb] or null*/, float* __restrict__ epsT_out /*[D][nb] or null*/,
-    long long* __restrict__ stamps /*timing experiments only, normally null*/) {
+    float* __restrict__ hT_out /*[64][nb] or null*/, float* __restrict__ epsT_out /*[D][nb] or null*/) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int H = 64;
     const int D = dm.D, J = dm.J;
@@ -54,10 +53,6 @@ __global__ __launch_bounds__(EP_THREADS, 1) void k_mvn_enc_fwd_p(
     const int p = l31;
     const int64_t i = i0 + p;
     if (i0 >= dm.nb) return;                                  // waves share nothing: no workgroup barrier below
-    auto stamp = [&](int idx) {
-        if (stamps && tid == 0 && blockIdx.x < 2048) stamps[blockIdx.x * 8 + idx] = (long long)__builtin_amdgcn_s_memtime();
-    };
-    stamp(0);
 
     // ---------------------------------------------------------------- stage this wave's response rows (bytes)
     // Dense mode (no row gather, J / 4 odd, not the last rows of y): the wave's 32 rows are one contiguous run of
@@ -98,7 +93,6 @@ __global__ __launch_bounds__(EP_THREADS, 1) void k_mvn_enc_fwd_p(
         }
     }
     __builtin_amdgcn_wave_barrier();
-    stamp(1);
     // ---------------------------------------------------------------- phase A: fc1 (+ softplus), both hidden tiles
     f32x16 hreg[2];
     {
@@ -177,7 +171,6 @@ __global__ __launch_bounds__(EP_THREADS, 1) void k_mvn_enc_fwd_p(
         }
     }
     __builtin_amdgcn_wave_barrier();                          // response bytes no longer needed
-    stamp(2);
     // ---------------------------------------------------------------- eps (zero padded to DS), x := 0
     {
         for (int e = lane; e < EP_WP * (DS + DX); e += 64) R1[e] = 0.f;
@@ -203,7 +196,6 @@ __global__ __launch_bounds__(EP_THREADS, 1) void k_mvn_enc_fwd_p(
 #pragma unroll 4
         for (int k = half; k < D; k += 2) epsT_out[(int64_t)k * dm.nb + i] = eps_lds[p * DS + k];
     }
-    stamp(3);
     // ---------------------------------------------------------------- phase B: packed head rows, 32 per tile
     float ent_acc = 0.f;
     {
@@ -285,7 +277,6 @@ __global__ __launch_bounds__(EP_THREADS, 1) void k_mvn_enc_fwd_p(
                 tile_off(A2, bA2, g2);
             }
             flush();
-            stamp(4);
             // ---- DIAG section (exp(M_kk) eps_k, entropy, ldT) and LOC section (the loc head): 2 * n_sec tiles, on the
             // same three-deep weight ring (A0 / A1 already hold the first two of them).  The 16 x entries a lane
             // updates are read together, updated and written together (one LDS round trip per tile).
@@ -335,7 +326,6 @@ __global__ __launch_bounds__(EP_THREADS, 1) void k_mvn_enc_fwd_p(
         }
     }
     __builtin_amdgcn_wave_barrier();
-    stamp(5);
     // ---------------------------------------------------------------- write x, entropy part
     {
         const int pv = (int)((dm.nb - i0) < EP_WP ? (dm.nb - i0) : EP_WP);
@@ -351,7 +341,6 @@ __global__ __launch_bounds__(EP_THREADS, 1) void k_mvn_enc_fwd_p(
             ent_out[i] = 0.5f * s + ent_acc;                  // -log q + const = 0.5|eps|^2 + sum_k M_kk
         }
     }
-    stamp(6);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -91,11 +91,9 @@ bool force_generic() {
     return v == 1;
 }
 
-// VX_MVN=fast keeps the reference row order (the pre-packing kernels); default is the packed head layout
+// shapes of the packed head layout (k_pack.hip); the others keep the reference row order
 bool packed_ok(const vx_irt_cfg* cfg) {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("VX_MVN"); v = (e && e[0] == 'f') ? 0 : 1; }
-    return v == 1 && !force_generic() && cfg->H == 64 && cfg->J % 4 == 0 && cfg->D % 4 == 0 &&
+    return !force_generic() && cfg->H == 64 && cfg->J % 4 == 0 && cfg->D % 4 == 0 &&
            enc_p_lds_floats(cfg->D, cfg->J) * sizeof(float) <= 160 * 1024 &&
            enc_bwdw_fast_lds_floats(cfg->D) * sizeof(float) <= 160 * 1024;
 }
@@ -144,30 +142,6 @@ struct ProfScope {
         if (g_prof_n < 8) { g_prof_slots[g_prof_n].name = name; g_prof_slots[g_prof_n].ev.emplace_back(a, b); ++g_prof_n; }
     }
 };
-
-// timing experiment (VX_STAMPS=1): s_memtime stamps of wave 0 of the first 2048 workgroups of a guide-forward kernel
-long long* stamps_alloc() {
-    long long* stamps = nullptr;
-    if (getenv("VX_STAMPS") && hipMalloc(&stamps, 2048 * 8 * sizeof(long long)) == hipSuccess)
-        (void)hipMemset(stamps, 0, 2048 * 8 * sizeof(long long));
-    return stamps;
-}
-void stamps_report(long long* stamps, const char* name, unsigned n_blocks) {
-    if (!stamps) return;
-    static long long hst[2048 * 8];
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpy(hst, stamps, sizeof(hst), hipMemcpyDeviceToHost);
-    (void)hipFree(stamps);
-    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
-    int nblk = 0;
-    for (int b = 0; b < 2048 && b < (int)n_blocks; ++b) {
-        if (!hst[b * 8 + 6]) continue;
-        for (int k2 = 0; k2 < 6; ++k2) acc[k2] += (double)(hst[b * 8 + k2 + 1] - hst[b * 8 + k2]);
-        ++nblk;
-    }
-    fprintf(stderr, "%s stamps (s_memtime ticks, mean over %d blocks): ystage %.0f fc1 %.0f eps %.0f off %.0f diagloc %.0f out %.0f\n",
-            name, nblk, acc[0] / nblk, acc[1] / nblk, acc[2] / nblk, acc[3] / nblk, acc[4] / nblk, acc[5] / nblk);
-}
 
 }  // namespace
 
@@ -328,48 +302,33 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
             rc = set_lds(k_mvn_enc_fwd_b, ldsb);
             if (rc) return rc;
             const dim3 gridb((unsigned)((nb + FB_WAVES * FB_WP - 1) / (FB_WAVES * FB_WP)));
-            long long* stamps = stamps_alloc();
             ProfScope ps("k_mvn_enc_fwd_b", (hipStream_t)hs);
             ximg_after.done = true;
             hipLaunchKernelGGL(k_mvn_enc_fwd_b, gridb, dim3(FB_THREADS), ldsb, (hipStream_t)hs, dm, y, rows, gid0,
                                (const uint8_t*)w1img, b1, (const uint8_t*)img, (const uint32_t*)gt2, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT,
-                               ximg, stamps);
+                               ximg);
             VX_CHECK_LAUNCH();
-            stamps_report(stamps, "fwd_b", gridb.x);
             return VX_OK;
         }
         const size_t ldsp = enc_p_lds_floats(dm.D, dm.J) * sizeof(float);
         rc = set_lds(k_mvn_enc_fwd_p, ldsp);
         if (rc) return rc;
         const dim3 gridp((unsigned)((nb + EP_WAVES * EP_WP - 1) / (EP_WAVES * EP_WP)));
-        long long* stamps = stamps_alloc();
         ProfScope ps("k_mvn_enc_fwd_p", (hipStream_t)hs);
         hipLaunchKernelGGL(k_mvn_enc_fwd_p, gridp, dim3(EP_THREADS), ldsp, (hipStream_t)hs, dm, y, rows, gid0, W1, b1, Wp,
-                           bp, gtab, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT, stamps);
+                           bp, gtab, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT);
         VX_CHECK_LAUNCH();
-        stamps_report(stamps, "fwd_p", gridp.x);
         return VX_OK;
     }
     if (!force_generic() && cfg->H == 64 && cfg->J % 4 == 0 && aligned16(y) && aligned16(W1) && aligned16(b1) &&
         aligned16(W21) && aligned16(W22) && aligned16(h)) {
-        static int variant = -1;                          // VX_ENC_FWD=atomic selects the previous (LDS-atomic) form
-        if (variant < 0) { const char* e = getenv("VX_ENC_FWD"); variant = (e && e[0] == 'a') ? 1 : 0; }
         const size_t ldsr = enc_r_lds_floats(dm.D, dm.J) * sizeof(float);
-        if (variant == 0 && ldsr <= 160 * 1024) {
+        if (ldsr <= 160 * 1024) {
             rc = set_lds(k_mvn_enc_fwd_r, ldsr);
             if (rc) return rc;
             const dim3 gridr((unsigned)((nb + ER_WAVES * ER_WP - 1) / (ER_WAVES * ER_WP)));
             hipLaunchKernelGGL(k_mvn_enc_fwd_r, gridr, dim3(ER_THREADS), ldsr, (hipStream_t)hs, dm, y, rows, gid0, W1, b1,
                                W21, b21, W22, b22, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent);
-            VX_CHECK_LAUNCH();
-            return VX_OK;
-        }
-        const size_t ldsf = enc_fwd_fast_lds_floats(dm.D, dm.J) * sizeof(float);
-        if (ldsf <= 160 * 1024) {
-            rc = set_lds(k_mvn_enc_fwd_fast, ldsf);
-            if (rc) return rc;
-            hipLaunchKernelGGL(k_mvn_enc_fwd_fast, grid, dim3(ENC_THREADS), ldsf, (hipStream_t)hs, dm, y, rows, gid0, W1,
-                               b1, W21, b21, W22, b22, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent);
             VX_CHECK_LAUNCH();
             return VX_OK;
         }
@@ -401,9 +360,7 @@ static void lik_plan(const vx_irt_cfg* cfg, int64_t nb, int& kt, int& nch, int& 
 
 // register-resident variant (k_irt_lik_r.hip): one 128-item chunk per workgroup, D + 1 in (64, 128]
 static bool lik_r_shape(const vx_irt_cfg* cfg) {
-    static int old = -1;
-    if (old < 0) { const char* e = getenv("VX_LIK"); old = (e && e[0] == 'o') ? 1 : 0; }
-    return !old && !force_generic() && cfg->D >= 64 && cfg->D <= 127;
+    return !force_generic() && cfg->D >= 64 && cfg->D <= 127;
 }
 static void lik_r_plan(const vx_irt_cfg* cfg, int64_t nb, int& groups, int& n_pr) {
     groups = (cfg->J + LR_JC - 1) / LR_JC;
@@ -659,9 +616,7 @@ static bool encb_fast_shape(const vx_irt_cfg* cfg) {
 
 // dimension-major weight-gradient kernel (k_mvn_bwd_t.hip): packed shape, 16-byte aligned person rows
 static bool bwt_shape(const vx_irt_cfg* cfg, int64_t nb) {
-    static int old = -1;
-    if (old < 0) { const char* e = getenv("VX_BWDW"); old = (e && e[0] == 'o') ? 1 : 0; }
-    return !old && packed_ok(cfg) && nb % 4 == 0 && cfg->D <= 124 && bt_lds_bytes(cfg->D) <= 160 * 1024;
+    return packed_ok(cfg) && nb % 4 == 0 && cfg->D <= 124 && bt_lds_bytes(cfg->D) <= 160 * 1024;
 }
 // opt-in (VX_BF16X3=1): the weight-gradient kernel on the bf16 MFMA with three-term operand splitting (k_mvn_bwd_b.hip)
 static bool bwb_shape(const vx_irt_cfg* cfg, int64_t nb) {
@@ -692,9 +647,7 @@ static void encb_plan(const vx_irt_cfg* cfg, int64_t nb, int& n_rowslabs, int& n
 
 int vx_mvn_enc_bwd_layout(const vx_irt_cfg* cfg, int64_t nb) {
     if (!enc_cfg_ok(cfg) || nb < 0) return VX_EINVAL;
-    static int oldh = -1;
-    if (oldh < 0) { const char* e = getenv("VX_BWDH"); oldh = (e && e[0] == 'o') ? 1 : 0; }
-    return (bwt_shape(cfg, nb) && !oldh && nb >= 4 && bh_lds_bytes(cfg->D) <= 160 * 1024) ? 1 : 0;
+    return (bwt_shape(cfg, nb) && nb >= 4 && bh_lds_bytes(cfg->D) <= 160 * 1024) ? 1 : 0;
 }
 
 // float offset, inside the workspace of vx_mvn_enc_backward, of gdT[D][nb] (the DIAG-row operand of the dimension-major
@@ -782,15 +735,13 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     if (packed) {
         const float* Wp = packws;
         const uint32_t* gtab = (const uint32_t*)(packws + Rp * 64 + Rp);
-        static int oldh = -1;
-        if (oldh < 0) { const char* e = getenv("VX_BWDH"); oldh = (e && e[0] == 'o') ? 1 : 0; }
         if (use_t && !(gd_ready && (slabs_f + (int64_t)n_prf * lenf) == workspace + encb_gd_offset(cfg, nb))) {
             float* gdT0 = slabs_f + (int64_t)n_prf * lenf;      // DIAG-row operand of both dimension-major kernels
             hipLaunchKernelGGL(k_mvn_gd, dim3(num_cu() * 8), dim3(256), 0, st, (const float4*)gxT, (const float4*)epsT,
                                (const float4*)ldT, cfg->scale, nb * D / 4, (float4*)gdT0);
             VX_CHECK_LAUNCH();
         }
-        if (use_t && !oldh && nb >= 4 && bh_lds_bytes(dm.D) <= 160 * 1024) {
+        if (use_t && nb >= 4 && bh_lds_bytes(dm.D) <= 160 * 1024) {
             const float* WpT = (const float*)(gtab + Rp / 8 + 8);
             const size_t lds = bh_lds_bytes(dm.D);
             rc = set_lds(k_mvn_enc_bwd_h_t, lds);
@@ -811,29 +762,11 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                                    f1t ? ghpre : (float*)nullptr);
                 VX_CHECK_LAUNCH();
             } else {
-            long long* stamps = nullptr;
-            if (getenv("VX_STAMPS") && hipMalloc(&stamps, 2048 * 8 * sizeof(long long)) == hipSuccess)
-                (void)hipMemset(stamps, 0, 2048 * 8 * sizeof(long long));
             ProfScope ps("k_mvn_enc_bwd_h_t", st);
             hipLaunchKernelGGL(k_mvn_enc_bwd_h_t, dim3((unsigned)((nb + BH_P - 1) / BH_P)), dim3(BH_THREADS), lds, st, dm,
                                cfg->scale, WpT, gtab, h, eps, ldT, gxT, slabs_f + (int64_t)n_prf * lenf, f1t ? (float*)nullptr : ghpre, hT,
-                               f1t ? ghpre : (float*)nullptr, stamps);
+                               f1t ? ghpre : (float*)nullptr);
             VX_CHECK_LAUNCH();
-            if (stamps) {                                   // timing experiment: phase durations of wave 0 per workgroup
-                static long long hst[2048 * 8];
-                (void)hipDeviceSynchronize();
-                (void)hipMemcpy(hst, stamps, sizeof(hst), hipMemcpyDeviceToHost);
-                (void)hipFree(stamps);
-                double acc[4] = {0, 0, 0, 0};
-                int nblk = 0;
-                for (int b = 0; b < 2048; ++b) {
-                    if (!hst[b * 8 + 4]) continue;
-                    for (int k2 = 0; k2 < 4; ++k2) acc[k2] += (double)(hst[b * 8 + k2 + 1] - hst[b * 8 + k2]);
-                    ++nblk;
-                }
-                if (nblk) fprintf(stderr, "bwd_h_t stamps (mean over %d blocks): prologue %.0f off %.0f tail %.0f out %.0f\n", nblk,
-                                  acc[0] / nblk, acc[1] / nblk, acc[2] / nblk, acc[3] / nblk);
-            }
             }
         } else {
             if (!gx) return VX_EINVAL;                     // the person-major kernel needs gx[nb][D]
