@@ -29,7 +29,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: dense bf16 matrix peak
 # an fp32 product computed as three bf16 terms per operand costs six bf16 MFMA products:
 PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_HBM_GBS = 8000.0
-PROFILE_TAG = "r01_v5"
+PROFILE_TAG = "r02_headline"
 
 WORKLOADS = {
     # name: (model, N, J, D, H, amortized, missing)
@@ -308,8 +308,20 @@ def main():
                                "peak_basis": "dense bf16 MFMA peak 2500 / 6 products per f32 product"
                                              if peak == PEAK_BF16X3_TFLOPS else "dense f32 MFMA peak",
                                "algorithmic_flops_per_launch": fl, "avg_launch_ms": priced[name]}
-        elif "irt1d" in phase_ms or "hodina" in phase_ms:
-            key = "irt1d" if "irt1d" in phase_ms else "hodina"
+        elif "hodina" in phase_ms:
+            # SURVEY.md section 8d, cfg 5: (2 K + J) C MACs forward, ~3x with the backward = compute-bound.  The pattern
+            # contractions run on the bf16 MFMA with one operand exact (0/1) and the other split into bf16 terms (three
+            # forward, two backward): priced at the dense bf16 peak / 3
+            fl = 3.0 * 2.0 * (2 * D + J) * (1 << D) * n_local
+            ach = fl / (phase_ms["hodina"] * 1e-3) / 1e12
+            peak = PEAK_BF16_MFMA_TFLOPS / 3.0
+            out["roofline"] = {"kernel": "k_hodina_m", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                               "frac": ach / peak, "traffic": None, "algorithmic_flops_per_launch": fl,
+                               "avg_launch_ms": phase_ms["hodina"],
+                               "peak_basis": "dense bf16 MFMA peak 2500 / 3 products per f32 x {0,1} product",
+                               "note": "the softmax over the 2^K patterns (VALU + exp) bounds this kernel, not the MFMA"}
+        elif "irt1d" in phase_ms:
+            key = "irt1d"
             by = (J + 48.0) * n_local                       # y row + 6 fp32 r/w per person
             ach = by / (phase_ms[key] * 1e-3) / 1e9
             out["roofline"] = {"kernel": "k_" + key, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS,
