@@ -45,7 +45,7 @@ typedef struct vx_irt_cfg {
     int32_t model;       /* enum vx_model */
     int32_t D;           /* x_feature: latent dimensions */
     int32_t J;           /* item_size */
-    int32_t H;           /* encoder hidden_dim (amortized guides), else 0 */
+    int32_t H;           /* encoder hidden_dim (amortized guides; <= 128), else 0 */
     float   Dc;          /* the scalar `D` of vi.py:549 (1 or 1.702) */
     float   scale;       /* plate scale N_global / B_global */
     uint64_t seed;       /* Philox key */
@@ -260,7 +260,7 @@ int vx_cdm_sf_grad(const vx_hodina_cfg* cfg, int32_t dino, int32_t clamp_t, floa
                    void* hip_stream);
 /* leave-one-out control variate over the S >= 2 particles of a step: out[i] = mean_{s' != s} lr_all[s'][i] */
 int vx_loo_baseline(const float* lr_all /*[S][nb]*/, int32_t S, int64_t nb, int32_t s, float* out, void* hip_stream);
-/* BinEncoder of VaeCDM (vi.py:458-470): h[nb][H] = softplus(W1 yin + b1), u[nb][K] = W2 h + b2 (logits; H <= 64).
+/* BinEncoder of VaeCDM (vi.py:458-470): h[nb][H] = softplus(W1 yin + b1), u[nb][K] = W2 h + b2 (logits; H <= 128).
  * genc = d LOSS / d [W1: H*J | b1: H | W2: K*H | b2: K] from gu = d LOSS / d u. */
 int64_t vx_bin_enc_param_floats(const vx_hodina_cfg* cfg);
 int vx_bin_enc_forward(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* W1,

@@ -67,6 +67,8 @@ def test_hip_replays_reference_score_function_steps(tag):
     (257, 65, 10, "dina", None, True, 64),
     (130, 9, 1, "dino", 50, True, 24),
     (700, 200, 4, "dina", None, True, 8),
+    (301, 40, 6, "dina", None, True, 96),            # hidden_dim > 64
+    (150, 33, 3, "dino", 60, True, 128),
 ])
 def test_cdm_sf_step_vs_oracle(N, J, K, cdm, B, amort, H):
     """Random problems; the attribute draws are made IN the kernel (Philox keyed by the global person id) and must equal
@@ -220,7 +222,8 @@ def test_hip_replays_reference_vaeccdm_steps(tag):
 
 
 @pytest.mark.parametrize("N,J,K,cdm,miss,B,H", [(600, 30, 8, "dina", 0.1, None, 64), (257, 70, 5, "dino", 0.0, 100, 24),
-                                                (130, 12, 2, "dina", 0.3, None, 8), (300, 140, 9, "dina", 0.05, 77, 32)])
+                                                (130, 12, 2, "dina", 0.3, None, 8), (300, 140, 9, "dina", 0.05, 77, 32),
+                                                (203, 25, 4, "dina", 0.1, None, 96), (150, 30, 7, "dino", 0.0, 64, 128)])
 def test_vaeccdm_step_vs_oracle(N, J, K, cdm, miss, B, H):
     from vipsy_amd.engine import VaeCcdmEngine
     rng = np.random.RandomState(N + J + K)

@@ -181,6 +181,8 @@ def _random_problem(N, J, D, H, model, miss, seed):
     (1040, 516, 64, 64, "irt_3pl", 0.2, None),      # ... with two 512-item groups and a ragged last person tile
     (64, 40, 8, 64, "irt_2pl", 0.0, None),
     (36, 40, 8, 64, "irt_2pl", 0.1, None),          # a single ragged person tile in every dimension-major kernel
+    (200, 90, 6, 96, "irt_2pl", 0.2, None),         # hidden_dim > 64 (vi.py:417-455 takes any width): generic kernels
+    (150, 260, 33, 128, "irt_4pl", 0.1, 60),        # ... up to 128
     (4, 36, 4, 64, "irt_2pl", 0.0, None),           # the smallest batch those kernels accept
     (2000, 500, 100, 64, "irt_2pl", 0.0, 1000),     # headline shape with a row gather (subsample): FAST == 2 staging
     # shapes aimed at the static structure of the bf16x3 kernels: k-blocks of 16 in the hidden gradient (one block,
@@ -371,12 +373,12 @@ def test_hodina_step_vs_oracle(N, J, K, miss, B, amort):
     (320, 500, "irt_2pl", 0.3, None),                # N % 16 == 0, full batch: item-major responses in the fc1 gradient
     (1040, 516, "irt_3pl", 0.1, None),               # ... two 512-item groups, ragged last person tile
 ])
-def test_irt1d_amortized_step_vs_oracle(N, J, model, miss, B):
+def test_irt1d_amortized_step_vs_oracle(N, J, model, miss, B, H=64):
     from vipsy_amd.engine import IrtEngine
     rng = np.random.RandomState(N + J)
     y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
     y[rng.rand(N, J) < miss] = 255
-    eng = IrtEngine(torch.from_numpy(y).to(_dev()), model=model, D=1, amortized=True, H=64, seed=5)
+    eng = IrtEngine(torch.from_numpy(y).to(_dev()), model=model, D=1, amortized=True, H=H, seed=5)
     eng.unconstrained("b").copy_(torch.from_numpy(0.7 * rng.randn(1, J)).float())
     if model != "irt_1pl":
         eng.unconstrained("a").copy_(torch.from_numpy(0.5 + 2 * rng.rand(1, J)).float())
@@ -522,3 +524,9 @@ def test_captured_step_equals_eager_step(miss, model):
         out.append((torch.stack(losses).cpu().numpy(), eng.P.cpu().numpy().copy(), eng.PP.cpu().numpy().copy()))
     for u, v in zip(out[0], out[1]):
         assert np.array_equal(u, v)
+
+
+@pytest.mark.parametrize("H", [96, 128])
+def test_irt1d_amortized_wide_hidden_layer(H):
+    """NormEncoder with hidden_dim > 64 (vi.py:417-435 takes any width)."""
+    test_irt1d_amortized_step_vs_oracle(300, 100, "irt_2pl", 0.2, None, H=H)

@@ -157,14 +157,17 @@ __global__ void k_cdm_sf_items(int J, int n_blocks, float scale, const int* __re
 }
 
 // ---- BinEncoder (vi.py:458-470): h = softplus(W1 yin + b1), u = W2 h + b2 (the logits of the attribute probabilities).
-// One block = 4 persons x 64 hidden-unit slots (H <= 64); yin = the response bytes as they are (0 / 1; 255 -> -1).
+// One block = 256 / HS persons x HS hidden-unit slots (H <= HS, HS = 64 or 128); yin = the response bytes as they are
+// (0 / 1; 255 -> -1).
+template <int HS>
 __global__ __launch_bounds__(256) void k_bin_enc_fwd(int K, int J, int H, int64_t nb, const uint8_t* __restrict__ y,
                                                      const int64_t* __restrict__ rows, const float* __restrict__ W1,
                                                      const float* __restrict__ b1, const float* __restrict__ W2,
                                                      const float* __restrict__ b2, float* __restrict__ h, float* __restrict__ u) {
-    __shared__ float hs[4][64];
-    const int tid = threadIdx.x, hh = tid & 63, sub = tid >> 6;
-    for (int64_t i0 = (int64_t)blockIdx.x * 4; i0 < nb; i0 += (int64_t)gridDim.x * 4) {
+    constexpr int PPB = 256 / HS;
+    __shared__ float hs[PPB][HS];
+    const int tid = threadIdx.x, hh = tid % HS, sub = tid / HS;
+    for (int64_t i0 = (int64_t)blockIdx.x * PPB; i0 < nb; i0 += (int64_t)gridDim.x * PPB) {
         const int64_t i = i0 + sub;
         float acc = 0.f;
         if (i < nb && hh < H) {
@@ -187,15 +190,17 @@ __global__ __launch_bounds__(256) void k_bin_enc_fwd(int K, int J, int H, int64_
 }
 
 // ghpre[i][hh] = (sum_k gu[i][k] W2[k][hh]) (1 - exp(-h)),  head-gradient slab per block: [W2: K*H | b2: K]  (d LOSS)
+template <int HS>
 __global__ __launch_bounds__(256) void k_bin_enc_bwd_small(int K, int H, int64_t nb, const float* __restrict__ W2,
                                                            const float* __restrict__ h, const float* __restrict__ gu,
                                                            float* __restrict__ ghpre, float* __restrict__ slabs) {
-    __shared__ float red[4][64];
-    const int tid = threadIdx.x, hh = tid & 63, sub = tid >> 6;
+    constexpr int PPB = 256 / HS;
+    __shared__ float red[PPB][HS];
+    const int tid = threadIdx.x, hh = tid % HS, sub = tid / HS;
     float gw[CS_MAXK], gb[CS_MAXK];
 #pragma unroll
     for (int k = 0; k < CS_MAXK; ++k) { gw[k] = 0.f; gb[k] = 0.f; }
-    for (int64_t i = (int64_t)blockIdx.x * 4 + sub; i < nb; i += (int64_t)gridDim.x * 4) {
+    for (int64_t i = (int64_t)blockIdx.x * PPB + sub; i < nb; i += (int64_t)gridDim.x * PPB) {
         const float hv = hh < H ? h[i * H + hh] : 0.f;
         float a = 0.f;
 #pragma unroll
@@ -212,11 +217,21 @@ __global__ __launch_bounds__(256) void k_bin_enc_bwd_small(int K, int H, int64_t
     for (int k = 0; k < K; ++k) {
         red[sub][hh] = gw[k];
         __syncthreads();
-        if (sub == 0 && hh < H) slab[k * H + hh] = (red[0][hh] + red[1][hh]) + (red[2][hh] + red[3][hh]);
+        if (sub == 0 && hh < H) {
+            float t = red[0][hh];
+#pragma unroll
+            for (int q = 1; q < PPB; ++q) t += red[q][hh];
+            slab[k * H + hh] = t;
+        }
         __syncthreads();
         red[sub][hh] = gb[k];
         __syncthreads();
-        if (tid == 0) slab[K * H + k] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        if (tid == 0) {
+            float t = red[0][0];
+#pragma unroll
+            for (int q = 1; q < PPB; ++q) t += red[q][0];
+            slab[K * H + k] = t;
+        }
         __syncthreads();
     }
 }

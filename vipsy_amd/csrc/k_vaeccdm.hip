@@ -6,14 +6,17 @@
 #pragma once
 #include "vx_common.h"
 
-// h[nb][H] = relu(W1 yin + b1) (yin = response bytes as int8: 255 -> -1, vi.py:884-886), z[nb][C] = W2 h + b2;  H <= 64
+// h[nb][H] = relu(W1 yin + b1) (yin = response bytes as int8: 255 -> -1, vi.py:884-886), z[nb][C] = W2 h + b2;
+// block = 256 / HS persons x HS hidden slots, H <= HS (64 or 128)
+template <int HS>
 __global__ __launch_bounds__(256) void k_sm_enc_fwd(int C, int J, int H, int64_t nb, const uint8_t* __restrict__ y,
                                                     const int64_t* __restrict__ rows, const float* __restrict__ W1,
                                                     const float* __restrict__ b1, const float* __restrict__ W2,
                                                     const float* __restrict__ b2, float* __restrict__ h, float* __restrict__ z) {
-    __shared__ float hs[4][64];
-    const int tid = threadIdx.x, hh = tid & 63, sub = tid >> 6;
-    for (int64_t i0 = (int64_t)blockIdx.x * 4; i0 < nb; i0 += (int64_t)gridDim.x * 4) {
+    constexpr int PPB = 256 / HS;
+    __shared__ float hs[PPB][HS];
+    const int tid = threadIdx.x, hh = tid % HS, sub = tid / HS;
+    for (int64_t i0 = (int64_t)blockIdx.x * PPB; i0 < nb; i0 += (int64_t)gridDim.x * PPB) {
         const int64_t i = i0 + sub;
         float acc = 0.f;
         if (i < nb && hh < H) {
@@ -27,7 +30,7 @@ __global__ __launch_bounds__(256) void k_sm_enc_fwd(int C, int J, int H, int64_t
         hs[sub][hh] = (hh < H) ? acc : 0.f;
         __syncthreads();
         if (i < nb) {
-            for (int c = hh; c < C; c += 64) {
+            for (int c = hh; c < C; c += HS) {
                 float a = b2[c];
                 for (int t = 0; t < H; ++t) a = fmaf(W2[(int64_t)c * H + t], hs[sub][t], a);
                 z[i * C + c] = a;
@@ -71,12 +74,14 @@ __global__ void k_vaeccdm_gz(const float* __restrict__ z, const float* __restric
     }
 }
 
-// ghpre[i][hh] = (sum_c gz[i][c] W2[c][hh]) [h > 0]   (relu');  block = 4 persons x 64 hidden slots
+// ghpre[i][hh] = (sum_c gz[i][c] W2[c][hh]) [h > 0]   (relu');  block = 256 / HS persons x HS hidden slots
+template <int HS>
 __global__ __launch_bounds__(256) void k_sm_enc_bwd_h(int C, int H, int64_t nb, const float* __restrict__ W2,
                                                       const float* __restrict__ h, const float* __restrict__ gz,
                                                       float* __restrict__ ghpre) {
-    const int tid = threadIdx.x, hh = tid & 63, sub = tid >> 6;
-    for (int64_t i = (int64_t)blockIdx.x * 4 + sub; i < nb; i += (int64_t)gridDim.x * 4) {
+    constexpr int PPB = 256 / HS;
+    const int tid = threadIdx.x, hh = tid % HS, sub = tid / HS;
+    for (int64_t i = (int64_t)blockIdx.x * PPB + sub; i < nb; i += (int64_t)gridDim.x * PPB) {
         if (hh < H) {
             float a = 0.f;
             for (int c = 0; c < C; ++c) a = fmaf(gz[i * C + c], W2[(int64_t)c * H + hh], a);
@@ -86,36 +91,38 @@ __global__ __launch_bounds__(256) void k_sm_enc_bwd_h(int C, int H, int64_t nb, 
 }
 
 // head-gradient slab per (column tile of 64 patterns, row slab): gW2[c][hh] = sum_i gz[i][c] h[i][hh], gb2[c] = sum_i gz[i][c]
-// slab layout: [W2: C*H | b2: C];  thread = (pattern c of the tile, group of 16 hidden units)
+// slab layout: [W2: C*H | b2: C];  thread = (pattern c of the tile, group of HS / 4 hidden units)
+template <int HS>
 __global__ __launch_bounds__(256) void k_sm_enc_bwd_w(int C, int H, int64_t nb, const float* __restrict__ h,
                                                       const float* __restrict__ gz, float* __restrict__ slabs) {
-    __shared__ float hs[16][64];
+    constexpr int HG = HS / 4;
+    __shared__ float hs[16][HS];
     const int tid = threadIdx.x, cl = tid & 63, hg = tid >> 6;
     const int c = blockIdx.x * 64 + cl;
     const int64_t per = (nb + gridDim.y - 1) / gridDim.y;
     const int64_t lo = (int64_t)blockIdx.y * per, hi = lo + per < nb ? lo + per : nb;
-    float acc[16], accb = 0.f;
+    float acc[HG], accb = 0.f;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+    for (int t = 0; t < HG; ++t) acc[t] = 0.f;
     for (int64_t i0 = lo; i0 < hi; i0 += 16) {
         __syncthreads();
-        for (int e = tid; e < 16 * 64; e += 256) {
-            const int r = e >> 6, t = e & 63;
+        for (int e = tid; e < 16 * HS; e += 256) {
+            const int r = e / HS, t = e % HS;
             hs[r][t] = (i0 + r < hi && t < H) ? h[(i0 + r) * H + t] : 0.f;
         }
         __syncthreads();
         for (int r = 0; r < 16 && i0 + r < hi; ++r) {
             const float gv = c < C ? gz[(i0 + r) * C + c] : 0.f;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) acc[t] = fmaf(gv, hs[r][16 * hg + t], acc[t]);
+            for (int t = 0; t < HG; ++t) acc[t] = fmaf(gv, hs[r][HG * hg + t], acc[t]);
             if (hg == 0) accb += gv;
         }
     }
     float* slab = slabs + (int64_t)blockIdx.y * ((int64_t)C * H + C);
     if (c < C) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
-            if (16 * hg + t < H) slab[(int64_t)c * H + 16 * hg + t] = acc[t];
+        for (int t = 0; t < HG; ++t)
+            if (HG * hg + t < H) slab[(int64_t)c * H + HG * hg + t] = acc[t];
         if (hg == 0) slab[(int64_t)C * H + c] = accb;
     }
 }

@@ -114,7 +114,7 @@ bool fwb_shape(const vx_irt_cfg* cfg) {
 }
 
 bool enc_cfg_ok(const vx_irt_cfg* cfg) {
-    return cfg && cfg->D >= 2 && cfg->D <= 127 && cfg->H >= 1 && cfg->H <= 64 && cfg->J >= 1;
+    return cfg && cfg->D >= 2 && cfg->D <= 127 && cfg->H >= 1 && cfg->H <= 128 && cfg->J >= 1;
 }
 
 
@@ -339,7 +339,7 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
     if (rc) return rc;                                                                                       \
     hipLaunchKernelGGL(k_mvn_enc_fwd<HT>, grid, dim3(ENC_THREADS), lds, (hipStream_t)hs, dm, y, rows, gid0, W1, \
                        b1, W21, b21, W22, b22, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent)
-    if (dm.Hp == 32) { LAUNCH_FWD(1); } else { LAUNCH_FWD(2); }
+    if (dm.Hp == 32) { LAUNCH_FWD(1); } else if (dm.Hp == 64) { LAUNCH_FWD(2); } else if (dm.Hp == 96) { LAUNCH_FWD(3); } else { LAUNCH_FWD(4); }
 #undef LAUNCH_FWD
     VX_CHECK_LAUNCH();
     return VX_OK;
@@ -837,7 +837,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     if (rc) return rc;                                                                                       \
     hipLaunchKernelGGL(k_mvn_enc_bwd_h<HT>, grid, dim3(ENC_THREADS), lds, st, dm, cfg->scale, W21, W22, h, eps, \
                        ldT, gx, ghpre)
-            if (dm.Hp == 32) { LAUNCH_BH(1); } else { LAUNCH_BH(2); }
+            if (dm.Hp == 32) { LAUNCH_BH(1); } else if (dm.Hp == 64) { LAUNCH_BH(2); } else if (dm.Hp == 96) { LAUNCH_BH(3); } else { LAUNCH_BH(4); }
 #undef LAUNCH_BH
             VX_CHECK_LAUNCH();
         }
@@ -849,7 +849,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     if (rc) return rc;                                                                                       \
     hipLaunchKernelGGL(k_mvn_enc_bwd_w<HT>, grid, dim3(ENC_THREADS), lds, st, dm, cfg->scale, h, eps, ldT, gx,  \
                        slabs_w, lenw)
-            if (dm.Hp == 32) { LAUNCH_BW(1); } else { LAUNCH_BW(2); }
+            if (dm.Hp == 32) { LAUNCH_BW(1); } else if (dm.Hp == 64) { LAUNCH_BW(2); } else if (dm.Hp == 96) { LAUNCH_BW(3); } else { LAUNCH_BW(4); }
 #undef LAUNCH_BW
             VX_CHECK_LAUNCH();
         }
@@ -875,7 +875,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     rc = set_lds(k_fc1_bwd<HT>, lds);                                                                        \
     if (rc) return rc;                                                                                       \
     hipLaunchKernelGGL(k_fc1_bwd<HT>, grid, dim3(ENC_THREADS), lds, st, dm, y, rows, ghpre, slabs_f, lenf, f1fast)
-            if (dm.Hp == 32) { LAUNCH_F1(1); } else { LAUNCH_F1(2); }
+            if (dm.Hp == 32) { LAUNCH_F1(1); } else if (dm.Hp == 64) { LAUNCH_F1(2); } else if (dm.Hp == 96) { LAUNCH_F1(3); } else { LAUNCH_F1(4); }
 #undef LAUNCH_F1
             VX_CHECK_LAUNCH();
         }
@@ -1048,7 +1048,7 @@ int vx_mvn_bbvi_backward(const vx_irt_cfg* cfg, int64_t nb, const int64_t* rows,
 }
 
 // ------------------------------------------------------------------------------------------------
-static bool nenc_cfg_ok(const vx_irt_cfg* cfg) { return cfg && cfg->H >= 1 && cfg->H <= 64 && cfg->J >= 1; }
+static bool nenc_cfg_ok(const vx_irt_cfg* cfg) { return cfg && cfg->H >= 1 && cfg->H <= 128 && cfg->J >= 1; }
 
 static void nenc_plan(const vx_irt_cfg* cfg, int64_t nb, int& nblk, int& n_jg, int& n_prf) {
     int hp = 1;
@@ -1094,7 +1094,7 @@ int vx_norm_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     if (rc) return rc;                                                                                       \
     hipLaunchKernelGGL(k_norm_enc_fwd<HT>, grid, dim3(ENC_THREADS), lds, (hipStream_t)hs, dm, y, rows, W1, b1, W21,  \
                        b21, W22, b22, h, loc, raw)
-    if (dm.Hp == 32) { LAUNCH_NF(1); } else { LAUNCH_NF(2); }
+    if (dm.Hp == 32) { LAUNCH_NF(1); } else if (dm.Hp == 64) { LAUNCH_NF(2); } else if (dm.Hp == 96) { LAUNCH_NF(3); } else { LAUNCH_NF(4); }
 #undef LAUNCH_NF
     VX_CHECK_LAUNCH();
     return VX_OK;
@@ -1158,7 +1158,7 @@ int vx_norm_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t*
     rc = set_lds(k_fc1_bwd<HT>, lds);                                                                        \
     if (rc) return rc;                                                                                       \
     hipLaunchKernelGGL(k_fc1_bwd<HT>, grid, dim3(ENC_THREADS), lds, st, dm, y, rows, ghpre, slabs_f, lenf, f1fast)
-        if (dm.Hp == 32) { LAUNCH_F1(1); } else { LAUNCH_F1(2); }
+        if (dm.Hp == 32) { LAUNCH_F1(1); } else if (dm.Hp == 64) { LAUNCH_F1(2); } else if (dm.Hp == 96) { LAUNCH_F1(3); } else { LAUNCH_F1(4); }
 #undef LAUNCH_F1
         VX_CHECK_LAUNCH();
     }
@@ -1329,7 +1329,7 @@ int vx_loo_baseline(const float* lr_all, int32_t S, int64_t nb, int32_t s, float
 }
 
 static bool bin_enc_cfg_ok(const vx_hodina_cfg* cfg) {
-    return cfg && cfg->K >= 1 && cfg->K <= CS_MAXK && cfg->H >= 1 && cfg->H <= 64 && cfg->J >= 1;
+    return cfg && cfg->K >= 1 && cfg->K <= CS_MAXK && cfg->H >= 1 && cfg->H <= 128 && cfg->J >= 1;
 }
 static void bin_enc_plan(const vx_hodina_cfg* cfg, int64_t nb, int& nblk, int& n_jg, int& n_prf) {
     int64_t b = (nb + 3) / 4;
@@ -1350,10 +1350,15 @@ int vx_bin_enc_forward(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t
                        const float* b1, const float* W2, const float* b2, float* h, float* u, void* hs) {
     if (!bin_enc_cfg_ok(cfg) || !y || !W1 || !b1 || !W2 || !b2 || !h || !u || nb < 0) return VX_EINVAL;
     if (nb == 0) return VX_OK;
-    int64_t blocks = (nb + 3) / 4;
+    const int ppb = cfg->H <= 64 ? 4 : 2;                              // persons per block: 256 / hidden slots
+    int64_t blocks = (nb + ppb - 1) / ppb;
     if (blocks > (int64_t)num_cu() * 8) blocks = (int64_t)num_cu() * 8;
-    hipLaunchKernelGGL(k_bin_enc_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hs, (int)cfg->K, (int)cfg->J, (int)cfg->H,
-                       nb, y, rows, W1, b1, W2, b2, h, u);
+    if (cfg->H <= 64)
+        hipLaunchKernelGGL(k_bin_enc_fwd<64>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hs, (int)cfg->K, (int)cfg->J,
+                           (int)cfg->H, nb, y, rows, W1, b1, W2, b2, h, u);
+    else
+        hipLaunchKernelGGL(k_bin_enc_fwd<128>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hs, (int)cfg->K, (int)cfg->J,
+                           (int)cfg->H, nb, y, rows, W1, b1, W2, b2, h, u);
     VX_CHECK_LAUNCH();
     return VX_OK;
 }
@@ -1380,7 +1385,8 @@ int vx_bin_enc_backward(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_
     hipError_t he = hipMemsetAsync(slabs_h, 0, sizeof(float) * (size_t)(nblk * lenh + n_prf * lenf), st);
     if (he != hipSuccess) return (int)he;
     if (nb > 0) {
-        hipLaunchKernelGGL(k_bin_enc_bwd_small, dim3(nblk), dim3(256), 0, st, (int)K, (int)H, nb, W2, h, gu, ghpre, slabs_h);
+        if (H <= 64) hipLaunchKernelGGL(k_bin_enc_bwd_small<64>, dim3(nblk), dim3(256), 0, st, (int)K, (int)H, nb, W2, h, gu, ghpre, slabs_h);
+        else hipLaunchKernelGGL(k_bin_enc_bwd_small<128>, dim3(nblk), dim3(256), 0, st, (int)K, (int)H, nb, W2, h, gu, ghpre, slabs_h);
         VX_CHECK_LAUNCH();
         EncDims dm;
         dm.D = 1; dm.J = cfg->J; dm.H = cfg->H; dm.Hp = (cfg->H + 31) / 32 * 32; dm.DS = 3; dm.T = 1; dm.nb = nb;
@@ -1391,7 +1397,7 @@ int vx_bin_enc_backward(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_
     rc = set_lds(k_fc1_bwd<HT>, lds);                                                                        \
     if (rc) return rc;                                                                                       \
     hipLaunchKernelGGL(k_fc1_bwd<HT>, grid, dim3(ENC_THREADS), lds, st, dm, y, rows, ghpre, slabs_f, lenf, 0)
-        if (dm.Hp == 32) { LAUNCH_F1(1); } else { LAUNCH_F1(2); }
+        if (dm.Hp == 32) { LAUNCH_F1(1); } else if (dm.Hp == 64) { LAUNCH_F1(2); } else if (dm.Hp == 96) { LAUNCH_F1(3); } else { LAUNCH_F1(4); }
 #undef LAUNCH_F1
         VX_CHECK_LAUNCH();
     }
@@ -1446,7 +1452,7 @@ int vx_synth_cdm(const vx_hodina_cfg* cfg, int32_t dino, int32_t hodina, float a
 // ------------------------------------------------------------------------------------------------
 // VaeCCDM (vi.py:866-891): SoftmaxEncoder prior over the patterns (k_vaeccdm.hip) + the enumeration of k_hodina.hip
 static bool sm_enc_cfg_ok(const vx_hodina_cfg* cfg) {
-    return cfg && cfg->K >= 1 && cfg->K <= 10 && cfg->H >= 1 && cfg->H <= 64 && cfg->J >= 1 && cfg->J <= 1024;
+    return cfg && cfg->K >= 1 && cfg->K <= 10 && cfg->H >= 1 && cfg->H <= 128 && cfg->J >= 1 && cfg->J <= 1024;
 }
 static int col_parts(int64_t nb) {
     int64_t p = (nb + 255) / 256;
@@ -1464,10 +1470,15 @@ int vx_sm_enc_forward(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t*
                       const float* b1, const float* W2, const float* b2, float* h, float* z, void* hs) {
     if (!sm_enc_cfg_ok(cfg) || !y || !W1 || !b1 || !W2 || !b2 || !h || !z || nb < 0) return VX_EINVAL;
     if (nb == 0) return VX_OK;
-    int64_t blocks = (nb + 3) / 4;
+    const int ppb = cfg->H <= 64 ? 4 : 2;
+    int64_t blocks = (nb + ppb - 1) / ppb;
     if (blocks > (int64_t)num_cu() * 8) blocks = (int64_t)num_cu() * 8;
-    hipLaunchKernelGGL(k_sm_enc_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hs, 1 << cfg->K, (int)cfg->J, (int)cfg->H,
-                       nb, y, rows, W1, b1, W2, b2, h, z);
+    if (cfg->H <= 64)
+        hipLaunchKernelGGL(k_sm_enc_fwd<64>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hs, 1 << cfg->K, (int)cfg->J,
+                           (int)cfg->H, nb, y, rows, W1, b1, W2, b2, h, z);
+    else
+        hipLaunchKernelGGL(k_sm_enc_fwd<128>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hs, 1 << cfg->K, (int)cfg->J,
+                           (int)cfg->H, nb, y, rows, W1, b1, W2, b2, h, z);
     VX_CHECK_LAUNCH();
     return VX_OK;
 }
@@ -1558,12 +1569,18 @@ int vx_sm_enc_backward(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t
     if (nb > 0) {
         hipLaunchKernelGGL(k_vaeccdm_gz, dim3(grid_1d(nb * C, 256)), dim3(256), 0, st, z, off, T, nb, (int)C, gla);
         VX_CHECK_LAUNCH();
-        int64_t blocks = (nb + 3) / 4;
+        const int ppb = H <= 64 ? 4 : 2;
+        int64_t blocks = (nb + ppb - 1) / ppb;
         if (blocks > (int64_t)num_cu() * 8) blocks = (int64_t)num_cu() * 8;
-        hipLaunchKernelGGL(k_sm_enc_bwd_h, dim3((unsigned)blocks), dim3(256), 0, st, (int)C, (int)H, nb, W2, h, (const float*)gla, ghpre);
+        if (H <= 64) hipLaunchKernelGGL(k_sm_enc_bwd_h<64>, dim3((unsigned)blocks), dim3(256), 0, st, (int)C, (int)H, nb, W2, h, (const float*)gla, ghpre);
+        else hipLaunchKernelGGL(k_sm_enc_bwd_h<128>, dim3((unsigned)blocks), dim3(256), 0, st, (int)C, (int)H, nb, W2, h, (const float*)gla, ghpre);
         VX_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_sm_enc_bwd_w, dim3((unsigned)((C + 63) / 64), (unsigned)n_rs), dim3(256), 0, st, (int)C, (int)H, nb, h,
-                           (const float*)gla, slabs_h);
+        if (H <= 64)
+            hipLaunchKernelGGL(k_sm_enc_bwd_w<64>, dim3((unsigned)((C + 63) / 64), (unsigned)n_rs), dim3(256), 0, st, (int)C, (int)H, nb, h,
+                               (const float*)gla, slabs_h);
+        else
+            hipLaunchKernelGGL(k_sm_enc_bwd_w<128>, dim3((unsigned)((C + 63) / 64), (unsigned)n_rs), dim3(256), 0, st, (int)C, (int)H, nb, h,
+                               (const float*)gla, slabs_h);
         VX_CHECK_LAUNCH();
         EncDims dm;
         dm.D = 1; dm.J = cfg->J; dm.H = cfg->H; dm.Hp = (cfg->H + 31) / 32 * 32; dm.DS = 3; dm.T = 1; dm.nb = nb;
@@ -1574,7 +1591,7 @@ int vx_sm_enc_backward(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t
     rc = set_lds(k_fc1_bwd<HT>, lds);                                                                        \
     if (rc) return rc;                                                                                       \
     hipLaunchKernelGGL(k_fc1_bwd<HT>, grid, dim3(ENC_THREADS), lds, st, dm, y, rows, ghpre, slabs_f, lenf, 0)
-        if (dm.Hp == 32) { LAUNCH_F1(1); } else { LAUNCH_F1(2); }
+        if (dm.Hp == 32) { LAUNCH_F1(1); } else if (dm.Hp == 64) { LAUNCH_F1(2); } else if (dm.Hp == 96) { LAUNCH_F1(3); } else { LAUNCH_F1(4); }
 #undef LAUNCH_F1
         VX_CHECK_LAUNCH();
     }
