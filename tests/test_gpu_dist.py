@@ -29,7 +29,8 @@ def _run(case, world, tmp_path, port):
     return [json.load(open(out + ".%d" % r)) for r in range(world)]
 
 
-@pytest.mark.parametrize("case,port", [("mvn", 29711), ("irt1d", 29713), ("hodina", 29715)])
+@pytest.mark.parametrize("case,port", [("mvn", 29711), ("irt1d", 29713), ("hodina", 29715), ("vaeccdm", 29717),
+                                       ("cdmsf", 29719)])
 def test_hip_two_ranks_match_one_rank(case, port, tmp_path):
     one = _run(case, 1, tmp_path, port)[0]
     two = _run(case, 2, tmp_path, port + 1)
