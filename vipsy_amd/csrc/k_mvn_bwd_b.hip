@@ -1,7 +1,8 @@
 // OPT-IN variant (VX_BF16X3=1) of k_mvn_enc_bwd_w_t: the same head weight gradients
 //     gWp[r][hh] = sum_p V[r][p] h[p][hh],   V = (G or GD row) * (E row or ones),
-// with every fp32 product computed as THREE bf16 terms per operand and SIX cross products on the bf16 MFMA
-// (v_mfma_f32_32x32x16_bf16, fp32 accumulate).  tools/bf16x3_ubench.hip: the result is closer to
+// on the bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate): h, the reused operand, as THREE bf16 terms; V, made and
+// split per element, as TWO (truncated head + rounded remainder, 2^-17 relative and unbiased -- below the fp32
+// accumulation noise of a sum over the persons); FIVE cross products (hh, hm, hl, mh, mm).  tools/bf16x3_ubench.hip: the result is closer to
 // the fp64 value than the exact fp32 MFMA chain (8.5e-8 vs 1.5e-7 of sum |a b|) at a third of the matrix-pipe time,
 // and a bf16 MFMA holds the vector issue port for 8 of its 32 cycles only, so the splitting of V runs in its shadow.
 //   h  : split once per step into three bf16 arrays hs[3][64][nb] (k_split3_bf16), staged by DMA, 16-byte fragments;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
         }
     };
 
-    // ---- compute: 2 chunks x BT_RT row tiles = 8 groups per tile, 12 MFMAs per group.  The fragments of group g + 1
+    // ---- compute: 2 chunks x BT_RT row tiles = 8 groups per tile, 10 MFMAs per group.  The fragments of group g + 1
     // (4 LDS reads, 4 products, 4 x (split of an element pair), the bias sum) are made in the shadow of the MFMAs of
     // group g, a few vector instructions after each MFMA; every slice is a pinned scheduling region.  The barrier of a
     // tile sits before its LAST group, whose operands are in registers already: behind it the buffer is free for the
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
     // Every instruction of a slice is a volatile asm statement: the optimizer otherwise re-vectorizes the scalar
     // arithmetic into v_pk_*_f32 across slices and sinks whole slices out of the MFMA shadow.
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    uint32_t fq[2][3][4];                                              // [parity of the group][h, m, l][element pair]
+    uint32_t fq[2][2][4];                                              // [parity of the group][h, m][element pair]
     bf16x8 hf[2][3][2];                                                // [parity of the chunk][split][hidden tile]
     f32x4 rg0, rg1, re0, re1;
     float pv_[8], pr_[8], s0, s1, s2, s3;
@@ -197,11 +198,14 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
         pr_[2 * p] = arem(pv_[2 * p]);
         pr_[2 * p + 1] = arem(pv_[2 * p + 1]);
     };
+    // V is split into TWO terms: h by truncation (its remainder is exact), m = the remainder rounded to nearest (+ half an
+    // ulp of bf16 on the bit pattern, then the upper half).  V = h + m to 2^-17 relative, unbiased -- the weight gradient
+    // is a sum over the persons whose fp32 accumulation noise (~ sqrt(N) 2^-24) is far above that, and h (the reused
+    // operand) keeps its three terms: five products instead of six, three vector instructions less per element.
+    auto arnd = [](float x) -> float { float d; asm volatile("v_add_u32 %0, 0x8000, %1" : "=v"(d) : "v"(x)); return d; };
     auto split_b = [&](auto pc, auto nc) __attribute__((always_inline)) {
         constexpr int p = decltype(pc)::value, nx = decltype(nc)::value;
-        fq[nx][1][p] = pack_hi(pr_[2 * p + 1], pr_[2 * p]);
-        const float l0 = arem(pr_[2 * p]), l1 = arem(pr_[2 * p + 1]);
-        fq[nx][2][p] = pack_hi(l1, l0);
+        fq[nx][1][p] = pack_hi(arnd(pr_[2 * p + 1]), arnd(pr_[2 * p]));
     };
     auto frag = [&](auto cc, auto kc) -> bf16x8 {
         constexpr int cu = decltype(cc)::value, k = decltype(kc)::value;
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
             const char* rb = smem_bb + (last ? 1 - b : b) * BUF;
             constexpr std::integral_constant<int, cur> curc{};
             constexpr std::integral_constant<int, nxt> nxtc{};
-            const bf16x8 vh = frag(curc, std::integral_constant<int, 0>{}), vm = frag(curc, std::integral_constant<int, 1>{}), vl = frag(curc, std::integral_constant<int, 2>{});
+            const bf16x8 vh = frag(curc, std::integral_constant<int, 0>{}), vm = frag(curc, std::integral_constant<int, 1>{});
             __builtin_amdgcn_sched_barrier(0);
             acc[t][0] = mfma_bf16(vh, hf[c][0][0], acc[t][0]);
             __builtin_amdgcn_sched_barrier(0);
@@ -250,33 +254,26 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
             acc[t][1] = mfma_bf16(vh, hf[c][2][1], acc[t][1]);
             __builtin_amdgcn_sched_barrier(0);
             split_b(std::integral_constant<int, 0>{}, nxtc);
+            split_a(std::integral_constant<int, 1>{}, nxtc);
             __builtin_amdgcn_sched_barrier(0);
             acc[t][0] = mfma_bf16(vm, hf[c][0][0], acc[t][0]);
             __builtin_amdgcn_sched_barrier(0);
-            split_a(std::integral_constant<int, 1>{}, nxtc); s2 = aadd(s2, s3);
+            split_b(std::integral_constant<int, 1>{}, nxtc); s2 = aadd(s2, s3); s0 = aadd(s0, s2);
             __builtin_amdgcn_sched_barrier(0);
             acc[t][1] = mfma_bf16(vm, hf[c][0][1], acc[t][1]);
             __builtin_amdgcn_sched_barrier(0);
-            split_b(std::integral_constant<int, 1>{}, nxtc);
+            split_a(std::integral_constant<int, 2>{}, nxtc);
+            if constexpr (last) bsum[tn] = aadd(bsum[tn], has_next ? s0 : 0.f); else bsum[tn] = aadd(bsum[tn], s0);
             __builtin_amdgcn_sched_barrier(0);
             acc[t][0] = mfma_bf16(vm, hf[c][1][0], acc[t][0]);
             __builtin_amdgcn_sched_barrier(0);
-            split_a(std::integral_constant<int, 2>{}, nxtc); s0 = aadd(s0, s2);
+            split_b(std::integral_constant<int, 2>{}, nxtc);
+            split_a(std::integral_constant<int, 3>{}, nxtc);
             __builtin_amdgcn_sched_barrier(0);
             acc[t][1] = mfma_bf16(vm, hf[c][1][1], acc[t][1]);
             __builtin_amdgcn_sched_barrier(0);
-            split_b(std::integral_constant<int, 2>{}, nxtc);
-            __builtin_amdgcn_sched_barrier(0);
-            acc[t][0] = mfma_bf16(vl, hf[c][0][0], acc[t][0]);
-            __builtin_amdgcn_sched_barrier(0);
-            split_a(std::integral_constant<int, 3>{}, nxtc);
-            if constexpr (last) bsum[tn] = aadd(bsum[tn], has_next ? s0 : 0.f); else bsum[tn] = aadd(bsum[tn], s0);
-            __builtin_amdgcn_sched_barrier(0);
-            acc[t][1] = mfma_bf16(vl, hf[c][0][1], acc[t][1]);
-            __builtin_amdgcn_sched_barrier(0);
             split_b(std::integral_constant<int, 3>{}, nxtc);
             __builtin_amdgcn_sched_barrier(0);
-            
         });
     };
 
