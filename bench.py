@@ -28,7 +28,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dens
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: dense bf16 matrix peak
 # an fp32 product computed as three bf16 terms per operand costs six bf16 MFMA products:
 PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
-PEAK_BF16X5_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 5.0   # weight-gradient sums: the per-element operand in two terms, five products
+PEAK_BF16X5_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 5.0   # backward kernels: the per-person operand in two terms, five products
 PEAK_HBM_GBS = 8000.0
 PROFILE_TAG = "r02_headline"
 
@@ -59,7 +59,7 @@ def kernel_model(name, J, D, H):
         "k_mvn_enc_fwd_b": (enc_fwd_flops_per_person(J, D, H), PEAK_BF16X3_TFLOPS, "f32 via bf16x3 on the bf16 MFMA"),
         "k_mvn_enc_fwd_p": (enc_fwd_flops_per_person(J, D, H), PEAK_F32_MFMA_TFLOPS, "f32 MFMA"),
         "k_mvn_enc_bwd_h_t": (heads, PEAK_F32_MFMA_TFLOPS, "f32 MFMA"),
-        "k_mvn_enc_bwd_h_b": (heads, PEAK_BF16X3_TFLOPS, "f32 via bf16x3 on the bf16 MFMA"),
+        "k_mvn_enc_bwd_h_b": (heads, PEAK_BF16X5_TFLOPS, "f32 via bf16 terms (3 x 2, five products) on the bf16 MFMA"),
         "k_mvn_enc_bwd_w_t": (heads, PEAK_F32_MFMA_TFLOPS, "f32 MFMA"),
         "k_mvn_enc_bwd_w_b": (heads, PEAK_BF16X5_TFLOPS, "f32 via bf16 terms (3 x 2, five products) on the bf16 MFMA"),
         "k_irt_lik_r": (2.0 * 3 * (D + 1) * J, PEAK_F32_MFMA_TFLOPS, "f32 MFMA"),        # Z, gx, GA

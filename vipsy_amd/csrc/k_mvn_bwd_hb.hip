@@ -1,16 +1,16 @@
-// Hidden-layer gradient of the amortized MVN guide on the bf16 MFMA (three-term operand splitting, fp32 accumulate):
+// Hidden-layer gradient of the amortized MVN guide on the bf16 MFMA (bf16-term operand splitting, fp32 accumulate):
 // the same result as k_mvn_enc_bwd_h_t (k_mvn_bwd_t.hip),
 //     gh[p][hh] = sum_r Wp[r][hh] V[r][p],    ghpre = gh * (1 - exp(-h))                          (autograd of vi.py:448-455)
 // but V is never formed.  For the off-diagonal rows V[(k,l)][p] = gx[p][k] eps[p][l] is a rank-one product, so
 //     gh[p][:] = sum_k gx[p][k] U_k[p][:],      U_k[p][hh] = sum_{l<k} W22[(k,l)][hh] eps[p][l]
-// and U_k is a GEMM whose per-person operand is eps alone: split ONCE per 32-person wave tile into bf16x3 fragments
+// and U_k is a GEMM whose per-person operand is eps alone: split ONCE per 32-person wave tile into bf16 fragments
 // that stay in registers for every k (the V of the fp32 kernel needed a multiply -- and would need a three-way split
 // -- per element).  The weights are split once per step into per-unit images (k_pack_heads_hb).  The multiplication by
 // gx[p][k] is a 32-FMA epilogue per k on the accumulator.  DIAG rows (operand gd = gx eps e^M + scale, k_mvn_gd) and
 // LOC rows (operand gx) are two more small GEMMs straight into the gh accumulator.
 //   MFMA 32x32x16: C rows = hidden units (two tiles of 32), columns = persons; contraction index = l (or k).
 //   unit (k, s) = the 16 contraction indices l = 16 s .. 16 s + 15 of one k: 6 fragments of 1 KB (2 hidden tiles x 3
-//   splits), 12 MFMAs.  Units stream through a ring of 8 slots in LDS by DMA, shared by the 8 waves of the workgroup
+//   splits), 10 MFMAs (five products a tile).  Units stream through a ring of 8 slots in LDS by DMA, shared by the 8 waves of the workgroup
 //   (pairs of units = 12 transfers = 3 for each of the waves 0..3, so `vmcnt(3)` counts whole pairs); one barrier per
 //   pair.  Two waves per SIMD (the kernel fits 256 registers): what one wave cannot overlap -- the epilogue per k,
 //   LDS waits, the barrier -- runs under the other wave's MFMAs.
@@ -75,6 +75,30 @@ __global__ void k_pack_heads_hb(int D, const float* __restrict__ W21, const floa
     }
 }
 
+// eight fp32 values -> two bf16 fragments: hi by truncation (v - hi is exact), mid = that remainder rounded to nearest
+// (half an ulp of bf16 added on the bit pattern, then the upper half): v = hi + mid to 2^-17 relative, unbiased.  gh of a
+// person only ever enters sums over the persons (fc1 weight / bias gradients), whose fp32 accumulation noise is far
+// above that -- so the third term of the per-person operand, and with it one product in six, is not spent.
+__device__ __forceinline__ void hb_split8(const float* v, bf16x8& fh, bf16x8& fm) {
+    typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+    u32x4v ph, pm;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t hb[2], mb[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float x = v[2 * q + e];
+            hb[e] = __builtin_bit_cast(uint32_t, x) & 0xffff0000u;
+            const float r1 = x - __builtin_bit_cast(float, hb[e]);
+            mb[e] = (__builtin_bit_cast(uint32_t, r1) + 0x8000u) & 0xffff0000u;
+        }
+        ph[q] = hb[1] | (hb[0] >> 16);
+        pm[q] = mb[1] | (mb[0] >> 16);
+    }
+    fh = __builtin_bit_cast(bf16x8, ph);
+    fm = __builtin_bit_cast(bf16x8, pm);
+}
+
 __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
     EncDims dm, const uint8_t* __restrict__ img, const float* __restrict__ h_in, const float* __restrict__ eps_in,
     const float* __restrict__ gxT, const float* __restrict__ gdT /*DIAG-row operand [D][nb]*/,
@@ -115,7 +139,7 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
     for (int k = half; k < D; k += 2) gx_lds[k * 32 + l31] = gxT[(int64_t)k * nb + ic];
 
     // ---- B fragments: contraction index c = 16 s + 8 half + j of person ic, three bf16 terms each
-    bf16x8 bf[3][HB_NS];
+    bf16x8 bf[2][HB_NS];                                               // the per-person operand in TWO bf16 terms (hb_split8)
     {
         const float* er = eps_in + ic * D;
 #pragma unroll
@@ -128,7 +152,7 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
                 if (c0 + 4 * q + 4 <= D) t = *(const f32x4*)(er + c0 + 4 * q);      // D % 4 == 0 on this path
                 v[4 * q + 0] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
             }
-            fb_split8(v, bf[0][s], bf[1][s], bf[2][s]);
+            hb_split8(v, bf[0][s], bf[1][s]);
         }
     }
     auto frags_from_T = [&](const float* __restrict__ srcT) __attribute__((always_inline)) {
@@ -140,7 +164,7 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
                 const int c = 16 * s + 8 * half + j;
                 v[j] = (c < D) ? srcT[(int64_t)c * nb + ic] : 0.f;
             }
-            fb_split8(v, bf[0][s], bf[1][s], bf[2][s]);
+            hb_split8(v, bf[0][s], bf[1][s]);
         }
     };
 
@@ -160,20 +184,18 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
         __syncthreads();
         stage_pair(q + 3);
     };
-    // one unit: 6 products per hidden tile (small terms first); the fragments of the NEXT unit are requested as soon as
+    // one unit: 5 products per hidden tile (weights in three terms, the per-person operand in two; small terms first); the fragments of the NEXT unit are requested as soon as
     // the registers are free: hidden tile 0 after the first six MFMAs, hidden tile 1 at the end
     auto unit = [&](auto sc, f32x16& U0, f32x16& U1) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
         if ((u & 1) == 0) sync_pair(u >> 1);
         U0 = mfma_bf16(A[2], bf[0][s], U0);
-        U0 = mfma_bf16(A[0], bf[2][s], U0);
         U0 = mfma_bf16(A[1], bf[1][s], U0);
         U0 = mfma_bf16(A[1], bf[0][s], U0);
         U0 = mfma_bf16(A[0], bf[1][s], U0);
         U0 = mfma_bf16(A[0], bf[0][s], U0);
         read_ht(u + 1, 0);
         U1 = mfma_bf16(A[5], bf[0][s], U1);
-        U1 = mfma_bf16(A[3], bf[2][s], U1);
         U1 = mfma_bf16(A[4], bf[1][s], U1);
         U1 = mfma_bf16(A[4], bf[0][s], U1);
         U1 = mfma_bf16(A[3], bf[1][s], U1);
