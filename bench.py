@@ -63,7 +63,8 @@ def kernel_model(name, J, D, H):
         "k_mvn_enc_bwd_w_t": (heads, PEAK_F32_MFMA_TFLOPS, "f32 MFMA"),
         "k_mvn_enc_bwd_w_b": (heads, PEAK_BF16X5_TFLOPS, "f32 via bf16 terms (3 x 2, five products) on the bf16 MFMA"),
         "k_irt_lik_r": (2.0 * 3 * (D + 1) * J, PEAK_F32_MFMA_TFLOPS, "f32 MFMA"),        # Z, gx, GA
-        "k_irt_lik_b": (2.0 * 3 * (D + 1) * J, PEAK_BF16X3_TFLOPS, "f32 via bf16x3 on the bf16 MFMA"),
+        "k_irt_lik_b": (2.0 * 3 * (D + 1) * J, PEAK_BF16_MFMA_TFLOPS * 3.0 / 16.0,
+                        "f32 via bf16 terms on the bf16 MFMA (Z: six products, gx and GA: five)"),
     }
     return table.get(name)
 
@@ -309,7 +310,9 @@ def main():
                                "peak_basis": "dense bf16 MFMA peak 2500 / 6 products per f32 product"
                                              if peak == PEAK_BF16X3_TFLOPS else
                                              "dense bf16 MFMA peak 2500 / 5 products per f32 product"
-                                             if peak == PEAK_BF16X5_TFLOPS else "dense f32 MFMA peak",
+                                             if peak == PEAK_BF16X5_TFLOPS else
+                                             "dense bf16 MFMA peak 2500 / (16 / 3) products per f32 product"
+                                             if peak == PEAK_BF16_MFMA_TFLOPS * 3.0 / 16.0 else "dense f32 MFMA peak",
                                "algorithmic_flops_per_launch": fl, "avg_launch_ms": priced[name]}
         elif "hodina" in phase_ms:
             # SURVEY.md section 8d, cfg 5: (2 K + J) C MACs forward, ~3x with the backward = compute-bound.  The pattern

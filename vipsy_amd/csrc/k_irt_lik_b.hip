@@ -107,8 +107,11 @@ __device__ __forceinline__ bf16x8 lb_frag(lb_u32x2 lo, lb_u32x2 hi) {
 }
 __device__ __forceinline__ bf16x8 lb_read128(lb_lds* p) { return *(__attribute__((address_space(3))) const bf16x8*)p; }
 
-// two fp32 values -> their three bf16 terms, packed pairwise (element 0 in the low half); one v_cvt_pk_bf16_f32 per term
-__device__ __forceinline__ void lb_split_pair(float a, float b, uint32_t& ph, uint32_t& pm, uint32_t& pl) {
+// two fp32 values -> their TWO leading bf16 terms (round to nearest each: v = hi + mid to 2^-17 relative, unbiased), packed
+// pairwise (element 0 in the low half); one v_cvt_pk_bf16_f32 per term.  R = dlogp/dz only feeds gx and GA, which end in
+// sums over the persons (encoder and item gradients) whose fp32 accumulation noise is far above 2^-17 / sqrt(N): the third
+// term, and with it one product in six of gx and GA, is not spent.  (x and a keep three terms: Z is exact to fp32.)
+__device__ __forceinline__ void lb_split_pair(float a, float b, uint32_t& ph, uint32_t& pm) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     // the conversions are paired (one instruction per term), the residuals are scalar on purpose: packed f32 adds cost
@@ -117,9 +120,6 @@ __device__ __forceinline__ void lb_split_pair(float a, float b, uint32_t& ph, ui
     float a1 = a - __builtin_bit_cast(float, ph << 16), b1 = b - __builtin_bit_cast(float, ph & 0xffff0000u);
     asm("" : "+v"(a1), "+v"(b1));
     pm = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a1, b1}, bf16x2));
-    float a2 = a1 - __builtin_bit_cast(float, pm << 16), b2 = b1 - __builtin_bit_cast(float, pm & 0xffff0000u);
-    asm("" : "+v"(a2), "+v"(b2));
-    pl = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a2, b2}, bf16x2));
 }
 
 // scheduling hint for one region: interleave its MFMAs with the vector work of the region (a bf16 MFMA holds the vector
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(LB_THREADS, 1) void k_irt_lik_b(
     };
 
     const float sdc = dm.scale * dm.Dc;
-    uint32_t Rp[2][3][8];                                           // [half][split][pair]: packed bf16 terms of R
+    uint32_t Rp[2][2][8];                                           // [half][term][pair]: packed bf16 terms of R
     float lpq[4];                                                   // log-lik terms of the current run of four registers
     f32x16 z0 = zero16();                                           // Z of persons 0..31 of the CURRENT tile (made one tile early)
     f32x16 gx1 = zero16();                                          // gx of persons 32..63: stored one tile late
@@ -352,9 +352,8 @@ __global__ __launch_bounds__(LB_THREADS, 1) void k_irt_lik_b(
     };
     auto ga_mma = [&](int ph, int u, const bf16x8& xh, const bf16x8& xm, const bf16x8& xl) {
         const int s2 = u >> 2, kt = u & 3;
-        const bf16x8 rh = rfrag(ph, 0, s2), rm = rfrag(ph, 1, s2), rl = rfrag(ph, 2, s2);
+        const bf16x8 rh = rfrag(ph, 0, s2), rm = rfrag(ph, 1, s2);
         ga[kt] = mfma_bf16(xl, rh, ga[kt]);
-        ga[kt] = mfma_bf16(xh, rl, ga[kt]);
         ga[kt] = mfma_bf16(xm, rm, ga[kt]);
         ga[kt] = mfma_bf16(xm, rh, ga[kt]);
         ga[kt] = mfma_bf16(xh, rm, ga[kt]);
@@ -365,11 +364,11 @@ __global__ __launch_bounds__(LB_THREADS, 1) void k_irt_lik_b(
         const int o = ph * 3 * LB_RPLANE + 1024 * s;
         fh = lb_frag(lb_tr_read(rRp0 + o), lb_tr_read(rRp1 + o));
         fm = lb_frag(lb_tr_read(rRp0 + o + LB_RPLANE), lb_tr_read(rRp1 + o + LB_RPLANE));
-        fl = lb_frag(lb_tr_read(rRp0 + o + 2 * LB_RPLANE), lb_tr_read(rRp1 + o + 2 * LB_RPLANE));
+        (void)fl;                                                   // R has two terms
     };
     auto gx_mma = [&](int s, f32x16& gx, const bf16x8& rh, const bf16x8& rm, const bf16x8& rl) {
+        (void)rl;
         gx = mfma_bf16(aG[2][s], rh, gx);
-        gx = mfma_bf16(aG[0][s], rl, gx);
         gx = mfma_bf16(aG[1][s], rm, gx);
         gx = mfma_bf16(aG[1][s], rh, gx);
         gx = mfma_bf16(aG[0][s], rm, gx);
@@ -405,14 +404,14 @@ __global__ __launch_bounds__(LB_THREADS, 1) void k_irt_lik_b(
             const float l2 = lp + dpp_mov0<0xB1, 0xF>(lp);          // + the terms of the three other items of the quad
             lpq[2 * (i & 1) + e] = l2 + dpp_mov0<0x4E, 0xF>(l2);
         }
-        lb_split_pair(rv[0], rv[1], Rp[ph][0][i], Rp[ph][1][i], Rp[ph][2][i]);
+        lb_split_pair(rv[0], rv[1], Rp[ph][0][i], Rp[ph][1][i]);
         if constexpr (i & 1) {                                      // registers 4 g4 .. 4 g4 + 3 are complete
             // item quad (l31 >> 2): lane qc of the quad stores register 4 g4 + qc = person 32 ph + 8 g4 + 4 half + qc
             const float t01 = (qc & 1) ? lpq[1] : lpq[0], t23 = (qc & 1) ? lpq[3] : lpq[2];
             *(__attribute__((address_space(3))) float*)(lpW + 128 * (32 * ph + 8 * g4)) = (qc & 2) ? t23 : t01;
             lb_lds* wb = rWp + ph * 3 * LB_RPLANE + 8u * (((2 * g4 + half) ^ rSw) & 7);
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp) {
+            for (int sp = 0; sp < 2; ++sp) {
                 const lb_u32x2 w = {Rp[ph][sp][i - 1], Rp[ph][sp][i]};
                 *(__attribute__((address_space(3))) lb_u32x2*)(wb + sp * LB_RPLANE) = w;
             }
@@ -479,7 +478,7 @@ __global__ __launch_bounds__(LB_THREADS, 1) void k_irt_lik_b(
                 ga_mma(0, u + 1, nh, nm, nl);
                 cell_pair(I1{}, dc_, z1, yq0, yq1, dm.scale);
                 stage_x_piece(nx, buf ^ 1, 7 + d2);
-                if constexpr (HINT) lb_interleave<12, 7, 6>();
+                if constexpr (HINT) lb_interleave<10, 8, 6>();
                 __builtin_amdgcn_sched_barrier(0);
             });
             static_for<4>([&](auto dc_) {                           // two gx steps + one cell pair per region
@@ -490,7 +489,7 @@ __global__ __launch_bounds__(LB_THREADS, 1) void k_irt_lik_b(
                 gx_mma(s + 1, gx0, nh, nm, nl);
                 cell_pair(I1{}, std::integral_constant<int, 4 + d2>{}, z1, yq0, yq1, dm.scale);
                 if constexpr (d2 < 2) stage_y_piece(nx, buf ^ 1, d2);
-                if constexpr (HINT) lb_interleave<12, 7, 6>();
+                if constexpr (HINT) lb_interleave<10, 8, 6>();
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
@@ -523,7 +522,7 @@ __global__ __launch_bounds__(LB_THREADS, 1) void k_irt_lik_b(
                 if constexpr (s + 2 < 8) gx_frags(1, s + 2, ch, cm, cl); else ga_frags(xb, 1, 0, ch, cm, cl);
                 gx_mma(s + 1, gx1, nh, nm, nl);
                 cell_pair(I0{}, dc_, z0, yq0, yq1, scale_next);
-                if constexpr (HINT) lb_interleave<12, 7, 6>();
+                if constexpr (HINT) lb_interleave<10, 8, 6>();
                 __builtin_amdgcn_sched_barrier(0);
             });
             static_for<4>([&](auto dc_) {
@@ -533,7 +532,7 @@ __global__ __launch_bounds__(LB_THREADS, 1) void k_irt_lik_b(
                 if constexpr (u + 2 < 8) ga_frags(xb, 1, u + 2, ch, cm, cl);
                 ga_mma(1, u + 1, nh, nm, nl);
                 cell_pair(I0{}, std::integral_constant<int, 4 + d2>{}, z0, yq0, yq1, scale_next);
-                if constexpr (HINT) lb_interleave<12, 7, 6>();
+                if constexpr (HINT) lb_interleave<10, 8, 6>();
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
