@@ -18,7 +18,20 @@ struct Irt1dDims {
 };
 
 // WPL = 4-item words per lane (items 256 w + 4 lane + 0..3); J <= 1024 -> WPL <= 4
-template <int MODEL, int WPL, bool WORDS>
+// HALF (WPL == 1, J <= 128): the items fit 32 lanes, so each lane half takes its own person (lanes 32..63 repeat the item
+// parameters and walk persons 32..63 of the group): two persons per wave iteration instead of one with half the lanes idle
+__device__ __forceinline__ float half_sums_dpp(float v, int half) {         // sum over the 32 lanes of this lane's half
+    v += dpp_mov0<0xB1, 0xF>(v);
+    v += dpp_mov0<0x4E, 0xF>(v);
+    v += dpp_mov0<0x141, 0xF>(v);
+    v += dpp_mov0<0x140, 0xF>(v);
+    v += dpp_mov0<0x142, 0xA>(v);                                          // row_bcast:15 -> lanes 31 / 63 hold the half sums
+    const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+    const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    return half ? hi : lo;
+}
+
+template <int MODEL, int WPL, bool WORDS, bool HALF = false>
 __global__ __launch_bounds__(I1_THREADS) void k_irt1d(
     Irt1dDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, int64_t gid0,
     const float* __restrict__ loc, const float* __restrict__ raw, const float* __restrict__ eps_in,
@@ -29,6 +42,9 @@ __global__ __launch_bounds__(I1_THREADS) void k_irt1d(
     __shared__ float el_w[I1_THREADS / 64];
     float el_acc = 0.f;
     if (step_dev) step = *step_dev;                                // replayed from a HIP graph: the counter lives on the device
+    static_assert(!HALF || WPL == 1, "HALF: one word per lane");
+    const int half = HALF ? (threadIdx.x >> 5) & 1 : 0;
+    const int ilane = HALF ? (threadIdx.x & 31) : (threadIdx.x & 63);       // the lane's position on the item axis
     constexpr int IPL = 4 * WPL;
     const int J = dm.J;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -38,7 +54,7 @@ __global__ __launch_bounds__(I1_THREADS) void k_irt1d(
     float aq[IPL], bq[IPL], cq[IPL], dq[IPL], oq[IPL], ga[IPL], gb[IPL], gc[IPL], gd[IPL];
 #pragma unroll
     for (int q = 0; q < IPL; ++q) {
-        const int j = 256 * (q >> 2) + 4 * lane + (q & 3);
+        const int j = 256 * (q >> 2) + 4 * ilane + (q & 3);
         const bool ok = j < J;
         aq[q] = (MODEL >= 2) ? (ok ? a[j] : 0.f) : 1.0f;
         bq[q] = ok ? b[j] : 0.f;
@@ -52,7 +68,7 @@ __global__ __launch_bounds__(I1_THREADS) void k_irt1d(
         const uint8_t* yr = y + prow * J;
 #pragma unroll
         for (int u = 0; u < WPL; ++u) {
-            const int j0 = 256 * u + 4 * lane;
+            const int j0 = 256 * u + 4 * ilane;
             if (WORDS) {                                   // J % 4 == 0: a word is entirely inside or outside
                 uint32_t v = 0xFEFEFEFEu;
                 if (j0 < J) v = *(const uint32_t*)(yr + j0);
@@ -81,23 +97,33 @@ __global__ __launch_bounds__(I1_THREADS) void k_irt1d(
         float my_ll = 0.f, my_gx = 0.f;
         const int cnt = (int)((dm.nb - grp * 64) < 64 ? (dm.nb - grp * 64) : 64);
         uint32_t wcur[WPL], wnext[WPL];
-        {
-            const int64_t prow = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(row_hi, 0) << 32) |
-                                           (uint32_t)__builtin_amdgcn_readlane(row_lo, 0));
-            load_words(wcur, prow);
-        }
-        for (int pp = 0; pp < cnt; ++pp) {
-            const int pn = (pp + 1 < cnt) ? pp + 1 : pp;                    // prefetch the next person's words
-            {
-                const int64_t prow = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(row_hi, pn) << 32) |
-                                               (uint32_t)__builtin_amdgcn_readlane(row_lo, pn));
-                load_words(wnext, prow);
+        // the response row of person pp (HALF: of person pp in the lower lane half, pp + 32 in the upper one; a person
+        // past the end of the group reads a valid row and is switched off below)
+        auto person_row = [&](int pp) -> int64_t {
+            const int64_t r0 = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(row_hi, pp) << 32) |
+                                         (uint32_t)__builtin_amdgcn_readlane(row_lo, pp));
+            if (!HALF) return r0;
+            const int p1 = (pp + 32 < cnt) ? pp + 32 : pp;
+            const int64_t r1 = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(row_hi, p1) << 32) |
+                                         (uint32_t)__builtin_amdgcn_readlane(row_lo, p1));
+            return half ? r1 : r0;
+        };
+        const int n_it = HALF ? (cnt < 32 ? cnt : 32) : cnt;
+        load_words(wcur, person_row(0));
+        for (int pp = 0; pp < n_it; ++pp) {
+            const int pn = (pp + 1 < n_it) ? pp + 1 : pp;                   // prefetch the next person's words
+            load_words(wnext, person_row(pn));
+            float x = lane_bcast(xv, pp);
+            bool live = true;                                               // HALF: the upper half may have run out of persons
+            if (HALF) {
+                const float x1 = lane_bcast(xv, pp + 32 < 64 ? pp + 32 : 63);
+                x = half ? x1 : x;
+                live = !half || pp + 32 < cnt;
             }
-            const float x = lane_bcast(xv, pp);
             float llp = 0.f, gxp = 0.f;
 #pragma unroll
             for (int q = 0; q < IPL; ++q) {
-                const unsigned yy = (wcur[q >> 2] >> (8 * (q & 3))) & 0xFFu;
+                const unsigned yy = live ? ((wcur[q >> 2] >> (8 * (q & 3))) & 0xFFu) : 254u;
                 const float z = dm.Dc * fmaf(x, aq[q], bq[q]);
                 float lp, dz, dc, dd;
                 irt_cell<MODEL>(z, yy, cq[q], dq[q], oq[q], lp, dz, dc, dd);    // branch-free; y >= 254 -> no gradient
@@ -109,9 +135,15 @@ __global__ __launch_bounds__(I1_THREADS) void k_irt1d(
                 if (MODEL >= 3) gc[q] += dc;
                 if (MODEL >= 4) gd[q] += dd;
             }
-            llp = wave_sum_dpp(llp);
-            gxp = wave_sum_dpp(gxp);
-            if (lane == pp) { my_ll = llp; my_gx = gxp; }
+            if (HALF) {
+                llp = half_sums_dpp(llp, half);
+                gxp = half_sums_dpp(gxp, half);
+                if (lane == pp + 32 * half) { my_ll = llp; my_gx = gxp; }
+            } else {
+                llp = wave_sum_dpp(llp);
+                gxp = wave_sum_dpp(gxp);
+                if (lane == pp) { my_ll = llp; my_gx = gxp; }
+            }
 #pragma unroll
             for (int u = 0; u < WPL; ++u) wcur[u] = wnext[u];
         }
@@ -134,8 +166,13 @@ __global__ __launch_bounds__(I1_THREADS) void k_irt1d(
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int q = 0; q < IPL; ++q) {
-        const int j = 256 * (q >> 2) + 4 * lane + (q & 3);
-        if (j < J) {
+        const int j = 256 * (q >> 2) + 4 * ilane + (q & 3);
+        if (HALF) {                                                        // the two lane halves hold the same items
+            ga[q] = half_sum32(ga[q]); gb[q] = half_sum32(gb[q]);
+            if (MODEL >= 3) gc[q] = half_sum32(gc[q]);
+            if (MODEL >= 4) gd[q] = half_sum32(gd[q]);
+        }
+        if (j < J && (!HALF || half == 0)) {
             if (MODEL >= 2) wslot[j] = ga[q];
             wslot[J + j] = gb[q];
             if (MODEL >= 3) wslot[2 * J + j] = gc[q];

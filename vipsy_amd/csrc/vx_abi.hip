@@ -935,8 +935,14 @@ int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, 
                        raw, eps_in, cfg->seed, cfg->step, step_dev, cfg->stream, a, b, c_un, d_un, gloc, graw, elbo, workspace)
 #define LAUNCH_1D(MODEL, WPL)                                      \
     if (words_ok) { LAUNCH_1DW(MODEL, WPL, true); } else { LAUNCH_1DW(MODEL, WPL, false); }
+#define LAUNCH_1DH(MODEL)                                          \
+    if (words_ok) { hipLaunchKernelGGL((k_irt1d<MODEL, 1, true, true>), dim3(blocks), dim3(I1_THREADS), lds, st, dm, y, rows, gid0, loc, \
+                       raw, eps_in, cfg->seed, cfg->step, step_dev, cfg->stream, a, b, c_un, d_un, gloc, graw, elbo, workspace); }    \
+    else { hipLaunchKernelGGL((k_irt1d<MODEL, 1, false, true>), dim3(blocks), dim3(I1_THREADS), lds, st, dm, y, rows, gid0, loc,     \
+                       raw, eps_in, cfg->seed, cfg->step, step_dev, cfg->stream, a, b, c_un, d_un, gloc, graw, elbo, workspace); }
 #define DISPATCH_IPL(MODEL)                                        \
-    if (wpl_need <= 1) { LAUNCH_1D(MODEL, 1); }                    \
+    if (cfg->J <= 128) { LAUNCH_1DH(MODEL); }                      \
+    else if (wpl_need <= 1) { LAUNCH_1D(MODEL, 1); }               \
     else if (wpl_need <= 2) { LAUNCH_1D(MODEL, 2); }               \
     else { LAUNCH_1D(MODEL, 4); }
     switch (cfg->model) {
@@ -946,6 +952,7 @@ int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, 
         default: DISPATCH_IPL(4) break;
     }
 #undef DISPATCH_IPL
+#undef LAUNCH_1DH
 #undef LAUNCH_1D
 #undef LAUNCH_1DW
     VX_CHECK_LAUNCH();
