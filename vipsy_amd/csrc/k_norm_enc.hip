@@ -142,3 +142,70 @@ __global__ __launch_bounds__(256) void k_norm_enc_bwd_small(
         slab[2 * H + 1] = s2;
     }
 }
+
+// The same for H == 64 with ghpre written DIMENSION-MAJOR (ghpreT[hh][nb], what k_fc1_bwd_b / k_fc1_bwd_t read): a block
+// takes 64 consecutive persons at a time, thread (hh, quarter) computes 16 of them, the 64 x 64 tile turns in LDS and goes
+// out as 256-byte rows.  Saves the person-major copy and the transpose pass over it.  Slab layout as above.
+__global__ __launch_bounds__(256) void k_norm_enc_bwd_t64(
+    int64_t nb, const float* __restrict__ W21, const float* __restrict__ W22, const float* __restrict__ h,
+    const float* __restrict__ gloc, const float* __restrict__ graw, float* __restrict__ ghpreT,
+    float* __restrict__ slabs) {
+    __shared__ float T[64][65];
+    __shared__ float red[2][4][64];
+    __shared__ float gl_s[64], gr_s[64];
+    const int tid = threadIdx.x, hh = tid & 63, pq = tid >> 6;
+    const float w21 = W21[hh], w22 = W22[hh];
+    float a21 = 0.f, a22 = 0.f, gb21 = 0.f, gb22 = 0.f;
+    const int64_t n_tiles = (nb + 63) / 64;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t i0 = tile * 64;
+        if (tid < 64) {
+            const int64_t i = i0 + tid;
+            gl_s[tid] = i < nb ? gloc[i] : 0.f;
+            gr_s[tid] = i < nb ? graw[i] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int p = pq + 4 * q;
+            const int64_t i = i0 + p;
+            float g = 0.f;
+            if (i < nb) {
+                const float hv = h[i * 64 + hh];
+                const float gl = gl_s[p], gr = gr_s[p];
+                g = -(gl * w21 + gr * w22) * (1.0f - __expf(-hv));
+                a21 -= gl * hv;
+                a22 -= gr * hv;
+                if (hh == 0) { gb21 -= gl; gb22 -= gr; }
+            }
+            T[p][hh] = g;
+        }
+        __syncthreads();
+        {
+            const int p = tid & 63, hq = tid >> 6;
+            const int64_t i = i0 + p;
+            if (i < nb) {
+#pragma unroll 4
+                for (int q = 0; q < 16; ++q) {
+                    const int r = hq + 4 * q;
+                    ghpreT[(int64_t)r * nb + i] = T[p][r];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    red[0][pq][hh] = a21; red[1][pq][hh] = a22;
+    __syncthreads();
+    float* slab = slabs + (int64_t)blockIdx.x * (2 * 64 + 2);
+    if (pq == 0) {
+        slab[hh] = (red[0][0][hh] + red[0][1][hh]) + (red[0][2][hh] + red[0][3][hh]);
+        slab[64 + 1 + hh] = (red[1][0][hh] + red[1][1][hh]) + (red[1][2][hh] + red[1][3][hh]);
+    }
+    __syncthreads();
+    red[0][pq][hh] = gb21; red[1][pq][hh] = gb22;
+    __syncthreads();
+    if (tid == 0) {
+        slab[64] = (red[0][0][0] + red[0][1][0]) + (red[0][2][0] + red[0][3][0]);
+        slab[2 * 64 + 1] = (red[1][0][0] + red[1][1][0]) + (red[1][2][0] + red[1][3][0]);
+    }
+}

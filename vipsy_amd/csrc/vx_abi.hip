@@ -1132,16 +1132,16 @@ int vx_norm_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t*
     if (he != hipSuccess) return (int)he;
     int rc;
     if (nb > 0) {
-        hipLaunchKernelGGL(k_norm_enc_bwd_small, dim3(nblk), dim3(256), 2 * 256 * sizeof(float), st, (int)H, nb, W21, W22,
-                           h, gloc, graw, ghpre, slabs_h);
-        VX_CHECK_LAUNCH();
         EncDims dm;
         dm.D = 1; dm.J = cfg->J; dm.H = cfg->H; dm.Hp = (cfg->H + 31) / 32 * 32; dm.DS = 3; dm.T = 1; dm.nb = nb;
-        if (!force_generic() && yT && !rows && cfg->H == 64 && nb % 4 == 0 && yT_stride % 16 == 0 && yT_stride >= nb &&
-            aligned16(yT) && cfg->J >= 32 && aligned16(workspace) && f1_lds_bytes(cfg->J) <= 160 * 1024) {
-            // dimension-major fc1 gradient (k_fc1_bwd_t): ghpreT = transpose(ghpre) lives behind the slabs
+        const bool tmajor = !force_generic() && yT && !rows && cfg->H == 64 && nb % 4 == 0 && yT_stride % 16 == 0 &&
+                            yT_stride >= nb && aligned16(yT) && cfg->J >= 32 && aligned16(workspace) &&
+                            f1_lds_bytes(cfg->J) <= 160 * 1024;
+        if (tmajor) {
+            // dimension-major fc1 gradient (k_fc1_bwd_b / k_fc1_bwd_t): ghpreT lives behind the slabs and is written
+            // directly (no person-major copy, no transpose pass)
             float* ghpreT = slabs_f + (((int64_t)n_prf * lenf + 3) & ~(int64_t)3);
-            hipLaunchKernelGGL(k_transpose, dim3(num_cu() * 8), dim3(256), 0, st, ghpre, ghpreT, nb, H);
+            hipLaunchKernelGGL(k_norm_enc_bwd_t64, dim3(nblk), dim3(256), 0, st, nb, W21, W22, h, gloc, graw, ghpreT, slabs_h);
             VX_CHECK_LAUNCH();
             if (bf16x3_mode() & 8) {
                 hipLaunchKernelGGL(k_fc1_bwd_b, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0,
@@ -1158,6 +1158,9 @@ int vx_norm_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t*
             if (rc) return rc;
             return vx_reduce_slabs(slabs_h, nblk, lenh, -1.0f, genc + lenf, hs);
         }
+        hipLaunchKernelGGL(k_norm_enc_bwd_small, dim3(nblk), dim3(256), 2 * 256 * sizeof(float), st, (int)H, nb, W21, W22,
+                           h, gloc, graw, ghpre, slabs_h);
+        VX_CHECK_LAUNCH();
         const size_t lds = fc1_bwd_lds_floats(dm.Hp) * sizeof(float);
         const dim3 grid((unsigned)n_jg, (unsigned)n_prf);
         const int f1fast = (!force_generic() && cfg->H == 64 && cfg->J % 4 == 0 && aligned16(ghpre) && aligned16(y)) ? 1 : 0;
