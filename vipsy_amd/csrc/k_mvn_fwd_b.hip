@@ -8,29 +8,28 @@
 //        are read from (12 KB of bf16 fragments + a bias fragment per 32-row tile);
 //   h  : split once per 32-person wave tile, in registers; the C layout of the fc1 MFMA already is the B fragment
 //        order (k-step s, lane half, element j  <->  hidden unit 16 s + 8 (j >> 2) + 4 half + (j & 3)).
-// One weight stream per WORKGROUP: a tile image arrives by global->LDS DMA (12 KB split over the 4 waves + the 1 KB
-// bias fragment, which every wave transfers: 4 transfers per wave and tile, so `s_waitcnt vmcnt(8)` counts whole
-// tiles), in a 4-stage ring, one barrier per tile.  Every wave pulls the fragments of tile t + 1 into registers while the MFMAs of
-// tile t run, and does the epsilon epilogue of tile t - 1 between them (the bf16 MFMA leaves the vector port free for
-// 24 of its 32 cycles).
+// Every wave streams the tile images by itself, global (L2) -> registers, one tile ahead: the 13 fragment loads of tile
+// t + 1 are issued at the head of tile t and consumed a tile later, so no LDS ring, no DMA and no workgroup barrier sit
+// in the head loop (round 1 shared one stream per workgroup through a 4-stage LDS ring with a barrier per tile: 3 %
+// slower on the same box, at a quarter of the L2 traffic -- the 2.3 MB image stays L2 resident either way).  The epsilon
+// epilogue of tile t - 1 goes between the MFMA groups of tile t (the bf16 MFMA leaves the vector port free for 24 of its
+// 32 cycles).
 // (included by vx_abi.hip after k_mvn_packed.hip and k_mvn_bwd_b.hip)
 
 #define FB_THREADS 256
 #define FB_WAVES 4
 #define FB_WP 32
-#define FB_NST 4
 #define FB_A_BYTES 12288
 #define FB_AUX_BYTES 1024                                            // the bias fragment
 #define FB_IMG_BYTES (FB_A_BYTES + FB_AUX_BYTES)                     // tile image in global memory
-#define FB_STAGE_BYTES FB_IMG_BYTES                                  // one ring stage in LDS
 
 __host__ __device__ inline int fb_tiles(int D) { return (pk_off_total(D) + 2 * pk_sec(D)) / 32; }
 __host__ __device__ inline int64_t fb_img_floats(int D) {               // tile images + the OFF group table
     return (int64_t)fb_tiles(D) * (FB_IMG_BYTES / 4) + (pk_off_total(D) / 8 + 8 + 3) / 4 * 4;
 }
 __host__ __device__ inline size_t fb_lds_bytes(int D, int J) {
-    return FB_WAVES * enc_p_wave_floats(D, J) * sizeof(float) + (size_t)FB_NST * FB_STAGE_BYTES +
-           (size_t)(pk_off_total(D) / 8 + 4) / 4 * 16;                  // wave regions | weight ring | OFF group table
+    return FB_WAVES * enc_p_wave_floats(D, J) * sizeof(float) +
+           (size_t)(pk_off_total(D) / 8 + 4) / 4 * 16;                  // wave regions | OFF group table
 }
 
 // tile image: fragment (split sp, k-step s) at byte (sp * 4 + s) * 1024 + lane * 16, lane = 32 half + row;
@@ -144,31 +143,17 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     int8_t* Yi = (int8_t*)R1;                                 // phase A
     float* eps_lds = R1;                                      // phase B  [32][DS]
     float* x_lds = R1 + FB_WP * DS;                           //          [32][DX]
-    const char* ring = (const char*)(smem + FB_WAVES * enc_p_wave_floats(D, J));
-    const uint32_t ring_lds = lds_addr_uniform(ring);
-    uint32_t* gt_lds = (uint32_t*)(ring + (size_t)FB_NST * FB_STAGE_BYTES);
+    uint32_t* gt_lds = (uint32_t*)(smem + FB_WAVES * enc_p_wave_floats(D, J));
     const int64_t i0 = ((int64_t)blockIdx.x * FB_WAVES + wave) * FB_WP;
     const int p = l31;
     const int64_t i = i0 + p;
-    // NOTE: no early exit -- every wave takes part in the workgroup barriers of the weight ring; waves (and lanes)
-    // past the last person compute on clamped inputs and store nothing.
+    // NOTE: no early exit -- every wave takes part in the workgroup barrier that publishes the group table; waves (and
+    // lanes) past the last person compute on clamped inputs and store nothing.
     const bool wave_live = i0 < dm.nb;
 
     const int n_off = pk_off_total(D) / 32;                   // multiple of 6
     const int n_sec = pk_sec(D) / 32;
     const int t_end = n_off + 2 * n_sec;
-    // ---- weight ring: this wave's 4 transfers of a tile (3 x 1 KB of the fragment image + its 256-byte aux copy)
-    const uint32_t voffA = (uint32_t)(wave * 1024 + lane * 16);
-    auto stage_tile = [&](int t) __attribute__((always_inline)) {
-        const int tc = t < t_end ? t : t_end - 1;             // past the end: a harmless duplicate of the last tile
-        const uint8_t* src = img + (int64_t)tc * FB_IMG_BYTES;
-        const uint32_t sb = ring_lds + (uint32_t)(t & (FB_NST - 1)) * FB_STAGE_BYTES;
-        dma16s(src, voffA, sb + (uint32_t)wave * 1024u);
-        dma16s(src, voffA + 4096u, sb + (uint32_t)wave * 1024u + 4096u);
-        dma16s(src, voffA + 8192u, sb + (uint32_t)wave * 1024u + 8192u);
-        dma16s(src, (uint32_t)(FB_A_BYTES + lane * 16), sb + FB_A_BYTES);   // the bias fragment: every wave, same bytes
-    };
-    stage_tile(0); stage_tile(1); stage_tile(2); stage_tile(3);   // in flight during staging / fc1 / eps
     for (int e = tid; e < 4 * n_off; e += FB_THREADS) gt_lds[e] = gt2[e];   // published by the barrier before the OFF loop
 
     // ---------------------------------------------------------------- stage this wave's response rows (bytes)
@@ -333,14 +318,15 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     const float* ep = eps_lds + p * DS;
     float* xp = x_lds + p * DX;
     struct TileRegs { bf16x8 a[3][4]; bf16x8 bias; };
-    // the fragments of tile t come out of the ring into registers one tile ahead
+    // the fragments of tile t come from the image into registers one tile ahead
     auto pull = [&](TileRegs& R, int t) __attribute__((always_inline)) {
-        const char* sb = ring + (size_t)(t & (FB_NST - 1)) * FB_STAGE_BYTES;
-        R.bias = *(const bf16x8*)(sb + FB_A_BYTES + lane * 16);
+        const int tc = t < t_end ? t : t_end - 1;              // past the end: a harmless duplicate of the last tile
+        const uint8_t* gb = img + (int64_t)tc * FB_IMG_BYTES + lane * 16;
+        R.bias = *(const bf16x8*)(gb + FB_A_BYTES);
 #pragma unroll
         for (int sp = 2; sp >= 0; --sp)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) R.a[sp][s] = *(const bf16x8*)(sb + (sp * 4 + s) * 1024 + lane * 16);
+            for (int s = 0; s < 4; ++s) R.a[sp][s] = *(const bf16x8*)(gb + (sp * 4 + s) * 1024);
     };
     const bf16x8 ones8 = __builtin_bit_cast(bf16x8, u32x4w{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
     // the chain starts from the bias (one MFMA against ones); products in order of increasing magnitude
@@ -390,11 +376,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         }
     };
 
-    // Tiles 0..3 of the ring were requested at the head of the kernel; loads complete in order and the fc1 phase has
-    // waited for W1 fragments requested after them, so they have landed -- no `vmcnt(0)` here: it would expose the
-    // completion latency of the output stores above (h, hT, eps, epsT; measured: no difference either way).  Stores
-    // still outstanding only make the counted waits of the first iterations stricter.
-    __syncthreads();
+    __syncthreads();                                           // the group table in LDS is complete
     TileRegs RA, RB;
     pull(RA, 0);
     f32x16 accP = zero16();                                    // accumulator of the tile before the current one
@@ -402,9 +384,6 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
 
     auto off_iter = [&](TileRegs& Rc, TileRegs& Rn, int t, auto firstc) __attribute__((always_inline)) {
         constexpr bool first = decltype(firstc)::value;
-        __builtin_amdgcn_s_waitcnt(0x0F78);                    // vmcnt(8): tile t + 1 has landed (t + 2, t + 3 in flight)
-        __syncthreads();                                       // ... for every wave; the stage of tile t is free
-        stage_tile(t + FB_NST);
         EpiOps E;
         if constexpr (!first) epi_read(E, codeP);
         pull(Rn, t + 1);
@@ -483,9 +462,6 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         }
     };
     auto sec_iter = [&](TileRegs& Rc, TileRegs& Rn, int t) __attribute__((always_inline)) {
-        vx_wait_vmem();
-        __syncthreads();
-        if (t + FB_NST < t_end) stage_tile(t + FB_NST);
         if (t + 1 < t_end) pull(Rn, t + 1);
         const f32x16 a = mma_hi(Rc, mma_lo(Rc));
         tile_sec(a, t);
