@@ -139,7 +139,8 @@ struct ProfScope {
         (void)hipEventRecord(b, st);
         for (int i = 0; i < g_prof_n; ++i)
             if (!strcmp(g_prof_slots[i].name, name)) { g_prof_slots[i].ev.emplace_back(a, b); return; }
-        if (g_prof_n < 8) { g_prof_slots[g_prof_n].name = name; g_prof_slots[g_prof_n].ev.emplace_back(a, b); ++g_prof_n; }
+        if (g_prof_n < 8) { g_prof_slots[g_prof_n].name = name; g_prof_slots[g_prof_n].ev.emplace_back(a, b); ++g_prof_n; return; }
+        (void)hipEventDestroy(a); (void)hipEventDestroy(b);           // more than eight kernel names: not recorded, not leaked
     }
 };
 
