@@ -522,3 +522,143 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         }
     }
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// NormEncoder forward (vi.py:417-435) for hidden_dim == 64, J % 4 == 0 on the bf16 MFMA: the same outputs as
+// k_norm_enc_fwd_fast (k_mvn_packed.hip).  The response bytes are exact in bf16, so fc1 is THREE products per 16-item
+// k-step (W1 in three bf16 terms).  k_norm_enc_fwd_fast had every wave stream all of W1 from L2 (4 GB a step at 1M x 500:
+// the kernel ran at L2 speed, not MFMA speed); here the four waves of a workgroup share one copy: the 256 threads fetch a
+// 64 x 16 slice of W1, split it and lay the six fragments down in LDS (double buffered, one barrier per k-step), so W1
+// crosses the L2 once per 128 persons.
+// ---------------------------------------------------------------------------------------------
+#define NB_THREADS 256
+#define NB_WAVES 4
+__host__ __device__ inline size_t nb_lds_bytes(int J) {
+    return (size_t)NB_WAVES * norm_fast_wave_floats(J) * sizeof(float) + 2 * 6 * 1024;      // response tiles | 2 x 6 fragments
+}
+
+__global__ __launch_bounds__(NB_THREADS, 2) void k_norm_enc_fwd_b(
+    EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, const float* __restrict__ W1,
+    const float* __restrict__ b1, const float* __restrict__ W21, const float* __restrict__ b21,
+    const float* __restrict__ W22, const float* __restrict__ b22, float* __restrict__ h_out,
+    float* __restrict__ loc_out, float* __restrict__ raw_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2w __attribute__((ext_vector_type(2)));
+    constexpr int H = 64;
+    const int J = dm.J, YS = ef_ys(J);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    float* R1 = smem + wave * norm_fast_wave_floats(J);
+    const int8_t* Yi = (const int8_t*)R1;
+    char* frag = (char*)(smem + NB_WAVES * norm_fast_wave_floats(J));      // [2][6][64 lanes][16 bytes]
+    const int64_t i0 = ((int64_t)blockIdx.x * NB_WAVES + wave) * EP_WP;    // waves past the end still serve the barriers
+    const int p = l31;
+    const int64_t i = i0 + p;
+    // ---- this wave's response rows (as in k_norm_enc_fwd_fast)
+    const int n_ydma = (32 * J + 1023) / 1024;
+    const bool ydense = !rows && ((J >> 2) & 1) && i0 + EP_WP <= dm.nb && (i0 * J + (int64_t)n_ydma * 1024 <= dm.nb * (int64_t)J);
+    const int ysr = ydense ? J : YS;
+    if (ydense) {
+        const uint8_t* src = y + i0 * J + 16 * lane;
+        const uint32_t lb = lds_addr_uniform(R1);
+        for (int d = 0; d < n_ydma; ++d) dma16(src + d * 1024, lb + (uint32_t)d * 1024u);
+    } else {
+        const int YW = YS / 4, JW = J / 4;
+        uint32_t* Yw = (uint32_t*)R1;
+        for (int e = lane; e < EP_WP * YW; e += 64) {
+            const int pp = e / YW, wq = e - pp * YW;
+            const int64_t ii = i0 + pp;
+            uint32_t v = 0u;
+            if (wq < JW && ii < dm.nb) {
+                const int64_t row = rows ? rows[ii] : ii;
+                v = *(const uint32_t*)(y + row * J + 4 * wq);              // bytes 0/1/255 == int8 0/1/-1 (vi.py:680-682)
+            }
+            Yw[e] = v;
+        }
+    }
+    // ---- W1 slices: thread = (hidden unit hh, quarter q of the 16 items of a k-step)
+    const int n_ks = (J + 15) / 16;
+    const int hh = tid >> 2, q = tid & 3;
+    const float* wrow = W1 + (int64_t)hh * J + 4 * q;
+    auto fetch_w = [&](int ks) -> float4 {
+        const int j0 = 16 * ks + 4 * q;
+        return (ks < n_ks && j0 + 4 <= J) ? *(const float4*)(wrow + 16 * ks) : make_float4(0.f, 0.f, 0.f, 0.f);   // J % 4 == 0
+    };
+    // fragment (hidden tile ht, term sp): lane (row = hh & 31, half) holds W1[32 ht + row][16 ks + 8 half + j], j = 0..7;
+    // this thread owns j = 4 (q & 1) .. + 3 of lane 32 (q >> 1) + (hh & 31): 8 bytes per term
+    char* wdst = frag + ((hh >> 5) * 3) * 1024 + (32 * (q >> 1) + (hh & 31)) * 16 + 8 * (q & 1);
+    auto put_w = [&](const float4& w, int buf) {
+        const float v[4] = {w.x, w.y, w.z, w.w};
+        uint16_t t[3][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const __bf16 a = (__bf16)v[e];
+            const float r1 = v[e] - (float)a;
+            const __bf16 m = (__bf16)r1;
+            const __bf16 l = (__bf16)(r1 - (float)m);
+            t[0][e] = __builtin_bit_cast(uint16_t, a); t[1][e] = __builtin_bit_cast(uint16_t, m); t[2][e] = __builtin_bit_cast(uint16_t, l);
+        }
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) {
+            const u32x2w pk = {(uint32_t)t[sp][0] | ((uint32_t)t[sp][1] << 16), (uint32_t)t[sp][2] | ((uint32_t)t[sp][3] << 16)};
+            *(u32x2w*)(wdst + buf * 6144 + sp * 1024) = pk;
+        }
+    };
+    put_w(fetch_w(0), 0);
+    float4 wn = fetch_w(1);
+    vx_wait_vmem();                                                       // the response rows (DMA) have landed
+    __syncthreads();
+    f32x16 acc0 = zero16(), acc1 = zero16();
+    for (int ks = 0; ks < n_ks; ++ks) {
+        const int buf = ks & 1;
+        const float4 wcur = wn;                                           // slice ks + 1, fetched an iteration ago
+        wn = fetch_w(ks + 2);
+        const char* fb = frag + buf * 6144 + lane * 16;
+        bf16x8 A[6];
+#pragma unroll
+        for (int f = 0; f < 6; ++f) A[f] = *(const bf16x8*)(fb + f * 1024);
+        // B fragment: items 16 ks + 8 half + 0..7 of person p; byte b in {0, 1, 255} -> bf16 {0, 1, -1}
+        const uint32_t* yw = (const uint32_t*)(Yi + p * ysr + 16 * ks + 8 * half);
+        const u32x2w w = {yw[0], yw[1]};
+        u32x4w qv;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t src = w[d >> 1];
+            const uint32_t t = (d & 1) ? __builtin_amdgcn_perm(0u, src, 0x0c030c02u) : __builtin_amdgcn_perm(0u, src, 0x0c010c00u);
+            qv[d] = (t & 0x00010001u) * 0x3F80u | ((t & 0x00800080u) << 8);
+        }
+        const bf16x8 yb = __builtin_bit_cast(bf16x8, qv);
+        acc0 = mfma_bf16(A[2], yb, acc0); acc1 = mfma_bf16(A[5], yb, acc1);
+        acc0 = mfma_bf16(A[1], yb, acc0); acc1 = mfma_bf16(A[4], yb, acc1);
+        acc0 = mfma_bf16(A[0], yb, acc0); acc1 = mfma_bf16(A[3], yb, acc1);
+        if (ks + 1 < n_ks) put_w(wcur, buf ^ 1);                          // the other buffer: read last in iteration ks - 1
+        __syncthreads();
+    }
+    if (i0 >= dm.nb) return;
+    // ---- softplus, the two 1-row heads as per-lane dot products over the 32 hidden units a lane holds
+    float sl = 0.f, sr = 0.f;
+#pragma unroll
+    for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int hh0 = 32 * ht + 8 * g + 4 * half;
+            const float4 bb = *(const float4*)(b1 + hh0);
+            const float4 w21 = make_float4(W21[hh0], W21[hh0 + 1], W21[hh0 + 2], W21[hh0 + 3]);
+            const float4 w22 = make_float4(W22[hh0], W22[hh0 + 1], W22[hh0 + 2], W22[hh0 + 3]);
+            float4 hv;
+            hv.x = softplusf_((ht ? acc1 : acc0)[4 * g + 0] + bb.x);               // vi.py:432
+            hv.y = softplusf_((ht ? acc1 : acc0)[4 * g + 1] + bb.y);
+            hv.z = softplusf_((ht ? acc1 : acc0)[4 * g + 2] + bb.z);
+            hv.w = softplusf_((ht ? acc1 : acc0)[4 * g + 3] + bb.w);
+            sl += hv.x * w21.x + hv.y * w21.y + hv.z * w21.z + hv.w * w21.w;
+            sr += hv.x * w22.x + hv.y * w22.y + hv.z * w22.z + hv.w * w22.w;
+            if (i < dm.nb) *(float4*)(h_out + i * H + hh0) = hv;
+        }
+    sl = half_sum32(sl);
+    sr = half_sum32(sr);
+    if (half == 0 && i < dm.nb) {
+        loc_out[i] = sl + b21[0];
+        raw_out[i] = sr + b22[0];
+    }
+}

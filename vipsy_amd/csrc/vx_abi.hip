@@ -1085,6 +1085,16 @@ int vx_norm_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     EncDims dm;
     dm.D = 1; dm.J = cfg->J; dm.H = cfg->H; dm.Hp = (cfg->H + 31) / 32 * 32; dm.DS = 3; dm.T = 1; dm.nb = nb;
     int rc;
+    if (!force_generic() && (bf16x3_mode() & 1) && cfg->H == 64 && cfg->J % 4 == 0 && aligned16(y) && aligned16(W1) &&
+        aligned16(b1) && aligned16(h) && nb_lds_bytes(cfg->J) <= 160 * 1024) {
+        const size_t ldsb = nb_lds_bytes(cfg->J);                       // fc1 on the bf16 MFMA, W1 shared by the workgroup
+        rc = set_lds(k_norm_enc_fwd_b, ldsb);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_norm_enc_fwd_b, dim3((unsigned)((nb + NB_WAVES * EP_WP - 1) / (NB_WAVES * EP_WP))),
+                           dim3(NB_THREADS), ldsb, (hipStream_t)hs, dm, y, rows, W1, b1, W21, b21, W22, b22, h, loc, raw);
+        VX_CHECK_LAUNCH();
+        return VX_OK;
+    }
     if (!force_generic() && cfg->H == 64 && cfg->J % 4 == 0 && aligned16(y) && aligned16(W1) && aligned16(b1) &&
         aligned16(h) && NE_WAVES * norm_fast_wave_floats(cfg->J) * sizeof(float) <= 160 * 1024) {
         const size_t ldsf = NE_WAVES * norm_fast_wave_floats(cfg->J) * sizeof(float);
