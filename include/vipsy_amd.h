@@ -314,6 +314,8 @@ int vx_reduce_slabs(const float* slabs, int64_t n_slabs, int64_t len, float alph
  * workspace: vx_sum_workspace_floats() floats */
 int64_t vx_sum_workspace_floats(void);
 int vx_sum(const float* v, int64_t n, float alpha, float* out, float* workspace, void* hip_stream);
+/* out[0] = alpha * (sum v1 + sum v2), both of length n, in one pass (the loss of the MVN guides: log-lik + entropy) */
+int vx_sum2(const float* v1, const float* v2, int64_t n, float alpha, float* out, float* workspace, void* hip_stream);
 
 /* ---- optimiser: torch.optim.Adam on a flat float32 buffer split into segments with their own
  * learning rate (pyro.optim.Adam with callable optim_args; vi.py:514, test.py:345-350), optional

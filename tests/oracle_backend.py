@@ -69,6 +69,9 @@ class OracleBackend(object):
     def sum_into(self, v, n, alpha, out, ws):
         out[0] = float(alpha) * float(v[:n].double().sum())
 
+    def sum2_into(self, v1, v2, n, alpha, out, ws):
+        out[0] = float(alpha) * (float(v1[:n].double().sum()) + float(v2[:n].double().sum()))
+
     def adam(self, p, g, m, v, free, n, segs, t, betas=(0.9, 0.999), eps=1e-8):
         b1, b2 = betas
         for (lo, hi, lr) in segs:

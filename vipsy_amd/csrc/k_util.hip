@@ -93,13 +93,15 @@ __global__ __launch_bounds__(256) void k_reduce_few(const float4* __restrict__ s
 }
 
 // two-stage fixed-order sum: stage 1 -> partial[blockIdx], stage 2 (1 block) -> out[0]
-__global__ void k_sum_stage1(const float* __restrict__ v, int64_t n, float* __restrict__ partial) {
+__global__ void k_sum_stage1(const float* __restrict__ v, int64_t n, float* __restrict__ partial,
+                             const float* __restrict__ v2 = nullptr /*optional second vector of the same length*/) {
     __shared__ float red[256 / VX_WAVE];
     float acc = 0.f;
     const int64_t per = (n + gridDim.x - 1) / gridDim.x;
     const int64_t lo = (int64_t)blockIdx.x * per;
     const int64_t hi = lo + per < n ? lo + per : n;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) acc += v[i];
+    if (v2) { for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) acc += v[i] + v2[i]; }
+    else { for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) acc += v[i]; }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();

@@ -233,7 +233,19 @@ int vx_sum(const float* v, int64_t n, float alpha, float* out, float* workspace,
     int nblk = (int)((n + 4095) / 4096);
     if (nblk < 1) nblk = 1;
     if (nblk > 1024) nblk = 1024;
-    hipLaunchKernelGGL(k_sum_stage1, dim3(nblk), dim3(256), 0, (hipStream_t)hs, v, n, workspace);
+    hipLaunchKernelGGL(k_sum_stage1, dim3(nblk), dim3(256), 0, (hipStream_t)hs, v, n, workspace, (const float*)nullptr);
+    VX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_sum_stage2, dim3(1), dim3(256), 0, (hipStream_t)hs, workspace, nblk, alpha, out);
+    VX_CHECK_LAUNCH();
+    return VX_OK;
+}
+
+int vx_sum2(const float* v1, const float* v2, int64_t n, float alpha, float* out, float* workspace, void* hs) {
+    if (!v1 || !v2 || !out || !workspace || n < 0) return VX_EINVAL;
+    int nblk = (int)((n + 4095) / 4096);
+    if (nblk < 1) nblk = 1;
+    if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL(k_sum_stage1, dim3(nblk), dim3(256), 0, (hipStream_t)hs, v1, n, workspace, v2);
     VX_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_sum_stage2, dim3(1), dim3(256), 0, (hipStream_t)hs, workspace, nblk, alpha, out);
     VX_CHECK_LAUNCH();

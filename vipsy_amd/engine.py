@@ -269,6 +269,10 @@ class HipBackend(object):
         rc = self.L.vx_sum(_hip.ptr(v), n, alpha, _hip.ptr(out), _hip.ptr(ws), _hip.stream_ptr())
         _hip.check(rc, "vx_sum")
 
+    def sum2_into(self, v1, v2, n, alpha, out, ws):
+        rc = self.L.vx_sum2(_hip.ptr(v1), _hip.ptr(v2), n, alpha, _hip.ptr(out), _hip.ptr(ws), _hip.stream_ptr())
+        _hip.check(rc, "vx_sum2")
+
     def adam(self, p, g, m, v, free, n, segs, t, betas=(0.9, 0.999), eps=1e-8, t_dev=None):
         arr = (_hip.AdamSeg * len(segs))(*[_hip.AdamSeg(b, e, lr, 0.0) for (b, e, lr) in segs])
         rc = self.L.vx_adam_step(_hip.ptr(p), _hip.ptr(g), _hip.ptr(m), _hip.ptr(v), _hip.ptr(free), n, arr,
@@ -684,10 +688,7 @@ class IrtEngine(_EngineBase):
                     gM.zero_()
                 be.mvn_bbvi_backward(cfg, nb, rows, Mq, self.share_cov, gx, fw["eps"], self.GP[:n * D], gM,
                                      self._buf("bbvi_ws", be.mvn_bbvi_bwd_workspace(cfg, nb, self.share_cov)))
-            tmp = self._buf("loss2", 2)
-            be.sum_into(ll, nb, -scale, tmp[0:1], self.sum_ws)
-            be.sum_into(fw["ent"], nb, -scale, tmp[1:2], self.sum_ws)
-            torch.add(tmp[0:1], tmp[1:2], out=lossslot)
+            be.sum2_into(ll, fw["ent"], nb, -scale, lossslot, self.sum_ws)        # loss = -scale * sum_i (ll_i + ent_i)
             self.last = {"fw": fw, "gx": gx, "ll": ll, "nb": nb}
         elif self.D > 1:
             D, H = self.D, self.H
@@ -722,10 +723,7 @@ class IrtEngine(_EngineBase):
                                     self.G[self.enc_off0:self.enc_off0 + self.n_enc], encb_ws, gxT=gxT,
                                     gd_ready=gdT is not None)
             # loss = -scale * sum_i (ll_i + ent_i)
-            tmp = self._buf("loss2", 2)
-            be.sum_into(ll, nb, -scale, tmp[0:1], self.sum_ws)
-            be.sum_into(fw["ent"], nb, -scale, tmp[1:2], self.sum_ws)
-            torch.add(tmp[0:1], tmp[1:2], out=lossslot)
+            be.sum2_into(ll, fw["ent"], nb, -scale, lossslot, self.sum_ws)        # loss = -scale * sum_i (ll_i + ent_i)
             self.last = {"fw": fw, "gx": gx, "gxT": gxT, "ll": ll, "nb": nb}
         else:
             # D = 1: the flat item layout [a: J | b: J | c: J | d: J] IS the kernels' gradient layout -> written in place
