@@ -78,10 +78,12 @@ __global__ void k_pack_heads(int D, int H, const float* __restrict__ W21, const 
 
 // out = alpha * sum_s slabs[s] gathered from packed rows back to the reference layout
 //   slab: [Wp-grad: Rp*H | bp-grad: Rp];  out: [W21: D*H | b21: D | W22: T*H | b22: T]
-__global__ void k_unpack_head_grads(int D, int H, const float* __restrict__ slabs, int n_slabs, int64_t slab_len,
-                                    float alpha, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_unpack_head_grads(int D, int H, const float* __restrict__ slabs, int n_slabs,
+                                                           int64_t slab_len, float alpha, float* __restrict__ out) {
+    // one wave per packed row (four rows a block): lane = hidden unit, the slabs summed in ascending order, eight loads
+    // in flight per lane
     const int T = D * (D + 1) / 2, Rp = pk_rows(D);
-    const int pr = blockIdx.x;
+    const int pr = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (pr >= Rp) return;
     int src;
     uint32_t gcode;
@@ -89,10 +91,11 @@ __global__ void k_unpack_head_grads(int D, int H, const float* __restrict__ slab
     if (src < 0) return;
     float* oW = (src < T) ? out + (int64_t)D * H + D + (int64_t)src * H : out + (int64_t)(src - T) * H;
     float* ob = (src < T) ? out + (int64_t)D * H + D + (int64_t)T * H + src : out + (int64_t)D * H + (src - T);
-    for (int hh = threadIdx.x; hh <= H; hh += blockDim.x) {
+    for (int hh = lane; hh <= H; hh += 64) {
         float acc = 0.f;
-        const int64_t off = (hh < H) ? (int64_t)pr * H + hh : (int64_t)Rp * H + pr;
-        for (int s = 0; s < n_slabs; ++s) acc += slabs[(int64_t)s * slab_len + off];
+        const float* sp = slabs + ((hh < H) ? (int64_t)pr * H + hh : (int64_t)Rp * H + pr);
+#pragma unroll 8
+        for (int s = 0; s < n_slabs; ++s) acc += sp[(int64_t)s * slab_len];
         if (hh < H) oW[hh] = alpha * acc; else *ob = alpha * acc;
     }
 }

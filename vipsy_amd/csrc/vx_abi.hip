@@ -900,7 +900,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     rc = vx_reduce_slabs(slabs_f, n_prf, lenf, -1.0f, genc, hs);
     if (rc) return rc;
     if (packed) {
-        hipLaunchKernelGGL(k_unpack_head_grads, dim3((unsigned)Rp), dim3(128), 0, st, (int)D, (int)H, slabs_w, n_prw,
+        hipLaunchKernelGGL(k_unpack_head_grads, dim3((unsigned)((Rp + 3) / 4)), dim3(256), 0, st, (int)D, (int)H, slabs_w, n_prw,
                            Rp * (H + 1), -1.0f, genc + lenf);
         VX_CHECK_LAUNCH();
         return VX_OK;
