@@ -10,6 +10,7 @@
 // (included by vx_abi.hip after k_mvn_fwd_b.hip)
 
 #define F1B_THREADS 256
+#define F1B_NS 6                                                     // operand stages in registers (k-steps of look-ahead + 1)
 
 __global__ __launch_bounds__(F1B_THREADS, 1) void k_fc1_bwd_b(
     EncDims dm, const uint8_t* __restrict__ yT, int64_t ystride, const float* __restrict__ ghpreT,
@@ -82,16 +83,21 @@ __global__ __launch_bounds__(F1B_THREADS, 1) void k_fc1_bwd_b(
     const int64_t n_ks = (nb + 15) / 16, per = (n_ks + gridDim.y - 1) / gridDim.y;
     int64_t ks = (int64_t)blockIdx.y * per;
     const int64_t ks_end = (ks + per < n_ks) ? ks + per : n_ks;
+    // operands run F1B_NS k-steps ahead of the MFMAs: the loads come from HBM (a wave streams its own rows of yT and
+    // ghpreT), one k-step is ~770 cycles of matrix time, so a single stage of look-ahead left the matrix pipe waiting
+    // (busy 0.21)
     if (ks < ks_end) {
-        Ops oa, ob;
-        load(oa, ks);
-        while (true) {
-            if (ks + 1 < ks_end) load(ob, ks + 1);
-            compute(oa);
-            if (++ks >= ks_end) break;
-            if (ks + 1 < ks_end) load(oa, ks + 1);
-            compute(ob);
-            if (++ks >= ks_end) break;
+        Ops st[F1B_NS];
+#pragma unroll
+        for (int u = 0; u < F1B_NS - 1; ++u)
+            if (ks + u < ks_end) load(st[u], ks + u);
+        while (ks < ks_end) {
+#pragma unroll
+            for (int u = 0; u < F1B_NS; ++u) {
+                if (ks + F1B_NS - 1 < ks_end) load(st[(u + F1B_NS - 1) % F1B_NS], ks + F1B_NS - 1);
+                if (ks < ks_end) compute(st[u]);
+                ++ks;
+            }
         }
     }
     // slab: [W1-grad: 64 * J | b1-grad: 64]
