@@ -240,6 +240,8 @@ def test_mvn_amortized_step_vs_oracle(N, J, D, H, model, miss, B):
     (300, 37, "irt_1pl", 0.6, None),
     (640, 200, "irt_3pl", 0.95, None),
     (4500, 60, "irt_2pl", 0.8, None),                # two sort windows; a few |x| > 8 (full-range slots of the list kernel)
+    (300, 1000, "irt_3pl", 0.8, None),               # list kernel at J near its limit (1024), asymptote gradients
+    (200, 7, "irt_4pl", 0.7, None),                  # ... and with lists shorter than one quad
 ])
 def test_irt1d_step_vs_oracle(N, J, model, miss, B):
     from vipsy_amd.engine import IrtEngine
