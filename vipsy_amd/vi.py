@@ -118,6 +118,7 @@ class BasePsy(object):
             raise ValueError("sample_size_global differs from the rows of `data` but no `group` shares the problem")
         self._gen = torch.Generator(device=dev)
         self._gen.manual_seed(self.seed * 7919 + self.gid0)
+        self._np_gen = np.random.Generator(np.random.PCG64([self.seed, self.gid0, 7919]))
         # engine keyword arguments shared by every model class (`backend` is the test seam of tests/oracle_backend.py)
         self._eng_kw = {"n_global": self.sample_size, "gid0": self.gid0, "seed": self.seed, "group": group}
         if kwargs.get("backend") is not None:
@@ -135,8 +136,16 @@ class BasePsy(object):
             return None, self.sample_size
         b_local = B // self.world if self.world > 1 else B
         b_local = max(1, min(b_local, self.sample_size_local))
-        idx = torch.randperm(self.sample_size_local, generator=self._gen, device=self.device)[:b_local]
-        return idx.contiguous(), b_local * self.world
+        n = self.sample_size_local
+        if 16 * b_local <= n:
+            # a small subset of many rows: a full permutation on the device is a radix sort of n keys (0.25 ms at 1M, a
+            # third of a B = 100 step).  numpy's Generator.choice draws b distinct rows in O(b); same distribution over
+            # subsets, ordered like the first b of a random permutation (shuffle=True)
+            host = torch.from_numpy(self._np_gen.choice(n, size=b_local, replace=False, shuffle=True).astype(np.int64))
+            idx = host.to(self.device, non_blocking=True)
+        else:
+            idx = torch.randperm(n, generator=self._gen, device=self.device)[:b_local].contiguous()
+        return idx, b_local * self.world
 
     def _loop(self, optim, loss, max_iter, progress):
         lrs = optim.spec()
