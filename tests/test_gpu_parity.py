@@ -532,3 +532,22 @@ def test_captured_step_equals_eager_step(miss, model):
 def test_irt1d_amortized_wide_hidden_layer(H):
     """NormEncoder with hidden_dim > 64 (vi.py:417-435 takes any width)."""
     test_irt1d_amortized_step_vs_oracle(300, 100, "irt_2pl", 0.2, None, H=H)
+
+
+def test_small_batch_forward_is_bit_reproducible():
+    """Small batches share the head tiles of a person tile among the four waves of a workgroup (k_mvn_enc_fwd_b<SPLIT>);
+    a k that straddles two ranges gets two partial sums by LDS float adds -- two addends commute, so the step must be
+    bit-identical from run to run."""
+    from vipsy_amd.engine import IrtEngine
+    rng = np.random.RandomState(8)
+    N, J, D = 333, 500, 100
+    y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+    y[rng.rand(N, J) < 0.1] = 255
+    outs = []
+    for _ in range(3):
+        eng = IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_2pl", D=D, amortized=True, H=64, seed=3)
+        eng.loss_and_grads()
+        torch.cuda.synchronize()
+        outs.append((eng.G.cpu().numpy().copy(), eng.last["fw"]["x"][:N * D].cpu().numpy().copy()))
+    for g, x in outs[1:]:
+        assert np.array_equal(g, outs[0][0]) and np.array_equal(x, outs[0][1])

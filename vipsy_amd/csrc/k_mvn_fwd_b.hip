@@ -30,7 +30,7 @@ __host__ __device__ inline int64_t fb_img_floats(int D) {               // tile 
 }
 __host__ __device__ inline size_t fb_lds_bytes(int D, int J) {
     return FB_WAVES * enc_p_wave_floats(D, J) * sizeof(float) +
-           (size_t)(pk_off_total(D) / 8 + 4) / 4 * 16;                  // wave regions | OFF group table
+           (size_t)(pk_off_total(D) / 8 + 4) / 4 * 16 + 512;            // wave regions | OFF group table | SPLIT: entropy parts
 }
 
 // tile image: fragment (split sp, k-step s) at byte (sp * 4 + s) * 1024 + lane * 16, lane = 32 half + row;
@@ -125,6 +125,13 @@ __device__ __forceinline__ void fb_split8(const float* v, bf16x8& fh, bf16x8& fm
     fl = __builtin_bit_cast(bf16x8, pl);
 }
 
+// SPLIT (small batches: at most FB_SPLIT_MAX persons): a workgroup takes ONE 32-person tile and its four waves share the
+// 176 head tiles (quarter ranges of the OFF tiles, one 32-row block of the DIAG / LOC sections each) instead of each
+// walking all of them for its own persons -- the per-wave chain of a step is what a small batch waits for.  Every wave
+// makes fc1 for the same persons (it needs h in registers); wave 0 owns the outputs and the eps / x tile in LDS; a k
+// whose rows straddle two ranges gets its two partial sums by commutative LDS float adds (two addends: order-free).
+#define FB_SPLIT_MAX 8192
+template <bool SPLIT>
 __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, int64_t gid0,
     const uint8_t* __restrict__ w1img, const float* __restrict__ b1, const uint8_t* __restrict__ img,
@@ -142,10 +149,13 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     const int half = lane >> 5, l31 = lane & 31;
     float* R1 = smem + wave * enc_p_wave_floats(D, J);
     int8_t* Yi = (int8_t*)R1;                                 // phase A
-    float* eps_lds = R1;                                      // phase B  [32][DS]
-    float* x_lds = R1 + FB_WP * DS;                           //          [32][DX]
+    float* S1 = SPLIT ? smem : R1;                            // SPLIT: the tile of wave 0 serves the workgroup
+    float* eps_lds = S1;                                      // phase B  [32][DS]
+    float* x_lds = S1 + FB_WP * DS;                           //          [32][DX]
     uint32_t* gt_lds = (uint32_t*)(smem + FB_WAVES * enc_p_wave_floats(D, J));
-    const int64_t i0 = ((int64_t)blockIdx.x * FB_WAVES + wave) * FB_WP;
+    float* ent_s = (float*)(gt_lds + ((pk_off_total(D) / 8 + 4) / 4 * 4));   // SPLIT: [4][32] partial entropy sums
+    const bool writer = !SPLIT || wave == 0;
+    const int64_t i0 = SPLIT ? (int64_t)blockIdx.x * FB_WP : ((int64_t)blockIdx.x * FB_WAVES + wave) * FB_WP;
     const int p = l31;
     const int64_t i = i0 + p;
     // NOTE: no early exit -- every wave takes part in the workgroup barrier that publishes the group table; waves (and
@@ -276,10 +286,10 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
                 hv.w = softplusf_((ht ? acc1 : acc0)[4 * g + 3] + bb.w);
                 hreg[ht][4 * g + 0] = hv.x; hreg[ht][4 * g + 1] = hv.y;
                 hreg[ht][4 * g + 2] = hv.z; hreg[ht][4 * g + 3] = hv.w;
-                if (i < dm.nb) *(float4*)(h_out + i * H + hh0) = hv;
+                if (writer && i < dm.nb) *(float4*)(h_out + i * H + hh0) = hv;
             }
         }
-        if (hT_out && i < dm.nb) {                            // dimension-major copy for the weight-gradient kernel
+        if (writer && hT_out && i < dm.nb) {                  // dimension-major copy for the weight-gradient kernel
 #pragma unroll
             for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
@@ -296,8 +306,8 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     }
     __builtin_amdgcn_wave_barrier();                          // response bytes no longer needed
     // ---------------------------------------------------------------- eps (zero padded to DS), x := 0
-    {
-        for (int e = lane; e < FB_WP * (DS + DX); e += 64) R1[e] = 0.f;
+    if (writer) {
+        for (int e = lane; e < FB_WP * (DS + DX); e += 64) S1[e] = 0.f;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < FB_EQ; ++q) {
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         }
     }
     __builtin_amdgcn_wave_barrier();
-    if (epsT_out && i < dm.nb) {                              // dimension-major copy: 128-byte rows per half-wave
+    if (writer && epsT_out && i < dm.nb) {                    // dimension-major copy: 128-byte rows per half-wave
 #pragma unroll 4
         for (int k = half; k < D; k += 2) epsT_out[(int64_t)k * dm.nb + i] = eps_lds[p * DS + k];
     }
@@ -372,14 +382,25 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         cur_part = fmaf(a[4 * g + 3], e.w, cur_part);
         if (__builtin_expect((int)code < 0, 0)) {                                 // wave-uniform, rare: the k ends here
             const float tot = half_sum32(cur_part);
-            if (half == 0) *(float*)(xp_b + ((code >> 12) & 0xFFFu)) = tot;
+            if (half == 0) {
+                if (SPLIT) atomicAdd((float*)(xp_b + ((code >> 12) & 0xFFFu)), tot);   // two ranges may share this k
+                else *(float*)(xp_b + ((code >> 12) & 0xFFFu)) = tot;
+            }
             cur_part = 0.f;
         }
     };
 
     __syncthreads();                                           // the group table in LDS is complete
+    // OFF tiles of this wave: all of them, or (SPLIT) a quarter -- even counts, the last range takes the remainder
+    int t_lo = 0, t_hi = n_off;
+    if (SPLIT) {
+        const int nr = (n_off / 2 < FB_WAVES) ? n_off / 2 : FB_WAVES;      // ranges in use (few tiles: fewer waves)
+        const int qn = (n_off / nr) & ~1;
+        t_lo = wave < nr ? wave * qn : n_off;
+        t_hi = (wave >= nr - 1) ? n_off : t_lo + qn;
+    }
     TileRegs RA, RB;
-    pull(RA, 0);
+    pull(RA, t_lo);
     f32x16 accP = zero16();                                    // accumulator of the tile before the current one
     uint4 codeP = make_uint4(0, 0, 0, 0);                      // its group words
 
@@ -419,20 +440,29 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         codeP.x = __builtin_amdgcn_readfirstlane(cv.x); codeP.y = __builtin_amdgcn_readfirstlane(cv.y);
         codeP.z = __builtin_amdgcn_readfirstlane(cv.z); codeP.w = __builtin_amdgcn_readfirstlane(cv.w);
     };
-    off_iter(RA, RB, 0, std::true_type{});
-    off_iter(RB, RA, 1, std::false_type{});
-    for (int t = 2; t < n_off; t += 2) {
-        off_iter(RA, RB, t, std::false_type{});
-        off_iter(RB, RA, t + 1, std::false_type{});
+    if (!SPLIT || t_lo < t_hi) {                               // wave-uniform
+        off_iter(RA, RB, t_lo, std::true_type{});
+        off_iter(RB, RA, t_lo + 1, std::false_type{});
+        for (int t = t_lo + 2; t < t_hi; t += 2) {
+            off_iter(RA, RB, t, std::false_type{});
+            off_iter(RB, RA, t + 1, std::false_type{});
+        }
+        {
+            EpiOps E;
+            epi_read(E, codeP);
+            epi_group(accP, E.e4[0], codeP.x, 0);
+            epi_group(accP, E.e4[1], codeP.y, 1);
+            epi_group(accP, E.e4[2], codeP.z, 2);
+            epi_group(accP, E.e4[3], codeP.w, 3);
+        }
+        if (SPLIT) {
+            // the range may end inside a k: its partial sum goes to x now (the range that finishes the k adds the rest)
+            const float tot = half_sum32(cur_part);
+            if (half == 0) atomicAdd((float*)(xp_b + ((codeP.w >> 12) & 0xFFFu)), tot);
+            cur_part = 0.f;
+        }
     }
-    {
-        EpiOps E;
-        epi_read(E, codeP);
-        epi_group(accP, E.e4[0], codeP.x, 0);
-        epi_group(accP, E.e4[1], codeP.y, 1);
-        epi_group(accP, E.e4[2], codeP.z, 2);
-        epi_group(accP, E.e4[3], codeP.w, 3);
-    }
+    if (SPLIT) __syncthreads();                                // every OFF row is in x: the sections update it in place
     // ---- DIAG section (exp(M_kk) eps_k, entropy, ldT) and LOC section (the loc head): 2 * n_sec tiles; RA holds the
     // first of them.  The 16 x entries a lane updates are read together, updated and written together.
     auto tile_sec = [&](const f32x16& a, int t2) __attribute__((always_inline)) {
@@ -467,14 +497,29 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         const f32x16 a = mma_hi(Rc, mma_lo(Rc));
         tile_sec(a, t);
     };
-    for (int t = n_off; t < t_end; t += 2) {                   // n_off and t_end are even
-        sec_iter(RA, RB, t);
-        sec_iter(RB, RA, t + 1);
+    if (SPLIT) {
+        // wave w takes the 32-row blocks w, w + 4, .. of both sections: the DIAG and the LOC tile of a block update the
+        // same 32 entries of x, no other wave touches them
+        for (int ts = wave; ts < n_sec; ts += FB_WAVES) {
+            pull(RA, n_off + ts);
+            tile_sec(mma_hi(RA, mma_lo(RA)), n_off + ts);
+            pull(RA, n_off + n_sec + ts);
+            tile_sec(mma_hi(RA, mma_lo(RA)), n_off + n_sec + ts);
+        }
+        const float ea = ent_acc + __shfl_xor(ent_acc, 32, 64);
+        if (half == 0) ent_s[wave * FB_WP + p] = ea;
+        __syncthreads();                                       // x and the entropy parts are complete
+        ent_acc = (ent_s[p] + ent_s[FB_WP + p]) + (ent_s[2 * FB_WP + p] + ent_s[3 * FB_WP + p]);
+    } else {
+        for (int t = n_off; t < t_end; t += 2) {               // n_off and t_end are even
+            sec_iter(RA, RB, t);
+            sec_iter(RB, RA, t + 1);
+        }
     }
-    vx_wait_vmem();                                            // no DMA may still be in flight when the LDS is released
+    vx_wait_vmem();
     __builtin_amdgcn_wave_barrier();
     // ---------------------------------------------------------------- write x, entropy part
-    if (ximg_out && i0 < (dm.nb + 63) / 64 * 64) {
+    if (writer && ximg_out && i0 < (dm.nb + 63) / 64 * 64) {
         // the likelihood kernel's operand: x_aug = [x, 1, 0..] as three bf16 terms, in its LDS tile order (lb_xoff): this
         // wave's 32 persons are one half of a 64-person tile (absent persons: all-zero rows); 14 chunks of 8 columns each
         const int pvi = (int)((dm.nb - i0) < FB_WP ? (dm.nb - i0) : FB_WP);       // may be <= 0
@@ -507,14 +552,14 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
             *(bf16x8*)(out + 2 * LB_PLANE + o) = fl;
         }
     }
-    if (wave_live) {
+    if (writer && wave_live) {
         const int pv = (int)((dm.nb - i0) < FB_WP ? (dm.nb - i0) : FB_WP);
         const int c4 = D >> 2;
         for (int e = lane; e < pv * c4; e += 64) {
             const int pp = e / c4, c = e - pp * c4;
             *(f32x4*)(x_out + (i0 + pp) * D + 4 * c) = *(const f32x4*)(x_lds + pp * DX + 4 * c);
         }
-        ent_acc += __shfl_xor(ent_acc, 32, 64);
+        if (!SPLIT) ent_acc += __shfl_xor(ent_acc, 32, 64);
         if (half == 0 && i < dm.nb) {
             float s = 0.f;
             for (int k = 0; k < D; ++k) { const float e = eps_lds[p * DS + k]; s += e * e; }

@@ -312,12 +312,24 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
                                pk_off_total(dm.D) / 8, Wp, bp, gtab, img, gt2);
             VX_CHECK_LAUNCH();
             const size_t ldsb = fb_lds_bytes(dm.D, dm.J);
-            rc = set_lds(k_mvn_enc_fwd_b, ldsb);
-            if (rc) return rc;
-            const dim3 gridb((unsigned)((nb + FB_WAVES * FB_WP - 1) / (FB_WAVES * FB_WP)));
             ProfScope ps("k_mvn_enc_fwd_b", (hipStream_t)hs);
             ximg_after.done = true;
-            hipLaunchKernelGGL(k_mvn_enc_fwd_b, gridb, dim3(FB_THREADS), ldsb, (hipStream_t)hs, dm, y, rows, gid0,
+            if (nb <= FB_SPLIT_MAX) {
+                // small batch: one 32-person tile per workgroup, its four waves share the head tiles
+                rc = set_lds(k_mvn_enc_fwd_b<true>, ldsb);
+                if (rc) return rc;
+                // (with an x image: whole 64-person tiles, the absent half gets its zero rows)
+                const unsigned gs = ximg ? (unsigned)(((nb + 63) / 64) * 2) : (unsigned)((nb + FB_WP - 1) / FB_WP);
+                hipLaunchKernelGGL(k_mvn_enc_fwd_b<true>, dim3(gs), dim3(FB_THREADS), ldsb,
+                                   (hipStream_t)hs, dm, y, rows, gid0, (const uint8_t*)w1img, b1, (const uint8_t*)img,
+                                   (const uint32_t*)gt2, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT, ximg);
+                VX_CHECK_LAUNCH();
+                return VX_OK;
+            }
+            rc = set_lds(k_mvn_enc_fwd_b<false>, ldsb);
+            if (rc) return rc;
+            const dim3 gridb((unsigned)((nb + FB_WAVES * FB_WP - 1) / (FB_WAVES * FB_WP)));
+            hipLaunchKernelGGL(k_mvn_enc_fwd_b<false>, gridb, dim3(FB_THREADS), ldsb, (hipStream_t)hs, dm, y, rows, gid0,
                                (const uint8_t*)w1img, b1, (const uint8_t*)img, (const uint32_t*)gt2, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT,
                                ximg);
             VX_CHECK_LAUNCH();
