@@ -31,7 +31,8 @@ __host__ __device__ inline int hb_units_off(int D) {
 __host__ __device__ inline int hb_units(int D) { return hb_units_off(D) + 2 * ((D + 15) / 16); }
 __host__ __device__ inline int64_t hb_img_floats(int D) { return (int64_t)hb_units(D) * (HB_UNIT_BYTES / 4); }
 __host__ __device__ inline size_t hb_lds_bytes(int D) {
-    return (size_t)HB_WAVES * D * 32 * sizeof(float) + (size_t)HB_NSLOT * HB_UNIT_BYTES;
+    const size_t a = (size_t)HB_WAVES * D * 32 * sizeof(float) + (size_t)HB_NSLOT * HB_UNIT_BYTES;
+    return a > 65536 ? a : 65536;                                      // SPLIT: [8 waves][32 registers][64 lanes] floats
 }
 
 // unit image: fragment (hidden tile ht, split sp) at byte (ht * 3 + sp) * 1024 + lane * 16, lane = 32 half + row;
@@ -99,6 +100,12 @@ __device__ __forceinline__ void hb_split8(const float* v, bf16x8& fh, bf16x8& fm
     fm = __builtin_bit_cast(bf16x8, pm);
 }
 
+// SPLIT (small batches, at most HB_SPLIT_MAX persons): a workgroup takes ONE 32-person tile and its eight waves share
+// the units -- wave w the rows k = 1 + w, 9 + w, .. and the section units s = w -- each reading its units straight from
+// the (L2-resident) image, one unit ahead; the eight partial gh tiles are summed through LDS in a fixed order.  The
+// per-wave chain (357 units at D = 100) is what a small batch waits for.
+#define HB_SPLIT_MAX 16384
+template <bool SPLIT>
 __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
     EncDims dm, const uint8_t* __restrict__ img, const float* __restrict__ h_in, const float* __restrict__ eps_in,
     const float* __restrict__ gxT, const float* __restrict__ gdT /*DIAG-row operand [D][nb]*/,
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
     float* gx_lds = (float*)smem_hb + (size_t)wave * D * 32;           // [D][32] of this wave
     const char* ring = smem_hb + (size_t)HB_WAVES * D * 32 * sizeof(float);
     const uint32_t ring_lds = lds_addr_uniform(ring);
-    const int64_t i0 = ((int64_t)blockIdx.x * HB_WAVES + wave) * 32;
+    const int64_t i0 = SPLIT ? (int64_t)blockIdx.x * 32 : ((int64_t)blockIdx.x * HB_WAVES + wave) * 32;
     const int64_t i = i0 + l31;
     const int64_t ic = i < nb ? i : nb - 1;                            // absent persons: a valid one, never stored
     const int n_units = hb_units(D);
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
         }
     };
     (void)voff;
-    stage_pair(0); stage_pair(1); stage_pair(2);
+    if (!SPLIT) { stage_pair(0); stage_pair(1); stage_pair(2); }
 
     // ---- this wave's gx tile [D][32] (lanes = persons: 128-byte rows of gxT)
     for (int k = half; k < D; k += 2) gx_lds[k * 32 + l31] = gxT[(int64_t)k * nb + ic];
@@ -204,6 +211,85 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
         ++u;
     };
 
+    if constexpr (SPLIT) {
+        // ---- this wave's share of the units, fragments global -> registers one unit ahead
+        auto uoff = [&](int k) -> int {                                // index of unit (k, 0): blocks of 16 k have kb + 1 units per k
+            const int kb2 = (k - 1) >> 4;
+            return 8 * kb2 * (kb2 + 1) + (k - 16 * kb2 - 1) * (kb2 + 1);
+        };
+        auto load_unit = [&](bf16x8 (&Au)[6], int uu) __attribute__((always_inline)) {
+            if (uu >= n_units) uu = n_units - 1;                       // past the end: a harmless duplicate
+            const uint8_t* g = img + (int64_t)uu * HB_UNIT_BYTES + lane * 16;
+#pragma unroll
+            for (int f = 0; f < 6; ++f) Au[f] = *(const bf16x8*)(g + f * 1024);
+        };
+        auto mma_unit = [&](const bf16x8 (&Au)[6], auto sc, f32x16& U0, f32x16& U1) __attribute__((always_inline)) {
+            constexpr int s = decltype(sc)::value;
+            U0 = mfma_bf16(Au[2], bf[0][s], U0);
+            U0 = mfma_bf16(Au[1], bf[1][s], U0);
+            U0 = mfma_bf16(Au[1], bf[0][s], U0);
+            U0 = mfma_bf16(Au[0], bf[1][s], U0);
+            U0 = mfma_bf16(Au[0], bf[0][s], U0);
+            U1 = mfma_bf16(Au[5], bf[0][s], U1);
+            U1 = mfma_bf16(Au[4], bf[1][s], U1);
+            U1 = mfma_bf16(Au[4], bf[0][s], U1);
+            U1 = mfma_bf16(Au[3], bf[1][s], U1);
+            U1 = mfma_bf16(Au[3], bf[0][s], U1);
+        };
+        bf16x8 Ac[6], An[6];
+        load_unit(Ac, uoff(1 + wave));
+        static_for<HB_NS>([&](auto kbc) {
+            constexpr int kb = decltype(kbc)::value;
+            const int k_lo = 16 * kb + 1, k_hi = (16 * kb + 16 < D - 1) ? 16 * kb + 16 : D - 1;
+            // the k of this wave in the block: k = 1 + wave (mod 8)
+            for (int k = k_lo + ((wave - (k_lo - 1)) & (HB_WAVES - 1)); k <= k_hi; k += HB_WAVES) {
+                f32x16 U0 = zero16(), U1 = zero16();
+                const int u0 = uoff(k);
+                static_for<kb + 1>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    load_unit(An, s < kb ? u0 + s + 1 : uoff(k + HB_WAVES));
+                    mma_unit(Ac, sc, U0, U1);
+#pragma unroll
+                    for (int f = 0; f < 6; ++f) Ac[f] = An[f];
+                });
+                const float gk = gx_lds[k * 32 + l31];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { gh0[r] = fmaf(gk, U0[r], gh0[r]); gh1[r] = fmaf(gk, U1[r], gh1[r]); }
+            }
+        });
+        // ---- DIAG (operand gd) and LOC (operand gx) units: s = wave, wave + 8, ..
+        const int u_sec = hb_units_off(D);
+        frags_from_T(gdT);
+        static_for<HB_NS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if (s < ns && (s & (HB_WAVES - 1)) == wave) { load_unit(Ac, u_sec + s); mma_unit(Ac, sc, gh0, gh1); }
+        });
+        frags_from_T(gxT);
+        static_for<HB_NS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if (s < ns && (s & (HB_WAVES - 1)) == wave) { load_unit(Ac, u_sec + ns + s); mma_unit(Ac, sc, gh0, gh1); }
+        });
+        // ---- sum of the eight partial tiles, fixed order; wave 0 keeps the result
+        __syncthreads();                                               // every wave is done with its gx tile
+        float* red = (float*)smem_hb;                                  // [8 waves][32 registers][64 lanes]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            red[((size_t)wave * 32 + r) * 64 + lane] = gh0[r];
+            red[((size_t)wave * 32 + 16 + r) * 64 + lane] = gh1[r];
+        }
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a0 = red[(size_t)r * 64 + lane], a1 = red[(size_t)(16 + r) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < HB_WAVES; ++w) {
+                a0 += red[((size_t)w * 32 + r) * 64 + lane];
+                a1 += red[((size_t)w * 32 + 16 + r) * 64 + lane];
+            }
+            gh0[r] = a0; gh1[r] = a1;
+        }
+    } else {
     vx_wait_vmem();                                                    // pairs 0..2 of the ring (and nothing else)
     __syncthreads();
     read_ht(0, 0);
@@ -234,6 +320,7 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
         if (s < ns) unit(sc, gh0, gh1);
     });
     vx_wait_vmem();                                                    // no DMA may be in flight when the LDS is released
+    }
 
     // ---- ghpre = gh * softplus'(pre) = gh * (1 - exp(-h));  C layout: rows hh = crow32(r, half), cols p
     if (ghpreT_out) {                                                  // dimension-major: 128-byte rows per half-wave

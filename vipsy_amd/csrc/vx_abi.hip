@@ -779,12 +779,20 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                 hipLaunchKernelGGL(k_pack_heads_hb, dim3(hb_units(dm.D)), dim3(256), 0, st, dm.D, W21, W22, himg);
                 VX_CHECK_LAUNCH();
                 const size_t ldsh = hb_lds_bytes(dm.D);
-                rc = set_lds(k_mvn_enc_bwd_h_b, ldsh);
-                if (rc) return rc;
                 ProfScope ps("k_mvn_enc_bwd_h_b", st);
-                hipLaunchKernelGGL(k_mvn_enc_bwd_h_b, dim3((unsigned)((nb + 32 * HB_WAVES - 1) / (32 * HB_WAVES))), dim3(HB_THREADS), ldsh, st, dm,
-                                   (const uint8_t*)himg, h, eps, gxT, (const float*)gdT1, f1t ? (float*)nullptr : ghpre, hT,
-                                   f1t ? ghpre : (float*)nullptr);
+                if (nb <= HB_SPLIT_MAX) {                               // small batch: the eight waves of a workgroup share the units
+                    rc = set_lds(k_mvn_enc_bwd_h_b<true>, ldsh);
+                    if (rc) return rc;
+                    hipLaunchKernelGGL(k_mvn_enc_bwd_h_b<true>, dim3((unsigned)((nb + 31) / 32)), dim3(HB_THREADS), ldsh, st, dm,
+                                       (const uint8_t*)himg, h, eps, gxT, (const float*)gdT1, f1t ? (float*)nullptr : ghpre, hT,
+                                       f1t ? ghpre : (float*)nullptr);
+                } else {
+                    rc = set_lds(k_mvn_enc_bwd_h_b<false>, ldsh);
+                    if (rc) return rc;
+                    hipLaunchKernelGGL(k_mvn_enc_bwd_h_b<false>, dim3((unsigned)((nb + 32 * HB_WAVES - 1) / (32 * HB_WAVES))), dim3(HB_THREADS), ldsh, st, dm,
+                                       (const uint8_t*)himg, h, eps, gxT, (const float*)gdT1, f1t ? (float*)nullptr : ghpre, hT,
+                                       f1t ? ghpre : (float*)nullptr);
+                }
                 VX_CHECK_LAUNCH();
             } else {
             ProfScope ps("k_mvn_enc_bwd_h_t", st);
