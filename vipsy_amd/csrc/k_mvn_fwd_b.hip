@@ -130,7 +130,7 @@ __device__ __forceinline__ void fb_split8(const float* v, bf16x8& fh, bf16x8& fm
 // walking all of them for its own persons -- the per-wave chain of a step is what a small batch waits for.  Every wave
 // makes fc1 for the same persons (it needs h in registers); wave 0 owns the outputs and the eps / x tile in LDS; a k
 // whose rows straddle two ranges gets its two partial sums by commutative LDS float adds (two addends: order-free).
-#define FB_SPLIT_MAX 16384
+#define FB_SPLIT_MAX 8192                                             // one round of workgroups on 256 CUs; beyond it the plain form wins (measured at 10 000)
 template <bool SPLIT>
 __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, int64_t gid0,
