@@ -87,7 +87,10 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y /*[n_local][J]*/,
                        float* eps /*[nb][D]*/, float* ldT /*[D][nb]*/, float* ent /*[nb]*/,
                        float* hT /*[H][nb] or NULL*/, float* epsT /*[D][nb] or NULL*/,
                        float* packws /*vx_mvn_pack_floats(cfg) floats or NULL*/,
-                       uint8_t* ximg /*vx_irt_lik_ximg_bytes(cfg, nb) bytes or NULL*/, void* hip_stream);
+                       uint8_t* ximg /*vx_irt_lik_ximg_bytes(cfg, nb) bytes or NULL*/,
+                       uint16_t* hs /*[3][64][nb] bf16 or NULL*/, void* hip_stream);
+/* hs (optional, with hT, hidden_dim 64): the three bf16 terms of hT, the operand of the head weight-gradient kernel --
+ * point it at workspace + vx_mvn_enc_bwd_hs_offset(cfg, nb) of the backward call and set bit 1 of its gd_ready. */
 /* ximg (optional): x once more, as the pre-split operand image of the bf16-MFMA likelihood kernel (three bf16 terms per
  * value in that kernel's LDS tile order); hand the same buffer to vx_irt_lik_grad, which otherwise makes it itself. */
 /* hT / epsT: optional dimension-major copies of h and eps (person-contiguous rows) for the weight-gradient kernel
@@ -139,9 +142,12 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                         const float* hT /*or NULL*/, const float* epsT /*or NULL*/, const float* gxT /*or NULL*/,
                         const uint8_t* yT /*[>= J][yT_stride] item-major copy of y (pad bytes 0 or 254), or NULL*/, int64_t yT_stride,
                         float* genc, float* workspace, const float* packws,
-                        int32_t gd_ready /*1: vx_irt_lik_grad already wrote gdT into the workspace*/, void* hip_stream);
+                        int32_t gd_ready /*bit 0: vx_irt_lik_grad already wrote gdT into the workspace; bit 1:
+                                           vx_mvn_enc_forward already wrote hs there*/, void* hip_stream);
 /* float offset of gdT[D][nb] inside the backward workspace, or -1 when this (cfg, nb) has no such operand */
 int64_t vx_mvn_enc_bwd_gd_offset(const vx_irt_cfg* cfg, int64_t nb);
+/* float offset of hs[3][64][nb] (bf16) inside the backward workspace, or -1 when this (cfg, nb) does not use it */
+int64_t vx_mvn_enc_bwd_hs_offset(const vx_irt_cfg* cfg, int64_t nb);
 /* With hT, epsT and gxT (the dimension-major copies made by the forward / likelihood calls) the head weight
  * gradients run on the DMA-staged kernel of k_mvn_bwd_t.hip; without them on the person-major one.
  * yT (full batch only, rows == NULL, yT_stride % 16 == 0): the responses item-major, which lets the fc1 weight

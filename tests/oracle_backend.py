@@ -139,6 +139,9 @@ class OracleBackend(object):
     def mvn_enc_bwd_workspace(self, cfg, nb):
         return 1
 
+    def mvn_enc_bwd_hs_offset(self, cfg, nb):
+        return -1
+
     def mvn_enc_bwd_gd_offset(self, cfg, nb):
         return -1
 

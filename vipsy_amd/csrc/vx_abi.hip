@@ -274,7 +274,7 @@ int vx_adam_step(float* p, const float* g, float* m, float* v, const float* free
 int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, int64_t gid0,
                        const float* W1, const float* b1, const float* W21, const float* b21, const float* W22,
                        const float* b22, const float* eps_in, float* h, float* x, float* eps, float* ldT,
-                       float* ent, float* hT, float* epsT, float* packws, uint8_t* ximg, void* hs) {
+                       float* ent, float* hT, float* epsT, float* packws, uint8_t* ximg, uint16_t* hs_out, void* hs) {
     if (!enc_cfg_ok(cfg) || !y || !W1 || !b1 || !W21 || !b21 || !W22 || !b22 || !h || !x || !eps || !ldT || !ent ||
         nb < 0)
         return VX_EINVAL;
@@ -291,6 +291,14 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
                 hipLaunchKernelGGL(k_lik_ximg, dim3((unsigned)((nb + LB_P - 1) / LB_P)), dim3(256), 0, st, (int)cfg->D, nb, x, img);
         }
     } ximg_after{ximg, cfg, nb, x, (hipStream_t)hs, false};
+    // ... and the bf16 terms of hT (the head weight-gradient kernel's operand) to this pass over hT
+    if (hs_out && (!hT || cfg->H != 64)) return VX_EINVAL;
+    struct HsAfter {
+        uint16_t* out; const float* hT; int64_t nb; hipStream_t st; bool done;
+        ~HsAfter() {
+            if (out && !done) hipLaunchKernelGGL(k_split3_bf16, dim3(num_cu() * 8), dim3(256), 0, st, hT, nb * 64, out);
+        }
+    } hs_after{hs_out, hT, nb, (hipStream_t)hs, false};
     if (packed_ok(cfg) && packws && aligned16(packws) && aligned16(y) && aligned16(W1) && aligned16(b1) &&
         aligned16(W21) && aligned16(W22) && aligned16(h)) {
         const int Rp = pk_rows(cfg->D);
@@ -314,6 +322,7 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
             const size_t ldsb = fb_lds_bytes(dm.D, dm.J);
             ProfScope ps("k_mvn_enc_fwd_b", (hipStream_t)hs);
             ximg_after.done = true;
+            hs_after.done = true;
             if (nb <= FB_SPLIT_MAX) {
                 // small batch: one 32-person tile per workgroup, its four waves share the head tiles
                 rc = set_lds(k_mvn_enc_fwd_b<true>, ldsb);
@@ -322,7 +331,7 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
                 const unsigned gs = ximg ? (unsigned)(((nb + 63) / 64) * 2) : (unsigned)((nb + FB_WP - 1) / FB_WP);
                 hipLaunchKernelGGL(k_mvn_enc_fwd_b<true>, dim3(gs), dim3(FB_THREADS), ldsb,
                                    (hipStream_t)hs, dm, y, rows, gid0, (const uint8_t*)w1img, b1, (const uint8_t*)img,
-                                   (const uint32_t*)gt2, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT, ximg);
+                                   (const uint32_t*)gt2, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT, ximg, hs_out);
                 VX_CHECK_LAUNCH();
                 return VX_OK;
             }
@@ -331,7 +340,7 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
             const dim3 gridb((unsigned)((nb + FB_WAVES * FB_WP - 1) / (FB_WAVES * FB_WP)));
             hipLaunchKernelGGL(k_mvn_enc_fwd_b<false>, gridb, dim3(FB_THREADS), ldsb, (hipStream_t)hs, dm, y, rows, gid0,
                                (const uint8_t*)w1img, b1, (const uint8_t*)img, (const uint32_t*)gt2, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT,
-                               ximg);
+                               ximg, hs_out);
             VX_CHECK_LAUNCH();
             return VX_OK;
         }
@@ -695,6 +704,12 @@ int64_t vx_mvn_enc_bwd_gd_offset(const vx_irt_cfg* cfg, int64_t nb) {
     return (o >= 0 && o % 4 == 0 && (nb * cfg->D) % 4 == 0) ? o : -1;
 }
 
+int64_t vx_mvn_enc_bwd_hs_offset(const vx_irt_cfg* cfg, int64_t nb) {
+    if (!enc_cfg_ok(cfg) || nb < 0) return VX_EINVAL;
+    const int64_t o = encb_gd_offset(cfg, nb);
+    return (o >= 0 && bwb_shape(cfg, nb)) ? o + nb * cfg->D + 4 : -1;
+}
+
 int64_t vx_mvn_pack_floats(const vx_irt_cfg* cfg) {
     if (!enc_cfg_ok(cfg)) return VX_EINVAL;
     const int64_t Rp = pk_rows(cfg->D);
@@ -760,7 +775,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     if (packed) {
         const float* Wp = packws;
         const uint32_t* gtab = (const uint32_t*)(packws + Rp * 64 + Rp);
-        if (use_t && !(gd_ready && (slabs_f + (int64_t)n_prf * lenf) == workspace + encb_gd_offset(cfg, nb))) {
+        if (use_t && !((gd_ready & 1) && (slabs_f + (int64_t)n_prf * lenf) == workspace + encb_gd_offset(cfg, nb))) {
             float* gdT0 = slabs_f + (int64_t)n_prf * lenf;      // DIAG-row operand of both dimension-major kernels
             hipLaunchKernelGGL(k_mvn_gd, dim3(num_cu() * 8), dim3(256), 0, st, (const float4*)gxT, (const float4*)epsT,
                                (const float4*)ldT, cfg->scale, nb * D / 4, (float4*)gdT0);
@@ -813,8 +828,10 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
         if (use_t && bwb_shape(cfg, nb)) {
             float* gdT = slabs_f + (int64_t)n_prf * lenf;
             uint16_t* hs3 = (uint16_t*)(gdT + nb * D + 4);
-            hipLaunchKernelGGL(k_split3_bf16, dim3(num_cu() * 8), dim3(256), 0, st, hT, nb * 64, hs3);
-            VX_CHECK_LAUNCH();
+            if (!(gd_ready & 2)) {                             // bit 1: the forward call already wrote the bf16 terms of hT here
+                hipLaunchKernelGGL(k_split3_bf16, dim3(num_cu() * 8), dim3(256), 0, st, hT, nb * 64, hs3);
+                VX_CHECK_LAUNCH();
+            }
             const size_t lds = bb_lds_bytes(dm.D);
             rc = set_lds(k_mvn_enc_bwd_w_b, lds);
             if (rc) return rc;

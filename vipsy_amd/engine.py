@@ -46,7 +46,8 @@ class HipBackend(object):
                                        _hip.ptr(eps_in), _hip.ptr(out["h"]), _hip.ptr(out["x"]),
                                        _hip.ptr(out["eps"]), _hip.ptr(out["ldT"]), _hip.ptr(out["ent"]),
                                        _hip.ptr(out.get("hT")), _hip.ptr(out.get("epsT")),
-                                       _hip.ptr(out.get("packws")), _hip.ptr(out.get("ximg")), _hip.stream_ptr())
+                                       _hip.ptr(out.get("packws")), _hip.ptr(out.get("ximg")), _hip.ptr(out.get("hs")),
+                                       _hip.stream_ptr())
         _hip.check(rc, "vx_mvn_enc_forward")
 
     def mvn_pack_floats(self, cfg):
@@ -88,14 +89,17 @@ class HipBackend(object):
     def mvn_enc_bwd_gd_offset(self, cfg, nb):
         return int(self.L.vx_mvn_enc_bwd_gd_offset(ctypes.byref(cfg), nb))
 
+    def mvn_enc_bwd_hs_offset(self, cfg, nb):
+        return int(self.L.vx_mvn_enc_bwd_hs_offset(ctypes.byref(cfg), nb))
+
     def mvn_enc_backward(self, cfg, y, rows, nb, enc, fw, gx, genc, ws, gxT=None, gd_ready=False):
         rc = self.L.vx_mvn_enc_backward(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb,
                                         _hip.ptr(enc["fc21.weight"]), _hip.ptr(enc["fc22.weight"]),
                                         _hip.ptr(fw["h"]), _hip.ptr(fw["eps"]), _hip.ptr(fw["ldT"]), _hip.ptr(gx),
                                         _hip.ptr(fw.get("hT")), _hip.ptr(fw.get("epsT")), _hip.ptr(gxT),
                                         _hip.ptr(fw.get("yT")), int(fw["yT"].shape[1]) if fw.get("yT") is not None else 0,
-                                        _hip.ptr(genc), _hip.ptr(ws), _hip.ptr(fw.get("packws")), int(bool(gd_ready)),
-                                        _hip.stream_ptr())
+                                        _hip.ptr(genc), _hip.ptr(ws), _hip.ptr(fw.get("packws")),
+                                        int(bool(gd_ready)) | (2 if fw.get("hs") is not None else 0), _hip.stream_ptr())
         _hip.check(rc, "vx_mvn_enc_backward")
 
     def irt1d_workspace(self, cfg, nb):
@@ -710,6 +714,9 @@ class IrtEngine(_EngineBase):
             enc = self._enc()
             lik_ws = self._buf("lik_ws", be.lik_workspace(cfg, nb))
             encb_ws = self._buf("encb_ws", be.mvn_enc_bwd_workspace(cfg, nb))
+            hs_off = be.mvn_enc_bwd_hs_offset(cfg, nb)     # the weight-gradient kernel's bf16 terms of hT, written by the forward
+            if hs_off >= 0:
+                fw["hs"] = encb_ws[hs_off:hs_off + nb * 96]
             with self._phase("guide_forward"):
                 be.mvn_enc_forward(cfg, self.y, rows, nb, self.gid0, enc, eps, fw)
             gd_off = be.mvn_enc_bwd_gd_offset(cfg, nb)     # the backward's DIAG-row operand, made in the likelihood's last pass
