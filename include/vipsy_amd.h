@@ -332,6 +332,12 @@ typedef struct vx_adam_seg { int64_t begin, end; float lr; float _pad; } vx_adam
 int vx_adam_step(float* p, const float* g, float* m, float* v, const float* free_mask /*or NULL*/,
                  int64_t n, const vx_adam_seg* segs /*host*/, int32_t n_segs, int32_t t, const uint32_t* t_dev,
                  float beta1, float beta2, float eps, void* hip_stream);
+/* the same for TWO buffers in one launch: A with its free mask (the replicated leaves), B without (the per-person rows
+ * of a BBVI guide); same t, betas and eps for both */
+int vx_adam_step2(float* pA, const float* gA, float* mA, float* vA, const float* freeA /*or NULL*/, int64_t nA,
+                  const vx_adam_seg* segsA, int32_t n_segsA, float* pB, const float* gB, float* mB, float* vB, int64_t nB,
+                  const vx_adam_seg* segsB, int32_t n_segsB, int32_t t, const uint32_t* t_dev, float beta1, float beta2,
+                  float eps, void* hip_stream);
 
 
 #ifdef __cplusplus

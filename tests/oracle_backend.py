@@ -81,6 +81,10 @@ class OracleBackend(object):
             denom = v[lo:hi].sqrt() / np.sqrt(1 - b2 ** t) + eps
             p[lo:hi] -= (lr / (1 - b1 ** t)) * m[lo:hi] / denom
 
+    def adam2(self, bufA, free, nA, segsA, bufB, nB, segsB, t, betas=(0.9, 0.999), eps=1e-8):
+        self.adam(bufA[0], bufA[1], bufA[2], bufA[3], free, nA, segsA, t, betas, eps)
+        self.adam(bufB[0], bufB[1], bufB[2], bufB[3], None, nB, segsB, t, betas, eps)
+
     # ---- amortized MVN guide + D >= 2 likelihood (restated through oracle.irt_particle pieces) ----------
     def mvn_enc_forward(self, cfg, y, rows, nb, gid0, enc, eps_in, out):
         D, J, H = cfg.D, cfg.J, cfg.H

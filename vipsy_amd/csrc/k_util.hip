@@ -160,3 +160,42 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
         p[i] = p[i] - (lr / bc1) * (mi / denom);
     }
 }
+
+// two parameter buffers in one launch (the replicated leaves and the per-person rows of a BBVI guide): indices
+// [0, nA) -> buffer A (with its free mask), [nA, nA + nB) -> buffer B
+struct AdamBuf { float* p; const float* g; float* m; float* v; const float* free_mask; int64_t n; };
+__global__ void k_adam2(AdamBuf A, AdamSegs sA, AdamBuf B, AdamSegs sB, float beta1, float beta2, float eps, float bc1,
+                        float bc2_sqrt, const uint32_t* __restrict__ t_dev) {
+    if (t_dev) {
+        __shared__ float bc[2];
+        if (threadIdx.x == 0) {
+            const double t = (double)*t_dev;
+            bc[0] = (float)(1.0 - pow((double)beta1, t));
+            bc[1] = (float)sqrt(1.0 - pow((double)beta2, t));
+        }
+        __syncthreads();
+        bc1 = bc[0]; bc2_sqrt = bc[1];
+    }
+    const int64_t n = A.n + B.n;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += (int64_t)gridDim.x * blockDim.x) {
+        const bool inA = i0 < A.n;
+        const int64_t i = inA ? i0 : i0 - A.n;
+        const AdamSegs& segs = inA ? sA : sB;
+        float lr = 0.f;
+        bool found = false;
+        for (int s = 0; s < segs.n; ++s)
+            if (i >= segs.begin[s] && i < segs.end[s]) { lr = segs.lr[s]; found = true; }
+        if (!found) continue;
+        float* p = inA ? A.p : B.p;
+        float* m = inA ? A.m : B.m;
+        float* v = inA ? A.v : B.v;
+        const float* fm = inA ? A.free_mask : B.free_mask;
+        float gi = (inA ? A.g : B.g)[i];
+        if (fm) gi *= fm[i];
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - (lr / bc1) * (mi / denom);
+    }
+}

@@ -270,6 +270,31 @@ int vx_adam_step(float* p, const float* g, float* m, float* v, const float* free
     return VX_OK;
 }
 
+int vx_adam_step2(float* pA, const float* gA, float* mA, float* vA, const float* freeA, int64_t nA, const vx_adam_seg* segsA,
+                  int32_t n_segsA, float* pB, const float* gB, float* mB, float* vB, int64_t nB, const vx_adam_seg* segsB,
+                  int32_t n_segsB, int32_t t, const uint32_t* t_dev, float beta1, float beta2, float eps, void* hs) {
+    if (!pA || !gA || !mA || !vA || !segsA || !pB || !gB || !mB || !vB || !segsB || n_segsA < 1 || n_segsA > VX_MAX_SEGS ||
+        n_segsB < 1 || n_segsB > VX_MAX_SEGS || nA < 0 || nB < 0 || (t < 1 && !t_dev))
+        return VX_EINVAL;
+    AdamSegs sa, sb;
+    sa.n = n_segsA; sb.n = n_segsB;
+    for (int i = 0; i < n_segsA; ++i) {
+        if (segsA[i].begin < 0 || segsA[i].end > nA || segsA[i].begin > segsA[i].end) return VX_EINVAL;
+        sa.begin[i] = segsA[i].begin; sa.end[i] = segsA[i].end; sa.lr[i] = segsA[i].lr;
+    }
+    for (int i = 0; i < n_segsB; ++i) {
+        if (segsB[i].begin < 0 || segsB[i].end > nB || segsB[i].begin > segsB[i].end) return VX_EINVAL;
+        sb.begin[i] = segsB[i].begin; sb.end[i] = segsB[i].end; sb.lr[i] = segsB[i].lr;
+    }
+    const AdamBuf A{pA, gA, mA, vA, freeA, nA}, B{pB, gB, mB, vB, nullptr, nB};
+    const double bc1 = 1.0 - pow((double)beta1, (double)(t_dev ? 1 : t));
+    const double bc2 = 1.0 - pow((double)beta2, (double)(t_dev ? 1 : t));
+    hipLaunchKernelGGL(k_adam2, dim3(grid_1d(nA + nB, 256)), dim3(256), 0, (hipStream_t)hs, A, sa, B, sb, beta1, beta2, eps,
+                       (float)bc1, (float)sqrt(bc2), t_dev);
+    VX_CHECK_LAUNCH();
+    return VX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, int64_t gid0,
                        const float* W1, const float* b1, const float* W21, const float* b21, const float* W22,

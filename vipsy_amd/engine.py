@@ -273,6 +273,14 @@ class HipBackend(object):
         rc = self.L.vx_sum(_hip.ptr(v), n, alpha, _hip.ptr(out), _hip.ptr(ws), _hip.stream_ptr())
         _hip.check(rc, "vx_sum")
 
+    def adam2(self, bufA, free, nA, segsA, bufB, nB, segsB, t, betas=(0.9, 0.999), eps=1e-8, t_dev=None):
+        arrA = (_hip.AdamSeg * len(segsA))(*[_hip.AdamSeg(b, e, lr, 0.0) for (b, e, lr) in segsA])
+        arrB = (_hip.AdamSeg * len(segsB))(*[_hip.AdamSeg(b, e, lr, 0.0) for (b, e, lr) in segsB])
+        rc = self.L.vx_adam_step2(*[_hip.ptr(x) for x in bufA], _hip.ptr(free), nA, arrA, len(segsA),
+                                  *[_hip.ptr(x) for x in bufB], nB, arrB, len(segsB), t, _hip.ptr(t_dev), betas[0], betas[1],
+                                  eps, _hip.stream_ptr())
+        _hip.check(rc, "vx_adam_step2")
+
     def sum2_into(self, v1, v2, n, alpha, out, ws):
         rc = self.L.vx_sum2(_hip.ptr(v1), _hip.ptr(v2), n, alpha, _hip.ptr(out), _hip.ptr(ws), _hip.stream_ptr())
         _hip.check(rc, "vx_sum2")
@@ -477,15 +485,21 @@ class _EngineBase(object):
                 (o, o + int(np.prod(self.shape[name])), float(lrs.lr_of(name))))
         sd = getattr(self, "_step_dev", None)
         kw = {"t_dev": sd} if sd is not None else {}         # captured step: Adam's t = the (already advanced) device counter
+        pp_hyper = {}
+        if self.per_person:
+            for nme, o in self.pp_off.items():
+                pp_hyper.setdefault(lrs.hyper_of(nme), []).append(
+                    (o, o + int(np.prod(self.pp_shape[nme])), float(lrs.lr_of(nme))))
+        if len(by_hyper) == 1 and len(pp_hyper) == 1 and list(by_hyper) == list(pp_hyper):
+            (betas, eps), segs = next(iter(by_hyper.items()))          # the usual case: one launch for both buffers
+            self.be.adam2((self.P, self.G, self.M, self.V), self.free, self.n_params, _merge_segments(segs),
+                          (self.PP, self.GP, self.MP, self.VP), self.pp_len, _merge_segments(pp_hyper[(betas, eps)]),
+                          self.t, betas, eps, **kw)
+            return
         for (betas, eps), segs in by_hyper.items():         # one launch per distinct (betas, eps): normally one
             self.be.adam(self.P, self.G, self.M, self.V, self.free, self.n_params, _merge_segments(segs), self.t, betas, eps, **kw)
-        if self.per_person:
-            by_hyper = {}
-            for nme, o in self.pp_off.items():
-                by_hyper.setdefault(lrs.hyper_of(nme), []).append(
-                    (o, o + int(np.prod(self.pp_shape[nme])), float(lrs.lr_of(nme))))
-            for (betas, eps), segs in by_hyper.items():
-                self.be.adam(self.PP, self.GP, self.MP, self.VP, None, self.pp_len, _merge_segments(segs), self.t, betas, eps, **kw)
+        for (betas, eps), segs in pp_hyper.items():
+            self.be.adam(self.PP, self.GP, self.MP, self.VP, None, self.pp_len, _merge_segments(segs), self.t, betas, eps, **kw)
 
     # -- the whole step as one HIP graph ---------------------------------------------------------
     # A D = 1 full-batch step is a handful of 10-100 us kernels: launched one by one the host (Python + ctypes, ~10 us a
