@@ -139,7 +139,8 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     float* __restrict__ x_out, float* __restrict__ eps_out, float* __restrict__ ldT, float* __restrict__ ent_out,
     float* __restrict__ hT_out /*[64][nb] or null*/, float* __restrict__ epsT_out /*[D][nb] or null*/,
     uint8_t* __restrict__ ximg_out /*bf16x3 tile images of x for k_irt_lik_b (k_irt_lik_b.hip), or null*/,
-    uint16_t* __restrict__ hs_out /*[3][64][nb] bf16 terms of h for k_mvn_enc_bwd_w_b (what k_split3_bf16 makes), or null*/) {
+    uint16_t* __restrict__ hs_out /*[3][64][nb] bf16 terms of h for k_mvn_enc_bwd_w_b (what k_split3_bf16 makes), or null*/,
+    int64_t i_base = 0 /*first person of this launch (a multiple of 64): the persons before it belong to another launch*/) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
     constexpr int H = 64;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     uint32_t* gt_lds = (uint32_t*)(smem + FB_WAVES * enc_p_wave_floats(D, J));
     float* ent_s = (float*)(gt_lds + ((pk_off_total(D) / 8 + 4) / 4 * 4));   // SPLIT: [4][32] partial entropy sums
     const bool writer = !SPLIT || wave == 0;
-    const int64_t i0 = SPLIT ? (int64_t)blockIdx.x * FB_WP : ((int64_t)blockIdx.x * FB_WAVES + wave) * FB_WP;
+    const int64_t i0 = i_base + (SPLIT ? (int64_t)blockIdx.x * FB_WP : ((int64_t)blockIdx.x * FB_WAVES + wave) * FB_WP);
     const int p = l31;
     const int64_t i = i0 + p;
     // NOTE: no early exit -- every wave takes part in the workgroup barrier that publishes the group table; waves (and

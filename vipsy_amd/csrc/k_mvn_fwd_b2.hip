@@ -1,0 +1,426 @@
+// Amortized MVN guide forward, SIXTY-FOUR persons per wave: the same mathematics and outputs as k_mvn_enc_fwd_b
+// (k_mvn_fwd_b.hip), for batches large enough to fill the chip with 256-person workgroups.
+//
+// What bounds k_mvn_enc_fwd_b is the instruction budget of a wave per head tile: 13 fragment loads, the group-table read,
+// four eps reads and ~120 vector instructions beside 25 MFMAs (measured: a second wave per SIMD buys nothing, the loads
+// alone cost 0.8 ms of 4.2).  Here every fragment of a head tile feeds TWO 32-person MFMA chains (person sets 0 and 1 of
+// the wave), so loads, table reads and k-end branches are spent once per 50 MFMAs; fc1 shares its W1 fragments the same
+// way.  Two person sets do not fit the LDS with an x tile each (832 B a person), so x is not kept in LDS at all: the OFF
+// rows' sums go to global memory as each k ends (write only), and the DIAG / LOC tiles of a 32-row block are taken
+// TOGETHER at the end: x = x_off (read back once) + exp(M_kk) eps_k + loc_k.
+// (included by vx_abi.hip after k_mvn_fwd_b.hip, whose images, tables and helpers it uses)
+
+#define FB2_THREADS 256
+#define FB2_WAVES 4
+#define FB2_NS 2                                                     // person sets of 32 per wave
+#define FB2_WP (32 * FB2_NS)
+
+__host__ __device__ inline size_t fb2_wave_floats(int D, int J) {
+    const size_t a = (size_t)FB2_WP * ef_ys(J) / 4, b = (size_t)FB2_WP * pk_dse(D);   // response bytes | eps tile
+    return ((a > b ? a : b) + 3) & ~(size_t)3;
+}
+__host__ __device__ inline size_t fb2_lds_bytes(int D, int J) {
+    return FB2_WAVES * fb2_wave_floats(D, J) * sizeof(float) + (size_t)(pk_off_total(D) / 8 + 4) / 4 * 16;
+}
+
+__global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
+    EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, int64_t gid0,
+    const uint8_t* __restrict__ w1img, const float* __restrict__ b1, const uint8_t* __restrict__ img,
+    const uint32_t* __restrict__ gt2, const float* __restrict__ eps_in, uint64_t seed, uint32_t step, uint32_t stream,
+    float* __restrict__ h_out, float* __restrict__ x_out, float* __restrict__ eps_out, float* __restrict__ ldT,
+    float* __restrict__ ent_out, float* __restrict__ hT_out, float* __restrict__ epsT_out, uint8_t* __restrict__ ximg_out,
+    uint16_t* __restrict__ hs_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2w __attribute__((ext_vector_type(2)));
+    constexpr int H = 64, NS = FB2_NS;
+    const int D = dm.D, J = dm.J;
+    const int DS = pk_dse(D);
+    const int YS = ef_ys(J);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    float* R1 = smem + wave * fb2_wave_floats(D, J);
+    int8_t* Yi = (int8_t*)R1;                                 // phase A: [64][ysr] response bytes
+    float* eps_lds = R1;                                      // phase B: [64][DS]
+    uint32_t* gt_lds = (uint32_t*)(smem + FB2_WAVES * fb2_wave_floats(D, J));
+    const int64_t i0 = ((int64_t)blockIdx.x * FB2_WAVES + wave) * FB2_WP;
+    const int p = l31;
+    int64_t iu[NS];                                           // this lane's person of set u
+#pragma unroll
+    for (int u = 0; u < NS; ++u) iu[u] = i0 + 32 * u + p;
+    // no early exit: every wave takes part in the barrier that publishes the group table; persons past the end compute on
+    // clamped inputs and store nothing
+
+    const int n_off = pk_off_total(D) / 32;                   // even
+    const int n_sec = pk_sec(D) / 32;
+    const int t_end = n_off + 2 * n_sec;
+    for (int e = tid; e < 4 * n_off; e += FB2_THREADS) gt_lds[e] = gt2[e];
+
+    // ---------------------------------------------------------------- response rows of the wave's 64 persons
+    const int n_ydma = (FB2_WP * J + 1023) / 1024;
+    const bool ydense = !rows && ((J >> 2) & 1) && i0 + FB2_WP <= dm.nb && (i0 * J + (int64_t)n_ydma * 1024 <= dm.nb * (int64_t)J) &&
+                        (size_t)n_ydma * 1024 <= fb2_wave_floats(D, J) * sizeof(float);
+    const int ysr = ydense ? J : YS;
+    if (ydense) {
+        const uint8_t* src = y + i0 * J + 16 * lane;
+        const uint32_t lb = lds_addr_uniform(R1);
+        for (int d = 0; d < n_ydma; ++d) dma16(src + d * 1024, lb + (uint32_t)d * 1024u);
+        vx_wait_vmem();
+    } else {
+        const int YW = YS / 4, JW = J / 4;
+        uint32_t* Yw = (uint32_t*)R1;
+        for (int e = lane; e < FB2_WP * YW; e += 64) {
+            const int pp = e / YW, wq = e - pp * YW;
+            const int64_t ii = i0 + pp;
+            uint32_t v = 0u;
+            if (wq < JW && ii < dm.nb) {
+                const int64_t row = rows ? rows[ii] : ii;
+                v = *(const uint32_t*)(y + row * J + 4 * wq);              // bytes 0/1/255 == int8 0/1/-1 (vi.py:689-691)
+            }
+            Yw[e] = v;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---------------------------------------------------------------- phase A: fc1 (+ softplus) of both person sets
+    bf16x8 hb[NS][3][4];                                      // [set][split][k-step]: B fragments of every head tile
+    {
+        f32x16 acc[NS][2];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) { acc[u][0] = zero16(); acc[u][1] = zero16(); }
+        const int n_ks = (J + 15) / 16;
+        auto loadA = [&](bf16x8 (&Af)[6], int ks) __attribute__((always_inline)) {
+            ks = ks < n_ks ? ks : n_ks - 1;
+            const uint8_t* src = w1img + (int64_t)ks * 6144 + lane * 16;
+#pragma unroll
+            for (int f = 0; f < 6; ++f) Af[f] = *(const bf16x8*)(src + f * 1024);
+        };
+        auto compute = [&](const bf16x8 (&Af)[6], int ks) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                const uint32_t* yw = (const uint32_t*)(Yi + (32 * u + p) * ysr + 16 * ks + 8 * half);
+                const u32x2w w = {yw[0], yw[1]};
+                u32x4w q;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const uint32_t src = w[d >> 1];
+                    const uint32_t t = (d & 1) ? __builtin_amdgcn_perm(0u, src, 0x0c030c02u) : __builtin_amdgcn_perm(0u, src, 0x0c010c00u);
+                    q[d] = (t & 0x00010001u) * 0x3F80u | ((t & 0x00800080u) << 8);
+                }
+                const bf16x8 yb = __builtin_bit_cast(bf16x8, q);
+                acc[u][0] = mfma_bf16(Af[2], yb, acc[u][0]); acc[u][1] = mfma_bf16(Af[5], yb, acc[u][1]);
+                acc[u][0] = mfma_bf16(Af[1], yb, acc[u][0]); acc[u][1] = mfma_bf16(Af[4], yb, acc[u][1]);
+                acc[u][0] = mfma_bf16(Af[0], yb, acc[u][0]); acc[u][1] = mfma_bf16(Af[3], yb, acc[u][1]);
+            }
+        };
+        {
+            bf16x8 A[4][6];
+            loadA(A[0], 0); loadA(A[1], 1); loadA(A[2], 2);
+            for (int c = 0; c < n_ks; c += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    loadA(A[(u + 3) & 3], c + u + 3);
+                    if (c + u < n_ks) compute(A[u], c + u);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int64_t i = iu[u];
+            f32x16 hreg[2];
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int hh0 = 32 * ht + 8 * g + 4 * half;
+                    const float4 bb = *(const float4*)(b1 + hh0);
+                    float4 hv;
+                    hv.x = softplusf_(acc[u][ht][4 * g + 0] + bb.x);               // vi.py:449
+                    hv.y = softplusf_(acc[u][ht][4 * g + 1] + bb.y);
+                    hv.z = softplusf_(acc[u][ht][4 * g + 2] + bb.z);
+                    hv.w = softplusf_(acc[u][ht][4 * g + 3] + bb.w);
+                    hreg[ht][4 * g + 0] = hv.x; hreg[ht][4 * g + 1] = hv.y;
+                    hreg[ht][4 * g + 2] = hv.z; hreg[ht][4 * g + 3] = hv.w;
+                    if (i < dm.nb) *(float4*)(h_out + i * H + hh0) = hv;
+                }
+            }
+            if (hT_out && i < dm.nb) {
+#pragma unroll
+                for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hT_out[(int64_t)(32 * ht + crow32(r, half)) * dm.nb + i] = hreg[ht][r];
+            }
+            if (hs_out && i < dm.nb) {                            // the three bf16 terms of hT (round to nearest, as k_split3_bf16)
+                const int64_t plane = (int64_t)64 * dm.nb;
+#pragma unroll
+                for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float xv = hreg[ht][r];
+                        const __bf16 t0 = (__bf16)xv;
+                        const float r1 = xv - (float)t0;
+                        const __bf16 t1 = (__bf16)r1;
+                        const __bf16 t2 = (__bf16)(r1 - (float)t1);
+                        const int64_t o = (int64_t)(32 * ht + crow32(r, half)) * dm.nb + i;
+                        hs_out[o] = __builtin_bit_cast(uint16_t, t0);
+                        hs_out[plane + o] = __builtin_bit_cast(uint16_t, t1);
+                        hs_out[2 * plane + o] = __builtin_bit_cast(uint16_t, t2);
+                    }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = hreg[s >> 1][8 * (s & 1) + j];
+                fb_split8(v, hb[u][0][s], hb[u][1][s], hb[u][2][s]);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();                          // response bytes no longer needed
+    // ---------------------------------------------------------------- eps of the 64 persons (zero padded to DS) -> LDS, global
+    const int nblk = D >> 2;                                  // D % 4 == 0 on this path
+    for (int e = lane; e < FB2_WP * DS; e += 64) R1[e] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < FB2_WP * nblk; e += 64) {
+        const int pp = e / nblk, blk = e - pp * nblk;
+        int64_t ii = i0 + pp;
+        const bool live = ii < dm.nb;
+        if (!live) ii = dm.nb - 1;                             // absent persons: any finite values, never stored
+        f32x4 z;
+        if (eps_in) {
+            z = *(const f32x4*)(eps_in + ii * D + 4 * blk);
+        } else {
+            const int64_t row = rows ? rows[ii] : ii;
+            z = philox_normal4(seed, step, stream, gid0 + row, (uint32_t)blk);
+        }
+        *(f32x4*)(eps_lds + pp * DS + 4 * blk) = z;
+        if (live) *(f32x4*)(eps_out + ii * D + 4 * blk) = z;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float eps2[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const float* er = eps_lds + (32 * u + p) * DS;
+        if (epsT_out && iu[u] < dm.nb) {
+#pragma unroll 4
+            for (int k = half; k < D; k += 2) epsT_out[(int64_t)k * dm.nb + iu[u]] = er[k];
+        }
+        float s2 = 0.f;
+        for (int k = 0; k < D; ++k) s2 = fmaf(er[k], er[k], s2);
+        eps2[u] = s2;
+    }
+    // ---------------------------------------------------------------- phase B: packed head rows, 32 per tile
+    struct TileRegs { bf16x8 a[3][4]; bf16x8 bias; };
+    auto pull = [&](TileRegs& R, int t) __attribute__((always_inline)) {
+        const int tc = t < t_end ? t : t_end - 1;
+        const uint8_t* gb = img + (int64_t)tc * FB_IMG_BYTES + lane * 16;
+        R.bias = *(const bf16x8*)(gb + FB_A_BYTES);
+#pragma unroll
+        for (int sp = 2; sp >= 0; --sp)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) R.a[sp][s] = *(const bf16x8*)(gb + (sp * 4 + s) * 1024);
+    };
+    const bf16x8 ones8 = __builtin_bit_cast(bf16x8, u32x4w{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+    auto mma_all = [&](const TileRegs& R, int u) __attribute__((always_inline)) -> f32x16 {
+        f32x16 a = mfma_bf16(R.bias, ones8, zero16());
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[2][s], hb[u][0][s], a);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[0][s], hb[u][2][s], a);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[1][s], hb[u][1][s], a);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[1][s], hb[u][0][s], a);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[0][s], hb[u][1][s], a);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[0][s], hb[u][0][s], a);
+        return a;
+    };
+    // ---- OFF section: the partial sum of the current k stays in a register per set and goes to x_out when the k ends
+    float cur_part[NS];
+    const char* ep_h[NS];
+    float* xrow[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        cur_part[u] = 0.f;
+        ep_h[u] = (const char*)(eps_lds + (32 * u + p) * DS + 4 * half);
+        xrow[u] = x_out + (iu[u] < dm.nb ? iu[u] : dm.nb - 1) * D;
+    }
+    struct EpiOps { float4 e4[NS][4]; };
+    auto epi_read = [&](EpiOps& E, const uint4& c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            E.e4[u][0] = *(const float4*)(ep_h[u] + (c.x & 0xFFFu));
+            E.e4[u][1] = *(const float4*)(ep_h[u] + (c.y & 0xFFFu));
+            E.e4[u][2] = *(const float4*)(ep_h[u] + (c.z & 0xFFFu));
+            E.e4[u][3] = *(const float4*)(ep_h[u] + (c.w & 0xFFFu));
+        }
+    };
+    auto epi_group = [&](const f32x16 (&a)[NS], const EpiOps& E, uint32_t code, int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const float4 e = E.e4[u][g];
+            cur_part[u] = fmaf(a[u][4 * g + 0], e.x, cur_part[u]);
+            cur_part[u] = fmaf(a[u][4 * g + 1], e.y, cur_part[u]);
+            cur_part[u] = fmaf(a[u][4 * g + 2], e.z, cur_part[u]);
+            cur_part[u] = fmaf(a[u][4 * g + 3], e.w, cur_part[u]);
+        }
+        if (__builtin_expect((int)code < 0, 0)) {                                 // wave-uniform, rare: the k ends here
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                const float tot = half_sum32(cur_part[u]);
+                if (half == 0 && iu[u] < dm.nb) *(float*)((char*)xrow[u] + ((code >> 12) & 0xFFFu)) = tot;
+                cur_part[u] = 0.f;
+            }
+        }
+    };
+
+    __syncthreads();                                           // the group table in LDS is complete
+    TileRegs RA, RB;
+    pull(RA, 0);
+    f32x16 accP[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) accP[u] = zero16();
+    uint4 codeP = make_uint4(0, 0, 0, 0);
+    auto off_iter = [&](TileRegs& Rc, TileRegs& Rn, int t, auto firstc) __attribute__((always_inline)) {
+        constexpr bool first = decltype(firstc)::value;
+        EpiOps E;
+        if constexpr (!first) epi_read(E, codeP);
+        pull(Rn, t + 1);
+        // two chains per tile (one per person set) on the same fragments; the epilogue of the previous tile between the
+        // product groups
+        f32x16 a[NS];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) a[u] = mfma_bf16(Rc.bias, ones8, zero16());
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int u = 0; u < NS; ++u) a[u] = mfma_bf16(Rc.a[2][s], hb[u][0][s], a[u]);
+        if constexpr (!first) epi_group(accP, E, codeP.x, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int u = 0; u < NS; ++u) a[u] = mfma_bf16(Rc.a[1][s], hb[u][1][s], a[u]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int u = 0; u < NS; ++u) a[u] = mfma_bf16(Rc.a[0][s], hb[u][2][s], a[u]);
+        if constexpr (!first) epi_group(accP, E, codeP.y, 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int u = 0; u < NS; ++u) a[u] = mfma_bf16(Rc.a[1][s], hb[u][0][s], a[u]);
+        if constexpr (!first) epi_group(accP, E, codeP.z, 2);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int u = 0; u < NS; ++u) a[u] = mfma_bf16(Rc.a[0][s], hb[u][1][s], a[u]);
+        if constexpr (!first) epi_group(accP, E, codeP.w, 3);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int u = 0; u < NS; ++u) a[u] = mfma_bf16(Rc.a[0][s], hb[u][0][s], a[u]);
+#pragma unroll
+        for (int u = 0; u < NS; ++u) accP[u] = a[u];
+        const uint4 cv = *(const uint4*)(gt_lds + 4 * t);
+        codeP.x = __builtin_amdgcn_readfirstlane(cv.x); codeP.y = __builtin_amdgcn_readfirstlane(cv.y);
+        codeP.z = __builtin_amdgcn_readfirstlane(cv.z); codeP.w = __builtin_amdgcn_readfirstlane(cv.w);
+    };
+    off_iter(RA, RB, 0, std::true_type{});
+    off_iter(RB, RA, 1, std::false_type{});
+    for (int t = 2; t < n_off; t += 2) {
+        off_iter(RA, RB, t, std::false_type{});
+        off_iter(RB, RA, t + 1, std::false_type{});
+    }
+    {
+        EpiOps E;
+        epi_read(E, codeP);
+        epi_group(accP, E, codeP.x, 0);
+        epi_group(accP, E, codeP.y, 1);
+        epi_group(accP, E, codeP.z, 2);
+        epi_group(accP, E, codeP.w, 3);
+    }
+    vx_wait_vmem();                                            // the OFF sums of this wave have reached memory: the sections read them back
+    // ---- sections: DIAG and LOC tile of each 32-row block together: x = x_off + exp(M_kk) eps_k + loc_k
+    float ent_acc[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) ent_acc[u] = 0.f;
+    for (int kb = 0; kb < n_sec; ++kb) {
+        const int k0 = 32 * kb;
+        if (k0 >= D) break;                                    // padding blocks of the sections
+        pull(RA, n_off + kb);
+        pull(RB, n_off + n_sec + kb);
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const bool live = iu[u] < dm.nb;
+            const float* er = eps_lds + (32 * u + p) * DS;
+            f32x4 xo[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int kk = k0 + 8 * g + 4 * half;
+                xo[g] = (kk < D) ? *(const f32x4*)(xrow[u] + kk) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (k0 == 0 && half == 0) xo[0][0] = 0.f;          // k = 0 has no OFF rows: nothing was stored there
+            const f32x16 aD = mma_all(RA, u), aL = mma_all(RB, u);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int kk = k0 + 8 * g + 4 * half;
+                if (kk < D) {
+                    const f32x4 ev = *(const f32x4*)(er + kk);
+                    f32x4 xn;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float ld = __expf(aD[4 * g + j]);   // exp(diag M) eps_k, entropy, ldT  (vi.py:686)
+                        xn[j] = fmaf(ld, ev[j], xo[g][j]) + aL[4 * g + j];
+                        ent_acc[u] += aD[4 * g + j];
+                        if (live) ldT[(int64_t)(kk + j) * dm.nb + iu[u]] = ld;
+                    }
+                    if (live) *(f32x4*)(xrow[u] + kk) = xn;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        ent_acc[u] += __shfl_xor(ent_acc[u], 32, 64);
+        if (half == 0 && iu[u] < dm.nb) ent_out[iu[u]] = 0.5f * eps2[u] + ent_acc[u];   // -log q + const = 0.5|eps|^2 + sum_k M_kk
+    }
+    // ---------------------------------------------------------------- the likelihood kernel's operand image of x
+    if (ximg_out && i0 < (dm.nb + 63) / 64 * 64) {
+        vx_wait_vmem();                                        // x of this wave is complete in memory
+        __builtin_amdgcn_wave_barrier();
+        // x_aug = [x, 1, 0..] as three bf16 terms in the LDS tile order of k_irt_lik_b (lb_xoff): the wave's 64 persons are
+        // one whole tile; absent persons: all-zero rows
+        const int pvi = (int)((dm.nb - i0) < FB2_WP ? (dm.nb - i0) : FB2_WP);
+        uint8_t* out = ximg_out + (i0 >> 6) * LB_XT_BYTES;
+        for (int e = lane; e < FB2_WP * 2 * LB_NKS; e += 64) {
+            // per 32 persons: 32 consecutive lanes fill one 512-byte subtile (8 persons x 4 chunks), then the 256-byte half
+            // subtiles (8 persons x 2 chunks)
+            const int hs2 = e / (32 * 2 * LB_NKS), e2 = e - hs2 * (32 * 2 * LB_NKS);
+            int pp, ch;
+            if (e2 < 4 * 3 * 32) {
+                const int blk = e2 >> 5, r = e2 & 31;
+                pp = 8 * (blk / 3) + (r >> 2);
+                ch = 4 * (blk % 3) + (r & 3);
+            } else {
+                const int r = e2 - 4 * 3 * 32;
+                pp = 8 * (r >> 4) + ((r >> 1) & 7);
+                ch = 12 + (r & 1);
+            }
+            pp += 32 * hs2;
+            float v[8];
+            const float* xr = x_out + (i0 + (pp < pvi ? pp : 0)) * D;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 8 * ch + j;
+                v[j] = (pp < pvi) ? (k < D ? xr[k] : (k == D ? 1.0f : 0.f)) : 0.f;
+            }
+            bf16x8 fh, fm, fl;
+            split3_frag(v, fh, fm, fl);
+            const uint32_t o = lb_xoff(pp, ch);
+            *(bf16x8*)(out + o) = fh;
+            *(bf16x8*)(out + LB_PLANE + o) = fm;
+            *(bf16x8*)(out + 2 * LB_PLANE + o) = fl;
+        }
+    }
+}

@@ -19,6 +19,7 @@
 #include "k_mvn_bwd_t.hip"
 #include "k_mvn_bwd_b.hip"
 #include "k_mvn_fwd_b.hip"
+#include "k_mvn_fwd_b2.hip"
 #include "k_mvn_bwd_hb.hip"
 #include "k_fc1_bwd_b.hip"
 #include "k_cdm_sf.hip"
@@ -360,12 +361,33 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
                 VX_CHECK_LAUNCH();
                 return VX_OK;
             }
+            int64_t n_done = 0;                                     // persons taken by the 64-per-wave kernel
+            if (fb2_lds_bytes(dm.D, dm.J) <= 160 * 1024) {
+                // large batch: 64 persons per wave, every head-tile fragment feeds two MFMA chains (k_mvn_fwd_b2.hip).  Its
+                // workgroups take 256 persons: a last round that fills less than half the chip goes to the 128-person
+                // kernel instead (1M persons: 15 full rounds + 16 960 persons)
+                const int64_t round2 = (int64_t)FB2_WAVES * FB2_WP * num_cu();
+                const int64_t rem = nb % round2;
+                n_done = (rem > 0 && 2 * rem <= round2) ? nb - rem : nb;
+            }
+            if (n_done > 0) {
+                const size_t lds2 = fb2_lds_bytes(dm.D, dm.J);
+                rc = set_lds(k_mvn_enc_fwd_b2, lds2);
+                if (rc) return rc;
+                EncDims dm2 = dm;
+                hipLaunchKernelGGL(k_mvn_enc_fwd_b2, dim3((unsigned)((n_done + FB2_WAVES * FB2_WP - 1) / (FB2_WAVES * FB2_WP))),
+                                   dim3(FB2_THREADS), lds2, (hipStream_t)hs, dm2, y, rows, gid0, (const uint8_t*)w1img, b1,
+                                   (const uint8_t*)img, (const uint32_t*)gt2, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps,
+                                   ldT, ent, hT, epsT, ximg, hs_out);      // the grid stops at n_done
+                VX_CHECK_LAUNCH();
+                if (n_done == nb) return VX_OK;
+            }
             rc = set_lds(k_mvn_enc_fwd_b<false>, ldsb);
             if (rc) return rc;
-            const dim3 gridb((unsigned)((nb + FB_WAVES * FB_WP - 1) / (FB_WAVES * FB_WP)));
+            const dim3 gridb((unsigned)((nb - n_done + FB_WAVES * FB_WP - 1) / (FB_WAVES * FB_WP)));
             hipLaunchKernelGGL(k_mvn_enc_fwd_b<false>, gridb, dim3(FB_THREADS), ldsb, (hipStream_t)hs, dm, y, rows, gid0,
                                (const uint8_t*)w1img, b1, (const uint8_t*)img, (const uint32_t*)gt2, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT,
-                               ximg, hs_out);
+                               ximg, hs_out, n_done);
             VX_CHECK_LAUNCH();
             return VX_OK;
         }
