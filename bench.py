@@ -57,6 +57,7 @@ def kernel_model(name, J, D, H):
     heads = 2.0 * (H * D + H * T)
     table = {
         "k_mvn_enc_fwd_b": (enc_fwd_flops_per_person(J, D, H), PEAK_BF16X3_TFLOPS, "f32 via bf16x3 on the bf16 MFMA"),
+        "k_mvn_enc_fwd_b2": (enc_fwd_flops_per_person(J, D, H), PEAK_BF16X3_TFLOPS, "f32 via bf16x3 on the bf16 MFMA"),
         "k_mvn_enc_fwd_p": (enc_fwd_flops_per_person(J, D, H), PEAK_F32_MFMA_TFLOPS, "f32 MFMA"),
         "k_mvn_enc_bwd_h_t": (heads, PEAK_F32_MFMA_TFLOPS, "f32 MFMA"),
         "k_mvn_enc_bwd_h_b": (heads, PEAK_BF16X5_TFLOPS, "f32 via bf16 terms (3 x 2, five products) on the bf16 MFMA"),
@@ -80,7 +81,7 @@ def measured_traffic(kernel_prefix):
     except (OSError, ValueError, KeyError):
         return None
     for name, v in kernels.items():
-        if name.startswith(kernel_prefix):
+        if name.split("<")[0].split("(")[0] == kernel_prefix:          # template arguments are part of the traced name
             return float(v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"])
     return None
 
@@ -255,12 +256,15 @@ def main():
             lrs.scheduler_step()
         sync()
     eng.events = None
-    kernel_ms = {}
+    kernel_ms, kernel_units = {}, {}
     import ctypes
     for slot in range(_hip.lib().vx_prof_count()):
         nm, ms, cnt = ctypes.create_string_buffer(64), ctypes.c_float(0), ctypes.c_int(0)
         if _hip.lib().vx_prof_read(slot, nm, 64, ctypes.byref(ms), ctypes.byref(cnt)) == 0 and cnt.value:
             kernel_ms[nm.value.decode()] = float(ms.value)
+            un = ctypes.c_int64(0)                             # persons of a launch that takes only part of the batch
+            if _hip.lib().vx_prof_units(slot, ctypes.byref(un)) == 0 and un.value:
+                kernel_units[nm.value.decode()] = int(un.value)
     _hip.lib().vx_prof_enable(0)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
     if world > 1:
@@ -298,7 +302,7 @@ def main():
             # by the library on the launch stream, vx_prof_*); achieved = algorithmic flops per launch / that duration
             name = max(priced, key=priced.get)
             fl_pp, peak, arith = kernel_model(name, J, D, H)
-            fl = fl_pp * n_local
+            fl = fl_pp * kernel_units.get(name, n_local)
             ach = fl / (priced[name] * 1e-3) / 1e12
             headline = args.workload == "irt2pl_100d_amortized_1Mx500" and world == 1 and not args.persons
             traffic = measured_traffic(name) if headline else None
@@ -313,7 +317,8 @@ def main():
                                              if peak == PEAK_BF16X5_TFLOPS else
                                              "dense bf16 MFMA peak 2500 / (16 / 3) products per f32 product"
                                              if peak == PEAK_BF16_MFMA_TFLOPS * 3.0 / 16.0 else "dense f32 MFMA peak",
-                               "algorithmic_flops_per_launch": fl, "avg_launch_ms": priced[name]}
+                               "algorithmic_flops_per_launch": fl, "avg_launch_ms": priced[name],
+                               "persons_per_launch": kernel_units.get(name, n_local)}
         elif "hodina" in phase_ms:
             # SURVEY.md section 8d, cfg 5: (2 K + J) C MACs forward, ~3x with the backward = compute-bound.  The pattern
             # contractions run on the bf16 MFMA with one operand exact (0/1) and the other split into bf16 terms (three

@@ -63,6 +63,9 @@ const char* vx_build_info(void);
 int vx_prof_enable(int on);
 int vx_prof_count(void);
 int vx_prof_read(int slot, char* name, int name_cap, float* mean_ms, int* launches);
+/* persons the last launch of that kernel took when the batch is divided between two kernels (the amortized forward gives
+ * whole chip rounds to k_mvn_enc_fwd_b2 and a short last round to k_mvn_enc_fwd_b); 0 = the whole batch */
+int vx_prof_units(int slot, int64_t* units);
 
 /* ---- RNG: eps[i, d] = N(0,1) keyed by the GLOBAL person id (Philox4x32-10 + Box-Muller).
  * gids == NULL means gid = gid0 + i.  Also used by tests to hand the oracle identical eps. */

@@ -50,6 +50,7 @@ SIGNATURES = {
     "vx_prof_count": (ctypes.c_int, []),
     "vx_prof_read": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                     ctypes.POINTER(ctypes.c_int)]),
+    "vx_prof_units": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]),
     "vx_philox_normals": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _U64, _U32, _U32, _P]),
     "vx_philox_raw": (ctypes.c_int, [_P, _I64, _I64, _U64, _U32, _U32, _P]),
     "vx_mvn_enc_forward": (ctypes.c_int, [_CFG, _P, _P, _I64, _I64] + [_P] * 6 + [_P] + [_P] * 5 + [_P, _P] + [_P, _P, _P, _P]),

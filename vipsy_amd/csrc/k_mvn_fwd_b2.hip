@@ -7,7 +7,10 @@
 // the wave), so loads, table reads and k-end branches are spent once per 50 MFMAs; fc1 shares its W1 fragments the same
 // way.  Two person sets do not fit the LDS with an x tile each (832 B a person), so x is not kept in LDS at all: the OFF
 // rows' sums go to global memory as each k ends (write only), and the DIAG / LOC tiles of a 32-row block are taken
-// TOGETHER at the end: x = x_off (read back once) + exp(M_kk) eps_k + loc_k.
+// TOGETHER at the end: x = x_off (read back once) + exp(M_kk) eps_k + loc_k.  The staging area is the wave's own
+// 64 x D region of eps_out, used as [D][64] so that a k-end is one full 128-byte line per person set (4-byte stores
+// into the x rows left partly written lines to the L2: +1.4 GB of HBM writes a step); eps_out itself is written last,
+// from the LDS tile.  A wave with fewer than 64 persons stages in its x rows instead.
 // (included by vx_abi.hip after k_mvn_fwd_b.hip, whose images, tables and helpers it uses)
 
 #define FB2_THREADS 256
@@ -192,8 +195,7 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
             const int64_t row = rows ? rows[ii] : ii;
             z = philox_normal4(seed, step, stream, gid0 + row, (uint32_t)blk);
         }
-        *(f32x4*)(eps_lds + pp * DS + 4 * blk) = z;
-        if (live) *(f32x4*)(eps_out + ii * D + 4 * blk) = z;
+        *(f32x4*)(eps_lds + pp * DS + 4 * blk) = z;             // (eps_out is written at the end: its region stages x first)
     }
     __builtin_amdgcn_wave_barrier();
     float eps2[NS];
@@ -240,11 +242,15 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
     float cur_part[NS];
     const char* ep_h[NS];
     float* xrow[NS];
+    float* xst[NS];                                           // staging of the OFF sums: element k at xst + (k << st_sh)
+    const bool whole = i0 + FB2_WP <= dm.nb;                  // wave-uniform
+    const int st_sh = whole ? 6 : 0;
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
         cur_part[u] = 0.f;
         ep_h[u] = (const char*)(eps_lds + (32 * u + p) * DS + 4 * half);
         xrow[u] = x_out + (iu[u] < dm.nb ? iu[u] : dm.nb - 1) * D;
+        xst[u] = whole ? eps_out + i0 * D + 32 * u + p : xrow[u];
     }
     struct EpiOps { float4 e4[NS][4]; };
     auto epi_read = [&](EpiOps& E, const uint4& c) __attribute__((always_inline)) {
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
 #pragma unroll
             for (int u = 0; u < NS; ++u) {
                 const float tot = half_sum32(cur_part[u]);
-                if (half == 0 && iu[u] < dm.nb) *(float*)((char*)xrow[u] + ((code >> 12) & 0xFFFu)) = tot;
+                if (half == 0 && iu[u] < dm.nb) *(float*)((char*)xst[u] + (((code >> 12) & 0xFFFu) << st_sh)) = tot;
                 cur_part[u] = 0.f;
             }
         }
@@ -358,7 +364,8 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int kk = k0 + 8 * g + 4 * half;
-                xo[g] = (kk < D) ? *(const f32x4*)(xrow[u] + kk) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xo[g][j] = (kk < D) ? xst[u][(int64_t)(kk + j) << st_sh] : 0.f;
             }
             if (k0 == 0 && half == 0) xo[0][0] = 0.f;          // k = 0 has no OFF rows: nothing was stored there
             const f32x16 aD = mma_all(RA, u), aL = mma_all(RB, u);
@@ -379,6 +386,11 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
                 }
             }
         }
+    }
+    vx_wait_vmem();                                            // every staged sum has been read: the eps_out region is free
+    for (int e = lane; e < FB2_WP * nblk; e += 64) {
+        const int pp = e / nblk, blk = e - pp * nblk;
+        if (i0 + pp < dm.nb) *(f32x4*)(eps_out + (i0 + pp) * D + 4 * blk) = *(const f32x4*)(eps_lds + pp * DS + 4 * blk);
     }
 #pragma unroll
     for (int u = 0; u < NS; ++u) {

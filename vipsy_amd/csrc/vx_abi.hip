@@ -122,7 +122,7 @@ bool enc_cfg_ok(const vx_irt_cfg* cfg) {
 // ---- measurement aid (vx_prof_enable / vx_prof_read): HIP events on the launch stream around the large kernels, so
 // that bench.py can price the dominant kernel against its roofline from inside the timed steps.  Off by default: the
 // entry points then record nothing.
-struct ProfSlot { const char* name; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
+struct ProfSlot { const char* name; int64_t units; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
 bool g_prof = false;
 ProfSlot g_prof_slots[8];
 int g_prof_n = 0;
@@ -130,7 +130,8 @@ struct ProfScope {
     hipEvent_t a = nullptr, b = nullptr;
     hipStream_t st;
     const char* name;
-    ProfScope(const char* nm, hipStream_t s) : st(s), name(nm) {
+    int64_t units;                                                    // persons of this launch when it is not the whole batch (else 0)
+    ProfScope(const char* nm, hipStream_t s, int64_t u = 0) : st(s), name(nm), units(u) {
         if (!g_prof) return;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = nullptr; return; }
         (void)hipEventRecord(a, st);
@@ -139,8 +140,11 @@ struct ProfScope {
         if (!a) return;
         (void)hipEventRecord(b, st);
         for (int i = 0; i < g_prof_n; ++i)
-            if (!strcmp(g_prof_slots[i].name, name)) { g_prof_slots[i].ev.emplace_back(a, b); return; }
-        if (g_prof_n < 8) { g_prof_slots[g_prof_n].name = name; g_prof_slots[g_prof_n].ev.emplace_back(a, b); ++g_prof_n; return; }
+            if (!strcmp(g_prof_slots[i].name, name)) { g_prof_slots[i].units = units; g_prof_slots[i].ev.emplace_back(a, b); return; }
+        if (g_prof_n < 8) {
+            g_prof_slots[g_prof_n].name = name; g_prof_slots[g_prof_n].units = units;
+            g_prof_slots[g_prof_n].ev.emplace_back(a, b); ++g_prof_n; return;
+        }
         (void)hipEventDestroy(a); (void)hipEventDestroy(b);           // more than eight kernel names: not recorded, not leaked
     }
 };
@@ -178,6 +182,12 @@ int vx_prof_read(int slot, char* name, int name_cap, float* mean_ms, int* launch
     }
     *launches = (int)s.ev.size();
     *mean_ms = s.ev.empty() ? 0.f : (float)(tot / s.ev.size());
+    return VX_OK;
+}
+
+int vx_prof_units(int slot, int64_t* units) {
+    if (slot < 0 || slot >= g_prof_n || !units) return VX_EINVAL;
+    *units = g_prof_slots[slot].units;
     return VX_OK;
 }
 
@@ -346,11 +356,11 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
                                pk_off_total(dm.D) / 8, Wp, bp, gtab, img, gt2);
             VX_CHECK_LAUNCH();
             const size_t ldsb = fb_lds_bytes(dm.D, dm.J);
-            ProfScope ps("k_mvn_enc_fwd_b", (hipStream_t)hs);
             ximg_after.done = true;
             hs_after.done = true;
             if (nb <= FB_SPLIT_MAX) {
                 // small batch: one 32-person tile per workgroup, its four waves share the head tiles
+                ProfScope ps("k_mvn_enc_fwd_b", (hipStream_t)hs);
                 rc = set_lds(k_mvn_enc_fwd_b<true>, ldsb);
                 if (rc) return rc;
                 // (with an x image: whole 64-person tiles, the absent half gets its zero rows)
@@ -374,9 +384,9 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
                 const size_t lds2 = fb2_lds_bytes(dm.D, dm.J);
                 rc = set_lds(k_mvn_enc_fwd_b2, lds2);
                 if (rc) return rc;
-                EncDims dm2 = dm;
+                ProfScope ps("k_mvn_enc_fwd_b2", (hipStream_t)hs, n_done);
                 hipLaunchKernelGGL(k_mvn_enc_fwd_b2, dim3((unsigned)((n_done + FB2_WAVES * FB2_WP - 1) / (FB2_WAVES * FB2_WP))),
-                                   dim3(FB2_THREADS), lds2, (hipStream_t)hs, dm2, y, rows, gid0, (const uint8_t*)w1img, b1,
+                                   dim3(FB2_THREADS), lds2, (hipStream_t)hs, dm, y, rows, gid0, (const uint8_t*)w1img, b1,
                                    (const uint8_t*)img, (const uint32_t*)gt2, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps,
                                    ldT, ent, hT, epsT, ximg, hs_out);      // the grid stops at n_done
                 VX_CHECK_LAUNCH();
@@ -384,6 +394,7 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
             }
             rc = set_lds(k_mvn_enc_fwd_b<false>, ldsb);
             if (rc) return rc;
+            ProfScope ps("k_mvn_enc_fwd_b", (hipStream_t)hs, nb - n_done);
             const dim3 gridb((unsigned)((nb - n_done + FB_WAVES * FB_WP - 1) / (FB_WAVES * FB_WP)));
             hipLaunchKernelGGL(k_mvn_enc_fwd_b<false>, gridb, dim3(FB_THREADS), ldsb, (hipStream_t)hs, dm, y, rows, gid0,
                                (const uint8_t*)w1img, b1, (const uint8_t*)img, (const uint32_t*)gt2, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT,
