@@ -54,6 +54,15 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
     // no early exit: every wave takes part in the barrier that publishes the group table; persons past the end compute on
     // clamped inputs and store nothing
 
+    // diagnostic build (make EXTRA=-DFB2_STAMPS): cycles per phase of two workgroups, printed at the end; in the shipped
+    // build no stamp executes
+#ifdef FB2_STAMPS
+    uint64_t st_[10]; int sn_ = 0;
+#define STAMP() do { __builtin_amdgcn_s_waitcnt(0); st_[sn_++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+    STAMP();
     const int n_off = pk_off_total(D) / 32;                   // even
     const int n_sec = pk_sec(D) / 32;
     const int t_end = n_off + 2 * n_sec;
@@ -84,6 +93,7 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
         }
     }
     __builtin_amdgcn_wave_barrier();
+    STAMP();                                                  // 1: y staged
     // ---------------------------------------------------------------- phase A: fc1 (+ softplus) of both person sets
     bf16x8 hb[NS][3][4];                                      // [set][split][k-step]: B fragments of every head tile
     {
@@ -116,16 +126,29 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
             }
         };
         {
-            bf16x8 A[4][6];
-            loadA(A[0], 0); loadA(A[1], 1); loadA(A[2], 2);
-            for (int c = 0; c < n_ks; c += 4) {
+            // W1 fragments five k-steps ahead (a k-step is ~500 cycles, an L2 round trip under load ~2 000)
+            constexpr int RG = 6;
+            bf16x8 A[RG][6];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    loadA(A[(u + 3) & 3], c + u + 3);
+            for (int u = 0; u < RG - 1; ++u) loadA(A[u], u);
+            for (int c = 0; c < n_ks; c += RG) {
+#pragma unroll
+                for (int u = 0; u < RG; ++u) {
+                    loadA(A[(u + RG - 1) % RG], c + u + RG - 1);
                     if (c + u < n_ks) compute(A[u], c + u);
                 }
             }
         }
+        STAMP();                                              // 2: fc1 MFMA loop
+        // Dimension-major outputs from the C layout are one 128-byte (hT) or 64-byte (hs) row piece per store instruction,
+        // 128 of them per person set, and the phase is bound by store issue.  A whole wave on 16-byte aligned rows
+        // transposes through the LDS region the response bytes have left instead: 16 bytes per lane, 20 instructions.
+        constexpr int ST_T = 36, ST_S = 40;                   // row strides of the stages: [64][36] f32 | [3 * 64][40] u16
+        const bool coal = i0 + FB2_WP <= dm.nb && (dm.nb & 7) == 0 && hT_out && hs_out &&
+                          (((uintptr_t)hT_out | (uintptr_t)hs_out) & 15) == 0 &&
+                          fb2_wave_floats(D, J) * sizeof(float) >= 64 * ST_T * 4 + 192 * ST_S * 2;   // wave-uniform
+        float* stT = R1;
+        uint16_t* stS = (uint16_t*)(R1 + 64 * ST_T);
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
             const int64_t i = iu[u];
@@ -146,13 +169,52 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
                     if (i < dm.nb) *(float4*)(h_out + i * H + hh0) = hv;
                 }
             }
-            if (hT_out && i < dm.nb) {
+            // the B fragments of every head tile: h = t0 + t1 + t2 exactly, each term the next 8 mantissa bits (truncation)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = hreg[s >> 1][8 * (s & 1) + j];
+                fb_split8(v, hb[u][0][s], hb[u][1][s], hb[u][2][s]);
+            }
+            if (coal) {
+                // (the hs planes take the fragments' terms: exact like the round-to-nearest terms of k_split3_bf16, and
+                // k_mvn_enc_bwd_w_b multiplies all three)
+                __builtin_amdgcn_wave_barrier();                  // (second set: the copies of the first have been read)
+#pragma unroll
+                for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) stT[(32 * ht + crow32(r, half)) * ST_T + p] = hreg[ht][r];
+#pragma unroll
+                for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const u32x4w w = __builtin_bit_cast(u32x4w, hb[u][t3][s]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int hh = 32 * (s >> 1) + crow32(8 * (s & 1) + j, half);
+                            stS[(64 * t3 + hh) * ST_S + p] = (uint16_t)((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xFFFFu));
+                        }
+                    }
+                __builtin_amdgcn_wave_barrier();
+                const int64_t c0 = i0 + 32 * u;
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {                  // hT: 64 rows x 8 pieces of 4 persons
+                    const int e = lane + 64 * it, hh = e >> 3, g = e & 7;
+                    *(f32x4*)(hT_out + (int64_t)hh * dm.nb + c0 + 4 * g) = *(const f32x4*)(stT + hh * ST_T + 4 * g);
+                }
+#pragma unroll
+                for (int it = 0; it < 12; ++it) {                 // hs: 3 x 64 rows x 4 pieces of 8 persons
+                    const int e = lane + 64 * it, row = e >> 2, g = e & 3;
+                    *(u32x4w*)(hs_out + (int64_t)row * dm.nb + c0 + 8 * g) = *(const u32x4w*)(stS + row * ST_S + 8 * g);
+                }
+            } else if (hT_out && i < dm.nb) {
 #pragma unroll
                 for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) hT_out[(int64_t)(32 * ht + crow32(r, half)) * dm.nb + i] = hreg[ht][r];
             }
-            if (hs_out && i < dm.nb) {                            // the three bf16 terms of hT (round to nearest, as k_split3_bf16)
+            if (!coal && hs_out && i < dm.nb) {                   // the three bf16 terms of hT (round to nearest, as k_split3_bf16)
                 const int64_t plane = (int64_t)64 * dm.nb;
 #pragma unroll
                 for (int ht = 0; ht < 2; ++ht)
@@ -169,20 +231,16 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
                         hs_out[2 * plane + o] = __builtin_bit_cast(uint16_t, t2);
                     }
             }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = hreg[s >> 1][8 * (s & 1) + j];
-                fb_split8(v, hb[u][0][s], hb[u][1][s], hb[u][2][s]);
-            }
         }
     }
+    STAMP();                                                  // 3: softplus, h outputs, fragments
     __builtin_amdgcn_wave_barrier();                          // response bytes no longer needed
     // ---------------------------------------------------------------- eps of the 64 persons (zero padded to DS) -> LDS, global
     const int nblk = D >> 2;                                  // D % 4 == 0 on this path
-    for (int e = lane; e < FB2_WP * DS; e += 64) R1[e] = 0.f;
+    for (int e = lane; e < FB2_WP * DS / 4; e += 64) *(f32x4*)(R1 + 4 * e) = f32x4{0.f, 0.f, 0.f, 0.f};   // DS % 4 == 0
     __builtin_amdgcn_wave_barrier();
+    // (unrolled: one Philox call is a dependent chain of ~60 instructions, and this wave is alone on its SIMD)
+#pragma unroll 5
     for (int e = lane; e < FB2_WP * nblk; e += 64) {
         const int pp = e / nblk, blk = e - pp * nblk;
         int64_t ii = i0 + pp;
@@ -198,11 +256,21 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
         *(f32x4*)(eps_lds + pp * DS + 4 * blk) = z;             // (eps_out is written at the end: its region stages x first)
     }
     __builtin_amdgcn_wave_barrier();
+    // dimension-major copy of eps: a whole wave writes 16 bytes (4 persons of one k) per lane, D / 4 store instructions
+    // instead of D
+    const bool coalE = i0 + FB2_WP <= dm.nb && (dm.nb & 3) == 0 && epsT_out && ((uintptr_t)epsT_out & 15) == 0;
+    if (coalE) {
+        for (int e = lane; e < D * 16; e += 64) {
+            const int k = e >> 4, g = e & 15;
+            const float* ec = eps_lds + 4 * g * DS + k;
+            *(f32x4*)(epsT_out + (int64_t)k * dm.nb + i0 + 4 * g) = f32x4{ec[0], ec[DS], ec[2 * DS], ec[3 * DS]};
+        }
+    }
     float eps2[NS];
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
         const float* er = eps_lds + (32 * u + p) * DS;
-        if (epsT_out && iu[u] < dm.nb) {
+        if (!coalE && epsT_out && iu[u] < dm.nb) {
 #pragma unroll 4
             for (int k = half; k < D; k += 2) epsT_out[(int64_t)k * dm.nb + iu[u]] = er[k];
         }
@@ -210,6 +278,7 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
         for (int k = 0; k < D; ++k) s2 = fmaf(er[k], er[k], s2);
         eps2[u] = s2;
     }
+    STAMP();                                                  // 3: eps
     // ---------------------------------------------------------------- phase B: packed head rows, 32 per tile
     struct TileRegs { bf16x8 a[3][4]; bf16x8 bias; };
     auto pull = [&](TileRegs& R, int t) __attribute__((always_inline)) {
@@ -347,28 +416,40 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
         epi_group(accP, E, codeP.w, 3);
     }
     vx_wait_vmem();                                            // the OFF sums of this wave have reached memory: the sections read them back
+    STAMP();                                                  // 4: OFF loop
     // ---- sections: DIAG and LOC tile of each 32-row block together: x = x_off + exp(M_kk) eps_k + loc_k
     float ent_acc[NS];
 #pragma unroll
     for (int u = 0; u < NS; ++u) ent_acc[u] = 0.f;
+    // the tiles of block kb + 1 are requested as soon as the MFMAs of block kb have read theirs (tile indices past the end are
+    // clamped by pull: a harmless extra load)
+    pull(RA, n_off);
+    pull(RB, n_off + n_sec);
     for (int kb = 0; kb < n_sec; ++kb) {
         const int k0 = 32 * kb;
         if (k0 >= D) break;                                    // padding blocks of the sections
-        pull(RA, n_off + kb);
-        pull(RB, n_off + n_sec + kb);
+        f32x4 xo[NS][4];
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
-            const bool live = iu[u] < dm.nb;
-            const float* er = eps_lds + (32 * u + p) * DS;
-            f32x4 xo[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int kk = k0 + 8 * g + 4 * half;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xo[g][j] = (kk < D) ? xst[u][(int64_t)(kk + j) << st_sh] : 0.f;
+                for (int j = 0; j < 4; ++j) xo[u][g][j] = (kk < D) ? xst[u][(int64_t)(kk + j) << st_sh] : 0.f;
             }
-            if (k0 == 0 && half == 0) xo[0][0] = 0.f;          // k = 0 has no OFF rows: nothing was stored there
-            const f32x16 aD = mma_all(RA, u), aL = mma_all(RB, u);
+            if (k0 == 0 && half == 0) xo[u][0][0] = 0.f;       // k = 0 has no OFF rows: nothing was stored there
+        }
+        f32x16 aD[NS], aL[NS];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) aD[u] = mma_all(RA, u);
+        pull(RA, n_off + kb + 1);
+#pragma unroll
+        for (int u = 0; u < NS; ++u) aL[u] = mma_all(RB, u);
+        pull(RB, n_off + n_sec + kb + 1);
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const bool live = iu[u] < dm.nb;
+            const float* er = eps_lds + (32 * u + p) * DS;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int kk = k0 + 8 * g + 4 * half;
@@ -377,9 +458,9 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
                     f32x4 xn;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float ld = __expf(aD[4 * g + j]);   // exp(diag M) eps_k, entropy, ldT  (vi.py:686)
-                        xn[j] = fmaf(ld, ev[j], xo[g][j]) + aL[4 * g + j];
-                        ent_acc[u] += aD[4 * g + j];
+                        const float ld = __expf(aD[u][4 * g + j]);   // exp(diag M) eps_k, entropy, ldT  (vi.py:686)
+                        xn[j] = fmaf(ld, ev[j], xo[u][g][j]) + aL[u][4 * g + j];
+                        ent_acc[u] += aD[u][4 * g + j];
                         if (live) ldT[(int64_t)(kk + j) * dm.nb + iu[u]] = ld;
                     }
                     if (live) *(f32x4*)(xrow[u] + kk) = xn;
@@ -397,6 +478,7 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
         ent_acc[u] += __shfl_xor(ent_acc[u], 32, 64);
         if (half == 0 && iu[u] < dm.nb) ent_out[iu[u]] = 0.5f * eps2[u] + ent_acc[u];   // -log q + const = 0.5|eps|^2 + sum_k M_kk
     }
+    STAMP();                                                  // 5: sections + eps_out
     // ---------------------------------------------------------------- the likelihood kernel's operand image of x
     if (ximg_out && i0 < (dm.nb + 63) / 64 * 64) {
         vx_wait_vmem();                                        // x of this wave is complete in memory
@@ -405,34 +487,61 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
         // one whole tile; absent persons: all-zero rows
         const int pvi = (int)((dm.nb - i0) < FB2_WP ? (dm.nb - i0) : FB2_WP);
         uint8_t* out = ximg_out + (i0 >> 6) * LB_XT_BYTES;
-        for (int e = lane; e < FB2_WP * 2 * LB_NKS; e += 64) {
-            // per 32 persons: 32 consecutive lanes fill one 512-byte subtile (8 persons x 4 chunks), then the 256-byte half
-            // subtiles (8 persons x 2 chunks)
-            const int hs2 = e / (32 * 2 * LB_NKS), e2 = e - hs2 * (32 * 2 * LB_NKS);
-            int pp, ch;
-            if (e2 < 4 * 3 * 32) {
-                const int blk = e2 >> 5, r = e2 & 31;
-                pp = 8 * (blk / 3) + (r >> 2);
-                ch = 4 * (blk % 3) + (r & 3);
-            } else {
-                const int r = e2 - 4 * 3 * 32;
-                pp = 8 * (r >> 4) + ((r >> 1) & 7);
-                ch = 12 + (r & 1);
-            }
-            pp += 32 * hs2;
-            float v[8];
-            const float* xr = x_out + (i0 + (pp < pvi ? pp : 0)) * D;
+        // seven work items per lane in flight (loads of all, then splits and stores): one at a time is a chain of L2
+        // latencies
+        constexpr int XU = 7;
+        static_assert((FB2_WP * 2 * LB_NKS) % (64 * XU) == 0, "x image work items");
+        for (int e0 = lane; e0 < FB2_WP * 2 * LB_NKS; e0 += 64 * XU) {
+            f32x4 q[XU][2];
+            uint32_t off[XU];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = 8 * ch + j;
-                v[j] = (pp < pvi) ? (k < D ? xr[k] : (k == D ? 1.0f : 0.f)) : 0.f;
+            for (int w = 0; w < XU; ++w) {
+                // per 32 persons: 32 consecutive lanes fill one 512-byte subtile (8 persons x 4 chunks), then the 256-byte half
+                // subtiles (8 persons x 2 chunks)
+                const int e = e0 + 64 * w;
+                const int hs2 = e / (32 * 2 * LB_NKS), e2 = e - hs2 * (32 * 2 * LB_NKS);
+                int pp, ch;
+                if (e2 < 4 * 3 * 32) {
+                    const int blk = e2 >> 5, r = e2 & 31;
+                    pp = 8 * (blk / 3) + (r >> 2);
+                    ch = 4 * (blk % 3) + (r & 3);
+                } else {
+                    const int r = e2 - 4 * 3 * 32;
+                    pp = 8 * (r >> 4) + ((r >> 1) & 7);
+                    ch = 12 + (r & 1);
+                }
+                pp += 32 * hs2;
+                off[w] = lb_xoff(pp, ch);
+                const float* xr = x_out + (i0 + (pp < pvi ? pp : 0)) * D;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {               // D % 4 == 0: a quad is inside the row, or at k == D, or past it
+                    const int k0 = 8 * ch + 4 * h2;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (pp < pvi) {
+                        if (k0 < D) v = *(const f32x4*)(xr + k0);
+                        else if (k0 == D) v[0] = 1.0f;
+                    }
+                    q[w][h2] = v;
+                }
             }
-            bf16x8 fh, fm, fl;
-            split3_frag(v, fh, fm, fl);
-            const uint32_t o = lb_xoff(pp, ch);
-            *(bf16x8*)(out + o) = fh;
-            *(bf16x8*)(out + LB_PLANE + o) = fm;
-            *(bf16x8*)(out + 2 * LB_PLANE + o) = fl;
+#pragma unroll
+            for (int w = 0; w < XU; ++w) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = q[w][j >> 2][j & 3];
+                bf16x8 fh, fm, fl;
+                split3_frag(v, fh, fm, fl);
+                *(bf16x8*)(out + off[w]) = fh;
+                *(bf16x8*)(out + LB_PLANE + off[w]) = fm;
+                *(bf16x8*)(out + 2 * LB_PLANE + off[w]) = fl;
+            }
         }
     }
+#ifdef FB2_STAMPS
+    STAMP();                                                  // 6: x image
+    if ((blockIdx.x == 100 || blockIdx.x == 2000) && lane == 0 && (wave == 0 || wave == 3))
+        printf("STAMPS blk %d wave %d: y %llu fc1 %llu hout %llu eps %llu off %llu sec %llu ximg %llu total %llu\n", (int)blockIdx.x, wave,
+               st_[1] - st_[0], st_[2] - st_[1], st_[3] - st_[2], st_[4] - st_[3], st_[5] - st_[4], st_[6] - st_[5], st_[7] - st_[6],
+               st_[7] - st_[0]);
+#endif
 }
