@@ -230,6 +230,32 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
         constexpr int p = decltype(pc)::value, nx = decltype(nc)::value;
         fq[nx][1][p] = pack_hi(pr_[2 * p + 1], pr_[2 * p]);
     };
+    // Third form of the split, six instructions per element pair instead of nine: head = v_cvt_pk_bf16_f32 (round to
+    // nearest, both elements at once), its two halves back as floats (shift / mask), the two exact remainders, and the
+    // remainders packed by the same conversion.  V = h + m to 2^-18 relative.
+    float th[2][2];                                                    // [pair parity][element]: the heads as floats
+    auto acvt = [](float x0, float x1) -> uint32_t {
+        uint32_t d; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(x0), "v"(x1)); return d; };
+    auto alsl16 = [](uint32_t x) -> float { float d; asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(d) : "v"(x)); return d; };
+    auto ahi16 = [](uint32_t x) -> float { float d; asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(d) : "v"(x)); return d; };
+    auto C1 = [&](auto pc, auto nc) __attribute__((always_inline)) {
+        constexpr int p = decltype(pc)::value, nx = decltype(nc)::value;
+        fq[nx][0][p] = acvt(pv_[2 * p], pv_[2 * p + 1]);
+    };
+    auto C2 = [&](auto pc, auto nc) __attribute__((always_inline)) {
+        constexpr int p = decltype(pc)::value, nx = decltype(nc)::value;
+        th[p & 1][0] = alsl16(fq[nx][0][p]);
+        th[p & 1][1] = ahi16(fq[nx][0][p]);
+    };
+    auto C3 = [&](auto pc) __attribute__((always_inline)) {
+        constexpr int p = decltype(pc)::value;
+        pr_[2 * p] = asub(pv_[2 * p], th[p & 1][0]);
+        pr_[2 * p + 1] = asub(pv_[2 * p + 1], th[p & 1][1]);
+    };
+    auto C4 = [&](auto pc, auto nc) __attribute__((always_inline)) {
+        constexpr int p = decltype(pc)::value, nx = decltype(nc)::value;
+        fq[nx][1][p] = acvt(pr_[2 * p], pr_[2 * p + 1]);
+    };
     auto frag = [&](auto cc, auto kc) -> bf16x8 {
         constexpr int cu = decltype(cc)::value, k = decltype(kc)::value;
         return __builtin_bit_cast(bf16x8, u32x4{fq[cu][k][0], fq[cu][k][1], fq[cu][k][2], fq[cu][k][3]});
@@ -276,29 +302,28 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
             __builtin_amdgcn_sched_barrier(0);
             acc[t][0] = mfma_bf16(vh, hf[c][2][0], acc[t][0]);
             __builtin_amdgcn_sched_barrier(0);
-            A1(I0); s0 = aadd(s0, s1); A2(I0, nxtc);
+            C1(I0, nxtc); C1(I1, nxtc); s0 = aadd(s0, s1); C2(I0, nxtc);
             __builtin_amdgcn_sched_barrier(0);
             acc[t][1] = mfma_bf16(vh, hf[c][2][1], acc[t][1]);
             __builtin_amdgcn_sched_barrier(0);
-            B1(I0); A1(I1); B2(I0, nxtc); A2(I1, nxtc);
+            C2(I1, nxtc); C3(I0); C1(I2, nxtc);
             __builtin_amdgcn_sched_barrier(0);
             acc[t][0] = mfma_bf16(vm, hf[c][0][0], acc[t][0]);
             __builtin_amdgcn_sched_barrier(0);
-            B1(I1); s2 = aadd(s2, s3); B2(I1, nxtc); s0 = aadd(s0, s2);
+            C3(I1); C4(I0, nxtc); s2 = aadd(s2, s3); C1(I3, nxtc); s0 = aadd(s0, s2);
             __builtin_amdgcn_sched_barrier(0);
             acc[t][1] = mfma_bf16(vm, hf[c][0][1], acc[t][1]);
             __builtin_amdgcn_sched_barrier(0);
-            A1(I2);
+            C2(I2, nxtc); C4(I1, nxtc); C2(I3, nxtc);
             if constexpr (last) bsum[tn] = aadd(bsum[tn], has_next ? s0 : 0.f); else bsum[tn] = aadd(bsum[tn], s0);
-            A2(I2, nxtc);
             __builtin_amdgcn_sched_barrier(0);
             acc[t][0] = mfma_bf16(vm, hf[c][1][0], acc[t][0]);
             __builtin_amdgcn_sched_barrier(0);
-            B1(I2); A1(I3); B2(I2, nxtc); A2(I3, nxtc);
+            C3(I2); C3(I3);
             __builtin_amdgcn_sched_barrier(0);
             acc[t][1] = mfma_bf16(vm, hf[c][1][1], acc[t][1]);
             __builtin_amdgcn_sched_barrier(0);
-            B1(I3); B2(I3, nxtc);
+            C4(I2, nxtc); C4(I3, nxtc);
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -317,7 +342,16 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
             for (int ht = 0; ht < 2; ++ht) hf[0][s3][ht] = *(const bf16x8*)(smem_bb + aHf[s3][ht][0]);
         products0();
         products1();
-        static_for<4>([&](auto pc) { split_a(pc, std::integral_constant<int, 0>{}); split_b(pc, std::integral_constant<int, 0>{}); });
+        {
+            constexpr std::integral_constant<int, 0> z{};
+            constexpr std::integral_constant<int, 1> o1{};
+            constexpr std::integral_constant<int, 2> o2{};
+            constexpr std::integral_constant<int, 3> o3{};
+            C1(z, z); C2(z, z); C3(z); C4(z, z);
+            C1(o1, z); C2(o1, z); C3(o1); C4(o1, z);
+            C1(o2, z); C2(o2, z); C3(o2); C4(o2, z);
+            C1(o3, z); C2(o3, z); C3(o3); C4(o3, z);
+        }
         bsum[0] += (s0 + s1) + (s2 + s3);
         int64_t tile = t0;
         while (tile < n_ptiles) {
