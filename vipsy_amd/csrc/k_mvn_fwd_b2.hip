@@ -332,14 +332,15 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
         }
     };
     auto epi_group = [&](const f32x16 (&a)[NS], const EpiOps& E, uint32_t code, int g) __attribute__((always_inline)) {
+        // (asm: plain fmaf calls are SLP-packed into v_pk_fma_f32 -- with v_mov to pair the operands -- and packed f32
+        // instructions wait for the matrix pipe beside MFMAs; the chains of the two person sets alternate)
 #pragma unroll
-        for (int u = 0; u < NS; ++u) {
-            const float4 e = E.e4[u][g];
-            cur_part[u] = fmaf(a[u][4 * g + 0], e.x, cur_part[u]);
-            cur_part[u] = fmaf(a[u][4 * g + 1], e.y, cur_part[u]);
-            cur_part[u] = fmaf(a[u][4 * g + 2], e.z, cur_part[u]);
-            cur_part[u] = fmaf(a[u][4 * g + 3], e.w, cur_part[u]);
-        }
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                const float ev = j == 0 ? E.e4[u][g].x : j == 1 ? E.e4[u][g].y : j == 2 ? E.e4[u][g].z : E.e4[u][g].w;
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(cur_part[u]) : "v"(a[u][4 * g + j]), "v"(ev));
+            }
         if (__builtin_expect((int)code < 0, 0)) {                                 // wave-uniform, rare: the k ends here
 #pragma unroll
             for (int u = 0; u < NS; ++u) {
