@@ -183,6 +183,7 @@ def _random_problem(N, J, D, H, model, miss, seed):
     (36, 40, 8, 64, "irt_2pl", 0.1, None),          # a single ragged person tile in every dimension-major kernel
     (9000, 40, 8, 64, "irt_2pl", 0.1, None),        # more than 8192 persons: whole 128-person workgroups (fwd_b<false>)
     (40000, 40, 8, 64, "irt_2pl", 0.1, None),       # over half a chip round: the 64-persons-per-wave forward (k_mvn_fwd_b2.hip), ragged end
+    (40008, 72, 12, 64, "irt_2pl", 0.1, None),      # ... whose last wave holds 8 persons (no LDS transposes, x rows as staging)
     (70200, 72, 12, 64, "irt_3pl", 0.2, 70000),     # one full round there + a 4 464-person tail on fwd_b<false>, row gather
     (200, 90, 6, 96, "irt_2pl", 0.2, None),         # hidden_dim > 64 (vi.py:417-455 takes any width): generic kernels
     (150, 260, 33, 128, "irt_4pl", 0.1, 60),        # ... up to 128
