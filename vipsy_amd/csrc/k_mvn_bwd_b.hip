@@ -98,7 +98,11 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
     constexpr int BB_MAXD = 15;
     const int dH0 = rH / 8, dGD0 = rGD / 8;
     const int n_dma = need_gd ? rOnes / 8 : dGD0;
-    // scalar region base (+ the tile's person offset, on the scalar unit) + fixed 32-bit per-lane byte offset
+    // per-lane 64-bit source address of transfer u at person 0, and the shift of a person index to bytes (bf16 planes 1,
+    // fp32 rows 2): a tile adds (i0 << shift) with ONE vector instruction per transfer.  (Choosing the region's base on
+    // the scalar unit per transfer kept 30 loop-invariant SGPRs alive; they spilled to VGPR lanes: 70 v_readlane a tile.)
+    const char* vbase[BB_MAXD];
+    uint32_t vsh[BB_MAXD];
     uint32_t voff[BB_MAXD];
 #pragma unroll
     for (int u = 0; u < BB_MAXD; ++u) {
@@ -116,13 +120,15 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
             if (rl >= D) rl = D - 1;                                   // padding rows of a region: a harmless duplicate
             voff[u] = (uint32_t)(((int64_t)rl * nb + 4 * c) * 4);
         }
+        const bool isH = d >= dH0 && d < dGD0;
+        const void* rbase = d >= dGD0 ? (const void*)gdT : isH ? (const void*)hs : d >= rE / 8 ? (const void*)epsT : (const void*)gxT;
+        vbase[u] = (const char*)rbase + voff[u];
+        vsh[u] = isH ? 1u : 2u;
     }
     auto stage = [&](int64_t tile, int b) __attribute__((always_inline)) {
         const int64_t i0 = tile * BT_P;
         const int pv = (int)((nb - i0) < BT_P ? (nb - i0) : BT_P);
         const uint32_t lbase = lds_addr_uniform(smem_bb + b * BUF) + (uint32_t)wave * 1024u;
-        const float *sG = gxT + i0, *sE = epsT + i0, *sGD = gdT + i0;
-        const uint16_t* sH = hs + i0;
         if (pv < BT_P) {                                               // the last tile: absent persons are zeros
             for (int e = tid; e < bb_rows(D) * 32; e += BT_THREADS) {
                 const int row = e >> 5;
@@ -135,9 +141,9 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
             const int d = wave + 4 * u;
             if (d < n_dma) {
                 const bool isH = d >= dH0 && d < dGD0;
-                const void* sb = d >= dGD0 ? (const void*)sGD : isH ? (const void*)sH : d >= rE / 8 ? (const void*)sE : (const void*)sG;
+                const char* src = vbase[u] + ((uint64_t)i0 << vsh[u]);
                 if (pv == BT_P) {
-                    dma16s(sb, voff[u], lbase + (uint32_t)u * 4096u);
+                    dma16(src, lbase + (uint32_t)u * 4096u);
                 } else {                                               // persons of this lane's 16 bytes: 8 (H) or 4 (fp32)
                     int p0;
                     if (isH) {
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
                     } else {
                         p0 = 4 * ((lane & 7) ^ (4 * (d & 1) + (lane >> 4)));
                     }
-                    if (p0 < pv) dma16s(sb, voff[u], lbase + (uint32_t)u * 4096u);
+                    if (p0 < pv) dma16(src, lbase + (uint32_t)u * 4096u);
                 }
             }
         }
