@@ -1,11 +1,12 @@
-// OPT-IN variant (VX_BF16X3=1) of k_mvn_enc_bwd_w_t: the same head weight gradients
+// The default form (VX_BF16X3=0 selects k_mvn_enc_bwd_w_t) of the head weight gradients
 //     gWp[r][hh] = sum_p V[r][p] h[p][hh],   V = (G or GD row) * (E row or ones),
 // on the bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate): h, the reused operand, as THREE bf16 terms; V, made and
-// split per element, as TWO (truncated head + rounded remainder, 2^-17 relative and unbiased -- below the fp32
+// split per element, as TWO (head rounded to nearest + rounded remainder, 2^-18 relative and unbiased -- below the fp32
 // accumulation noise of a sum over the persons); FIVE cross products (hh, hm, hl, mh, mm).  tools/bf16x3_ubench.hip: the result is closer to
 // the fp64 value than the exact fp32 MFMA chain (8.5e-8 vs 1.5e-7 of sum |a b|) at a third of the matrix-pipe time,
 // and a bf16 MFMA holds the vector issue port for 8 of its 32 cycles only, so the splitting of V runs in its shadow.
-//   h  : split once per step into three bf16 arrays hs[3][64][nb] (k_split3_bf16), staged by DMA, 16-byte fragments;
+//   h  : three bf16 arrays hs[3][64][nb] written by the forward kernel (k_split3_bf16 otherwise), staged by DMA, 16-byte
+//        fragments;
 //   V  : fp32 product as before (8 persons per lane half and chunk), then split in registers.
 // Fragment layout of the 32x32x16 MFMA: lane (r = lane & 31, h = lane >> 5) holds A[row r][k = 8h + j] and
 // B[k = 8h + j][col r], j = 0..7; here k = person within a 16-person chunk.
@@ -164,26 +165,23 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
     // tile sits before its LAST group, whose operands are in registers already: behind it the buffer is free for the
     // DMA of the tile after next, and the prefetch of that group reads the next tile from the other buffer.
     // Vector instructions in the shadow of a bf16 MFMA (tools/slice_ubench.hip): about five single-pass ones are free;
-    // v_pk_*_f32 are NOT (they wait for the matrix pipe) and v_cvt_pk_bf16_f32 takes two passes.  So the split is by
-    // truncation -- h = top 8 mantissa bits, m = top 8 of the rest, l = the last 8: v = h + m + l exactly -- with
-    // and / sub / v_perm_b32 (packs the upper halves of two dwords) only.
+    // v_pk_*_f32 are NOT (they wait for the matrix pipe).  V is split into TWO terms, six instructions per element pair:
+    // head = v_cvt_pk_bf16_f32 (round to nearest, both elements at once), its two halves back as floats (shift / mask),
+    // the two exact remainders, and the remainders packed by the same conversion: V = h + m to 2^-18 relative, unbiased
+    // -- the weight gradient is a sum over the persons whose fp32 accumulation noise (~ sqrt(N) 2^-24) is far above
+    // that, and h (the reused operand) keeps its three terms: five products instead of six.  (Earlier forms: truncation
+    // with and / sub / v_perm_b32, nine instructions a pair.)
     // Every instruction of a slice is a volatile asm statement: the optimizer otherwise re-vectorizes the scalar
-    // arithmetic into v_pk_*_f32 across slices and sinks whole slices out of the MFMA shadow.
+    // arithmetic into v_pk_*_f32 across slices and sinks whole slices out of the MFMA shadow.  A slice alternates pieces
+    // of two element pairs: a vector instruction that depends on the one issued just before it waits for it (measured
+    // 1.66 x the issue time).
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     uint32_t fq[2][2][4];                                              // [parity of the group][h, m][element pair]
     bf16x8 hf[2][3][2];                                                // [parity of the chunk][split][hidden tile]
     f32x4 rg0, rg1, re0, re1;
     float pv_[8], pr_[8], s0, s1, s2, s3;
-    const uint32_t psel = 0x07060302u;                                 // v_perm_b32: upper halves of (src0, src1)
     auto amul = [](float x, float y) -> float { float d; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; };
     auto aadd = [](float x, float y) -> float { float d; asm volatile("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; };
-    auto arem = [](float x) -> float {                                 // x - (x with the low 16 bits cleared)
-        float t, d;
-        asm volatile("v_and_b32 %1, 0xffff0000, %2\n\tv_sub_f32 %0, %2, %1" : "=v"(d), "=&v"(t) : "v"(x));
-        return d;
-    };
-    auto pack_hi = [&](float x1, float x0) -> uint32_t {
-        uint32_t d; asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(x1), "v"(x0), "s"(psel)); return d; };
     auto read_raw = [&](const char* rb, uint32_t ag, uint32_t ae) __attribute__((always_inline)) {
         rg0 = *(const f32x4*)(rb + ag); rg1 = *(const f32x4*)(rb + (ag ^ 16u));
         re0 = *(const f32x4*)(rb + ae); re1 = *(const f32x4*)(rb + (ae ^ 16u));
@@ -198,47 +196,7 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
         for (int j = 0; j < 4; ++j) pv_[4 + j] = amul(rg1[j], re1[j]);
         s2 = aadd(pv_[4], pv_[5]); s3 = aadd(pv_[6], pv_[7]);
     };
-    auto split_a = [&](auto pc, auto nc) __attribute__((always_inline)) {
-        constexpr int p = decltype(pc)::value, nx = decltype(nc)::value;
-        fq[nx][0][p] = pack_hi(pv_[2 * p + 1], pv_[2 * p]);
-        pr_[2 * p] = arem(pv_[2 * p]);
-        pr_[2 * p + 1] = arem(pv_[2 * p + 1]);
-    };
-    // V is split into TWO terms: h by truncation (its remainder is exact), m = the remainder rounded to nearest (+ half an
-    // ulp of bf16 on the bit pattern, then the upper half).  V = h + m to 2^-17 relative, unbiased -- the weight gradient
-    // is a sum over the persons whose fp32 accumulation noise (~ sqrt(N) 2^-24) is far above that, and h (the reused
-    // operand) keeps its three terms: five products instead of six, three vector instructions less per element.
-    auto arnd = [](float x) -> float { float d; asm volatile("v_add_u32 %0, 0x8000, %1" : "=v"(d) : "v"(x)); return d; };
-    auto split_b = [&](auto pc, auto nc) __attribute__((always_inline)) {
-        constexpr int p = decltype(pc)::value, nx = decltype(nc)::value;
-        fq[nx][1][p] = pack_hi(arnd(pr_[2 * p + 1]), arnd(pr_[2 * p]));
-    };
-    // the same splits in four pieces per element pair, so that a slice can alternate instructions of two pairs: a vector
-    // instruction that depends on the one issued just before it waits for it (measured 1.66 x the issue time)
-    float tq[2];
-    auto aand = [](float x) -> float { float d; asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(d) : "v"(x)); return d; };
     auto asub = [](float x, float y) -> float { float d; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; };
-    auto A1 = [&](auto pc) __attribute__((always_inline)) {
-        constexpr int p = decltype(pc)::value;
-        tq[0] = aand(pv_[2 * p]); tq[1] = aand(pv_[2 * p + 1]);
-    };
-    auto A2 = [&](auto pc, auto nc) __attribute__((always_inline)) {
-        constexpr int p = decltype(pc)::value, nx = decltype(nc)::value;
-        fq[nx][0][p] = pack_hi(pv_[2 * p + 1], pv_[2 * p]);
-        pr_[2 * p] = asub(pv_[2 * p], tq[0]);
-        pr_[2 * p + 1] = asub(pv_[2 * p + 1], tq[1]);
-    };
-    auto B1 = [&](auto pc) __attribute__((always_inline)) {
-        constexpr int p = decltype(pc)::value;
-        pr_[2 * p] = arnd(pr_[2 * p]); pr_[2 * p + 1] = arnd(pr_[2 * p + 1]);
-    };
-    auto B2 = [&](auto pc, auto nc) __attribute__((always_inline)) {
-        constexpr int p = decltype(pc)::value, nx = decltype(nc)::value;
-        fq[nx][1][p] = pack_hi(pr_[2 * p + 1], pr_[2 * p]);
-    };
-    // Third form of the split, six instructions per element pair instead of nine: head = v_cvt_pk_bf16_f32 (round to
-    // nearest, both elements at once), its two halves back as floats (shift / mask), the two exact remainders, and the
-    // remainders packed by the same conversion.  V = h + m to 2^-18 relative.
     float th[2][2];                                                    // [pair parity][element]: the heads as floats
     auto acvt = [](float x0, float x1) -> uint32_t {
         uint32_t d; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(x0), "v"(x1)); return d; };

@@ -710,7 +710,7 @@ static bool encb_fast_shape(const vx_irt_cfg* cfg) {
 static bool bwt_shape(const vx_irt_cfg* cfg, int64_t nb) {
     return packed_ok(cfg) && nb % 4 == 0 && cfg->D <= 124 && bt_lds_bytes(cfg->D) <= 160 * 1024;
 }
-// opt-in (VX_BF16X3=1): the weight-gradient kernel on the bf16 MFMA with three-term operand splitting (k_mvn_bwd_b.hip)
+// the default (VX_BF16X3=0 turns it off): the weight-gradient kernel on the bf16 MFMA, operands in bf16 terms (k_mvn_bwd_b.hip)
 static bool bwb_shape(const vx_irt_cfg* cfg, int64_t nb) {
     const bool on = (bf16x3_mode() & 2) != 0;
     return on && bwt_shape(cfg, nb) && nb % 8 == 0 && nb < ((int64_t)1 << 23) && bb_lds_bytes(cfg->D) <= 160 * 1024;
