@@ -297,6 +297,10 @@ class HipBackend(object):
         _hip.check(rc, "vx_philox_normals")
 
 
+_ADAM_NOOP = {"weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+              "differentiable": False, "fused": None}
+
+
 class LrSpec(object):
     """Per-tensor learning rates + MultiStepLR, as pyro.optim.Adam / PyroLRScheduler give them
     (vi.py:514, 639-640; test.py:321-327, 345-359)."""
@@ -316,6 +320,9 @@ class LrSpec(object):
             d = dict(self.lr)
         else:
             d = {"lr": self.lr}
+        for k, noop in _ADAM_NOOP.items():                 # torch.optim.Adam defaults spelled out change nothing
+            if k in d and (d[k] is None if noop is None else d[k] == noop):
+                del d[k]
         unknown = set(d) - {"lr", "betas", "eps"}
         if unknown:
             raise NotImplementedError("Adam option(s) %s are not on the HIP path" % sorted(unknown))
@@ -512,9 +519,18 @@ class _EngineBase(object):
         return (self.use_graph and getattr(self, "D", 0) == 1 and not getattr(self, "amortized", True)
                 and self.group is None and self.events is None and isinstance(self.be, HipBackend))
 
+    def _graph_key(self, lrs):
+        """Everything a captured step bakes into its kernel arguments: the (begin, end, lr) segments and (betas, eps) of
+        every leaf as apply_optim computes them now (a new fit(), a scheduler milestone or a callable optim_args whose
+        answer changed all change it), and the addresses of the buffers the kernels were handed (a workspace that
+        _buf() has re-allocated since the capture would leave the graph writing into the old one)."""
+        hyp = tuple((name, float(lrs.lr_of(name))) + lrs.hyper_of(name) for name in self.all_names())
+        ptrs = tuple(sorted((k, t.data_ptr()) for k, t in self._ws.items()))
+        return hyp, ptrs
+
     def _step_graph(self, lrs):
         st = self._graph
-        key = (id(lrs), sum(1 for m in lrs.milestones if m <= lrs.epoch))
+        key = self._graph_key(lrs)
         if st["graph"] is None or st["key"] != key:
             ctr = torch.zeros(1, dtype=torch.int32, device=self.dev)
             torch.cuda.synchronize()

@@ -9,11 +9,9 @@ pyro.clear_param_store, test.py:66,73-87), so the reference's demos read the sam
     a_hat = param('a')
 
 What runs underneath is NOT pyro: every iteration is one vipsy_amd.engine step, i.e. the HIP kernels behind
-include/vipsy_amd.h (no CPU fallback).  Classes of the reference that are outside the accelerated path
-(VCDM, VaeCDM, VaeCCDM: SURVEY.md section 8f-3) raise NotImplementedError with that explanation; VCCDM is built.
+include/vipsy_amd.h (no CPU fallback).  Every model class of the reference is built: VIRT, VaeIRT, VCDM, VaeCDM, VCCDM,
+VaeCCDM, VCHoDina, VaeCHoDina.
 """
-import math
-
 import numpy as np
 import torch
 
@@ -266,15 +264,6 @@ class VaeCHoDina(_HoDinaBase):
     amortized = True
 
 
-def _out_of_scope(name, cite):
-    class _C(object):
-        def __init__(self, *a, **k):
-            raise NotImplementedError("%s (%s) is outside the accelerated hot path of this build "
-                                      "(SURVEY.md section 8f-3); use the reference for it" % (name, cite))
-    _C.__name__ = name
-    return _C
-
-
 class _CdmSfBase(BasePsy):
     """BaseCDM (vi.py:726-782) with a Bernoulli guide: the score-function (REINFORCE) estimator of pyro's Trace_ELBO.
     Extra keyword arguments of this build: attr_prior (None = the reference's Bernoulli(1.5) prior, vi.py:753; a float
@@ -328,8 +317,12 @@ class VCDM(_CdmSfBase):
 
 
 class VaeCDM(_CdmSfBase):
-    """Amortized VI for DINA / DINO with the BinEncoder guide (vi.py:785-804, 458-470)."""
+    """Amortized VI for DINA / DINO with the BinEncoder guide (vi.py:785-804, 458-470).  Positional order as in the
+    reference: (hidden_dim, q, model) (vi.py:785-793)."""
     amortized = True
+
+    def __init__(self, hidden_dim=64, q=None, model="dina", *args, **kwargs):
+        super().__init__(q, model, hidden_dim, *args, **kwargs)
 
 
 class VCCDM(BasePsy):
@@ -410,5 +403,3 @@ def IrtMultiDim(x_feature, model="irt_2pl", **kw):
 def HoDina(amortized=False, **kw):
     return (VaeCHoDina if amortized else VCHoDina)(**kw)
 
-
-_ = math
