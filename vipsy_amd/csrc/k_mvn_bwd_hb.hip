@@ -1,25 +1,27 @@
-// Hidden-layer gradient of the amortized MVN guide on the bf16 MFMA (bf16-term operand splitting, fp32 accumulate):
-// the same result as k_mvn_enc_bwd_h_t (k_mvn_bwd_t.hip),
+// Hidden-layer gradient of the amortized MVN guide on the fp16 MFMA (two-term operand splitting "f16x2", vx_common.h; fp32
+// accumulate): the same result as k_mvn_enc_bwd_h_t (k_mvn_bwd_t.hip),
 //     gh[p][hh] = sum_r Wp[r][hh] V[r][p],    ghpre = gh * (1 - exp(-h))                          (autograd of vi.py:448-455)
 // but V is never formed.  For the off-diagonal rows V[(k,l)][p] = gx[p][k] eps[p][l] is a rank-one product, so
 //     gh[p][:] = sum_k gx[p][k] U_k[p][:],      U_k[p][hh] = sum_{l<k} W22[(k,l)][hh] eps[p][l]
-// and U_k is a GEMM whose per-person operand is eps alone: split ONCE per 32-person wave tile into bf16 fragments
-// that stay in registers for every k (the V of the fp32 kernel needed a multiply -- and would need a three-way split
-// -- per element).  The weights are split once per step into per-unit images (k_pack_heads_hb).  The multiplication by
-// gx[p][k] is a 32-FMA epilogue per k on the accumulator.  DIAG rows (operand gd = gx eps e^M + scale, k_mvn_gd) and
-// LOC rows (operand gx) are two more small GEMMs straight into the gh accumulator.
+// and U_k is a GEMM whose per-person operand is eps alone: scaled and split ONCE per 32-person wave tile into fp16
+// fragments that stay in registers for every k.  The weights are scaled and split once per step into per-unit images
+// (k_pack_heads_hb).  The multiplication by gx[p][k] -- with the powers of two of both operands folded into it -- is a
+// 32-FMA epilogue per k on the accumulator.  DIAG rows (operand gd = gx eps e^M + scale, k_mvn_gd) and LOC rows (operand gx)
+// are two more small GEMMs, each with the power of two of its own operand.
+//   The per-person operands take their power of two from the largest magnitude among the wave's 32 persons (wave maximum):
+//   no bound is assumed.
 //   MFMA 32x32x16: C rows = hidden units (two tiles of 32), columns = persons; contraction index = l (or k).
-//   unit (k, s) = the 16 contraction indices l = 16 s .. 16 s + 15 of one k: 6 fragments of 1 KB (2 hidden tiles x 3
-//   splits), 10 MFMAs (five products a tile).  Units stream through a ring of 8 slots in LDS by DMA, shared by the 8 waves of the workgroup
-//   (pairs of units = 12 transfers = 3 for each of the waves 0..3, so `vmcnt(3)` counts whole pairs); one barrier per
-//   pair.  Two waves per SIMD (the kernel fits 256 registers): what one wave cannot overlap -- the epilogue per k,
-//   LDS waits, the barrier -- runs under the other wave's MFMAs.
+//   unit (k, s) = the 16 contraction indices l = 16 s .. 16 s + 15 of one k: 4 fragments of 1 KB (2 hidden tiles x 2
+//   terms), 6 MFMAs (three products a tile).  Units stream through a ring of 8 slots in LDS by DMA, shared by the 8 waves
+//   of the workgroup (pairs of units = 8 transfers = 2 for each of the waves 0..3, so `vmcnt(2)` counts whole pairs); one
+//   barrier per pair.  Two waves per SIMD (the kernel fits 256 registers): what one wave cannot overlap -- the epilogue
+//   per k, LDS waits, the barrier -- runs under the other wave's MFMAs.
 //   k runs in blocks of 16 so that the number of units per k -- and with it every fragment register -- is static.
 // (included by vx_abi.hip after k_mvn_fwd_b.hip)
 
 #define HB_THREADS 512
 #define HB_WAVES 8                                                     // two per SIMD: one wave's epilogue / waits under the other's MFMAs
-#define HB_UNIT_BYTES 6144
+#define HB_UNIT_BYTES 4096
 #define HB_NSLOT 8
 #define HB_NS 8                                                        // k-steps of 16 covering D <= 128
 
@@ -35,14 +37,19 @@ __host__ __device__ inline size_t hb_lds_bytes(int D) {
     return a > 65536 ? a : 65536;                                      // SPLIT: [8 waves][32 registers][64 lanes] floats
 }
 
-// unit image: fragment (hidden tile ht, split sp) at byte (ht * 3 + sp) * 1024 + lane * 16, lane = 32 half + row;
-// element j = the weight of hidden unit 32 ht + row for contraction index c = 16 s + 8 half + j:
+// unit image: fragment (hidden tile ht, term sp) at byte (ht * 2 + sp) * 1024 + lane * 16, lane = 32 half + row;
+// element j = the weight (times 2^sw, sc[2] of k_enc_scales) of hidden unit 32 ht + row for contraction index
+// c = 16 s + 8 half + j:
 //   OFF unit (k, s): W22[(k, c)] for c < k;   DIAG unit s: W22[(c, c)];   LOC unit s: W21[c]       (zero past the end)
+// Block 0 also clears the words that collect the largest |gx|, |gd|, |eps| and |ghpre| of the step (the kernel below adds
+// its waves' maxima; k_mvn_enc_bwd_w_b and k_fc1_bwd_b scale by them).
 __global__ void k_pack_heads_hb(int D, const float* __restrict__ W21, const float* __restrict__ W22,
-                                uint8_t* __restrict__ img) {
+                                const float* __restrict__ sc, uint8_t* __restrict__ img, uint32_t* __restrict__ maxw) {
     const int n_off = hb_units_off(D), ns = (D + 15) / 16;
     const int u = blockIdx.x;
+    if (u == 0 && threadIdx.x < 4 && maxw) maxw[threadIdx.x] = 0u;
     if (u >= n_off + 2 * ns) return;
+    const float w_scale = sc[2];
     int type = 0, k = 0, s = 0;                                        // 0 OFF, 1 DIAG, 2 LOC
     if (u < n_off) {
         int rem = u;
@@ -65,39 +72,9 @@ __global__ void k_pack_heads_hb(int D, const float* __restrict__ W21, const floa
         if (type == 0) { if (c < k) v = W22[((int64_t)k * (k + 1) / 2 + c) * 64 + hh]; }
         else if (type == 1) { if (c < D) v = W22[((int64_t)c * (c + 1) / 2 + c) * 64 + hh]; }
         else { if (c < D) v = W21[(int64_t)c * 64 + hh]; }
-        const __bf16 h = (__bf16)v;
-        const float r1 = v - (float)h;
-        const __bf16 m = (__bf16)r1;
-        const __bf16 l = (__bf16)(r1 - (float)m);
-        uint16_t* o = (uint16_t*)(out + (ht * 3) * 1024 + lane * 16) + j;
-        o[0] = __builtin_bit_cast(uint16_t, h);
-        o[512] = __builtin_bit_cast(uint16_t, m);
-        o[1024] = __builtin_bit_cast(uint16_t, l);
+        uint16_t* o = (uint16_t*)(out + (ht * 2) * 1024 + lane * 16) + j;
+        split2h_bits(w_scale * v, o[0], o[512]);
     }
-}
-
-// eight fp32 values -> two bf16 fragments: hi by truncation (v - hi is exact), mid = that remainder rounded to nearest
-// (half an ulp of bf16 added on the bit pattern, then the upper half): v = hi + mid to 2^-17 relative, unbiased.  gh of a
-// person only ever enters sums over the persons (fc1 weight / bias gradients), whose fp32 accumulation noise is far
-// above that -- so the third term of the per-person operand, and with it one product in six, is not spent.
-__device__ __forceinline__ void hb_split8(const float* v, bf16x8& fh, bf16x8& fm) {
-    typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
-    u32x4v ph, pm;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        uint32_t hb[2], mb[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const float x = v[2 * q + e];
-            hb[e] = __builtin_bit_cast(uint32_t, x) & 0xffff0000u;
-            const float r1 = x - __builtin_bit_cast(float, hb[e]);
-            mb[e] = (__builtin_bit_cast(uint32_t, r1) + 0x8000u) & 0xffff0000u;
-        }
-        ph[q] = hb[1] | (hb[0] >> 16);
-        pm[q] = mb[1] | (mb[0] >> 16);
-    }
-    fh = __builtin_bit_cast(bf16x8, ph);
-    fm = __builtin_bit_cast(bf16x8, pm);
 }
 
 // SPLIT (small batches, at most HB_SPLIT_MAX persons): a workgroup takes ONE 32-person tile and its eight waves share
@@ -107,10 +84,11 @@ __device__ __forceinline__ void hb_split8(const float* v, bf16x8& fh, bf16x8& fm
 #define HB_SPLIT_MAX 16384
 template <bool SPLIT>
 __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
-    EncDims dm, const uint8_t* __restrict__ img, const float* __restrict__ h_in, const float* __restrict__ eps_in,
-    const float* __restrict__ gxT, const float* __restrict__ gdT /*DIAG-row operand [D][nb]*/,
+    EncDims dm, const uint8_t* __restrict__ img, const float* __restrict__ sc /*k_enc_scales*/, const float* __restrict__ h_in,
+    const float* __restrict__ eps_in, const float* __restrict__ gxT, const float* __restrict__ gdT /*DIAG-row operand [D][nb]*/,
     float* __restrict__ ghpre_out /*[nb][64] or null*/, const float* __restrict__ hT /*[64][nb], with ghpreT_out*/,
-    float* __restrict__ ghpreT_out /*[64][nb] or null*/) {
+    float* __restrict__ ghpreT_out /*[64][nb] or null*/,
+    uint32_t* __restrict__ maxw /*float bits: largest |gx|, |gd|, |eps|, |ghpre| of the launch, or null*/) {
     extern __shared__ __attribute__((aligned(16))) char smem_hb[];
     constexpr int H = 64;
     const int D = dm.D;
@@ -131,27 +109,25 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
     auto stage_pair = [&](int q) __attribute__((always_inline)) {
         if (wave >= 4) return;                                         // waves 0..3 feed the ring for all eight
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int piece = wave + 4 * c;                            // 0..11: unit piece / 6, fragment piece % 6
-            int u = 2 * q + (piece >= 6 ? 1 : 0);
-            const uint32_t dst = ring_lds + (uint32_t)(u & (HB_NSLOT - 1)) * HB_UNIT_BYTES + (uint32_t)(piece % 6) * 1024u;
+        for (int c = 0; c < 2; ++c) {
+            const int piece = wave + 4 * c;                            // 0..7: unit piece / 4, fragment piece % 4
+            int u = 2 * q + (piece >= 4 ? 1 : 0);
+            const uint32_t dst = ring_lds + (uint32_t)(u & (HB_NSLOT - 1)) * HB_UNIT_BYTES + (uint32_t)(piece % 4) * 1024u;
             if (u >= n_units) u = n_units - 1;                         // past the end: a harmless duplicate
-            dma16s(img + (int64_t)u * HB_UNIT_BYTES, (uint32_t)((piece % 6) * 1024 + lane * 16), dst);
+            dma16s(img + (int64_t)u * HB_UNIT_BYTES, (uint32_t)((piece % 4) * 1024 + lane * 16), dst);
         }
     };
     (void)voff;
     if (!SPLIT) { stage_pair(0); stage_pair(1); stage_pair(2); }
 
-    // ---- this wave's gx tile [D][32] (lanes = persons: 128-byte rows of gxT)
-    for (int k = half; k < D; k += 2) gx_lds[k * 32 + l31] = gxT[(int64_t)k * nb + ic];
-
-    // ---- B fragments: contraction index c = 16 s + 8 half + j of person ic, three bf16 terms each
-    bf16x8 bf[2][HB_NS];                                               // the per-person operand in TWO bf16 terms (hb_split8)
+    // ---- B fragments: contraction index c = 16 s + 8 half + j of person ic as two fp16 terms of v 2^e; e from the largest
+    // magnitude among the wave's persons (two passes over the values: the maximum, then the split)
+    const float w_inv = 1.0f / sc[2];                                  // 2^-sw (a power of two: exact)
+    f16x8 bf[2][HB_NS];
+    float e_max = 0.f;
     {
         const float* er = eps_in + ic * D;
-#pragma unroll
-        for (int s = 0; s < HB_NS; ++s) {
-            float v[8];
+        auto load8 = [&](int s, float (&v)[8]) __attribute__((always_inline)) {
             const int c0 = 16 * s + 8 * half;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -159,10 +135,46 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
                 if (c0 + 4 * q + 4 <= D) t = *(const f32x4*)(er + c0 + 4 * q);      // D % 4 == 0 on this path
                 v[4 * q + 0] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
             }
-            hb_split8(v, bf[0][s], bf[1][s]);
+        };
+        float m = 0.f;
+#pragma unroll
+        for (int s = 0; s < HB_NS; ++s) {
+            float v[8];
+            load8(s, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
+        }
+        e_max = wave_max_dpp(m);
+        const float e_scale = ldexpf(1.0f, f16_scale_exp(e_max));
+#pragma unroll
+        for (int s = 0; s < HB_NS; ++s) {
+            float v[8];
+            load8(s, v);
+            split2h_frag(v, e_scale, bf[0][s], bf[1][s]);
         }
     }
-    auto frags_from_T = [&](const float* __restrict__ srcT) __attribute__((always_inline)) {
+    const float u_inv = w_inv * ldexpf(1.0f, -f16_scale_exp(e_max));   // takes 2^(sw + se) off U_k, folded into gx[p][k]
+    // ---- this wave's gx tile [D][32] (lanes = persons: 128-byte rows of gxT), times u_inv
+    float g_max = 0.f;
+    for (int k = half; k < D; k += 2) {
+        const float g = gxT[(int64_t)k * nb + ic];
+        g_max = fmaxf(g_max, fabsf(g));
+        gx_lds[k * 32 + l31] = g * u_inv;
+    }
+    g_max = wave_max_dpp(g_max);
+    // fragments of a dimension-major operand; returns the power of two that takes its scale (and the weights') off
+    auto frags_from_T = [&](const float* __restrict__ srcT, float& vmax) __attribute__((always_inline)) -> float {
+        float m = 0.f;
+#pragma unroll
+        for (int s = 0; s < HB_NS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = 16 * s + 8 * half + j;
+                if (c < D) m = fmaxf(m, fabsf(srcT[(int64_t)c * nb + ic]));
+            }
+        vmax = wave_max_dpp(m);
+        const int se = f16_scale_exp(vmax);
+        const float scl = ldexpf(1.0f, se);
 #pragma unroll
         for (int s = 0; s < HB_NS; ++s) {
             float v[8];
@@ -171,45 +183,42 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
                 const int c = 16 * s + 8 * half + j;
                 v[j] = (c < D) ? srcT[(int64_t)c * nb + ic] : 0.f;
             }
-            hb_split8(v, bf[0][s], bf[1][s]);
+            split2h_frag(v, scl, bf[0][s], bf[1][s]);
         }
+        return w_inv * ldexpf(1.0f, -se);
     };
 
     f32x16 gh0 = zero16(), gh1 = zero16();
-    bf16x8 A[6];                                                       // fragments of the CURRENT unit: [ht * 3 + split]
+    f16x8 A[4];                                                        // fragments of the CURRENT unit: [ht * 2 + term]
     int u = 0;                                                         // unit counter (uniform)
     auto slot_of = [&](int uu) -> const char* { return ring + (size_t)(uu & (HB_NSLOT - 1)) * HB_UNIT_BYTES; };
     auto read_ht = [&](int uu, int ht) __attribute__((always_inline)) {
-        const char* sb = slot_of(uu) + ht * 3072 + lane * 16;
-        A[3 * ht + 0] = *(const bf16x8*)(sb);
-        A[3 * ht + 1] = *(const bf16x8*)(sb + 1024);
-        A[3 * ht + 2] = *(const bf16x8*)(sb + 2048);
+        const char* sb = slot_of(uu) + ht * 2048 + lane * 16;
+        A[2 * ht + 0] = *(const f16x8*)(sb);
+        A[2 * ht + 1] = *(const f16x8*)(sb + 1024);
     };
     // pair boundary: pair q + 1 has landed for every wave, the slots of pair q - 1 are free for pair q + 3
     auto sync_pair = [&](int q) __attribute__((always_inline)) {
-        if (wave < 4) __builtin_amdgcn_s_waitcnt(0x0F73);              // vmcnt(3): only pair q + 2 may be in flight
+        if (wave < 4) __builtin_amdgcn_s_waitcnt(0x0F72);              // vmcnt(2): only pair q + 2 may be in flight
         __syncthreads();
         stage_pair(q + 3);
     };
-    // one unit: 5 products per hidden tile (weights in three terms, the per-person operand in two; small terms first); the fragments of the NEXT unit are requested as soon as
-    // the registers are free: hidden tile 0 after the first six MFMAs, hidden tile 1 at the end
+    // one unit: 3 products per hidden tile (small terms first); the fragments of the NEXT unit are requested as soon as
+    // the registers are free: hidden tile 0 after the first three MFMAs, hidden tile 1 at the end
     auto unit = [&](auto sc, f32x16& U0, f32x16& U1) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
         if ((u & 1) == 0) sync_pair(u >> 1);
-        U0 = mfma_bf16(A[2], bf[0][s], U0);
-        U0 = mfma_bf16(A[1], bf[1][s], U0);
-        U0 = mfma_bf16(A[1], bf[0][s], U0);
-        U0 = mfma_bf16(A[0], bf[1][s], U0);
-        U0 = mfma_bf16(A[0], bf[0][s], U0);
+        U0 = mfma_f16(A[1], bf[0][s], U0);
+        U0 = mfma_f16(A[0], bf[1][s], U0);
+        U0 = mfma_f16(A[0], bf[0][s], U0);
         read_ht(u + 1, 0);
-        U1 = mfma_bf16(A[5], bf[0][s], U1);
-        U1 = mfma_bf16(A[4], bf[1][s], U1);
-        U1 = mfma_bf16(A[4], bf[0][s], U1);
-        U1 = mfma_bf16(A[3], bf[1][s], U1);
-        U1 = mfma_bf16(A[3], bf[0][s], U1);
+        U1 = mfma_f16(A[3], bf[0][s], U1);
+        U1 = mfma_f16(A[2], bf[1][s], U1);
+        U1 = mfma_f16(A[2], bf[0][s], U1);
         read_ht(u + 1, 1);
         ++u;
     };
+    float d_max = 0.f, x_max = 0.f;                                    // wave maxima of |gd| and (again) |gx|
 
     if constexpr (SPLIT) {
         // ---- this wave's share of the units, fragments global -> registers one unit ahead
@@ -217,26 +226,22 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
             const int kb2 = (k - 1) >> 4;
             return 8 * kb2 * (kb2 + 1) + (k - 16 * kb2 - 1) * (kb2 + 1);
         };
-        auto load_unit = [&](bf16x8 (&Au)[6], int uu) __attribute__((always_inline)) {
+        auto load_unit = [&](f16x8 (&Au)[4], int uu) __attribute__((always_inline)) {
             if (uu >= n_units) uu = n_units - 1;                       // past the end: a harmless duplicate
             const uint8_t* g = img + (int64_t)uu * HB_UNIT_BYTES + lane * 16;
 #pragma unroll
-            for (int f = 0; f < 6; ++f) Au[f] = *(const bf16x8*)(g + f * 1024);
+            for (int f = 0; f < 4; ++f) Au[f] = *(const f16x8*)(g + f * 1024);
         };
-        auto mma_unit = [&](const bf16x8 (&Au)[6], auto sc, f32x16& U0, f32x16& U1) __attribute__((always_inline)) {
+        auto mma_unit = [&](const f16x8 (&Au)[4], auto sc, f32x16& U0, f32x16& U1) __attribute__((always_inline)) {
             constexpr int s = decltype(sc)::value;
-            U0 = mfma_bf16(Au[2], bf[0][s], U0);
-            U0 = mfma_bf16(Au[1], bf[1][s], U0);
-            U0 = mfma_bf16(Au[1], bf[0][s], U0);
-            U0 = mfma_bf16(Au[0], bf[1][s], U0);
-            U0 = mfma_bf16(Au[0], bf[0][s], U0);
-            U1 = mfma_bf16(Au[5], bf[0][s], U1);
-            U1 = mfma_bf16(Au[4], bf[1][s], U1);
-            U1 = mfma_bf16(Au[4], bf[0][s], U1);
-            U1 = mfma_bf16(Au[3], bf[1][s], U1);
-            U1 = mfma_bf16(Au[3], bf[0][s], U1);
+            U0 = mfma_f16(Au[1], bf[0][s], U0);
+            U0 = mfma_f16(Au[0], bf[1][s], U0);
+            U0 = mfma_f16(Au[0], bf[0][s], U0);
+            U1 = mfma_f16(Au[3], bf[0][s], U1);
+            U1 = mfma_f16(Au[2], bf[1][s], U1);
+            U1 = mfma_f16(Au[2], bf[0][s], U1);
         };
-        bf16x8 Ac[6], An[6];
+        f16x8 Ac[4], An[4];
         load_unit(Ac, uoff(1 + wave));
         static_for<HB_NS>([&](auto kbc) {
             constexpr int kb = decltype(kbc)::value;
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
                     load_unit(An, s < kb ? u0 + s + 1 : uoff(k + HB_WAVES));
                     mma_unit(Ac, sc, U0, U1);
 #pragma unroll
-                    for (int f = 0; f < 6; ++f) Ac[f] = An[f];
+                    for (int f = 0; f < 4; ++f) Ac[f] = An[f];
                 });
                 const float gk = gx_lds[k * 32 + l31];
 #pragma unroll
@@ -259,16 +264,26 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
         });
         // ---- DIAG (operand gd) and LOC (operand gx) units: s = wave, wave + 8, ..
         const int u_sec = hb_units_off(D);
-        frags_from_T(gdT);
-        static_for<HB_NS>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            if (s < ns && (s & (HB_WAVES - 1)) == wave) { load_unit(Ac, u_sec + s); mma_unit(Ac, sc, gh0, gh1); }
-        });
-        frags_from_T(gxT);
-        static_for<HB_NS>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            if (s < ns && (s & (HB_WAVES - 1)) == wave) { load_unit(Ac, u_sec + ns + s); mma_unit(Ac, sc, gh0, gh1); }
-        });
+        {
+            const float cinv = frags_from_T(gdT, d_max);
+            f32x16 S0 = zero16(), S1 = zero16();
+            static_for<HB_NS>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                if (s < ns && (s & (HB_WAVES - 1)) == wave) { load_unit(Ac, u_sec + s); mma_unit(Ac, sc, S0, S1); }
+            });
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { gh0[r] = fmaf(cinv, S0[r], gh0[r]); gh1[r] = fmaf(cinv, S1[r], gh1[r]); }
+        }
+        {
+            const float cinv = frags_from_T(gxT, x_max);
+            f32x16 S0 = zero16(), S1 = zero16();
+            static_for<HB_NS>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                if (s < ns && (s & (HB_WAVES - 1)) == wave) { load_unit(Ac, u_sec + ns + s); mma_unit(Ac, sc, S0, S1); }
+            });
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { gh0[r] = fmaf(cinv, S0[r], gh0[r]); gh1[r] = fmaf(cinv, S1[r], gh1[r]); }
+        }
         // ---- sum of the eight partial tiles, fixed order; wave 0 keeps the result
         __syncthreads();                                               // every wave is done with its gx tile
         float* red = (float*)smem_hb;                                  // [8 waves][32 registers][64 lanes]
@@ -278,6 +293,11 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
             red[((size_t)wave * 32 + 16 + r) * 64 + lane] = gh1[r];
         }
         __syncthreads();
+        if (lane == 0 && maxw) {                                       // (before the partial waves leave)
+            atomicMax(maxw + 0, __builtin_bit_cast(uint32_t, fmaxf(g_max, x_max)));
+            atomicMax(maxw + 1, __builtin_bit_cast(uint32_t, d_max));
+            atomicMax(maxw + 2, __builtin_bit_cast(uint32_t, e_max));
+        }
         if (wave != 0) return;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -308,31 +328,51 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
             for (int r = 0; r < 16; ++r) { gh0[r] = fmaf(gk, U0[r], gh0[r]); gh1[r] = fmaf(gk, U1[r], gh1[r]); }
         }
     });
-    // ---- DIAG rows (operand gd) and LOC rows (operand gx): straight into the accumulators
-    frags_from_T(gdT);
-    static_for<HB_NS>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        if (s < ns) unit(sc, gh0, gh1);
-    });
-    frags_from_T(gxT);
-    static_for<HB_NS>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        if (s < ns) unit(sc, gh0, gh1);
-    });
+    // ---- DIAG rows (operand gd) and LOC rows (operand gx): an accumulator pair of their own, added with their power of two
+    {
+        const float cinv = frags_from_T(gdT, d_max);
+        f32x16 S0 = zero16(), S1 = zero16();
+        static_for<HB_NS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if (s < ns) unit(sc, S0, S1);
+        });
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { gh0[r] = fmaf(cinv, S0[r], gh0[r]); gh1[r] = fmaf(cinv, S1[r], gh1[r]); }
+    }
+    {
+        const float cinv = frags_from_T(gxT, x_max);
+        f32x16 S0 = zero16(), S1 = zero16();
+        static_for<HB_NS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if (s < ns) unit(sc, S0, S1);
+        });
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { gh0[r] = fmaf(cinv, S0[r], gh0[r]); gh1[r] = fmaf(cinv, S1[r], gh1[r]); }
+    }
     vx_wait_vmem();                                                    // no DMA may be in flight when the LDS is released
+    if (lane == 0 && maxw) {
+        atomicMax(maxw + 0, __builtin_bit_cast(uint32_t, fmaxf(g_max, x_max)));
+        atomicMax(maxw + 1, __builtin_bit_cast(uint32_t, d_max));
+        atomicMax(maxw + 2, __builtin_bit_cast(uint32_t, e_max));
+    }
     }
 
     // ---- ghpre = gh * softplus'(pre) = gh * (1 - exp(-h));  C layout: rows hh = crow32(r, half), cols p
     if (ghpreT_out) {                                                  // dimension-major: 128-byte rows per half-wave
+        float p_max = 0.f;
         if (i < nb) {
 #pragma unroll
             for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int64_t o = (int64_t)(32 * ht + crow32(r, half)) * nb + i;
-                    ghpreT_out[o] = (ht ? gh1 : gh0)[r] * (1.0f - __expf(-hT[o]));
+                    const float gp = (ht ? gh1 : gh0)[r] * (1.0f - __expf(-hT[o]));
+                    p_max = fmaxf(p_max, fabsf(gp));
+                    ghpreT_out[o] = gp;
                 }
         }
+        p_max = wave_max_dpp(p_max);
+        if (lane == 0 && maxw) atomicMax(maxw + 3, __builtin_bit_cast(uint32_t, p_max));
     } else if (i < nb) {
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht)

@@ -1,26 +1,26 @@
-// Amortized MVN guide forward with the head GEMM on the bf16 MFMA (three-term operand splitting, fp32 accumulate):
-// the same mathematics and outputs as k_mvn_enc_fwd_p (k_mvn_packed.hip; vi.py:448-455,686-693).
-//   M[p, r] = bias[r] + sum_hh Wp[r][hh] h[p][hh]  is computed as six bf16 products per 16-deep k-step
-//   (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid) on v_mfma_f32_32x32x16_bf16: 24 MFMAs of 32 cycles per 32x32 tile
-//   instead of 33 fp32 MFMAs of 64 cycles, at the accuracy of the fp32 chain (tools/bf16x3_ubench.hip).
+// Amortized MVN guide forward with the head GEMM on the fp16 MFMA (two-term operand splitting "f16x2", vx_common.h; fp32
+// accumulate): the same mathematics and outputs as k_mvn_enc_fwd_p (k_mvn_packed.hip; vi.py:448-455,686-693).
+//   M[p, r] = bias[r] + sum_hh Wp[r][hh] h[p][hh]  is computed as three fp16 products per 16-deep k-step
+//   (lo*hi, hi*lo, hi*hi of the scaled operands) on v_mfma_f32_32x32x16_f16: 13 MFMAs of 32 cycles per 32x32 tile
+//   (round 2: six bf16 products, 25 MFMAs; round 1: 33 fp32 MFMAs of 64 cycles), at the accuracy of the fp32 chain.
 // Both operands are reused, so the splitting costs nothing in the loop:
-//   Wp : split once per step by k_pack_heads_b into a per-tile IMAGE that is exactly the LDS layout the fragments
-//        are read from (12 KB of bf16 fragments + a bias fragment per 32-row tile);
-//   h  : split once per 32-person wave tile, in registers; the C layout of the fc1 MFMA already is the B fragment
-//        order (k-step s, lane half, element j  <->  hidden unit 16 s + 8 (j >> 2) + 4 half + (j & 3)).
-// Every wave streams the tile images by itself, global (L2) -> registers, one tile ahead: the 13 fragment loads of tile
+//   Wp : scaled and split once per step by k_pack_heads_b into a per-tile IMAGE that is exactly the order the fragments
+//        are read in (8 KB of fp16 fragments + a bias fragment per 32-row tile);
+//   h  : scaled and split once per 32-person wave tile, in registers; the C layout of the fc1 MFMA already is the B
+//        fragment order (k-step s, lane half, element j  <->  hidden unit 16 s + 8 (j >> 2) + 4 half + (j & 3)).
+// The powers of two (k_enc_scales) come off the accumulator where it is consumed: the OFF sums once per k, the DIAG /
+// LOC values per element.
+// Every wave streams the tile images by itself, global (L2) -> registers, one tile ahead: the 9 fragment loads of tile
 // t + 1 are issued at the head of tile t and consumed a tile later, so no LDS ring, no DMA and no workgroup barrier sit
-// in the head loop (round 1 shared one stream per workgroup through a 4-stage LDS ring with a barrier per tile: 3 %
-// slower on the same box, at a quarter of the L2 traffic -- the 2.3 MB image stays L2 resident either way).  The epsilon
-// epilogue of tile t - 1 goes between the MFMA groups of tile t (the bf16 MFMA leaves the vector port free for 24 of its
-// 32 cycles).
+// in the head loop.  The epsilon epilogue of tile t - 1 goes between the MFMA groups of tile t (the MFMA leaves the
+// vector port free for 24 of its 32 cycles).
 // (included by vx_abi.hip after k_mvn_packed.hip and k_mvn_bwd_b.hip)
 
 #define FB_THREADS 256
 #define FB_WAVES 4                                                   // one per SIMD: 5 or 6 (LDS allows 6) load the SIMDs unevenly -- measured 10-20 % slower
 
 #define FB_WP 32
-#define FB_A_BYTES 12288
+#define FB_A_BYTES 8192                                              // 2 terms x 4 k-steps x 1 KB
 #define FB_AUX_BYTES 1024                                            // the bias fragment
 #define FB_IMG_BYTES (FB_A_BYTES + FB_AUX_BYTES)                     // tile image in global memory
 
@@ -33,13 +33,61 @@ __host__ __device__ inline size_t fb_lds_bytes(int D, int J) {
            (size_t)(pk_off_total(D) / 8 + 4) / 4 * 16 + 512;            // wave regions | OFF group table | SPLIT: entropy parts
 }
 
-// tile image: fragment (split sp, k-step s) at byte (sp * 4 + s) * 1024 + lane * 16, lane = 32 half + row;
-// element j of it = Wp[32 T + row][16 s + 8 (j >> 2) + 4 half + (j & 3)];  a 13th fragment at FB_A_BYTES carries the bias
+// ---- powers of two of the f16x2 operands (vx_common.h), recomputed from the parameters every step by ONE small block.
+// sc[]: 0 W1 scale | 1 its inverse | 2 head-weight scale 2^sw | 3 h scale 2^sh | 4 2^-(sw + sh) | 5 bias scale 2^sb |
+//       6 the bias product's constant 2^(sw + sh - sb) | 7 bound of h | 8 max |W21, W22| | 9 max |b21, b22| | 10 max |W1|
+// h = softplus(W1 y + b1) with y in {-1, 0, 1} is bounded by softplus(max_u (|W1[u, :]|_1 + |b1[u]|)): a scale from that
+// bound cannot overflow, and a bound a few binades above the values costs nothing (fp16 pairs keep 2^-22 relative down
+// to 2^-3 and 2^-25 absolute below it).
+#define FB_NSCALES 16
+__global__ __launch_bounds__(1024) void k_enc_scales(int D, int J, const float* __restrict__ W1, const float* __restrict__ b1,
+                                                     const float* __restrict__ W21, const float* __restrict__ b21,
+                                                     const float* __restrict__ W22, const float* __restrict__ b22,
+                                                     float* __restrict__ sc) {
+    __shared__ float red[4][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = D * (D + 1) / 2;
+    float mw = 0.f, mb = 0.f, m1 = 0.f, l1 = 0.f;
+    for (int e = tid; e < D * 64; e += 1024) mw = fmaxf(mw, fabsf(W21[e]));
+    for (int e = tid; e < T * 64; e += 1024) mw = fmaxf(mw, fabsf(W22[e]));
+    for (int e = tid; e < D; e += 1024) mb = fmaxf(mb, fabsf(b21[e]));
+    for (int e = tid; e < T; e += 1024) mb = fmaxf(mb, fabsf(b22[e]));
+    for (int u = wave; u < 64; u += 16) {                      // hidden unit u: |W1[u, :]|_1 + |b1[u]|
+        float sacc = 0.f;
+        for (int j = lane; j < J; j += 64) { const float w = fabsf(W1[(int64_t)u * J + j]); sacc += w; m1 = fmaxf(m1, w); }
+        sacc = wave_sum(sacc) + fabsf(b1[u]);
+        l1 = fmaxf(l1, sacc);
+    }
+    mw = wave_max_dpp(mw); mb = wave_max_dpp(mb); m1 = wave_max_dpp(m1);
+    if (lane == 0) { red[0][wave] = mw; red[1][wave] = mb; red[2][wave] = m1; red[3][wave] = l1; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w) {
+            mw = fmaxf(mw, red[0][w]); mb = fmaxf(mb, red[1][w]); m1 = fmaxf(m1, red[2][w]); l1 = fmaxf(l1, red[3][w]);
+        }
+        const float hbound = 1.001f * (fmaxf(l1, 0.f) + log1pf(expf(-fabsf(l1)))) + 1e-30f;     // softplus(l1), a hair over
+        const int sw1 = f16_scale_exp(m1), sh = f16_scale_exp(hbound);
+        int sw = f16_scale_exp(mw), sb = f16_scale_exp(mb), eb = sw + sh - sb;
+        // the bias enters the accumulator chain as one more product, (b 2^sb) x 2^eb: the constant must be an fp16 normal
+        if (eb > 15) { sw -= eb - 15; eb = 15; }                // a bias far above |W| |h|: the weights give up headroom
+        if (eb < -14) { sb = sw + sh + 14; eb = -14; }          // a bias far below: it sits lower in the fp16 range
+        sc[0] = ldexpf(1.f, sw1); sc[1] = ldexpf(1.f, -sw1);
+        sc[2] = ldexpf(1.f, sw); sc[3] = ldexpf(1.f, sh); sc[4] = ldexpf(1.f, -(sw + sh));
+        sc[5] = ldexpf(1.f, sb); sc[6] = ldexpf(1.f, eb);
+        sc[7] = hbound; sc[8] = mw; sc[9] = mb; sc[10] = m1;
+    }
+}
+
+// tile image: fragment (term sp, k-step s) at byte (sp * 4 + s) * 1024 + lane * 16, lane = 32 half + row; sp = 0: heads, 1:
+// remainders of Wp 2^sw; element j of it = Wp[32 T + row][16 s + 8 (j >> 2) + 4 half + (j & 3)];  a 9th fragment at
+// FB_A_BYTES carries the bias
 // gt2[group] (OFF groups only): byte offset of eps[l0] | byte offset of x[k] << 12 | (last group of its k) << 31
 __global__ void k_pack_heads_b(int n_tiles, int n_off_groups, const float* __restrict__ Wp, const float* __restrict__ bp,
-                               const uint32_t* __restrict__ gtab, uint8_t* __restrict__ img, uint32_t* __restrict__ gt2) {
+                               const uint32_t* __restrict__ gtab, const float* __restrict__ sc, uint8_t* __restrict__ img,
+                               uint32_t* __restrict__ gt2) {
     const int T = blockIdx.x;
     if (T >= n_tiles) return;
+    const float w_scale = sc[2], b_scale = sc[5];
     uint8_t* out = img + (int64_t)T * FB_IMG_BYTES;
     if (threadIdx.x < 4 && 4 * T + (int)threadIdx.x < n_off_groups) {
         const int G = 4 * T + threadIdx.x;
@@ -50,57 +98,60 @@ __global__ void k_pack_heads_b(int n_tiles, int n_off_groups, const float* __res
     for (int e = threadIdx.x; e < 4 * 64 * 8; e += blockDim.x) {          // (s, lane, j)
         const int j = e & 7, lane = (e >> 3) & 63, s = e >> 9;
         const int half = lane >> 5, row = lane & 31;
-        const float v = Wp[((int64_t)T * 32 + row) * 64 + 16 * s + 8 * (j >> 2) + 4 * half + (j & 3)];
-        const __bf16 h = (__bf16)v;
-        const float r1 = v - (float)h;
-        const __bf16 m = (__bf16)r1;
-        const __bf16 l = (__bf16)(r1 - (float)m);
+        const float v = w_scale * Wp[((int64_t)T * 32 + row) * 64 + 16 * s + 8 * (j >> 2) + 4 * half + (j & 3)];
         uint16_t* o = (uint16_t*)(out + s * 1024 + lane * 16) + j;
-        o[0] = __builtin_bit_cast(uint16_t, h);
-        o[2048] = __builtin_bit_cast(uint16_t, m);                        // + 4 fragments = 4096 bytes
-        o[4096] = __builtin_bit_cast(uint16_t, l);
+        split2h_bits(v, o[0], o[2048]);                                   // + 4 fragments = 4096 bytes
     }
-    // bias fragment (13th): lane = row (half 0), elements 0..2 = the three bf16 terms of the row's bias, the rest zero;
-    // one MFMA against a fragment of ones starts the accumulator chain from the bias
+    // bias fragment (9th): lane = row (half 0), elements 0, 1 = the two fp16 terms of the row's bias 2^sb, the rest zero; one
+    // MFMA against a fragment of the constant 2^(sw + sh - sb) starts the accumulator chain from the (scaled) bias
     for (int e = threadIdx.x; e < FB_AUX_BYTES / 2; e += blockDim.x) {
         const int j = e & 7, lane = e >> 3;
         uint16_t w = 0;
-        if (lane < 32 && j < 3) {
-            const float v = bp[T * 32 + lane];
-            const __bf16 h = (__bf16)v;
-            const float r1 = v - (float)h;
-            const __bf16 m = (__bf16)r1;
-            const __bf16 l = (__bf16)(r1 - (float)m);
-            w = __builtin_bit_cast(uint16_t, j == 0 ? h : j == 1 ? m : l);
+        if (lane < 32 && j < 2) {
+            uint16_t bh, bl;
+            split2h_bits(b_scale * bp[T * 32 + lane], bh, bl);
+            w = j == 0 ? bh : bl;
         }
         ((uint16_t*)(out + FB_A_BYTES))[e] = w;
     }
 }
 
-// fc1 weights as k-step images: k-step ks (items 16 ks .. + 15), fragment (hidden tile ht, split sp) at byte
-// ks * 6144 + (ht * 3 + sp) * 1024 + lane * 16, lane = 32 half + row; element j = W1[32 ht + row][16 ks + 8 half + j]
+// fc1 weights as k-step images: k-step ks (items 16 ks .. + 15), fragment (hidden tile ht, term sp) at byte
+// ks * FB_W1_KS + (ht * 2 + sp) * 1024 + lane * 16, lane = 32 half + row; element j = W1[32 ht + row][16 ks + 8 half + j] 2^sw1
 // (zero past J)
-__host__ __device__ inline int64_t fb_w1img_floats(int J) { return (int64_t)((J + 15) / 16) * (6144 / 4); }
-__global__ void k_pack_w1_b(int J, const float* __restrict__ W1, uint8_t* __restrict__ w1img) {
+#define FB_W1_KS 4096
+__host__ __device__ inline int64_t fb_w1img_floats(int J) { return (int64_t)((J + 15) / 16) * (FB_W1_KS / 4); }
+__global__ void k_pack_w1_b(int J, const float* __restrict__ W1, const float* __restrict__ sc, uint8_t* __restrict__ w1img) {
     const int ks = blockIdx.x;
-    uint8_t* out = w1img + (int64_t)ks * 6144;
+    const float w1_scale = sc[0];
+    uint8_t* out = w1img + (int64_t)ks * FB_W1_KS;
     for (int e = threadIdx.x; e < 2 * 64 * 8; e += blockDim.x) {       // (ht, lane, j)
         const int j = e & 7, lane = (e >> 3) & 63, ht = e >> 9;
         const int half = lane >> 5, hh = 32 * ht + (lane & 31);
         const int it = 16 * ks + 8 * half + j;
-        const float v = it < J ? W1[(int64_t)hh * J + it] : 0.f;
-        const __bf16 h = (__bf16)v;
-        const float r1 = v - (float)h;
-        const __bf16 m = (__bf16)r1;
-        const __bf16 l = (__bf16)(r1 - (float)m);
-        uint16_t* o = (uint16_t*)(out + (ht * 3) * 1024 + lane * 16) + j;
-        o[0] = __builtin_bit_cast(uint16_t, h);
-        o[512] = __builtin_bit_cast(uint16_t, m);
-        o[1024] = __builtin_bit_cast(uint16_t, l);
+        const float v = it < J ? w1_scale * W1[(int64_t)hh * J + it] : 0.f;
+        uint16_t* o = (uint16_t*)(out + (ht * 2) * 1024 + lane * 16) + j;
+        split2h_bits(v, o[0], o[512]);
     }
 }
 
-// eight fp32 values -> three bf16 fragments by truncation: v = hi + mid + lo exactly (8 + 8 + 8 significand bits)
+// the response bytes of one B fragment (items 16 ks + 8 half + 0..7 of a person) as fp16: byte b in {0, 1, 255} ->
+// {0, 1, -1} = (b & 1) * 0x3C00 | (b & 0x80) << 8, two bytes per dword
+__device__ __forceinline__ f16x8 fb_y_frag(const uint32_t* yw) {
+    typedef uint32_t u32x4y __attribute__((ext_vector_type(4)));
+    const uint32_t w0 = yw[0], w1 = yw[1];
+    u32x4y q;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const uint32_t src = (d >> 1) ? w1 : w0;
+        const uint32_t t = (d & 1) ? __builtin_amdgcn_perm(0u, src, 0x0c030c02u) : __builtin_amdgcn_perm(0u, src, 0x0c010c00u);
+        q[d] = (t & 0x00010001u) * 0x3C00u | ((t & 0x00800080u) << 8);
+    }
+    return __builtin_bit_cast(f16x8, q);
+}
+
+// eight fp32 values -> three bf16 fragments by truncation: v = hi + mid + lo exactly (8 + 8 + 8 significand bits); the
+// fc1 weight-gradient kernel (k_fc1_bwd_b.hip) splits ghpre with it
 __device__ __forceinline__ void fb_split8(const float* v, bf16x8& fh, bf16x8& fm, bf16x8& fl) {
     typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
     u32x4v ph, pm, pl;
@@ -135,7 +186,8 @@ template <bool SPLIT>
 __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, int64_t gid0,
     const uint8_t* __restrict__ w1img, const float* __restrict__ b1, const uint8_t* __restrict__ img,
-    const uint32_t* __restrict__ gt2, const float* __restrict__ eps_in, uint64_t seed, uint32_t step, uint32_t stream, float* __restrict__ h_out,
+    const uint32_t* __restrict__ gt2, const float* __restrict__ sc /*k_enc_scales*/, const float* __restrict__ eps_in, uint64_t seed,
+    uint32_t step, uint32_t stream, float* __restrict__ h_out,
     float* __restrict__ x_out, float* __restrict__ eps_out, float* __restrict__ ldT, float* __restrict__ ent_out,
     float* __restrict__ hT_out /*[64][nb] or null*/, float* __restrict__ epsT_out /*[D][nb] or null*/,
     uint8_t* __restrict__ ximg_out /*bf16x3 tile images of x for k_irt_lik_b (k_irt_lik_b.hip), or null*/,
@@ -168,6 +220,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     const int n_sec = pk_sec(D) / 32;
     const int t_end = n_off + 2 * n_sec;
     for (int e = tid; e < 4 * n_off; e += FB_THREADS) gt_lds[e] = gt2[e];   // published by the barrier before the OFF loop
+    const float w1_inv = sc[1], h_scale = sc[3], acc_inv = sc[4];
 
     // ---------------------------------------------------------------- stage this wave's response rows (bytes)
     const int n_ydma = (32 * J + 1023) / 1024;
@@ -232,40 +285,27 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     }
     __builtin_amdgcn_wave_barrier();
     // ---------------------------------------------------------------- phase A: fc1 (+ softplus), both hidden tiles
-    bf16x8 hb[3][4];                                          // [split][k-step]: B fragments of every head tile
+    f16x8 hb[2][4];                                           // [term][k-step]: B fragments of every head tile
     {
         f32x16 hreg[2];
         f32x16 acc0 = zero16(), acc1 = zero16();
-        // pre[hh][p] = sum_j W1[hh][j] yin[p][j] on the bf16 MFMA: the response bytes (-1 / 0 / 1) are exact in bf16, so
-        // three products per 16-item k-step and hidden tile (W1 hi, mid, lo -- split once per step into w1img by
-        // k_pack_w1_b); the six 16-byte fragments of a k-step go global -> registers three k-steps ahead.
+        // pre[hh][p] = sum_j W1[hh][j] yin[p][j] on the fp16 MFMA: the response bytes (-1 / 0 / 1) are exact in fp16, so
+        // two products per 16-item k-step and hidden tile (W1 2^sw1 hi, lo -- split once per step into w1img by
+        // k_pack_w1_b); the four 16-byte fragments of a k-step go global -> registers three k-steps ahead.
         const int n_ks = (J + 15) / 16;
-        auto loadA = [&](bf16x8 (&Af)[6], int ks) __attribute__((always_inline)) {
+        auto loadA = [&](f16x8 (&Af)[4], int ks) __attribute__((always_inline)) {
             ks = ks < n_ks ? ks : n_ks - 1;                   // past the end: reload the last k-step (never used)
-            const uint8_t* src = w1img + (int64_t)ks * 6144 + lane * 16;
+            const uint8_t* src = w1img + (int64_t)ks * FB_W1_KS + lane * 16;
 #pragma unroll
-            for (int f = 0; f < 6; ++f) Af[f] = *(const bf16x8*)(src + f * 1024);
+            for (int f = 0; f < 4; ++f) Af[f] = *(const f16x8*)(src + f * 1024);
         };
-        typedef uint32_t u32x2w __attribute__((ext_vector_type(2)));
-        auto compute = [&](const bf16x8 (&Af)[6], int ks) __attribute__((always_inline)) {
-            // B fragment: items 16 ks + 8 half + 0..7 of person p; byte b in {0, 1, 255} -> bf16 {0, 1, -1}:
-            // (b & 1) * 0x3F80 | (b & 0x80) << 8, two bytes per dword
-            const uint32_t* yw = (const uint32_t*)(Yi + p * ysr + 16 * ks + 8 * half);   // rows are 4-byte aligned
-            const u32x2w w = {yw[0], yw[1]};
-            u32x4w q;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const uint32_t src = w[d >> 1];
-                const uint32_t t = (d & 1) ? __builtin_amdgcn_perm(0u, src, 0x0c030c02u) : __builtin_amdgcn_perm(0u, src, 0x0c010c00u);
-                q[d] = (t & 0x00010001u) * 0x3F80u | ((t & 0x00800080u) << 8);
-            }
-            const bf16x8 yb = __builtin_bit_cast(bf16x8, q);
-            acc0 = mfma_bf16(Af[2], yb, acc0); acc1 = mfma_bf16(Af[5], yb, acc1);
-            acc0 = mfma_bf16(Af[1], yb, acc0); acc1 = mfma_bf16(Af[4], yb, acc1);
-            acc0 = mfma_bf16(Af[0], yb, acc0); acc1 = mfma_bf16(Af[3], yb, acc1);
+        auto compute = [&](const f16x8 (&Af)[4], int ks) __attribute__((always_inline)) {
+            const f16x8 yb = fb_y_frag((const uint32_t*)(Yi + p * ysr + 16 * ks + 8 * half));   // rows are 4-byte aligned
+            acc0 = mfma_f16(Af[1], yb, acc0); acc1 = mfma_f16(Af[3], yb, acc1);
+            acc0 = mfma_f16(Af[0], yb, acc0); acc1 = mfma_f16(Af[2], yb, acc1);
         };
         {
-            bf16x8 A[4][6];
+            f16x8 A[4][4];
             loadA(A[0], 0); loadA(A[1], 1); loadA(A[2], 2);
             for (int c = 0; c < n_ks; c += 4) {
 #pragma unroll
@@ -282,10 +322,10 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
                 const int hh0 = 32 * ht + 8 * g + 4 * half;
                 const float4 bb = *(const float4*)(b1 + hh0);
                 float4 hv;
-                hv.x = softplusf_((ht ? acc1 : acc0)[4 * g + 0] + bb.x);            // vi.py:449
-                hv.y = softplusf_((ht ? acc1 : acc0)[4 * g + 1] + bb.y);
-                hv.z = softplusf_((ht ? acc1 : acc0)[4 * g + 2] + bb.z);
-                hv.w = softplusf_((ht ? acc1 : acc0)[4 * g + 3] + bb.w);
+                hv.x = softplusf_(fmaf((ht ? acc1 : acc0)[4 * g + 0], w1_inv, bb.x));   // vi.py:449
+                hv.y = softplusf_(fmaf((ht ? acc1 : acc0)[4 * g + 1], w1_inv, bb.y));
+                hv.z = softplusf_(fmaf((ht ? acc1 : acc0)[4 * g + 2], w1_inv, bb.z));
+                hv.w = softplusf_(fmaf((ht ? acc1 : acc0)[4 * g + 3], w1_inv, bb.w));
                 hreg[ht][4 * g + 0] = hv.x; hreg[ht][4 * g + 1] = hv.y;
                 hreg[ht][4 * g + 2] = hv.z; hreg[ht][4 * g + 3] = hv.w;
                 if (writer && i < dm.nb) *(float4*)(h_out + i * H + hh0) = hv;
@@ -320,7 +360,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = hreg[s >> 1][8 * (s & 1) + j];
-            fb_split8(v, hb[0][s], hb[1][s], hb[2][s]);
+            split2h_frag(v, h_scale, hb[0][s], hb[1][s]);
         }
     }
     __builtin_amdgcn_wave_barrier();                          // response bytes no longer needed
@@ -347,36 +387,33 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     float ent_acc = 0.f;
     const float* ep = eps_lds + p * DS;
     float* xp = x_lds + p * DX;
-    struct TileRegs { bf16x8 a[3][4]; bf16x8 bias; };
+    struct TileRegs { f16x8 a[2][4]; f16x8 bias; };
     // the fragments of tile t come from the image into registers one tile ahead
     auto pull = [&](TileRegs& R, int t) __attribute__((always_inline)) {
         const int tc = t < t_end ? t : t_end - 1;              // past the end: a harmless duplicate of the last tile
         const uint8_t* gb = img + (int64_t)tc * FB_IMG_BYTES + lane * 16;
-        R.bias = *(const bf16x8*)(gb + FB_A_BYTES);
+        R.bias = *(const f16x8*)(gb + FB_A_BYTES);
 #pragma unroll
-        for (int sp = 2; sp >= 0; --sp)
+        for (int sp = 1; sp >= 0; --sp)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) R.a[sp][s] = *(const bf16x8*)(gb + (sp * 4 + s) * 1024);
+            for (int s = 0; s < 4; ++s) R.a[sp][s] = *(const f16x8*)(gb + (sp * 4 + s) * 1024);
     };
-    const bf16x8 ones8 = __builtin_bit_cast(bf16x8, u32x4w{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
-    // the chain starts from the bias (one MFMA against ones); products in order of increasing magnitude
-    auto mma_lo = [&](const TileRegs& R) __attribute__((always_inline)) -> f32x16 {
-        f32x16 a = mfma_bf16(R.bias, ones8, zero16());
+    // the bias product's constant 2^(sw + sh - sb) in every element (the bias fragment is zero past its two terms)
+    f16x8 cfrag;
+    {
+        const _Float16 c16 = (_Float16)sc[6];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[2][s], hb[0][s], a);
+        for (int j = 0; j < 8; ++j) cfrag[j] = c16;
+    }
+    // the chain starts from the bias (one MFMA against the constant); products in order of increasing magnitude
+    auto mma_all = [&](const TileRegs& R) __attribute__((always_inline)) -> f32x16 {
+        f32x16 a = mfma_f16(R.bias, cfrag, zero16());
 #pragma unroll
-        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[0][s], hb[2][s], a);
+        for (int s = 0; s < 4; ++s) a = mfma_f16(R.a[1][s], hb[0][s], a);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[1][s], hb[1][s], a);
-        return a;
-    };
-    auto mma_hi = [&](const TileRegs& R, f32x16 a) __attribute__((always_inline)) -> f32x16 {
+        for (int s = 0; s < 4; ++s) a = mfma_f16(R.a[0][s], hb[1][s], a);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[1][s], hb[0][s], a);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[0][s], hb[1][s], a);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[0][s], hb[0][s], a);
+        for (int s = 0; s < 4; ++s) a = mfma_f16(R.a[0][s], hb[0][s], a);
         return a;
     };
     // ---- OFF section: x[p][k] += sum_l M[p,(k,l)] eps[p,l]; the partial sum of the current k stays in a register and
@@ -400,7 +437,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         cur_part = fmaf(a[4 * g + 2], e.z, cur_part);
         cur_part = fmaf(a[4 * g + 3], e.w, cur_part);
         if (__builtin_expect((int)code < 0, 0)) {                                 // wave-uniform, rare: the k ends here
-            const float tot = half_sum32(cur_part);
+            const float tot = half_sum32(cur_part) * acc_inv;                     // the powers of two come off once per k
             if (half == 0) {
                 if (SPLIT) atomicAdd((float*)(xp_b + ((code >> 12) & 0xFFFu)), tot);   // two ranges may share this k
                 else *(float*)(xp_b + ((code >> 12) & 0xFFFu)) = tot;
@@ -428,29 +465,25 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         EpiOps E;
         if constexpr (!first) epi_read(E, codeP);
         pull(Rn, t + 1);
-        // the chain starts from the bias (one MFMA against ones); products in order of increasing magnitude; the
-        // epilogue of the previous tile goes between its five parts
-        f32x16 a = mfma_bf16(Rc.bias, ones8, zero16());
-#pragma unroll
-        for (int s = 0; s < 4; ++s) a = mfma_bf16(Rc.a[2][s], hb[0][s], a);
+        // the chain starts from the bias (one MFMA against the constant); products in order of increasing magnitude; the
+        // epilogue of the previous tile goes between its parts
+        f32x16 a = mfma_f16(Rc.bias, cfrag, zero16());
+        a = mfma_f16(Rc.a[1][0], hb[0][0], a);
+        a = mfma_f16(Rc.a[1][1], hb[0][1], a);
         if constexpr (!first) epi_group(accP, E.e4[0], codeP.x, 0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) a = mfma_bf16(Rc.a[1][s], hb[1][s], a);
-        a = mfma_bf16(Rc.a[0][0], hb[2][0], a);
+        a = mfma_f16(Rc.a[1][2], hb[0][2], a);
+        a = mfma_f16(Rc.a[1][3], hb[0][3], a);
+        a = mfma_f16(Rc.a[0][0], hb[1][0], a);
         if constexpr (!first) epi_group(accP, E.e4[1], codeP.y, 1);
-#pragma unroll
-        for (int s = 1; s < 4; ++s) a = mfma_bf16(Rc.a[0][s], hb[2][s], a);
-        a = mfma_bf16(Rc.a[1][0], hb[0][0], a);
-        a = mfma_bf16(Rc.a[1][1], hb[0][1], a);
+        a = mfma_f16(Rc.a[0][1], hb[1][1], a);
+        a = mfma_f16(Rc.a[0][2], hb[1][2], a);
+        a = mfma_f16(Rc.a[0][3], hb[1][3], a);
         if constexpr (!first) epi_group(accP, E.e4[2], codeP.z, 2);
-        a = mfma_bf16(Rc.a[1][2], hb[0][2], a);
-        a = mfma_bf16(Rc.a[1][3], hb[0][3], a);
-#pragma unroll
-        for (int s = 0; s < 3; ++s) a = mfma_bf16(Rc.a[0][s], hb[1][s], a);
+        a = mfma_f16(Rc.a[0][0], hb[0][0], a);
+        a = mfma_f16(Rc.a[0][1], hb[0][1], a);
         if constexpr (!first) epi_group(accP, E.e4[3], codeP.w, 3);
-        a = mfma_bf16(Rc.a[0][3], hb[1][3], a);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) a = mfma_bf16(Rc.a[0][s], hb[0][s], a);
+        a = mfma_f16(Rc.a[0][2], hb[0][2], a);
+        a = mfma_f16(Rc.a[0][3], hb[0][3], a);
         accP = a;
         // the group words of this tile, for its epilogue in the next iteration, from the table in LDS (a scalar load
         // would share lgkmcnt with the LDS reads and return out of order: while one is outstanding every LDS wait
@@ -476,7 +509,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         }
         if (SPLIT) {
             // the range may end inside a k: its partial sum goes to x now (the range that finishes the k adds the rest)
-            const float tot = half_sum32(cur_part);
+            const float tot = half_sum32(cur_part) * acc_inv;
             if (half == 0) atomicAdd((float*)(xp_b + ((codeP.w >> 12) & 0xFFFu)), tot);
             cur_part = 0.f;
         }
@@ -498,14 +531,15 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
                     const f32x4 ev = *(const f32x4*)(ep + kk);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float ld = __expf(a[4 * g + j]);
+                        const float mkk = a[4 * g + j] * acc_inv;
+                        const float ld = __expf(mkk);
                         xo[j] = fmaf(ld, ev[j], xo[j]);
-                        ent_acc += a[4 * g + j];
+                        ent_acc += mkk;
                         if (i < dm.nb) ldT[(int64_t)(kk + j) * dm.nb + i] = ld;
                     }
                 } else {                                       // loc head (vi.py:450)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) xo[j] += a[4 * g + j];
+                    for (int j = 0; j < 4; ++j) xo[j] = fmaf(a[4 * g + j], acc_inv, xo[j]);
                 }
                 *(f32x4*)(xp + kk) = xo;
             }
@@ -513,7 +547,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     };
     auto sec_iter = [&](TileRegs& Rc, TileRegs& Rn, int t) __attribute__((always_inline)) {
         if (t + 1 < t_end) pull(Rn, t + 1);
-        const f32x16 a = mma_hi(Rc, mma_lo(Rc));
+        const f32x16 a = mma_all(Rc);
         tile_sec(a, t);
     };
     if (SPLIT) {
@@ -521,9 +555,9 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         // same 32 entries of x, no other wave touches them
         for (int ts = wave; ts < n_sec; ts += FB_WAVES) {
             pull(RA, n_off + ts);
-            tile_sec(mma_hi(RA, mma_lo(RA)), n_off + ts);
+            tile_sec(mma_all(RA), n_off + ts);
             pull(RA, n_off + n_sec + ts);
-            tile_sec(mma_hi(RA, mma_lo(RA)), n_off + n_sec + ts);
+            tile_sec(mma_all(RA), n_off + n_sec + ts);
         }
         const float ea = ent_acc + __shfl_xor(ent_acc, 32, 64);
         if (half == 0) ent_s[wave * FB_WP + p] = ea;

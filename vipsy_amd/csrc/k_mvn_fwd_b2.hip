@@ -29,8 +29,8 @@ __host__ __device__ inline size_t fb2_lds_bytes(int D, int J) {
 __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
     EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, int64_t gid0,
     const uint8_t* __restrict__ w1img, const float* __restrict__ b1, const uint8_t* __restrict__ img,
-    const uint32_t* __restrict__ gt2, const float* __restrict__ eps_in, uint64_t seed, uint32_t step, uint32_t stream,
-    float* __restrict__ h_out, float* __restrict__ x_out, float* __restrict__ eps_out, float* __restrict__ ldT,
+    const uint32_t* __restrict__ gt2, const float* __restrict__ sc /*k_enc_scales*/, const float* __restrict__ eps_in,
+    uint64_t seed, uint32_t step, uint32_t stream, float* __restrict__ h_out, float* __restrict__ x_out, float* __restrict__ eps_out, float* __restrict__ ldT,
     float* __restrict__ ent_out, float* __restrict__ hT_out, float* __restrict__ epsT_out, uint8_t* __restrict__ ximg_out,
     uint16_t* __restrict__ hs_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -67,6 +67,7 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
     const int n_sec = pk_sec(D) / 32;
     const int t_end = n_off + 2 * n_sec;
     for (int e = tid; e < 4 * n_off; e += FB2_THREADS) gt_lds[e] = gt2[e];
+    const float w1_inv = sc[1], h_scale = sc[3], acc_inv = sc[4];
 
     // ---------------------------------------------------------------- response rows of the wave's 64 persons
     const int n_ydma = (FB2_WP * J + 1023) / 1024;
@@ -95,40 +96,30 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
     __builtin_amdgcn_wave_barrier();
     STAMP();                                                  // 1: y staged
     // ---------------------------------------------------------------- phase A: fc1 (+ softplus) of both person sets
-    bf16x8 hb[NS][3][4];                                      // [set][split][k-step]: B fragments of every head tile
+    f16x8 hb[NS][2][4];                                       // [set][term][k-step]: B fragments of every head tile
     {
         f32x16 acc[NS][2];
 #pragma unroll
         for (int u = 0; u < NS; ++u) { acc[u][0] = zero16(); acc[u][1] = zero16(); }
         const int n_ks = (J + 15) / 16;
-        auto loadA = [&](bf16x8 (&Af)[6], int ks) __attribute__((always_inline)) {
+        auto loadA = [&](f16x8 (&Af)[4], int ks) __attribute__((always_inline)) {
             ks = ks < n_ks ? ks : n_ks - 1;
-            const uint8_t* src = w1img + (int64_t)ks * 6144 + lane * 16;
+            const uint8_t* src = w1img + (int64_t)ks * FB_W1_KS + lane * 16;
 #pragma unroll
-            for (int f = 0; f < 6; ++f) Af[f] = *(const bf16x8*)(src + f * 1024);
+            for (int f = 0; f < 4; ++f) Af[f] = *(const f16x8*)(src + f * 1024);
         };
-        auto compute = [&](const bf16x8 (&Af)[6], int ks) __attribute__((always_inline)) {
+        auto compute = [&](const f16x8 (&Af)[4], int ks) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < NS; ++u) {
-                const uint32_t* yw = (const uint32_t*)(Yi + (32 * u + p) * ysr + 16 * ks + 8 * half);
-                const u32x2w w = {yw[0], yw[1]};
-                u32x4w q;
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const uint32_t src = w[d >> 1];
-                    const uint32_t t = (d & 1) ? __builtin_amdgcn_perm(0u, src, 0x0c030c02u) : __builtin_amdgcn_perm(0u, src, 0x0c010c00u);
-                    q[d] = (t & 0x00010001u) * 0x3F80u | ((t & 0x00800080u) << 8);
-                }
-                const bf16x8 yb = __builtin_bit_cast(bf16x8, q);
-                acc[u][0] = mfma_bf16(Af[2], yb, acc[u][0]); acc[u][1] = mfma_bf16(Af[5], yb, acc[u][1]);
-                acc[u][0] = mfma_bf16(Af[1], yb, acc[u][0]); acc[u][1] = mfma_bf16(Af[4], yb, acc[u][1]);
-                acc[u][0] = mfma_bf16(Af[0], yb, acc[u][0]); acc[u][1] = mfma_bf16(Af[3], yb, acc[u][1]);
+                const f16x8 yb = fb_y_frag((const uint32_t*)(Yi + (32 * u + p) * ysr + 16 * ks + 8 * half));
+                acc[u][0] = mfma_f16(Af[1], yb, acc[u][0]); acc[u][1] = mfma_f16(Af[3], yb, acc[u][1]);
+                acc[u][0] = mfma_f16(Af[0], yb, acc[u][0]); acc[u][1] = mfma_f16(Af[2], yb, acc[u][1]);
             }
         };
         {
-            // W1 fragments five k-steps ahead (a k-step is ~500 cycles, an L2 round trip under load ~2 000)
-            constexpr int RG = 6;
-            bf16x8 A[RG][6];
+            // W1 fragments seven k-steps ahead (a k-step is ~300 cycles, an L2 round trip under load ~2 000)
+            constexpr int RG = 8;
+            f16x8 A[RG][4];
 #pragma unroll
             for (int u = 0; u < RG - 1; ++u) loadA(A[u], u);
             for (int c = 0; c < n_ks; c += RG) {
@@ -160,41 +151,40 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
                     const int hh0 = 32 * ht + 8 * g + 4 * half;
                     const float4 bb = *(const float4*)(b1 + hh0);
                     float4 hv;
-                    hv.x = softplusf_(acc[u][ht][4 * g + 0] + bb.x);               // vi.py:449
-                    hv.y = softplusf_(acc[u][ht][4 * g + 1] + bb.y);
-                    hv.z = softplusf_(acc[u][ht][4 * g + 2] + bb.z);
-                    hv.w = softplusf_(acc[u][ht][4 * g + 3] + bb.w);
+                    hv.x = softplusf_(fmaf(acc[u][ht][4 * g + 0], w1_inv, bb.x));   // vi.py:449
+                    hv.y = softplusf_(fmaf(acc[u][ht][4 * g + 1], w1_inv, bb.y));
+                    hv.z = softplusf_(fmaf(acc[u][ht][4 * g + 2], w1_inv, bb.z));
+                    hv.w = softplusf_(fmaf(acc[u][ht][4 * g + 3], w1_inv, bb.w));
                     hreg[ht][4 * g + 0] = hv.x; hreg[ht][4 * g + 1] = hv.y;
                     hreg[ht][4 * g + 2] = hv.z; hreg[ht][4 * g + 3] = hv.w;
                     if (i < dm.nb) *(float4*)(h_out + i * H + hh0) = hv;
                 }
             }
-            // the B fragments of every head tile: h = t0 + t1 + t2 exactly, each term the next 8 mantissa bits (truncation)
+            // the B fragments of every head tile: h 2^sh as two fp16 terms
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = hreg[s >> 1][8 * (s & 1) + j];
-                fb_split8(v, hb[u][0][s], hb[u][1][s], hb[u][2][s]);
+                split2h_frag(v, h_scale, hb[u][0][s], hb[u][1][s]);
             }
             if (coal) {
-                // (the hs planes take the fragments' terms: exact like the round-to-nearest terms of k_split3_bf16, and
-                // k_mvn_enc_bwd_w_b multiplies all three)
                 __builtin_amdgcn_wave_barrier();                  // (second set: the copies of the first have been read)
 #pragma unroll
                 for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) stT[(32 * ht + crow32(r, half)) * ST_T + p] = hreg[ht][r];
-#pragma unroll
-                for (int t3 = 0; t3 < 3; ++t3)
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const u32x4w w = __builtin_bit_cast(u32x4w, hb[u][t3][s]);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const int hh = 32 * (s >> 1) + crow32(8 * (s & 1) + j, half);
-                            stS[(64 * t3 + hh) * ST_S + p] = (uint16_t)((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xFFFFu));
-                        }
+                    for (int r = 0; r < 16; ++r) {
+                        const int hh = 32 * ht + crow32(r, half);
+                        const float xv = hreg[ht][r];
+                        stT[hh * ST_T + p] = xv;
+                        // the hs planes: the three bf16 terms of h (round to nearest, as k_split3_bf16)
+                        const __bf16 t0 = (__bf16)xv;
+                        const float r1 = xv - (float)t0;
+                        const __bf16 t1 = (__bf16)r1;
+                        const __bf16 t2 = (__bf16)(r1 - (float)t1);
+                        stS[hh * ST_S + p] = __builtin_bit_cast(uint16_t, t0);
+                        stS[(64 + hh) * ST_S + p] = __builtin_bit_cast(uint16_t, t1);
+                        stS[(128 + hh) * ST_S + p] = __builtin_bit_cast(uint16_t, t2);
                     }
                 __builtin_amdgcn_wave_barrier();
                 const int64_t c0 = i0 + 32 * u;
@@ -280,31 +270,30 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
     }
     STAMP();                                                  // 3: eps
     // ---------------------------------------------------------------- phase B: packed head rows, 32 per tile
-    struct TileRegs { bf16x8 a[3][4]; bf16x8 bias; };
+    struct TileRegs { f16x8 a[2][4]; f16x8 bias; };
     auto pull = [&](TileRegs& R, int t) __attribute__((always_inline)) {
         const int tc = t < t_end ? t : t_end - 1;
         const uint8_t* gb = img + (int64_t)tc * FB_IMG_BYTES + lane * 16;
-        R.bias = *(const bf16x8*)(gb + FB_A_BYTES);
+        R.bias = *(const f16x8*)(gb + FB_A_BYTES);
 #pragma unroll
-        for (int sp = 2; sp >= 0; --sp)
+        for (int sp = 1; sp >= 0; --sp)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) R.a[sp][s] = *(const bf16x8*)(gb + (sp * 4 + s) * 1024);
+            for (int s = 0; s < 4; ++s) R.a[sp][s] = *(const f16x8*)(gb + (sp * 4 + s) * 1024);
     };
-    const bf16x8 ones8 = __builtin_bit_cast(bf16x8, u32x4w{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+    f16x8 cfrag;                                              // the bias product's constant 2^(sw + sh - sb)
+    {
+        const _Float16 c16 = (_Float16)sc[6];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cfrag[j] = c16;
+    }
     auto mma_all = [&](const TileRegs& R, int u) __attribute__((always_inline)) -> f32x16 {
-        f32x16 a = mfma_bf16(R.bias, ones8, zero16());
+        f32x16 a = mfma_f16(R.bias, cfrag, zero16());
 #pragma unroll
-        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[2][s], hb[u][0][s], a);
+        for (int s = 0; s < 4; ++s) a = mfma_f16(R.a[1][s], hb[u][0][s], a);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[0][s], hb[u][2][s], a);
+        for (int s = 0; s < 4; ++s) a = mfma_f16(R.a[0][s], hb[u][1][s], a);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[1][s], hb[u][1][s], a);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[1][s], hb[u][0][s], a);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[0][s], hb[u][1][s], a);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) a = mfma_bf16(R.a[0][s], hb[u][0][s], a);
+        for (int s = 0; s < 4; ++s) a = mfma_f16(R.a[0][s], hb[u][0][s], a);
         return a;
     };
     // ---- OFF section: the partial sum of the current k stays in a register per set and goes to x_out when the k ends
@@ -344,7 +333,7 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
         if (__builtin_expect((int)code < 0, 0)) {                                 // wave-uniform, rare: the k ends here
 #pragma unroll
             for (int u = 0; u < NS; ++u) {
-                const float tot = half_sum32(cur_part[u]);
+                const float tot = half_sum32(cur_part[u]) * acc_inv;               // the powers of two come off once per k
                 if (half == 0 && iu[u] < dm.nb) *(float*)((char*)xst[u] + (((code >> 12) & 0xFFFu) << st_sh)) = tot;
                 cur_part[u] = 0.f;
             }
@@ -367,35 +356,33 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
         // product groups
         f32x16 a[NS];
 #pragma unroll
-        for (int u = 0; u < NS; ++u) a[u] = mfma_bf16(Rc.bias, ones8, zero16());
+        for (int u = 0; u < NS; ++u) a[u] = mfma_f16(Rc.bias, cfrag, zero16());
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int u = 0; u < NS; ++u) a[u] = mfma_bf16(Rc.a[2][s], hb[u][0][s], a[u]);
+            for (int u = 0; u < NS; ++u) a[u] = mfma_f16(Rc.a[1][s], hb[u][0][s], a[u]);
         if constexpr (!first) epi_group(accP, E, codeP.x, 0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 2; s < 4; ++s)
 #pragma unroll
-            for (int u = 0; u < NS; ++u) a[u] = mfma_bf16(Rc.a[1][s], hb[u][1][s], a[u]);
+            for (int u = 0; u < NS; ++u) a[u] = mfma_f16(Rc.a[1][s], hb[u][0][s], a[u]);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int u = 0; u < NS; ++u) a[u] = mfma_bf16(Rc.a[0][s], hb[u][2][s], a[u]);
+        for (int u = 0; u < NS; ++u) a[u] = mfma_f16(Rc.a[0][0], hb[u][1][0], a[u]);
         if constexpr (!first) epi_group(accP, E, codeP.y, 1);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 1; s < 4; ++s)
 #pragma unroll
-            for (int u = 0; u < NS; ++u) a[u] = mfma_bf16(Rc.a[1][s], hb[u][0][s], a[u]);
+            for (int u = 0; u < NS; ++u) a[u] = mfma_f16(Rc.a[0][s], hb[u][1][s], a[u]);
         if constexpr (!first) epi_group(accP, E, codeP.z, 2);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int u = 0; u < NS; ++u) a[u] = mfma_bf16(Rc.a[0][s], hb[u][1][s], a[u]);
+            for (int u = 0; u < NS; ++u) a[u] = mfma_f16(Rc.a[0][s], hb[u][0][s], a[u]);
         if constexpr (!first) epi_group(accP, E, codeP.w, 3);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 2; s < 4; ++s)
 #pragma unroll
-            for (int u = 0; u < NS; ++u) a[u] = mfma_bf16(Rc.a[0][s], hb[u][0][s], a[u]);
+            for (int u = 0; u < NS; ++u) a[u] = mfma_f16(Rc.a[0][s], hb[u][0][s], a[u]);
 #pragma unroll
         for (int u = 0; u < NS; ++u) accP[u] = a[u];
         const uint4 cv = *(const uint4*)(gt_lds + 4 * t);
@@ -459,9 +446,10 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
                     f32x4 xn;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float ld = __expf(aD[u][4 * g + j]);   // exp(diag M) eps_k, entropy, ldT  (vi.py:686)
-                        xn[j] = fmaf(ld, ev[j], xo[u][g][j]) + aL[u][4 * g + j];
-                        ent_acc[u] += aD[u][4 * g + j];
+                        const float mkk = aD[u][4 * g + j] * acc_inv;
+                        const float ld = __expf(mkk);                // exp(diag M) eps_k, entropy, ldT  (vi.py:686)
+                        xn[j] = fmaf(aL[u][4 * g + j], acc_inv, fmaf(ld, ev[j], xo[u][g][j]));
+                        ent_acc[u] += mkk;
                         if (live) ldT[(int64_t)(kk + j) * dm.nb + iu[u]] = ld;
                     }
                     if (live) *(f32x4*)(xrow[u] + kk) = xn;

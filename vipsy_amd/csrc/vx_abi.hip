@@ -345,15 +345,20 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
         hipLaunchKernelGGL(k_pack_heads, dim3(Rp), dim3(64), 0, (hipStream_t)hs, (int)cfg->D, 64, W21, b21, W22, b22, Wp,
                            bp, gtab, WpT);
         VX_CHECK_LAUNCH();
+        // the powers of two of the f16x2 operands (the backward kernels read them too: pack_scales below)
+        float* sc = packws + vx_mvn_pack_floats(cfg) - FB_NSCALES;
+        hipLaunchKernelGGL(k_enc_scales, dim3(1), dim3(1024), 0, (hipStream_t)hs, (int)dm.D, (int)dm.J, W1, b1, W21, b21, W22,
+                           b22, sc);
+        VX_CHECK_LAUNCH();
         if (fwb_shape(cfg)) {
             uint8_t* img = (uint8_t*)(WpT + (int64_t)Rp * 64);
             const int n_tiles = fb_tiles(dm.D);
             uint32_t* gt2 = (uint32_t*)(img + (int64_t)n_tiles * FB_IMG_BYTES);
             uint8_t* w1img = img + fb_img_floats(dm.D) * 4;
-            hipLaunchKernelGGL(k_pack_w1_b, dim3((dm.J + 15) / 16), dim3(256), 0, (hipStream_t)hs, dm.J, W1, w1img);
+            hipLaunchKernelGGL(k_pack_w1_b, dim3((dm.J + 15) / 16), dim3(256), 0, (hipStream_t)hs, dm.J, W1, (const float*)sc, w1img);
             VX_CHECK_LAUNCH();
             hipLaunchKernelGGL(k_pack_heads_b, dim3(n_tiles), dim3(256), 0, (hipStream_t)hs, n_tiles,
-                               pk_off_total(dm.D) / 8, Wp, bp, gtab, img, gt2);
+                               pk_off_total(dm.D) / 8, Wp, bp, gtab, (const float*)sc, img, gt2);
             VX_CHECK_LAUNCH();
             const size_t ldsb = fb_lds_bytes(dm.D, dm.J);
             ximg_after.done = true;
@@ -367,7 +372,7 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
                 const unsigned gs = ximg ? (unsigned)(((nb + 63) / 64) * 2) : (unsigned)((nb + FB_WP - 1) / FB_WP);
                 hipLaunchKernelGGL(k_mvn_enc_fwd_b<true>, dim3(gs), dim3(FB_THREADS), ldsb,
                                    (hipStream_t)hs, dm, y, rows, gid0, (const uint8_t*)w1img, b1, (const uint8_t*)img,
-                                   (const uint32_t*)gt2, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT, ximg, hs_out);
+                                   (const uint32_t*)gt2, (const float*)sc, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT, ximg, hs_out);
                 VX_CHECK_LAUNCH();
                 return VX_OK;
             }
@@ -387,8 +392,8 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
                 ProfScope ps("k_mvn_enc_fwd_b2", (hipStream_t)hs, n_done);
                 hipLaunchKernelGGL(k_mvn_enc_fwd_b2, dim3((unsigned)((n_done + FB2_WAVES * FB2_WP - 1) / (FB2_WAVES * FB2_WP))),
                                    dim3(FB2_THREADS), lds2, (hipStream_t)hs, dm, y, rows, gid0, (const uint8_t*)w1img, b1,
-                                   (const uint8_t*)img, (const uint32_t*)gt2, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps,
-                                   ldT, ent, hT, epsT, ximg, hs_out);      // the grid stops at n_done
+                                   (const uint8_t*)img, (const uint32_t*)gt2, (const float*)sc, eps_in, cfg->seed, cfg->step,
+                                   cfg->stream, h, x, eps, ldT, ent, hT, epsT, ximg, hs_out);      // the grid stops at n_done
                 VX_CHECK_LAUNCH();
                 if (n_done == nb) return VX_OK;
             }
@@ -397,8 +402,8 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
             ProfScope ps("k_mvn_enc_fwd_b", (hipStream_t)hs, nb - n_done);
             const dim3 gridb((unsigned)((nb - n_done + FB_WAVES * FB_WP - 1) / (FB_WAVES * FB_WP)));
             hipLaunchKernelGGL(k_mvn_enc_fwd_b<false>, gridb, dim3(FB_THREADS), ldsb, (hipStream_t)hs, dm, y, rows, gid0,
-                               (const uint8_t*)w1img, b1, (const uint8_t*)img, (const uint32_t*)gt2, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT,
-                               ximg, hs_out, n_done);
+                               (const uint8_t*)w1img, b1, (const uint8_t*)img, (const uint32_t*)gt2, (const float*)sc, eps_in, cfg->seed,
+                               cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT, ximg, hs_out, n_done);
             VX_CHECK_LAUNCH();
             return VX_OK;
         }
@@ -771,8 +776,8 @@ int64_t vx_mvn_enc_bwd_hs_offset(const vx_irt_cfg* cfg, int64_t nb) {
 int64_t vx_mvn_pack_floats(const vx_irt_cfg* cfg) {
     if (!enc_cfg_ok(cfg)) return VX_EINVAL;
     const int64_t Rp = pk_rows(cfg->D);
-    // Wp | bp | gtab | WpT | bf16x3 tile images of the heads | bf16x3 k-step images of fc1
-    return Rp * 64 + Rp + Rp / 8 + 8 + Rp * 64 + fb_img_floats(cfg->D) + fb_w1img_floats(cfg->J);
+    // Wp | bp | gtab | WpT | f16x2 tile images of the heads | f16x2 k-step images of fc1 | the operands' powers of two
+    return Rp * 64 + Rp + Rp / 8 + 8 + Rp * 64 + fb_img_floats(cfg->D) + fb_w1img_floats(cfg->J) + FB_NSCALES;
 }
 
 int64_t vx_mvn_enc_param_floats(const vx_irt_cfg* cfg) {
@@ -795,7 +800,8 @@ int64_t vx_mvn_enc_bwd_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
     }
     return nb * H + (int64_t)n_prw * lenw + (int64_t)n_prf * (H * J + H) + (bwt_shape(cfg, nb) ? nb * D + 4 : 0) +
            (bwb_shape(cfg, nb) ? nb * 96 : 0) +            // three bf16 copies of hT
-           (bwhb_shape(cfg, nb) ? hb_img_floats(cfg->D) : 0);   // unit images of the hidden-gradient kernel
+           (bwhb_shape(cfg, nb) ? hb_img_floats(cfg->D) : 0) +  // unit images of the hidden-gradient kernel
+           8;                                              // the step's operand maxima (k_pack_heads_hb)
 }
 
 int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
@@ -825,6 +831,10 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
         n_prw_ws = np0 > np1 ? np0 : np1;
     }
     float* ghpre = workspace;
+    // written by the forward call of this step (k_enc_scales): the powers of two of the f16x2 weight images
+    const float* sc = packws ? packws + vx_mvn_pack_floats(cfg) - FB_NSCALES : nullptr;
+    // the step's largest |gx|, |gd|, |eps|, |ghpre| (float bits; the last words of the workspace)
+    uint32_t* maxw = (uint32_t*)(workspace + vx_mvn_enc_bwd_workspace_floats(cfg, nb) - 8);
     float* slabs_w = ghpre + nb * H;
     float* slabs_f = slabs_w + (int64_t)n_prw_ws * lenw;
     hipStream_t st = (hipStream_t)hs;
@@ -849,7 +859,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
             if (bwhb_shape(cfg, nb)) {
                 float* gdT1 = slabs_f + (int64_t)n_prf * lenf;
                 uint8_t* himg = (uint8_t*)(gdT1 + nb * D + 4 + (bwb_shape(cfg, nb) ? nb * 96 : 0));
-                hipLaunchKernelGGL(k_pack_heads_hb, dim3(hb_units(dm.D)), dim3(256), 0, st, dm.D, W21, W22, himg);
+                hipLaunchKernelGGL(k_pack_heads_hb, dim3(hb_units(dm.D)), dim3(256), 0, st, dm.D, W21, W22, sc, himg, maxw);
                 VX_CHECK_LAUNCH();
                 const size_t ldsh = hb_lds_bytes(dm.D);
                 ProfScope ps("k_mvn_enc_bwd_h_b", st);
@@ -857,14 +867,14 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                     rc = set_lds(k_mvn_enc_bwd_h_b<true>, ldsh);
                     if (rc) return rc;
                     hipLaunchKernelGGL(k_mvn_enc_bwd_h_b<true>, dim3((unsigned)((nb + 31) / 32)), dim3(HB_THREADS), ldsh, st, dm,
-                                       (const uint8_t*)himg, h, eps, gxT, (const float*)gdT1, f1t ? (float*)nullptr : ghpre, hT,
-                                       f1t ? ghpre : (float*)nullptr);
+                                       (const uint8_t*)himg, sc, h, eps, gxT, (const float*)gdT1, f1t ? (float*)nullptr : ghpre, hT,
+                                       f1t ? ghpre : (float*)nullptr, maxw);
                 } else {
                     rc = set_lds(k_mvn_enc_bwd_h_b<false>, ldsh);
                     if (rc) return rc;
                     hipLaunchKernelGGL(k_mvn_enc_bwd_h_b<false>, dim3((unsigned)((nb + 32 * HB_WAVES - 1) / (32 * HB_WAVES))), dim3(HB_THREADS), ldsh, st, dm,
-                                       (const uint8_t*)himg, h, eps, gxT, (const float*)gdT1, f1t ? (float*)nullptr : ghpre, hT,
-                                       f1t ? ghpre : (float*)nullptr);
+                                       (const uint8_t*)himg, sc, h, eps, gxT, (const float*)gdT1, f1t ? (float*)nullptr : ghpre, hT,
+                                       f1t ? ghpre : (float*)nullptr, maxw);
                 }
                 VX_CHECK_LAUNCH();
             } else {

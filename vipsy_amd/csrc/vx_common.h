@@ -52,6 +52,58 @@ __device__ __forceinline__ void split3_frag(const float (&v)[8], bf16x8& fh, bf1
 }
 
 // ---------------------------------------------------------------------------------------------
+// fp16 MFMA 32x32x16 (v_mfma_f32_32x32x16_f16, 32 cycles / SIMD, fp32 accumulate; fragment layout as the bf16 form).
+// f16x2: an fp32 operand, scaled by a power of two into the fp16 range, as TWO fp16 terms v 2^s = hi + lo (round to
+// nearest at both stages: 11 + 11 significand bits, |v 2^s - hi - lo| <= max(2^-22 |v 2^s|, 2^-25) -- fp16 subnormals are
+// honoured by the MFMA, tools/f16_ubench.hip); THREE cross products (lo hi, hi lo, hi hi) reproduce the fp32 product
+// chain (tools/sim16.py: 2.2e-7 of sum |a b| against 2.4e-7 for the fp32 chain itself) in half the matrix-pipe time of
+// the six bf16 products.  The power of two comes off the fp32 accumulator (exact).
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// two fp32 values (already scaled) -> packed fp16 heads and packed fp16 remainders: v_cvt_pk_f16_f32 (round to nearest),
+// the two halves back as floats, the two exact remainders, one more packed conversion
+__device__ __forceinline__ void split2h_pair(float a, float b, uint32_t& ph, uint32_t& pl) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f16x2 h = __builtin_convertvector((f32x2){a, b}, f16x2);
+    float ra = a - (float)h[0], rb = b - (float)h[1];
+    asm("" : "+v"(ra), "+v"(rb));                      // scalar subtractions: packed f32 adds cost more beside MFMAs
+    ph = __builtin_bit_cast(uint32_t, h);
+    pl = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){ra, rb}, f16x2));
+}
+// eight fp32 values times `scale` (a power of two) -> the two fp16 fragments
+__device__ __forceinline__ void split2h_frag(const float (&v)[8], float scale, f16x8& fh, f16x8& fl) {
+    typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+    u32x4s ph, pl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t a, b;
+        split2h_pair(v[2 * q] * scale, v[2 * q + 1] * scale, a, b);
+        ph[q] = a; pl[q] = b;
+    }
+    fh = __builtin_bit_cast(f16x8, ph);
+    fl = __builtin_bit_cast(f16x8, pl);
+}
+// one value for the image builders (host-rate code): bit patterns of the two terms
+__device__ __forceinline__ void split2h_bits(float v, uint16_t& bh, uint16_t& bl) {
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    bh = __builtin_bit_cast(uint16_t, h);
+    bl = __builtin_bit_cast(uint16_t, l);
+}
+// the power of two that brings |v| <= vmax under 2^15 (fp16 overflows at 65504): 2^(15 - e), vmax = m 2^e, 0.5 <= m < 1;
+// vmax = 0 or not finite: 1
+__host__ __device__ __forceinline__ int f16_scale_exp(float vmax) {
+    if (!(vmax > 0.f) || !(vmax < 3.0e38f)) return 0;
+    int e;
+    (void)frexpf(vmax, &e);
+    return 15 - e;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Philox4x32-10 (same spec as oracle/vi_oracle.py::philox4x32_10)
 // ---------------------------------------------------------------------------------------------
 struct u32x4 { uint32_t x, y, z, w; };
