@@ -1,52 +1,61 @@
-// The default form (VX_BF16X3=0 selects k_mvn_enc_bwd_w_t) of the head weight gradients
+// The default form (VX_F16X2=0 selects k_mvn_enc_bwd_w_t) of the head weight gradients
 //     gWp[r][hh] = sum_p V[r][p] h[p][hh],   V = (G or GD row) * (E row or ones),
-// on the bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate): h, the reused operand, as THREE bf16 terms; V, made and
-// split per element, as TWO (head rounded to nearest + rounded remainder, 2^-18 relative and unbiased -- below the fp32
-// accumulation noise of a sum over the persons); FIVE cross products (hh, hm, hl, mh, mm).  tools/bf16x3_ubench.hip: the result is closer to
-// the fp64 value than the exact fp32 MFMA chain (8.5e-8 vs 1.5e-7 of sum |a b|) at a third of the matrix-pipe time,
-// and a bf16 MFMA holds the vector issue port for 8 of its 32 cycles only, so the splitting of V runs in its shadow.
-//   h  : three bf16 arrays hs[3][64][nb] written by the forward kernel (k_split3_bf16 otherwise), staged by DMA, 16-byte
-//        fragments;
-//   V  : fp32 product as before (8 persons per lane half and chunk), then split in registers.
+// on the fp16 MFMA (v_mfma_f32_32x32x16_f16, fp32 accumulate) with two-term operands ("f16x2", vx_common.h): THREE cross
+// products (lo hi, hi lo, hi hi) at the accuracy of the fp32 chain.
+//   h  : two fp16 arrays hs[2][64][nb] (h 2^sh, sc[3] of k_enc_scales) written by the forward kernel (k_split2_f16
+//        otherwise), staged by DMA, 16-byte fragments;
+//   V  : fp32 product (8 persons per lane half and chunk), scaled by ONE power of two for the whole launch -- from the
+//        largest |gx|, |eps|, |gd| of the step, collected by the hidden-gradient kernel that runs before this one
+//        (k_mvn_enc_bwd_h_b; k_absmax3 otherwise) -- then split in registers.
 // Fragment layout of the 32x32x16 MFMA: lane (r = lane & 31, h = lane >> 5) holds A[row r][k = 8h + j] and
 // B[k = 8h + j][col r], j = 0..7; here k = person within a 16-person chunk.
 // (included by vx_abi.hip after k_mvn_bwd_t.hip, whose row layout and helpers it shares)
 
 typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
 
-// row map (128-byte row units): G [0, DR) | E [DR, 2 DR) | H area: 3 splits x 64 rows x 64 bytes = 96 units |
-// GD [2 DR + 96, 3 DR + 96) | C (ones, zeros) [3 DR + 96, 3 DR + 112)
+// row map (128-byte row units): G [0, DR) | E [DR, 2 DR) | H area: 2 terms x 64 rows x 64 bytes = 64 units |
+// GD [2 DR + 64, 3 DR + 64) | C (ones, zeros) [3 DR + 64, 3 DR + 80)   -- the map of k_mvn_bwd_t.hip
 __host__ __device__ inline int bb_row_H(int D) { return 2 * bt_dr(D); }
-__host__ __device__ inline int bb_row_GD(int D) { return 2 * bt_dr(D) + 96; }
-__host__ __device__ inline int bb_row_ones(int D) { return 3 * bt_dr(D) + 96; }
-__host__ __device__ inline int bb_rows(int D) { return 3 * bt_dr(D) + 112; }
-#define BB_BUF 63488
+__host__ __device__ inline int bb_row_GD(int D) { return 2 * bt_dr(D) + 64; }
+__host__ __device__ inline int bb_row_ones(int D) { return 3 * bt_dr(D) + 64; }
+__host__ __device__ inline int bb_rows(int D) { return 3 * bt_dr(D) + 80; }
+#define BB_BUF 59392
 __host__ __device__ inline size_t bb_lds_bytes(int D) { return (size_t)BB_BUF + (size_t)bb_rows(D) * 128; }
-// byte offset inside the H area of hidden row hh of split s3, 16-byte slot s (persons 8 s .. 8 s + 7 of the tile):
+// byte offset inside the H area of hidden row hh of term s3, 16-byte slot s (persons 8 s .. 8 s + 7 of the tile):
 // four rows share a 256-byte bank row; the slot is XORed with (hh >> 2) & 3 so that the 16 lanes of a ds_read_b128
 // group (hh = 0-3, 12-15, 20-27 (+32)) land on 16 different slots
 __host__ __device__ inline uint32_t bb_haddr(int s3, int hh, int s) {
     return (uint32_t)(s3 * 4096 + (hh >> 2) * 256 + ((((hh & 3) << 2) | (s ^ ((hh >> 2) & 3))) << 4));
 }
 
-// hs[s][i] (s = 0, 1, 2) = the three bf16 terms of v[i], round-to-nearest at each stage: v = h + m + l up to 2^-24
-__global__ void k_split3_bf16(const float* __restrict__ v, int64_t n, uint16_t* __restrict__ hs) {
+// hs[s][i] (s = 0, 1) = the two fp16 terms of v[i] * scale[0] (round to nearest at both stages)
+__global__ void k_split2_f16(const float* __restrict__ v, int64_t n, const float* __restrict__ scale, uint16_t* __restrict__ hs) {
+    const float sc0 = scale[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        split2h_bits(v[i] * sc0, hs[i], hs[n + i]);
+}
+
+// out[w] = float bits of max |v_w|, w = 0, 1, 2 (the step's operand maxima when the hidden-gradient kernel that normally
+// collects them is not the one that ran); out must have been cleared
+__global__ void k_absmax3(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, int64_t n,
+                          uint32_t* __restrict__ out) {
+    float m[3] = {0.f, 0.f, 0.f};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float x = v[i];
-        const __bf16 h = (__bf16)x;
-        const float r1 = x - (float)h;
-        const __bf16 m = (__bf16)r1;
-        const __bf16 l = (__bf16)(r1 - (float)m);
-        hs[i] = __builtin_bit_cast(uint16_t, h);
-        hs[n + i] = __builtin_bit_cast(uint16_t, m);
-        hs[2 * n + i] = __builtin_bit_cast(uint16_t, l);
+        m[0] = fmaxf(m[0], fabsf(a[i])); m[1] = fmaxf(m[1], fabsf(b[i])); m[2] = fmaxf(m[2], fabsf(c[i]));
+    }
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+        const float r = wave_max_dpp(m[w]);
+        if ((threadIdx.x & 63) == 0) atomicMax(out + w, __builtin_bit_cast(uint32_t, r));
     }
 }
+__global__ void k_clear_words(uint32_t* __restrict__ w, int n) { if ((int)threadIdx.x < n) w[threadIdx.x] = 0u; }
 
 
 __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
-    EncDims dm, const uint16_t* __restrict__ hs /*[3][64][nb] bf16*/, const float* __restrict__ epsT,
+    EncDims dm, const uint16_t* __restrict__ hs /*[2][64][nb] fp16 terms of h 2^sh*/, const float* __restrict__ epsT,
     const float* __restrict__ gdT, const float* __restrict__ gxT, const uint32_t* __restrict__ gtab,
+    const float* __restrict__ sc /*k_enc_scales*/, const uint32_t* __restrict__ maxw /*float bits: max |gx|, |gd|, |eps|*/,
     float* __restrict__ slabs, int64_t slab_len) {
     extern __shared__ __attribute__((aligned(16))) char smem_bb[];
     const int D = dm.D;
@@ -60,9 +69,17 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
     const int64_t rbase = (int64_t)rb_ * BT_ROWS + (int64_t)wave * BT_RT * 32;
     const int rE = bt_row_E(D), rH = bb_row_H(D), rGD = bb_row_GD(D), rOnes = bb_row_ones(D), rZero = rOnes + 1;
     const bool need_gd = (int64_t)(rb_ + 1) * BT_ROWS > pk_off_total(D);
+    // one power of two for every V of the launch: |V| <= max(|gx|max |eps|max, |gd|max, |gx|max)
+    float v_scale, out_inv;
+    {
+        const float gm = __builtin_bit_cast(float, maxw[0]), dmx = __builtin_bit_cast(float, maxw[1]), em = __builtin_bit_cast(float, maxw[2]);
+        const int sv = f16_scale_exp(fmaxf(fmaxf(gm * em, dmx), gm));
+        v_scale = ldexpf(1.0f, sv);
+        out_inv = ldexpf(1.0f, -sv) / sc[3];                              // takes 2^(sv + sh) off the accumulators
+    }
 
     // ---- per-lane LDS addresses: fp32 rows, persons 16 c + 8 half + 0..7 = chunks 4c + 2 half and + 1
-    uint32_t aG[BT_RT][2], aE[BT_RT][2], aHf[3][2][2];                 // [..][chunk c]; H: [split][hidden tile][chunk]
+    uint32_t aG[BT_RT][2], aE[BT_RT][2], aHf[2][2][2];                 // [..][chunk c]; H: [term][hidden tile][chunk]
 #pragma unroll
     for (int t = 0; t < BT_RT; ++t) {
         const int64_t pr = rbase + 32 * t + l31;
@@ -79,7 +96,7 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
     }
     // second 16-byte piece of a row's pair: chunk index + 1 = slot XOR 1 (4c + 2 half is even)
 #pragma unroll
-    for (int s3 = 0; s3 < 3; ++s3)
+    for (int s3 = 0; s3 < 2; ++s3)
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
@@ -94,9 +111,9 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
     for (int t = 0; t < BT_RT; ++t) { bsum[t] = 0.f; acc[t][0] = zero16(); acc[t][1] = zero16(); }
 
     const int64_t n_ptiles = (nb + BT_P - 1) / BT_P;
-    // DMA transfers of 1 KB (see k_mvn_bwd_t.hip): d < rH / 8: G / E rows; the next 12: the H area (4 per split);
+    // DMA transfers of 1 KB (see k_mvn_bwd_t.hip): d < rH / 8: G / E rows; the next 8: the H area (4 per term);
     // then GD rows.  Per-lane global addresses are fixed; only the person offset of the tile is added.
-    constexpr int BB_MAXD = 15;
+    constexpr int BB_MAXD = 14;
     const int dH0 = rH / 8, dGD0 = rGD / 8;
     const int n_dma = need_gd ? rOnes / 8 : dGD0;
     // per-lane 64-bit source address of transfer u at person 0, and the shift of a person index to bytes (bf16 planes 1,
@@ -108,7 +125,7 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
 #pragma unroll
     for (int u = 0; u < BB_MAXD; ++u) {
         const int d = wave + 4 * u;
-        if (d >= dH0 && d < dGD0) {                                    // H area: 16 hidden rows of one split
+        if (d >= dH0 && d < dGD0) {                                    // H area: 16 hidden rows of one term
             const int dd = d - dH0, s3 = dd >> 2;
             const int hh = 16 * (dd & 3) + 4 * (lane >> 4) + ((lane & 15) >> 2);
             const int s = (lane & 3) ^ ((hh >> 2) & 3);
@@ -159,29 +176,29 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
         }
     };
 
-    // ---- compute: 2 chunks x BT_RT row tiles = 8 groups per tile, 10 MFMAs per group.  The fragments of group g + 1
-    // (4 LDS reads, 4 products, 4 x (split of an element pair), the bias sum) are made in the shadow of the MFMAs of
-    // group g, a few vector instructions after each MFMA; every slice is a pinned scheduling region.  The barrier of a
-    // tile sits before its LAST group, whose operands are in registers already: behind it the buffer is free for the
+    // ---- compute: 2 chunks x BT_RT row tiles = 8 groups per tile, 6 MFMAs per group.  The fragments of group g + 1
+    // (4 LDS reads, 8 products, their scaling, 4 x (split of an element pair), the bias sum) are made in the shadow of the
+    // MFMAs of group g, a few vector instructions after each MFMA; every slice is a pinned scheduling region.  The barrier
+    // of a tile sits before its LAST group, whose operands are in registers already: behind it the buffer is free for the
     // DMA of the tile after next, and the prefetch of that group reads the next tile from the other buffer.
-    // Vector instructions in the shadow of a bf16 MFMA (tools/slice_ubench.hip): about five single-pass ones are free;
-    // v_pk_*_f32 are NOT (they wait for the matrix pipe).  V is split into TWO terms, six instructions per element pair:
-    // head = v_cvt_pk_bf16_f32 (round to nearest, both elements at once), its two halves back as floats (shift / mask),
-    // the two exact remainders, and the remainders packed by the same conversion: V = h + m to 2^-18 relative, unbiased
-    // -- the weight gradient is a sum over the persons whose fp32 accumulation noise (~ sqrt(N) 2^-24) is far above
-    // that, and h (the reused operand) keeps its three terms: five products instead of six.  (Earlier forms: truncation
-    // with and / sub / v_perm_b32, nine instructions a pair.)
+    // Vector instructions in the shadow of an MFMA (tools/slice_ubench.hip): about five single-pass ones are free;
+    // v_pk_*_f32 are NOT (they wait for the matrix pipe).  V 2^sv is split into two fp16 terms, six instructions per
+    // element pair: heads = v_cvt_pk_f16_f32 (round to nearest, both elements at once), the two halves back as floats
+    // (v_cvt_f32_f16, the upper one through SDWA), the two exact remainders, and the remainders packed by the same
+    // conversion.
     // Every instruction of a slice is a volatile asm statement: the optimizer otherwise re-vectorizes the scalar
     // arithmetic into v_pk_*_f32 across slices and sinks whole slices out of the MFMA shadow.  A slice alternates pieces
     // of two element pairs: a vector instruction that depends on the one issued just before it waits for it (measured
     // 1.66 x the issue time).
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    uint32_t fq[2][2][4];                                              // [parity of the group][h, m][element pair]
-    bf16x8 hf[2][3][2];                                                // [parity of the chunk][split][hidden tile]
+    uint32_t fq[2][2][4];                                              // [parity of the group][hi, lo][element pair]
+    f16x8 hf[2][2][2];                                                 // [parity of the chunk][term][hidden tile]
     f32x4 rg0, rg1, re0, re1;
-    float pv_[8], pr_[8], s0, s1, s2, s3;
+    float pv_[8], ps_[8], pr_[8], s0, s1, s2, s3;
     auto amul = [](float x, float y) -> float { float d; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; };
+    auto amuls = [](float x, float y) -> float { float d; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(d) : "s"(x), "v"(y)); return d; };
     auto aadd = [](float x, float y) -> float { float d; asm volatile("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; };
+    const float vsc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v_scale)));
     auto read_raw = [&](const char* rb, uint32_t ag, uint32_t ae) __attribute__((always_inline)) {
         rg0 = *(const f32x4*)(rb + ag); rg1 = *(const f32x4*)(rb + (ag ^ 16u));
         re0 = *(const f32x4*)(rb + ae); re1 = *(const f32x4*)(rb + (ae ^ 16u));
@@ -190,39 +207,44 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
 #pragma unroll
         for (int j = 0; j < 4; ++j) pv_[j] = amul(rg0[j], re0[j]);
         s0 = aadd(pv_[0], pv_[1]); s1 = aadd(pv_[2], pv_[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ps_[j] = amuls(vsc, pv_[j]);
     };
     auto products1 = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) pv_[4 + j] = amul(rg1[j], re1[j]);
         s2 = aadd(pv_[4], pv_[5]); s3 = aadd(pv_[6], pv_[7]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ps_[4 + j] = amuls(vsc, pv_[4 + j]);
     };
     auto asub = [](float x, float y) -> float { float d; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; };
     float th[2][2];                                                    // [pair parity][element]: the heads as floats
     auto acvt = [](float x0, float x1) -> uint32_t {
-        uint32_t d; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(x0), "v"(x1)); return d; };
-    auto alsl16 = [](uint32_t x) -> float { float d; asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(d) : "v"(x)); return d; };
-    auto ahi16 = [](uint32_t x) -> float { float d; asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(d) : "v"(x)); return d; };
+        uint32_t d; asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d) : "v"(x0), "v"(x1)); return d; };
+    auto alo16 = [](uint32_t x) -> float { float d; asm volatile("v_cvt_f32_f16_e32 %0, %1" : "=v"(d) : "v"(x)); return d; };
+    auto ahi16 = [](uint32_t x) -> float {
+        float d; asm volatile("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(d) : "v"(x)); return d; };
     auto C1 = [&](auto pc, auto nc) __attribute__((always_inline)) {
         constexpr int p = decltype(pc)::value, nx = decltype(nc)::value;
-        fq[nx][0][p] = acvt(pv_[2 * p], pv_[2 * p + 1]);
+        fq[nx][0][p] = acvt(ps_[2 * p], ps_[2 * p + 1]);
     };
     auto C2 = [&](auto pc, auto nc) __attribute__((always_inline)) {
         constexpr int p = decltype(pc)::value, nx = decltype(nc)::value;
-        th[p & 1][0] = alsl16(fq[nx][0][p]);
+        th[p & 1][0] = alo16(fq[nx][0][p]);
         th[p & 1][1] = ahi16(fq[nx][0][p]);
     };
     auto C3 = [&](auto pc) __attribute__((always_inline)) {
         constexpr int p = decltype(pc)::value;
-        pr_[2 * p] = asub(pv_[2 * p], th[p & 1][0]);
-        pr_[2 * p + 1] = asub(pv_[2 * p + 1], th[p & 1][1]);
+        pr_[2 * p] = asub(ps_[2 * p], th[p & 1][0]);
+        pr_[2 * p + 1] = asub(ps_[2 * p + 1], th[p & 1][1]);
     };
     auto C4 = [&](auto pc, auto nc) __attribute__((always_inline)) {
         constexpr int p = decltype(pc)::value, nx = decltype(nc)::value;
         fq[nx][1][p] = acvt(pr_[2 * p], pr_[2 * p + 1]);
     };
-    auto frag = [&](auto cc, auto kc) -> bf16x8 {
+    auto frag = [&](auto cc, auto kc) -> f16x8 {
         constexpr int cu = decltype(cc)::value, k = decltype(kc)::value;
-        return __builtin_bit_cast(bf16x8, u32x4{fq[cu][k][0], fq[cu][k][1], fq[cu][k][2], fq[cu][k][3]});
+        return __builtin_bit_cast(f16x8, u32x4{fq[cu][k][0], fq[cu][k][1], fq[cu][k][2], fq[cu][k][3]});
     };
     auto tile_body = [&](auto bc, bool has_next, int64_t stage_tile) {
         constexpr int b = decltype(bc)::value;
@@ -242,50 +264,38 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
             constexpr std::integral_constant<int, 1> I1{};
             constexpr std::integral_constant<int, 2> I2{};
             constexpr std::integral_constant<int, 3> I3{};
-            const bf16x8 vh = frag(curc, I0), vm = frag(curc, I1);
+            const f16x8 vh = frag(curc, I0), vl = frag(curc, I1);
             __builtin_amdgcn_sched_barrier(0);
-            acc[t][0] = mfma_bf16(vh, hf[c][0][0], acc[t][0]);
+            acc[t][0] = mfma_f16(vl, hf[c][0][0], acc[t][0]);
             __builtin_amdgcn_sched_barrier(0);
             read_raw(rb, aG[tn][cn], aE[tn][cn]);
             if constexpr (t == BT_RT - 1) {
 #pragma unroll
-                for (int s3 = 0; s3 < 3; ++s3)
+                for (int s3 = 0; s3 < 2; ++s3)
 #pragma unroll
-                    for (int ht = 0; ht < 2; ++ht) hf[cn][s3][ht] = *(const bf16x8*)(rb + aHf[s3][ht][cn]);
+                    for (int ht = 0; ht < 2; ++ht) hf[cn][s3][ht] = *(const f16x8*)(rb + aHf[s3][ht][cn]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            acc[t][1] = mfma_bf16(vh, hf[c][0][1], acc[t][1]);
-            __builtin_amdgcn_sched_barrier(0);
-            acc[t][0] = mfma_bf16(vh, hf[c][1][0], acc[t][0]);
+            acc[t][1] = mfma_f16(vl, hf[c][0][1], acc[t][1]);
             __builtin_amdgcn_sched_barrier(0);
             products0();
             __builtin_amdgcn_sched_barrier(0);
-            acc[t][1] = mfma_bf16(vh, hf[c][1][1], acc[t][1]);
+            acc[t][0] = mfma_f16(vh, hf[c][1][0], acc[t][0]);
             __builtin_amdgcn_sched_barrier(0);
             products1();
             __builtin_amdgcn_sched_barrier(0);
-            acc[t][0] = mfma_bf16(vh, hf[c][2][0], acc[t][0]);
+            acc[t][1] = mfma_f16(vh, hf[c][1][1], acc[t][1]);
             __builtin_amdgcn_sched_barrier(0);
-            C1(I0, nxtc); C1(I1, nxtc); s0 = aadd(s0, s1); C2(I0, nxtc);
-            __builtin_amdgcn_sched_barrier(0);
-            acc[t][1] = mfma_bf16(vh, hf[c][2][1], acc[t][1]);
-            __builtin_amdgcn_sched_barrier(0);
-            C2(I1, nxtc); C3(I0); C1(I2, nxtc);
-            __builtin_amdgcn_sched_barrier(0);
-            acc[t][0] = mfma_bf16(vm, hf[c][0][0], acc[t][0]);
-            __builtin_amdgcn_sched_barrier(0);
+            C1(I0, nxtc); C1(I1, nxtc); s0 = aadd(s0, s1); C2(I0, nxtc); C2(I1, nxtc); C3(I0); C1(I2, nxtc);
             C3(I1); C4(I0, nxtc); s2 = aadd(s2, s3); C1(I3, nxtc); s0 = aadd(s0, s2);
             __builtin_amdgcn_sched_barrier(0);
-            acc[t][1] = mfma_bf16(vm, hf[c][0][1], acc[t][1]);
+            acc[t][0] = mfma_f16(vh, hf[c][0][0], acc[t][0]);
             __builtin_amdgcn_sched_barrier(0);
             C2(I2, nxtc); C4(I1, nxtc); C2(I3, nxtc);
             if constexpr (last) bsum[tn] = aadd(bsum[tn], has_next ? s0 : 0.f); else bsum[tn] = aadd(bsum[tn], s0);
-            __builtin_amdgcn_sched_barrier(0);
-            acc[t][0] = mfma_bf16(vm, hf[c][1][0], acc[t][0]);
-            __builtin_amdgcn_sched_barrier(0);
             C3(I2); C3(I3);
             __builtin_amdgcn_sched_barrier(0);
-            acc[t][1] = mfma_bf16(vm, hf[c][1][1], acc[t][1]);
+            acc[t][1] = mfma_f16(vh, hf[c][0][1], acc[t][1]);
             __builtin_amdgcn_sched_barrier(0);
             C4(I2, nxtc); C4(I3, nxtc);
             __builtin_amdgcn_sched_barrier(0);
@@ -301,9 +311,9 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
         // fragments of the first group, outside the pipeline
         read_raw(smem_bb, aG[0][0], aE[0][0]);
 #pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3)
+        for (int s3 = 0; s3 < 2; ++s3)
 #pragma unroll
-            for (int ht = 0; ht < 2; ++ht) hf[0][s3][ht] = *(const bf16x8*)(smem_bb + aHf[s3][ht][0]);
+            for (int ht = 0; ht < 2; ++ht) hf[0][s3][ht] = *(const f16x8*)(smem_bb + aHf[s3][ht][0]);
         products0();
         products1();
         {
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = rbase + 32 * t + crow32(r, half);
-                if (row < Rp) slab[row * 64 + hh] = acc[t][ht][r];
+                if (row < Rp) slab[row * 64 + hh] = acc[t][ht][r] * out_inv;
             }
         }
         const float bt = half_sum32(bsum[t]);

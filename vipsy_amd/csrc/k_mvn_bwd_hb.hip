@@ -40,7 +40,8 @@ __host__ __device__ inline size_t hb_lds_bytes(int D) {
 // unit image: fragment (hidden tile ht, term sp) at byte (ht * 2 + sp) * 1024 + lane * 16, lane = 32 half + row;
 // element j = the weight (times 2^sw, sc[2] of k_enc_scales) of hidden unit 32 ht + row for contraction index
 // c = 16 s + 8 half + j:
-//   OFF unit (k, s): W22[(k, c)] for c < k;   DIAG unit s: W22[(c, c)];   LOC unit s: W21[c]       (zero past the end)
+//   OFF unit (k, s): W22[(k, c)] for c < k;   LOC unit s: W21[c];   DIAG unit s: W22[(c, c)]       (zero past the end)
+// in that order (the 64-person kernel replaces its gx tile by the gd tile while the LOC units run).
 // Block 0 also clears the words that collect the largest |gx|, |gd|, |eps| and |ghpre| of the step (the kernel below adds
 // its waves' maxima; k_mvn_enc_bwd_w_b and k_fc1_bwd_b scale by them).
 __global__ void k_pack_heads_hb(int D, const float* __restrict__ W21, const float* __restrict__ W22,
@@ -60,7 +61,7 @@ __global__ void k_pack_heads_hb(int D, const float* __restrict__ W21, const floa
         }
         s = rem;
     } else {
-        type = (u - n_off) < ns ? 1 : 2;
+        type = (u - n_off) < ns ? 2 : 1;                               // the LOC units first, the DIAG units last
         s = (u - n_off) % ns;
     }
     uint8_t* out = img + (int64_t)u * HB_UNIT_BYTES;
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
         // ---- DIAG (operand gd) and LOC (operand gx) units: s = wave, wave + 8, ..
         const int u_sec = hb_units_off(D);
         {
-            const float cinv = frags_from_T(gdT, d_max);
+            const float cinv = frags_from_T(gxT, x_max);
             f32x16 S0 = zero16(), S1 = zero16();
             static_for<HB_NS>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
             for (int r = 0; r < 16; ++r) { gh0[r] = fmaf(cinv, S0[r], gh0[r]); gh1[r] = fmaf(cinv, S1[r], gh1[r]); }
         }
         {
-            const float cinv = frags_from_T(gxT, x_max);
+            const float cinv = frags_from_T(gdT, d_max);
             f32x16 S0 = zero16(), S1 = zero16();
             static_for<HB_NS>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
@@ -328,9 +329,9 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
             for (int r = 0; r < 16; ++r) { gh0[r] = fmaf(gk, U0[r], gh0[r]); gh1[r] = fmaf(gk, U1[r], gh1[r]); }
         }
     });
-    // ---- DIAG rows (operand gd) and LOC rows (operand gx): an accumulator pair of their own, added with their power of two
+    // ---- LOC rows (operand gx) and DIAG rows (operand gd): an accumulator pair of their own, added with their power of two
     {
-        const float cinv = frags_from_T(gdT, d_max);
+        const float cinv = frags_from_T(gxT, x_max);
         f32x16 S0 = zero16(), S1 = zero16();
         static_for<HB_NS>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
         for (int r = 0; r < 16; ++r) { gh0[r] = fmaf(cinv, S0[r], gh0[r]); gh1[r] = fmaf(cinv, S1[r], gh1[r]); }
     }
     {
-        const float cinv = frags_from_T(gxT, x_max);
+        const float cinv = frags_from_T(gdT, d_max);
         f32x16 S0 = zero16(), S1 = zero16();
         static_for<HB_NS>([&](auto sc) {
             constexpr int s = decltype(sc)::value;

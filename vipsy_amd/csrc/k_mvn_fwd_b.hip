@@ -191,7 +191,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     float* __restrict__ x_out, float* __restrict__ eps_out, float* __restrict__ ldT, float* __restrict__ ent_out,
     float* __restrict__ hT_out /*[64][nb] or null*/, float* __restrict__ epsT_out /*[D][nb] or null*/,
     uint8_t* __restrict__ ximg_out /*bf16x3 tile images of x for k_irt_lik_b (k_irt_lik_b.hip), or null*/,
-    uint16_t* __restrict__ hs_out /*[3][64][nb] bf16 terms of h for k_mvn_enc_bwd_w_b (what k_split3_bf16 makes), or null*/,
+    uint16_t* __restrict__ hs_out /*[2][64][nb] fp16 terms of h 2^sh for k_mvn_enc_bwd_w_b (what k_split2_f16 makes), or null*/,
     int64_t i_base = 0 /*first person of this launch (a multiple of 64): the persons before it belong to another launch*/) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
@@ -337,21 +337,14 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) hT_out[(int64_t)(32 * ht + crow32(r, half)) * dm.nb + i] = hreg[ht][r];
         }
-        if (writer && hs_out && i < dm.nb) {                  // ... and its three bf16 terms (round to nearest, as k_split3_bf16)
+        if (writer && hs_out && i < dm.nb) {                  // ... and the two fp16 terms of h 2^sh (as k_split2_f16)
             const int64_t plane = (int64_t)64 * dm.nb;
 #pragma unroll
             for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float xv = hreg[ht][r];
-                    const __bf16 t0 = (__bf16)xv;
-                    const float r1 = xv - (float)t0;
-                    const __bf16 t1 = (__bf16)r1;
-                    const __bf16 t2 = (__bf16)(r1 - (float)t1);
                     const int64_t o = (int64_t)(32 * ht + crow32(r, half)) * dm.nb + i;
-                    hs_out[o] = __builtin_bit_cast(uint16_t, t0);
-                    hs_out[plane + o] = __builtin_bit_cast(uint16_t, t1);
-                    hs_out[2 * plane + o] = __builtin_bit_cast(uint16_t, t2);
+                    split2h_bits(hreg[ht][r] * h_scale, hs_out[o], hs_out[plane + o]);
                 }
         }
         // k-step s of the head GEMM takes accumulator registers 8 (s & 1) .. + 7 of hidden tile s >> 1

@@ -134,10 +134,10 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
         // Dimension-major outputs from the C layout are one 128-byte (hT) or 64-byte (hs) row piece per store instruction,
         // 128 of them per person set, and the phase is bound by store issue.  A whole wave on 16-byte aligned rows
         // transposes through the LDS region the response bytes have left instead: 16 bytes per lane, 20 instructions.
-        constexpr int ST_T = 36, ST_S = 40;                   // row strides of the stages: [64][36] f32 | [3 * 64][40] u16
+        constexpr int ST_T = 36, ST_S = 40;                   // row strides of the stages: [64][36] f32 | [2 * 64][40] u16
         const bool coal = i0 + FB2_WP <= dm.nb && (dm.nb & 7) == 0 && hT_out && hs_out &&
                           (((uintptr_t)hT_out | (uintptr_t)hs_out) & 15) == 0 &&
-                          fb2_wave_floats(D, J) * sizeof(float) >= 64 * ST_T * 4 + 192 * ST_S * 2;   // wave-uniform
+                          fb2_wave_floats(D, J) * sizeof(float) >= 64 * ST_T * 4 + 128 * ST_S * 2;   // wave-uniform
         float* stT = R1;
         uint16_t* stS = (uint16_t*)(R1 + 64 * ST_T);
 #pragma unroll
@@ -173,18 +173,18 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
 #pragma unroll
                 for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int hh = 32 * ht + crow32(r, half);
-                        const float xv = hreg[ht][r];
-                        stT[hh * ST_T + p] = xv;
-                        // the hs planes: the three bf16 terms of h (round to nearest, as k_split3_bf16)
-                        const __bf16 t0 = (__bf16)xv;
-                        const float r1 = xv - (float)t0;
-                        const __bf16 t1 = (__bf16)r1;
-                        const __bf16 t2 = (__bf16)(r1 - (float)t1);
-                        stS[hh * ST_S + p] = __builtin_bit_cast(uint16_t, t0);
-                        stS[(64 + hh) * ST_S + p] = __builtin_bit_cast(uint16_t, t1);
-                        stS[(128 + hh) * ST_S + p] = __builtin_bit_cast(uint16_t, t2);
+                    for (int r = 0; r < 16; ++r) stT[(32 * ht + crow32(r, half)) * ST_T + p] = hreg[ht][r];
+                // the hs planes (operand of k_mvn_enc_bwd_w_b) take the fragments' two fp16 terms of h 2^sh
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const u32x4w w = __builtin_bit_cast(u32x4w, hb[u][t2][s]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int hh = 32 * (s >> 1) + crow32(8 * (s & 1) + j, half);
+                            stS[(64 * t2 + hh) * ST_S + p] = (uint16_t)((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xFFFFu));
+                        }
                     }
                 __builtin_amdgcn_wave_barrier();
                 const int64_t c0 = i0 + 32 * u;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
                     *(f32x4*)(hT_out + (int64_t)hh * dm.nb + c0 + 4 * g) = *(const f32x4*)(stT + hh * ST_T + 4 * g);
                 }
 #pragma unroll
-                for (int it = 0; it < 12; ++it) {                 // hs: 3 x 64 rows x 4 pieces of 8 persons
+                for (int it = 0; it < 8; ++it) {                  // hs: 2 x 64 rows x 4 pieces of 8 persons
                     const int e = lane + 64 * it, row = e >> 2, g = e & 3;
                     *(u32x4w*)(hs_out + (int64_t)row * dm.nb + c0 + 8 * g) = *(const u32x4w*)(stS + row * ST_S + 8 * g);
                 }
@@ -204,21 +204,14 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
 #pragma unroll
                     for (int r = 0; r < 16; ++r) hT_out[(int64_t)(32 * ht + crow32(r, half)) * dm.nb + i] = hreg[ht][r];
             }
-            if (!coal && hs_out && i < dm.nb) {                   // the three bf16 terms of hT (round to nearest, as k_split3_bf16)
+            if (!coal && hs_out && i < dm.nb) {                   // the two fp16 terms of hT 2^sh (as k_split2_f16)
                 const int64_t plane = (int64_t)64 * dm.nb;
 #pragma unroll
                 for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float xv = hreg[ht][r];
-                        const __bf16 t0 = (__bf16)xv;
-                        const float r1 = xv - (float)t0;
-                        const __bf16 t1 = (__bf16)r1;
-                        const __bf16 t2 = (__bf16)(r1 - (float)t1);
                         const int64_t o = (int64_t)(32 * ht + crow32(r, half)) * dm.nb + i;
-                        hs_out[o] = __builtin_bit_cast(uint16_t, t0);
-                        hs_out[plane + o] = __builtin_bit_cast(uint16_t, t1);
-                        hs_out[2 * plane + o] = __builtin_bit_cast(uint16_t, t2);
+                        split2h_bits(hreg[ht][r] * h_scale, hs_out[o], hs_out[plane + o]);
                     }
             }
         }

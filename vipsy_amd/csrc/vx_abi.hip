@@ -21,6 +21,7 @@
 #include "k_mvn_fwd_b.hip"
 #include "k_mvn_fwd_b2.hip"
 #include "k_mvn_bwd_hb.hip"
+#include "k_mvn_bwd_hb2.hip"
 #include "k_fc1_bwd_b.hip"
 #include "k_cdm_sf.hip"
 #include "k_synth.hip"
@@ -330,11 +331,12 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
     // ... and the bf16 terms of hT (the head weight-gradient kernel's operand) to this pass over hT
     if (hs_out && (!hT || cfg->H != 64)) return VX_EINVAL;
     struct HsAfter {
-        uint16_t* out; const float* hT; int64_t nb; hipStream_t st; bool done;
+        uint16_t* out; const float* hT; int64_t nb; hipStream_t st; bool done; const float* hscale;
         ~HsAfter() {
-            if (out && !done) hipLaunchKernelGGL(k_split3_bf16, dim3(num_cu() * 8), dim3(256), 0, st, hT, nb * 64, out);
+            if (out && !done && hscale)
+                hipLaunchKernelGGL(k_split2_f16, dim3(num_cu() * 8), dim3(256), 0, st, hT, nb * 64, hscale, out);
         }
-    } hs_after{hs_out, hT, nb, (hipStream_t)hs, false};
+    } hs_after{hs_out, hT, nb, (hipStream_t)hs, false, nullptr};
     if (packed_ok(cfg) && packws && aligned16(packws) && aligned16(y) && aligned16(W1) && aligned16(b1) &&
         aligned16(W21) && aligned16(W22) && aligned16(h)) {
         const int Rp = pk_rows(cfg->D);
@@ -347,6 +349,7 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
         VX_CHECK_LAUNCH();
         // the powers of two of the f16x2 operands (the backward kernels read them too: pack_scales below)
         float* sc = packws + vx_mvn_pack_floats(cfg) - FB_NSCALES;
+        hs_after.hscale = sc + 3;
         hipLaunchKernelGGL(k_enc_scales, dim3(1), dim3(1024), 0, (hipStream_t)hs, (int)dm.D, (int)dm.J, W1, b1, W21, b21, W22,
                            b22, sc);
         VX_CHECK_LAUNCH();
@@ -799,7 +802,7 @@ int64_t vx_mvn_enc_bwd_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
         if (np > n_prw) n_prw = np;
     }
     return nb * H + (int64_t)n_prw * lenw + (int64_t)n_prf * (H * J + H) + (bwt_shape(cfg, nb) ? nb * D + 4 : 0) +
-           (bwb_shape(cfg, nb) ? nb * 96 : 0) +            // three bf16 copies of hT
+           (bwb_shape(cfg, nb) ? nb * 64 : 0) +            // two fp16 copies of hT 2^sh
            (bwhb_shape(cfg, nb) ? hb_img_floats(cfg->D) : 0) +  // unit images of the hidden-gradient kernel
            8;                                              // the step's operand maxima (k_pack_heads_hb)
 }
@@ -840,6 +843,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     hipStream_t st = (hipStream_t)hs;
     int rc;
     bool f1t = false;                                      // fc1 gradient on the dimension-major kernel (ghpre holds ghpreT)
+    bool maxw_ready = false;                               // k_mvn_enc_bwd_h_b ran: the operand maxima of the step are collected
     if (packed) {
         const float* Wp = packws;
         const uint32_t* gtab = (const uint32_t*)(packws + Rp * 64 + Rp);
@@ -858,9 +862,10 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                   f1_lds_bytes(cfg->J) <= 160 * 1024;
             if (bwhb_shape(cfg, nb)) {
                 float* gdT1 = slabs_f + (int64_t)n_prf * lenf;
-                uint8_t* himg = (uint8_t*)(gdT1 + nb * D + 4 + (bwb_shape(cfg, nb) ? nb * 96 : 0));
+                uint8_t* himg = (uint8_t*)(gdT1 + nb * D + 4 + (bwb_shape(cfg, nb) ? nb * 64 : 0));
                 hipLaunchKernelGGL(k_pack_heads_hb, dim3(hb_units(dm.D)), dim3(256), 0, st, dm.D, W21, W22, sc, himg, maxw);
                 VX_CHECK_LAUNCH();
+                maxw_ready = true;
                 const size_t ldsh = hb_lds_bytes(dm.D);
                 ProfScope ps("k_mvn_enc_bwd_h_b", st);
                 if (nb <= HB_SPLIT_MAX) {                               // small batch: the eight waves of a workgroup share the units
@@ -869,6 +874,14 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                     hipLaunchKernelGGL(k_mvn_enc_bwd_h_b<true>, dim3((unsigned)((nb + 31) / 32)), dim3(HB_THREADS), ldsh, st, dm,
                                        (const uint8_t*)himg, sc, h, eps, gxT, (const float*)gdT1, f1t ? (float*)nullptr : ghpre, hT,
                                        f1t ? ghpre : (float*)nullptr, maxw);
+                } else if (dm.D <= 112 && hb2_lds_bytes(dm.D) <= 160 * 1024) {
+                    // large batch: 64 persons per wave, batches of four units per barrier (k_mvn_bwd_hb2.hip)
+                    const size_t lds2 = hb2_lds_bytes(dm.D);
+                    rc = set_lds(k_mvn_enc_bwd_h_b2<7>, lds2);
+                    if (rc) return rc;
+                    hipLaunchKernelGGL(k_mvn_enc_bwd_h_b2<7>, dim3((unsigned)((nb + HB2_WAVES * HB2_WP - 1) / (HB2_WAVES * HB2_WP))),
+                                       dim3(HB2_THREADS), lds2, st, dm, (const uint8_t*)himg, sc, h, eps, gxT, (const float*)gdT1,
+                                       f1t ? (float*)nullptr : ghpre, hT, f1t ? ghpre : (float*)nullptr, maxw);
                 } else {
                     rc = set_lds(k_mvn_enc_bwd_h_b<false>, ldsh);
                     if (rc) return rc;
@@ -896,8 +909,13 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
         if (use_t && bwb_shape(cfg, nb)) {
             float* gdT = slabs_f + (int64_t)n_prf * lenf;
             uint16_t* hs3 = (uint16_t*)(gdT + nb * D + 4);
-            if (!(gd_ready & 2)) {                             // bit 1: the forward call already wrote the bf16 terms of hT here
-                hipLaunchKernelGGL(k_split3_bf16, dim3(num_cu() * 8), dim3(256), 0, st, hT, nb * 64, hs3);
+            if (!(gd_ready & 2)) {                             // bit 1: the forward call already wrote the fp16 terms of hT here
+                hipLaunchKernelGGL(k_split2_f16, dim3(num_cu() * 8), dim3(256), 0, st, hT, nb * 64, sc + 3, hs3);
+                VX_CHECK_LAUNCH();
+            }
+            if (!maxw_ready) {                                 // the operand maxima, normally collected by k_mvn_enc_bwd_h_b
+                hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(64), 0, st, maxw, 4);
+                hipLaunchKernelGGL(k_absmax3, dim3(num_cu() * 8), dim3(256), 0, st, gxT, (const float*)gdT, epsT, nb * D, maxw);
                 VX_CHECK_LAUNCH();
             }
             const size_t lds = bb_lds_bytes(dm.D);
@@ -905,7 +923,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
             if (rc) return rc;
             ProfScope ps("k_mvn_enc_bwd_w_b", st);
             hipLaunchKernelGGL(k_mvn_enc_bwd_w_b, dim3((unsigned)n_rowslabs, (unsigned)n_prw), dim3(BT_THREADS), lds, st,
-                               dm, hs3, epsT, gdT, gxT, gtab, slabs_w, Rp * (H + 1));
+                               dm, hs3, epsT, gdT, gxT, gtab, sc, (const uint32_t*)maxw, slabs_w, Rp * (H + 1));
             VX_CHECK_LAUNCH();
         } else if (use_t) {
             const size_t lds = bt_lds_bytes(dm.D);

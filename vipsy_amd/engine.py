@@ -746,7 +746,7 @@ class IrtEngine(_EngineBase):
             encb_ws = self._buf("encb_ws", be.mvn_enc_bwd_workspace(cfg, nb))
             hs_off = be.mvn_enc_bwd_hs_offset(cfg, nb)     # the weight-gradient kernel's bf16 terms of hT, written by the forward
             if hs_off >= 0:
-                fw["hs"] = encb_ws[hs_off:hs_off + nb * 96]
+                fw["hs"] = encb_ws[hs_off:hs_off + nb * 64]
             with self._phase("guide_forward"):
                 be.mvn_enc_forward(cfg, self.y, rows, nb, self.gid0, enc, eps, fw)
             gd_off = be.mvn_enc_bwd_gd_offset(cfg, nb)     # the backward's DIAG-row operand, made in the likelihood's last pass
