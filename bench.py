@@ -7,7 +7,9 @@ to 1M persons).  One "step" = one svi.step: guide forward, likelihood + gradient
 the 1M-person problem is fixed, every rank owns N / world persons).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            # N > 1, no launcher around it: starts its N ranks itself
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W               # under a launcher: one rank per GPU, RCCL
 
 Prints ONE JSON line on rank 0 (see the field notes in DESIGN.md section "Measurement").
 """
@@ -25,12 +27,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: dense bf16 matrix peak
-# an fp32 product computed as three bf16 terms per operand costs six bf16 MFMA products:
-PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
-PEAK_BF16X5_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 5.0   # backward kernels: the per-person operand in two terms, five products
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: dense bf16 / fp16 matrix peak (the fp16 forms take the same cycles)
+# an fp32 product computed from two fp16 terms per operand costs three fp16 MFMA products:
+PEAK_F16X2_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBS = 8000.0
-PROFILE_TAG = "r02_headline"
+PROFILE_TAG = "r03_headline"
 
 WORKLOADS = {
     # name: (model, N, J, D, H, amortized, missing)
@@ -55,14 +56,15 @@ def kernel_model(name, J, D, H):
     multidimensional step (2 flops per multiply-add)."""
     T = D * (D + 1) // 2
     heads = 2.0 * (H * D + H * T)
+    f16x2 = "f32 via two fp16 terms per operand (f16x2, 2^-22), three products on the fp16 MFMA, fp32 accumulate"
     table = {
-        "k_mvn_enc_fwd_b": (enc_fwd_flops_per_person(J, D, H), PEAK_BF16X3_TFLOPS, "f32 via bf16x3 on the bf16 MFMA"),
-        "k_mvn_enc_fwd_b2": (enc_fwd_flops_per_person(J, D, H), PEAK_BF16X3_TFLOPS, "f32 via bf16x3 on the bf16 MFMA"),
+        "k_mvn_enc_fwd_b": (enc_fwd_flops_per_person(J, D, H), PEAK_F16X2_TFLOPS, f16x2),
+        "k_mvn_enc_fwd_b2": (enc_fwd_flops_per_person(J, D, H), PEAK_F16X2_TFLOPS, f16x2),
         "k_mvn_enc_fwd_p": (enc_fwd_flops_per_person(J, D, H), PEAK_F32_MFMA_TFLOPS, "f32 MFMA"),
         "k_mvn_enc_bwd_h_t": (heads, PEAK_F32_MFMA_TFLOPS, "f32 MFMA"),
-        "k_mvn_enc_bwd_h_b": (heads, PEAK_BF16X5_TFLOPS, "f32 via bf16 terms (3 x 2, five products) on the bf16 MFMA"),
+        "k_mvn_enc_bwd_h_b": (heads, PEAK_F16X2_TFLOPS, f16x2),
         "k_mvn_enc_bwd_w_t": (heads, PEAK_F32_MFMA_TFLOPS, "f32 MFMA"),
-        "k_mvn_enc_bwd_w_b": (heads, PEAK_BF16X5_TFLOPS, "f32 via bf16 terms (3 x 2, five products) on the bf16 MFMA"),
+        "k_mvn_enc_bwd_w_b": (heads, PEAK_F16X2_TFLOPS, f16x2),
         "k_irt_lik_r": (2.0 * 3 * (D + 1) * J, PEAK_F32_MFMA_TFLOPS, "f32 MFMA"),        # Z, gx, GA
         "k_irt_lik_b": (2.0 * 3 * (D + 1) * J, PEAK_BF16_MFMA_TFLOPS * 3.0 / 16.0,
                         "f32 via bf16 terms on the bf16 MFMA (Z: six products, gx and GA: five)"),
@@ -84,6 +86,25 @@ def measured_traffic(kernel_prefix):
         if name.split("<")[0].split("(")[0] == kernel_prefix:          # template arguments are part of the traced name
             return float(v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"])
     return None
+
+
+def physical_bytes(workload):
+    """HBM bytes one launch of the D = 1 step kernel physically moves (PMC, committed summaries of round 2: the kernels of
+    these workloads have not changed since), or None."""
+    tag = {"irt2pl_1d_bbvi_missing90_1Mx500": "r02_cfg4", "irt4pl_1d_bbvi_100kx100": "r02_cfg2"}.get(workload)
+    if tag is None:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", tag + "_hbm_traffic.json")) as f:
+            kernels = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    best = None
+    for name, v in kernels.items():
+        if name.startswith("k_irt1d"):
+            tot = float(v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"])
+            best = tot if best is None or tot > best else best
+    return best
 
 
 def cpu_baseline(J, D, H, n_sample, min_seconds=6.0):
@@ -122,6 +143,17 @@ def cpu_baseline(J, D, H, n_sample, min_seconds=6.0):
     if threadpool_info is not None:
         pools = [p.get("num_threads", 1) for p in threadpool_info()]
         threads = max(pools) if pools else 1
+    # a plain PyTorch float32 restatement (autograd + torch.optim.Adam, the (B, D, D) scale matrix
+    # materialised as the reference does) under torch.set_num_threads, on one thread and on all
+    from oracle import torch_step
+    n_torch = min(n_sample, 1000)
+    try:
+        n_cpu = len(os.sched_getaffinity(0))               # the cores this process may use (a GPU box hands out a share)
+    except AttributeError:                                  # pragma: no cover
+        n_cpu = os.cpu_count()
+    torch_sec = {1: torch_step.time_step(J, D, H, n_torch, 1, min_seconds / 2),
+                 n_cpu: torch_step.time_step(J, D, H, n_torch, n_cpu, min_seconds / 2)}
+    torch_b100 = torch_step.time_step(J, D, H, 100, n_cpu, min_seconds / 3)
     sec_all = timed(n_sample, min_seconds)
     sec_b100 = timed(100, min_seconds / 3)
     if threadpool_limits is not None:
@@ -129,7 +161,8 @@ def cpu_baseline(J, D, H, n_sample, min_seconds=6.0):
             sec_one = timed(n_sample, min_seconds)
     else:                                                   # pragma: no cover
         sec_one = None
-    return {"sec_all": sec_all, "sec_one": sec_one, "sec_b100": sec_b100, "threads": threads}
+    return {"sec_all": sec_all, "sec_one": sec_one, "sec_b100": sec_b100, "threads": threads,
+            "torch_sec": torch_sec, "torch_n": n_torch, "torch_b100": torch_b100}
 
 
 def self_launch(args, argv):
@@ -249,6 +282,7 @@ def main():
         lrs.scheduler_step()
     sync()
     dt = time.perf_counter() - t0
+    loss_v = float(loss.item())                            # (a view of the loss slot: read before any further step)
     if graphed:
         eng.events = ev
         for _ in range(min(args.steps, 20)):
@@ -270,7 +304,6 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
-    loss_v = float(loss.item())
 
     phases = {}
     for name, e0, e1 in ev:
@@ -285,6 +318,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "persons": N, "items": J, "dims": D, "hidden": H,
+                       "arithmetic": ("results f32; the guide's GEMMs (fc1, heads, their gradients) from two fp16 terms per operand "
+                                      "(2^-22 relative, three products, fp32 accumulate); the likelihood's from bf16 terms (x, a: three; "
+                                      "dlogp/dz: two, 2^-17)") if (D > 1 and amortized) else "f32",
                        "guide": "amortized MvnEncoder" if amortized else "BBVI per-person", "batch": "full (B=N)",
                        "particles": 1, "missing_rate": missing, "persons_per_rank": per,
                        "parallelism": "persons sharded x%d, 1 all-reduce/step" % world,
@@ -292,8 +328,8 @@ def main():
             "person_rows_per_s": N * args.steps / dt,
             "loss_last": loss_v, "phase_ms": phase_ms,
         }
-        if os.environ.get("VX_BF16X3"):                     # non-default kernel selection: say so in the line itself
-            out["config"]["kernel_switch"] = "VX_BF16X3=" + os.environ["VX_BF16X3"]
+        if os.environ.get("VX_MFMA16"):                     # non-default kernel selection: say so in the line itself
+            out["config"]["kernel_switch"] = "VX_MFMA16=" + os.environ["VX_MFMA16"]
         if kernel_ms:
             out["kernel_ms"] = kernel_ms
         priced = {k: v for k, v in kernel_ms.items() if kernel_model(k, J, D, H)}
@@ -311,10 +347,8 @@ def main():
                                "traffic_source": ("profiles/%s_hbm_traffic.json (PMC, bytes per launch)" % PROFILE_TAG)
                                                  if traffic is not None else None,
                                "arithmetic": arith,
-                               "peak_basis": "dense bf16 MFMA peak 2500 / 6 products per f32 product"
-                                             if peak == PEAK_BF16X3_TFLOPS else
-                                             "dense bf16 MFMA peak 2500 / 5 products per f32 product"
-                                             if peak == PEAK_BF16X5_TFLOPS else
+                               "peak_basis": "dense fp16 MFMA peak 2500 / 3 products per f32 product"
+                                             if peak == PEAK_F16X2_TFLOPS else
                                              "dense bf16 MFMA peak 2500 / (16 / 3) products per f32 product"
                                              if peak == PEAK_BF16_MFMA_TFLOPS * 3.0 / 16.0 else "dense f32 MFMA peak",
                                "algorithmic_flops_per_launch": fl, "avg_launch_ms": priced[name],
@@ -337,7 +371,13 @@ def main():
             ach = by / (phase_ms[key] * 1e-3) / 1e9
             out["roofline"] = {"kernel": "k_" + key, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS,
                                "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None,
-                               "algorithmic_bytes_per_launch": by, "avg_launch_ms": phase_ms[key]}
+                               "algorithmic_bytes_per_launch": by, "avg_launch_ms": phase_ms[key],
+                               "achieved_note": "an ALGORITHMIC rate: SURVEY.md section 8d's dense J + 48 bytes per person over the "
+                                                "launch time; the bytes a launch physically moves are physical_bytes_per_launch"}
+            phys = physical_bytes(args.workload)
+            if phys is not None:
+                out["roofline"]["physical_bytes_per_launch"] = phys
+                out["roofline"]["physical_GBs"] = phys / (phase_ms[key] * 1e-3) / 1e9
             if graphed:
                 out["config"]["launch"] = "whole step replayed from one HIP graph"
                 out["roofline"]["avg_launch_ms_source"] = ("HIP events around the kernel in an eager pass after the "
@@ -375,6 +415,11 @@ def main():
                                                         "note": "the reference's own B = 100 step (test.py:338): CPU port on "
                                                                 "all threads; gpu_steps_per_s = the same step on this GPU, "
                                                                 "rows subsampled per step, after the timed region"},
+                                   "torch_f32": {"sample": "%d persons, full step (autograd + torch.optim.Adam), float32, the (B, D, D) "
+                                                           "scale matrix materialised as vi.py does; scaled linearly" % cb["torch_n"],
+                                                 "steps_per_s_by_threads": {str(k): 1.0 / (v * N / cb["torch_n"])
+                                                                            for k, v in cb["torch_sec"].items()},
+                                                 "native_minibatch_steps_per_s": 1.0 / cb["torch_b100"]},
                                    "host_cpus": os.cpu_count()}
         print(json.dumps(out))
     if world > 1:

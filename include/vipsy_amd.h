@@ -175,6 +175,21 @@ int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, 
                   float* gloc, float* graw, float* elbo, float* gitem, float* loss, uint32_t* step_dev,
                   float* workspace, void* hip_stream);
 
+/* Score-function (REINFORCE) estimator with a control-variate baseline for the Normal guide of the D = 1 models
+ * (BASELINE.json north_star).  The reference takes pathwise gradients for these guides (vi.py:684,705:
+ * Normal has rsample), so this mode has no reference output to match: an opt-in of this build (IrtEngine(estimator=
+ * "score")), checked against oracle/vi_oracle.py::irt_particle(estimator="score").  Called AFTER vx_irt1d_grad of the same
+ * batch (whose item gradients and loss stand): overwrites gloc / graw [nb] with
+ *     d LOSS / d loc_i = -(log_r_i - baseline_i) eps_i exp(-raw_i),   d LOSS / d raw_i = -(log_r_i - baseline_i) (eps_i^2 - 1),
+ *     log_r_i = scale * elbo[i].
+ * eps[nb]: the draws the step used (vx_philox_normals with the step's seed / step / stream, or the caller's own);
+ * baseline: NULL, an explicit control variate in batch order (base_beta < 0), or a decaying average updated after use
+ * (base_beta >= 0: baseline <- beta baseline + (1 - beta) log_r), indexed by rows[i] when base_by_row != 0 and rows != NULL;
+ * log_r: optional output [nb]. */
+int vx_irt1d_score_grad(int64_t nb, float scale, const float* elbo, const float* eps, const float* raw, const int64_t* rows,
+                        float* baseline, float base_beta, int32_t base_by_row, float* log_r, float* gloc, float* graw,
+                        void* hip_stream);
+
 /* ---- black-box MVN guide with per-person or shared Cholesky rows (VIRT.guide, x_feature > 1, vi.py:706-723).
  *   loc: [n_local][D];  M: [n_local][D][D] unconstrained (shared == 0) or [D][D] (shared == 1, share_cov=True)
  *   forward : x[nb][D] = loc[row] + L eps, eps[nb][D], ent[nb] = 0.5|eps|^2 + sum_k M_kk

@@ -252,11 +252,15 @@ ENC_KEYS = ("fc1.weight", "fc1.bias", "fc21.weight", "fc21.bias", "fc22.weight",
 # ------------------------------------------------------------------------------------------------
 # One particle of the IRT ELBO -> loss and grads w.r.t. unconstrained leaves
 # ------------------------------------------------------------------------------------------------
-def irt_particle(spec, params, y_u8_full, idx, eps):
-    """spec: dict(model, D, Dc, N, amortized, share_cov, a_free (D,J bool or None)).
+def irt_particle(spec, params, y_u8_full, idx, eps, baseline=None, want_log_r=False):
+    """spec: dict(model, D, Dc, N, amortized, share_cov, a_free (D,J bool or None)[, estimator]).
     params: unconstrained leaves keyed by the reference's param-store names.
     idx: (B,) int64 rows of the plate subsample; eps: (B,D) standard normal draws.
-    Returns (loss, grads) for ONE particle (not yet divided by num_particles)."""
+    spec["estimator"] == "score" (D = 1 only; SURVEY.md App. A.5 -- NOT what the reference does for its Normal guides,
+    vi.py:684,705 are reparameterised): the guide's gradient is the score-function one, (log_r_i - baseline_i) d log q / d phi
+    with log_r_i = scale (ll_i + log p(x_i) - log q(x_i)) detached and the score term unscaled; the item gradients stay
+    pathwise.  baseline: (B,) control variate or None.
+    Returns (loss, grads) for ONE particle (not yet divided by num_particles); with want_log_r also log_r (B,)."""
     model, D, Dc, N = spec["model"], spec["D"], spec["Dc"], spec["N"]
     dt = params["b"].dtype
     B = len(idx)
@@ -318,7 +322,14 @@ def irt_particle(spec, params, y_u8_full, idx, eps):
 
     gx = scale * (g["x"] - x)                                    # d ELBO / d x (likelihood + prior)
     g_loc = gx
-    if D == 1:
+    log_r = scale * (ll + logp_x - logq)
+    if spec.get("estimator", "pathwise") == "score":
+        if D != 1:
+            raise NotImplementedError("score-function mode: D = 1 Normal guides")
+        f = (log_r - (0.0 if baseline is None else np.asarray(baseline, dt)))[:, None]
+        g_loc = f * eps / sig                                    # d log q / d loc = (x - loc) / sigma^2 = eps / sigma
+        g_raw = f * (eps ** 2 - 1.0)                             # d log q / d raw (sigma = exp(raw))
+    elif D == 1:
         g_raw = gx * sig * eps + scale                           # + scale from -logq
     else:
         gM = np.einsum("bi,bj->bij", gx, eps)
@@ -342,6 +353,8 @@ def irt_particle(spec, params, y_u8_full, idx, eps):
             gs = np.zeros_like(params["x_scale"])
             np.add.at(gs, idx, -g_raw)
             grads["x_scale"] = gs
+    if want_log_r:
+        return loss, grads, log_r
     return loss, grads
 
 

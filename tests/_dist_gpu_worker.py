@@ -71,6 +71,7 @@ def main():
             if n.endswith("fc2.bias"):
                 eng.unconstrained(n).zero_()
     res = {"loss": losses, "P": eng.P.double().cpu().numpy().tolist(),
+           "graphed": bool((getattr(eng, "_graph", None) or {}).get("graph")),
            "backend": "nccl" if (world > 1 and n_dev >= world) else ("gloo" if world > 1 else "none")}
     if eng.per_person:
         res["PP"] = eng.PP.double().cpu().numpy().tolist()

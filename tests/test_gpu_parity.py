@@ -397,12 +397,12 @@ np.savez(sys.argv[2], loss=float(eng.G[eng.n_params].item()), g=eng.G[:eng.n_par
          x=eng.last["fw"]["x"][:N * D].cpu().numpy())
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    # the two test seams of the library: VX_FORCE_GENERIC=1 (shape-generic kernels only) and VX_BF16X3 (0: the fp32-MFMA
+    # the two test seams of the library: VX_FORCE_GENERIC=1 (shape-generic kernels only) and VX_MFMA16 (0: the fp32-MFMA
     # kernels; f / w / h / g: one of the four guide kernels on the bf16 MFMA, the rest fp32)
     switches = {"0": {}, "1": {"VX_FORCE_GENERIC": "1"}}
     if N == 512:
-        switches.update({"fp32": {"VX_BF16X3": "0"}, "b3f": {"VX_BF16X3": "f"}, "b3w": {"VX_BF16X3": "w"},
-                         "b3h": {"VX_BF16X3": "h"}, "b3g": {"VX_BF16X3": "g"}})
+        switches.update({"fp32": {"VX_MFMA16": "0"}, "b3f": {"VX_MFMA16": "f"}, "b3w": {"VX_MFMA16": "w"},
+                         "b3h": {"VX_MFMA16": "h"}, "b3g": {"VX_MFMA16": "g"}})
     for mode, extra in switches.items():
         env = dict(os.environ, VX_FORCE_GENERIC="0")
         env.update(extra)
@@ -611,7 +611,7 @@ def test_captured_step_equals_eager_step(miss, model):
         lrs = LrSpec(lambda m, p: {"lr": 1e-2 if p in ("a", "b") else 1e-3}, milestones=(3,), gamma=0.5)
         losses = []
         for _ in range(7):
-            losses.append(eng.step(lrs))
+            losses.append(eng.step(lrs).clone())          # the returned scalar is a view of the step's loss slot
             lrs.scheduler_step()
         torch.cuda.synchronize()
         assert eng.t == 7
@@ -644,3 +644,70 @@ def test_small_batch_forward_is_bit_reproducible():
         outs.append((eng.G.cpu().numpy().copy(), eng.last["fw"]["x"][:N * D].cpu().numpy().copy()))
     for g, x in outs[1:]:
         assert np.array_equal(g, outs[0][0]) and np.array_equal(x, outs[0][1])
+
+
+@pytest.mark.parametrize("amort,model,B,baseline", [(False, "irt_2pl", None, "none"), (False, "irt_4pl", 100, "avg"),
+                                                     (True, "irt_2pl", None, "avg"), (True, "irt_3pl", 77, "none")])
+def test_irt_score_function_step_vs_oracle(amort, model, B, baseline):
+    """estimator='score' (north_star's REINFORCE mode for the IRT guide): the HIP step against the
+    oracle's score mode on the same Philox draws -- per-person (BBVI) and amortized Normal guide, full batch and subsample,
+    with the per-person decaying-average baseline carried over two steps."""
+    from vipsy_amd.engine import IrtEngine
+    N, J = 640, 60
+    rng = np.random.RandomState(N + J + (1 if amort else 0))
+    y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+    y[rng.rand(N, J) < 0.15] = 255
+    eng = IrtEngine(torch.from_numpy(y).to(_dev()), model=model, D=1, amortized=amort, H=64, seed=5, estimator="score",
+                    baseline=baseline, baseline_beta=0.8)
+    eng.unconstrained("b").copy_(torch.from_numpy(0.7 * rng.randn(1, J)).float())
+    eng.unconstrained("a").copy_(torch.from_numpy(0.5 + rng.rand(1, J)).float())
+    if not amort:
+        eng.PP.copy_(torch.from_numpy(np.concatenate([0.5 * rng.randn(N), -0.3 + 0.2 * rng.randn(N)])).float())
+    spec = {"family": "irt", "model": model, "D": 1, "Dc": 1.0, "N": N, "amortized": amort, "share_cov": False, "a_free": None,
+            "estimator": "score"}
+    base = np.zeros(N)
+    for t in range(2):
+        idx = np.arange(N) if B is None else np.sort(rng.permutation(N)[:B])
+        rows = None if B is None else torch.from_numpy(idx).to(_dev())
+        eng.t = t                                                    # the Philox step of this pass
+        eps = vo.philox_normals(5, t, 0, idx, 1)
+        eng.loss_and_grads(rows, len(idx))
+        torch.cuda.synchronize()
+        names = eng.names() + ([] if amort else ["x_local", "x_scale"])
+        params = {n: eng.unconstrained(n).cpu().numpy().astype(np.float64) for n in names}
+        bl = base[idx] if baseline == "avg" else None
+        loss_o, g_o, log_r = vo.irt_particle(spec, params, y, idx, eps, baseline=bl, want_log_r=True)
+        if baseline == "avg":
+            base[idx] = 0.8 * base[idx] + 0.2 * log_r
+            np.testing.assert_allclose(eng.base.cpu().numpy(), base, rtol=2e-5, atol=2e-4)
+        assert float(eng.G[eng.n_params].item()) == pytest.approx(loss_o, rel=3e-5)
+        for name, go in g_o.items():
+            gh = eng.unconstrained(name, eng.GP if (eng.per_person and name in eng.pp_off) else eng.G).cpu().numpy()
+            sc = max(1e-6, float(np.abs(go).max()))
+            assert np.abs(gh - go).max() / sc < 3e-4, (name, t, np.abs(gh - go).max() / sc)
+
+
+def test_irt_score_function_loo_baseline_through_step():
+    """baseline='loo' through IrtEngine.step: three particles share the batch, each with the leave-one-out mean of the others'
+    log_r as its control variate (lr = 0 keeps the parameters, so the averaged gradient can be checked)."""
+    from vipsy_amd.engine import IrtEngine, LrSpec
+    N, J, S = 512, 40, 3
+    rng = np.random.RandomState(12)
+    y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+    eng = IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_2pl", D=1, seed=9, estimator="score", baseline="loo")
+    eng.PP.copy_(torch.from_numpy(np.concatenate([0.5 * rng.randn(N), -0.3 + 0.2 * rng.randn(N)])).float())
+    spec = {"family": "irt", "model": "irt_2pl", "D": 1, "Dc": 1.0, "N": N, "amortized": False, "share_cov": False, "a_free": None,
+            "estimator": "score"}
+    params = {n: eng.unconstrained(n).cpu().numpy().astype(np.float64) for n in eng.names() + ["x_local", "x_scale"]}
+    idx = np.arange(N)
+    eps = [vo.philox_normals(9, 0, s, idx, 1) for s in range(S)]        # the particle index is the Philox stream
+    lrs = [vo.irt_particle(spec, params, y, idx, e, want_log_r=True)[2] for e in eps]
+    outs = [vo.irt_particle(spec, params, y, idx, e, baseline=(sum(lrs) - lrs[s]) / (S - 1)) for s, e in enumerate(eps)]
+    loss_h = float(eng.step(LrSpec(0.0), num_particles=S).item())
+    torch.cuda.synchronize()
+    assert loss_h == pytest.approx(np.mean([o[0] for o in outs]), rel=3e-5)
+    for name in ("a", "b", "x_local", "x_scale"):
+        go = np.mean([o[1][name] for o in outs], axis=0)
+        gh = eng.unconstrained(name, eng.GP if name in eng.pp_off else eng.G).cpu().numpy()
+        sc = max(1e-6, float(np.abs(go).max()))
+        assert np.abs(gh - go).max() / sc < 3e-4, (name, np.abs(gh - go).max() / sc)

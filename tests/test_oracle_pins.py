@@ -108,3 +108,42 @@ def test_score_function_baselines_keep_the_estimator_unbiased_and_cut_its_varian
     se = plain.std(0) / np.sqrt(reps)
     assert np.all(np.abs(plain.mean(0) - loo.mean(0)) < 6 * se + 1e-9)          # same expectation
     assert loo.var(0).mean() < 0.5 * plain.var(0).mean()                        # the control variate pays
+
+
+def test_irt_score_function_estimator_is_unbiased_and_baseline_cuts_its_variance():
+    """north_star's 'REINFORCE score-function gradient with control-variate baseline' for the IRT guide (SURVEY.md App. A.5;
+    the reference itself is pathwise there): over many draws the score-function gradient of (loc, log scale) has the same
+    mean as the pathwise one, with and without a leave-one-out baseline, and the baseline cuts its variance."""
+    from oracle import vi_oracle as vo
+    rng = np.random.RandomState(7)
+    N, J, S, reps = 6, 12, 4, 4000
+    y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+    y[rng.rand(N, J) < 0.1] = 255
+    spec = {"family": "irt", "model": "irt_2pl", "D": 1, "Dc": 1.0, "N": N, "amortized": False, "share_cov": False, "a_free": None}
+    params = vo.init_irt_params(spec, J, np.float64)
+    params["a"] = 0.5 + rng.rand(1, J)
+    params["b"] = 0.5 * rng.randn(1, J)
+    params["x_local"] = 0.3 * rng.randn(N, 1)
+    params["x_scale"] = -0.5 + 0.2 * rng.randn(N, 1)
+    idx = np.arange(N)
+    sc = dict(spec, estimator="score")
+    path, plain, loo = [], [], []
+    for _ in range(reps):
+        eps = [rng.randn(N, 1) for _ in range(S)]
+        path.append(np.mean([np.concatenate([vo.irt_particle(spec, params, y, idx, e)[1][k].ravel() for k in ("x_local", "x_scale")])
+                             for e in eps], axis=0))
+        outs = [vo.irt_particle(sc, params, y, idx, e, want_log_r=True) for e in eps]
+        lrs = [o[2] for o in outs]
+        plain.append(np.mean([np.concatenate([o[1][k].ravel() for k in ("x_local", "x_scale")]) for o in outs], axis=0))
+        loo.append(np.mean([np.concatenate([vo.irt_particle(sc, params, y, idx, e, baseline=(sum(lrs) - lrs[s]) / (S - 1))[1][k].ravel()
+                                            for k in ("x_local", "x_scale")]) for s, e in enumerate(eps)], axis=0))
+        # the item gradients do not depend on the estimator
+    path, plain, loo = np.array(path), np.array(plain), np.array(loo)
+    se = np.sqrt(plain.var(0) / reps + path.var(0) / reps)
+    assert np.all(np.abs(plain.mean(0) - path.mean(0)) < 6 * se + 1e-9)            # same expectation as the pathwise gradient
+    se2 = np.sqrt(loo.var(0) / reps + path.var(0) / reps)
+    assert np.all(np.abs(loo.mean(0) - path.mean(0)) < 6 * se2 + 1e-9)
+    assert loo.var(0).mean() < 0.7 * plain.var(0).mean()                          # the control variate pays
+    l0, g0 = vo.irt_particle(spec, params, y, idx, eps[0])
+    l1, g1 = vo.irt_particle(sc, params, y, idx, eps[0])
+    assert l0 == l1 and all(np.array_equal(g0[k], g1[k]) for k in ("a", "b"))

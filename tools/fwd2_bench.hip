@@ -1,0 +1,75 @@
+// Standalone timing harness for k_mvn_enc_fwd_b2 (compiles in ~30 s instead of the library's 2.5 min): synthetic operands at
+// the headline shape, the library's own kernel sources and pack kernels.  -DFB2_STAMPS prints the per-phase cycle stamps.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -o tools/fwd2_bench tools/fwd2_bench.hip
+#include "../vipsy_amd/csrc/vx_common.h"
+#include "../vipsy_amd/csrc/k_mvn_enc.hip"
+#include "../vipsy_amd/csrc/k_mvn_packed.hip"
+#include "../vipsy_amd/csrc/k_irt_lik.hip"
+#include "../vipsy_amd/csrc/k_irt_lik_r.hip"
+#include "../vipsy_amd/csrc/k_irt_lik_b.hip"
+#include "../vipsy_amd/csrc/k_mvn_bwd_t.hip"
+#include "../vipsy_amd/csrc/k_mvn_bwd_b.hip"
+#include "../vipsy_amd/csrc/k_mvn_fwd_b.hip"
+#include "../vipsy_amd/csrc/k_mvn_fwd_b2.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %d at %s:%d\n", (int)e_, __FILE__, __LINE__); return 1; } } while (0)
+
+__global__ void k_fill(float* p, int64_t n, float amp, uint32_t seed) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t x = (uint32_t)i * 2654435761u + seed; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+        p[i] = amp * ((float)(x & 0xFFFF) / 32768.0f - 1.0f);
+    }
+}
+__global__ void k_fill_y(uint8_t* p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t x = (uint32_t)i * 2654435761u + 77u; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+        p[i] = (uint8_t)((x >> 7) & 1);
+    }
+}
+
+int main(int argc, char** argv) {
+    const int D = 100, H = 64, J = 500;
+    const int64_t nb = argc > 1 ? atoll(argv[1]) : 983040;
+    const int Rp = pk_rows(D), T = D * (D + 1) / 2;
+    float *W1, *b1, *W21, *b21, *W22, *b22, *Wp, *bp, *WpT, *sc, *h, *x, *eps, *ldT, *ent, *hT, *epsT;
+    uint32_t *gtab, *gt2; uint8_t *y, *img, *w1img, *ximg; uint16_t* hs;
+    CK(hipMalloc(&W1, H * J * 4)); CK(hipMalloc(&b1, H * 4)); CK(hipMalloc(&W21, D * 64 * 4)); CK(hipMalloc(&b21, D * 4));
+    CK(hipMalloc(&W22, (size_t)T * 64 * 4)); CK(hipMalloc(&b22, T * 4));
+    CK(hipMalloc(&Wp, (size_t)Rp * 64 * 4)); CK(hipMalloc(&bp, Rp * 4)); CK(hipMalloc(&WpT, (size_t)Rp * 64 * 4)); CK(hipMalloc(&gtab, (Rp / 8 + 8) * 4));
+    CK(hipMalloc(&sc, 64)); CK(hipMalloc(&y, nb * J));
+    const int n_tiles = fb_tiles(D);
+    CK(hipMalloc(&img, fb_img_floats(D) * 4)); gt2 = (uint32_t*)(img + (int64_t)n_tiles * FB_IMG_BYTES);
+    CK(hipMalloc(&w1img, fb_w1img_floats(J) * 4));
+    CK(hipMalloc(&h, nb * 64 * 4)); CK(hipMalloc(&x, nb * D * 4)); CK(hipMalloc(&eps, nb * D * 4)); CK(hipMalloc(&ldT, nb * D * 4));
+    CK(hipMalloc(&ent, nb * 4)); CK(hipMalloc(&hT, nb * 64 * 4)); CK(hipMalloc(&epsT, nb * D * 4)); CK(hipMalloc(&hs, nb * 64 * 4));
+    CK(hipMalloc(&ximg, (size_t)((nb + 63) / 64) * LB_XT_BYTES));
+    k_fill<<<256, 256>>>(W1, H * J, 0.045f, 1); k_fill<<<1, 64>>>(b1, H, 0.045f, 2);
+    k_fill<<<64, 256>>>(W21, D * 64, 0.125f, 3); k_fill<<<1, 128>>>(b21, D, 0.125f, 4);
+    k_fill<<<1024, 256>>>(W22, (int64_t)T * 64, 0.125f, 5); k_fill<<<32, 256>>>(b22, T, 0.125f, 6);
+    k_fill_y<<<4096, 256>>>(y, nb * J);
+    hipLaunchKernelGGL(k_pack_heads, dim3(Rp), dim3(64), 0, 0, D, 64, W21, b21, W22, b22, Wp, bp, gtab, WpT);
+    hipLaunchKernelGGL(k_enc_scales, dim3(1), dim3(1024), 0, 0, D, J, W1, b1, W21, b21, W22, b22, sc);
+    hipLaunchKernelGGL(k_pack_w1_b, dim3((J + 15) / 16), dim3(256), 0, 0, J, W1, (const float*)sc, w1img);
+    hipLaunchKernelGGL(k_pack_heads_b, dim3(n_tiles), dim3(256), 0, 0, n_tiles, pk_off_total(D) / 8, Wp, bp, gtab, (const float*)sc, img, gt2);
+    EncDims dm; dm.D = D; dm.J = J; dm.H = 64; dm.Hp = 64; dm.DS = enc_ds(D); dm.T = T; dm.nb = nb;
+    const size_t lds = fb2_lds_bytes(D, J);
+    CK(hipFuncSetAttribute((const void*)k_mvn_enc_fwd_b2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_mvn_enc_fwd_b2, dim3((unsigned)((nb + 255) / 256)), dim3(FB2_THREADS), lds, 0, dm, (const uint8_t*)y,
+                           (const int64_t*)nullptr, (int64_t)0, (const uint8_t*)w1img, (const float*)b1, (const uint8_t*)img,
+                           (const uint32_t*)gt2, (const float*)sc, (const float*)nullptr, (uint64_t)1234, 0u, 0u, h, x, eps, ldT, ent, hT,
+                           epsT, ximg, hs);
+        hipEventRecord(e1); CK(hipEventSynchronize(e1));
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("k_mvn_enc_fwd_b2 nb=%lld: %.3f ms (lds %zu)\n", (long long)nb, ms, lds);
+    }
+    std::vector<float> out(4);
+    CK(hipMemcpy(out.data(), x + 1000, 16, hipMemcpyDeviceToHost));
+    printf("check %g %g %g %g\n", out[0], out[1], out[2], out[3]);
+    return 0;
+}

@@ -1,4 +1,4 @@
-"""A/B of the bf16x3 kernels (the default) against the fp32-MFMA ones (VX_BF16X3=0) and the shape-generic
+"""A/B of the 16-bit-MFMA kernels (f16x2 / bf16 terms: the default) against the fp32-MFMA ones (VX_MFMA16=0) and the shape-generic
 kernels: each mode in a child process (the switches are read once per process).  Run on a GPU box."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,7 +18,7 @@ np.save(sys.argv[2], eng.G[:eng.n_params + 1].double().cpu().numpy())
 ''' % ROOT
 for N in (512, 520, 1000, 4096):
     g = {}
-    for mode, extra in {"fp32": {"VX_BF16X3": "0"}, "bf16x3": {"VX_BF16X3": "1"}, "generic": {"VX_FORCE_GENERIC": "1"}}.items():
+    for mode, extra in {"fp32": {"VX_MFMA16": "0"}, "mfma16": {"VX_MFMA16": "1"}, "generic": {"VX_FORCE_GENERIC": "1"}}.items():
         env = dict(os.environ, VX_FORCE_GENERIC="0"); env.update(extra)
         out = "/tmp/bfx_%s.npy" % mode
         p = subprocess.run([sys.executable, "-c", CODE, str(N), out], env=env, capture_output=True, text=True, timeout=600)
@@ -26,6 +26,6 @@ for N in (512, 520, 1000, 4096):
         import numpy as np
         g[mode] = np.load(out)
     s = abs(g["generic"]).max()
-    print("N=%d  |fp32-generic|=%.3g  |bf16x3-generic|=%.3g  |bf16x3-fp32|=%.3g  (scale %.3g)" % (
-        N, abs(g["fp32"] - g["generic"]).max() / s, abs(g["bf16x3"] - g["generic"]).max() / s,
-        abs(g["bf16x3"] - g["fp32"]).max() / s, s), flush=True)
+    print("N=%d  |fp32-generic|=%.3g  |mfma16-generic|=%.3g  |mfma16-fp32|=%.3g  (scale %.3g)" % (
+        N, abs(g["fp32"] - g["generic"]).max() / s, abs(g["mfma16"] - g["generic"]).max() / s,
+        abs(g["mfma16"] - g["fp32"]).max() / s, s), flush=True)

@@ -194,3 +194,33 @@ __global__ __launch_bounds__(I1_THREADS) void k_irt1d(
         slab[4 * J] = dm.scale * acc;
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Score-function (REINFORCE) estimator for the Normal guide of the D = 1 models (north_star; SURVEY.md App. A.5 -- the
+// reference itself takes pathwise gradients there, vi.py:684,705): the same forward and item gradients as k_irt1d, and
+//     log_r_i = scale (ll_i + log p(x_i) - log q(x_i))                       (= scale * elbo[i] of the step kernel)
+//     d loss / d loc_i = - (log_r_i - baseline_i) eps_i exp(-raw_i)          (d log q / d loc = (x - loc) / sigma^2)
+//     d loss / d raw_i = - (log_r_i - baseline_i) (eps_i^2 - 1)              (d log q / d raw, sigma = exp(raw))
+// baseline: none, an explicit control variate (base_beta < 0), or a decaying average updated after use (base_beta >= 0),
+// indexed by rows[i] when rows are given and base_by_row is set (a per-person average of a subsampled run).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_irt1d_score(int64_t nb, float scale, const float* __restrict__ elbo, const float* __restrict__ eps,
+                              const float* __restrict__ raw, const int64_t* __restrict__ rows, float* __restrict__ baseline,
+                              float base_beta, int base_by_row, float* __restrict__ log_r_out, float* __restrict__ gloc,
+                              float* __restrict__ graw) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += (int64_t)gridDim.x * blockDim.x) {
+        const float lr = scale * elbo[i];
+        float f = lr;
+        if (baseline) {
+            const int64_t bi = (base_by_row && rows) ? rows[i] : i;
+            const float bv = baseline[bi];
+            f = lr - bv;
+            if (base_beta >= 0.f) baseline[bi] = fmaf(base_beta, bv, (1.0f - base_beta) * lr);
+        }
+        const float e = eps[i];
+        gloc[i] = -f * e * __expf(-raw[i]);
+        graw[i] = -f * (e * e - 1.0f);
+        if (log_r_out) log_r_out[i] = lr;
+    }
+}
+

@@ -100,19 +100,20 @@ bool packed_ok(const vx_irt_cfg* cfg) {
            enc_bwdw_fast_lds_floats(cfg->D) * sizeof(float) <= 160 * 1024;
 }
 
-// bf16x3 kernels (three-term bf16 operand splitting on the bf16 MFMA, fp32 accumulate; results at the accuracy of the
-// fp32-MFMA chain): the default.  VX_BF16X3 = 0 selects the fp32-MFMA kernels, f / w / h / g only the guide forward / the
-// head weight gradient / the hidden gradient / the fc1 weight gradient on the bf16 MFMA.
-int bf16x3_mode() {
+// 16-bit-MFMA kernels (fp32 operands as fp16 pairs -- f16x2, vx_common.h -- or, in the likelihood and the fc1 gradient, as
+// bf16 terms; fp32 accumulate; results at the accuracy of the fp32-MFMA chain): the default.  VX_MFMA16 = 0 selects the
+// fp32-MFMA kernels, f / w / h / g only the guide forward / the head weight gradient / the hidden gradient / the fc1 weight
+// gradient on the 16-bit MFMA (a test seam: tests/test_gpu_parity.py::test_generic_and_fast_kernels_agree).
+int mfma16_mode() {
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("VX_BF16X3");
+        const char* e = getenv("VX_MFMA16");
         v = (!e || e[0] == '1') ? 15 : (e[0] == 'f' ? 1 : e[0] == 'w' ? 2 : e[0] == 'h' ? 4 : e[0] == 'g' ? 8 : 0);
     }
     return v;
 }
 bool fwb_shape(const vx_irt_cfg* cfg) {
-    return (bf16x3_mode() & 1) && packed_ok(cfg) && cfg->D <= 128 && fb_lds_bytes(cfg->D, cfg->J) <= 160 * 1024;
+    return (mfma16_mode() & 1) && packed_ok(cfg) && cfg->D <= 128 && fb_lds_bytes(cfg->D, cfg->J) <= 160 * 1024;
 }
 
 bool enc_cfg_ok(const vx_irt_cfg* cfg) {
@@ -718,13 +719,13 @@ static bool encb_fast_shape(const vx_irt_cfg* cfg) {
 static bool bwt_shape(const vx_irt_cfg* cfg, int64_t nb) {
     return packed_ok(cfg) && nb % 4 == 0 && cfg->D <= 124 && bt_lds_bytes(cfg->D) <= 160 * 1024;
 }
-// the default (VX_BF16X3=0 turns it off): the weight-gradient kernel on the bf16 MFMA, operands in bf16 terms (k_mvn_bwd_b.hip)
+// the default (VX_MFMA16=0 turns it off): the weight-gradient kernel on the bf16 MFMA, operands in bf16 terms (k_mvn_bwd_b.hip)
 static bool bwb_shape(const vx_irt_cfg* cfg, int64_t nb) {
-    const bool on = (bf16x3_mode() & 2) != 0;
+    const bool on = (mfma16_mode() & 2) != 0;
     return on && bwt_shape(cfg, nb) && nb % 8 == 0 && nb < ((int64_t)1 << 23) && bb_lds_bytes(cfg->D) <= 160 * 1024;
 }
 static bool bwhb_shape(const vx_irt_cfg* cfg, int64_t nb) {
-    return (bf16x3_mode() & 4) && bwt_shape(cfg, nb) && nb >= 4 && cfg->D <= 16 * HB_NS && hb_lds_bytes(cfg->D) <= 160 * 1024;
+    return (mfma16_mode() & 4) && bwt_shape(cfg, nb) && nb >= 4 && cfg->D <= 16 * HB_NS && hb_lds_bytes(cfg->D) <= 160 * 1024;
 }
 static void bwt_plan(const vx_irt_cfg* cfg, int64_t nb, int& n_rowslabs, int& n_prw) {
     n_rowslabs = (pk_rows(cfg->D) + BT_ROWS - 1) / BT_ROWS;
@@ -990,7 +991,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
             VX_CHECK_LAUNCH();
         }
     }
-    if (nb > 0 && f1t && (bf16x3_mode() & 8)) {
+    if (nb > 0 && f1t && (mfma16_mode() & 8)) {
         ProfScope ps("k_fc1_bwd_b", st);
         hipLaunchKernelGGL(k_fc1_bwd_b, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0, st, dm,
                            yT, yT_stride, ghpre, slabs_f, lenf);
@@ -1093,6 +1094,17 @@ int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, 
 #undef LAUNCH_1DW
     VX_CHECK_LAUNCH();
     return reduce_step_slabs(workspace, blocks, cfg->J, gitem, loss, step_dev, hs);
+}
+
+int vx_irt1d_score_grad(int64_t nb, float scale, const float* elbo, const float* eps, const float* raw, const int64_t* rows,
+                        float* baseline, float base_beta, int32_t base_by_row, float* log_r, float* gloc, float* graw,
+                        void* hs) {
+    if (nb < 0 || !elbo || !eps || !raw || !gloc || !graw) return VX_EINVAL;
+    if (nb == 0) return VX_OK;
+    hipLaunchKernelGGL(k_irt1d_score, dim3(grid_1d(nb, 256)), dim3(256), 0, (hipStream_t)hs, nb, scale, elbo, eps, raw, rows,
+                       baseline, base_beta, (int)base_by_row, log_r, gloc, graw);
+    VX_CHECK_LAUNCH();
+    return VX_OK;
 }
 
 // ---- D = 1 on the host-compacted lists of observed cells (k_irt1d_sparse.hip); full batch only
@@ -1220,7 +1232,7 @@ int vx_norm_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     EncDims dm;
     dm.D = 1; dm.J = cfg->J; dm.H = cfg->H; dm.Hp = (cfg->H + 31) / 32 * 32; dm.DS = 3; dm.T = 1; dm.nb = nb;
     int rc;
-    if (!force_generic() && (bf16x3_mode() & 1) && cfg->H == 64 && cfg->J % 4 == 0 && aligned16(y) && aligned16(W1) &&
+    if (!force_generic() && (mfma16_mode() & 1) && cfg->H == 64 && cfg->J % 4 == 0 && aligned16(y) && aligned16(W1) &&
         aligned16(b1) && aligned16(h) && nb_lds_bytes(cfg->J) <= 160 * 1024) {
         const size_t ldsb = nb_lds_bytes(cfg->J);                       // fc1 on the bf16 MFMA, W1 shared by the workgroup
         rc = set_lds(k_norm_enc_fwd_b, ldsb);
@@ -1289,7 +1301,7 @@ int vx_norm_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t*
             float* ghpreT = slabs_f + (((int64_t)n_prf * lenf + 3) & ~(int64_t)3);
             hipLaunchKernelGGL(k_norm_enc_bwd_t64, dim3(nblk), dim3(256), 0, st, nb, W21, W22, h, gloc, graw, ghpreT, slabs_h);
             VX_CHECK_LAUNCH();
-            if (bf16x3_mode() & 8) {
+            if (mfma16_mode() & 8) {
                 hipLaunchKernelGGL(k_fc1_bwd_b, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0,
                                    st, dm, yT, yT_stride, ghpreT, slabs_f, lenf);
             } else {

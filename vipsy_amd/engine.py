@@ -211,6 +211,12 @@ class HipBackend(object):
                                    _hip.ptr(attr_out), _hip.ptr(gitem), _hip.ptr(ws), _hip.stream_ptr())
         _hip.check(rc, "vx_cdm_sf_grad")
 
+    def irt1d_score_grad(self, nb, scale, elbo, eps, raw, rows, baseline, base_beta, base_by_row, log_r, gloc, graw):
+        rc = self.L.vx_irt1d_score_grad(nb, float(scale), _hip.ptr(elbo), _hip.ptr(eps), _hip.ptr(raw), _hip.ptr(rows),
+                                        _hip.ptr(baseline), float(base_beta), int(base_by_row), _hip.ptr(log_r),
+                                        _hip.ptr(gloc), _hip.ptr(graw), _hip.stream_ptr())
+        _hip.check(rc, "vx_irt1d_score_grad")
+
     def loo_baseline(self, lr_all, S, nb, s, out):
         _hip.check(self.L.vx_loo_baseline(_hip.ptr(lr_all), int(S), nb, int(s), _hip.ptr(out), _hip.stream_ptr()),
                    "vx_loo_baseline")
@@ -516,8 +522,14 @@ class _EngineBase(object):
     use_graph = True
 
     def _graphable(self):
-        return (self.use_graph and getattr(self, "D", 0) == 1 and not getattr(self, "amortized", True)
-                and self.group is None and self.events is None and isinstance(self.be, HipBackend))
+        """The D = 1 per-person step is a handful of short kernels: replayed from ONE HIP graph.  With a process group the
+        all-reduce is captured with it (RCCL collectives are capturable on the capture stream: loss_and_grads -> all_reduce(G)
+        -> Adam stay one replay per step); a gloo group (CPU rehearsal) reduces through the host and cannot be captured."""
+        if not (self.use_graph and getattr(self, "D", 0) == 1 and not getattr(self, "amortized", True)
+                and getattr(self, "estimator", "pathwise") == "pathwise"
+                and self.events is None and isinstance(self.be, HipBackend)):
+            return False
+        return self.group is None or torch.distributed.get_backend(self.group) == "nccl"
 
     def _graph_key(self, lrs):
         """Everything a captured step bakes into its kernel arguments: the (begin, end, lr) segments and (betas, eps) of
@@ -537,25 +549,37 @@ class _EngineBase(object):
             g = torch.cuda.CUDAGraph()
             t0 = self.t
             self._step_dev = ctr
+            captured = True
             try:
                 with torch.cuda.graph(g):
                     self.loss_and_grads(None, None, None, 0)  # reads the counter as the Philox step, then advances it
+                    self.allreduce()                          # (a no-op without a group)
                     self.apply_optim(lrs)                     # reads it as Adam's t
+            except Exception:
+                if self.group is None:
+                    raise
+                captured = False                             # a collective this stack cannot capture
             finally:
                 self._step_dev = None
                 self.t = t0                                  # capture records, it does not run
+            if not captured:                                 # the sharded step stays correct, launched kernel by kernel
+                self.use_graph = False
+                self._graph = None
+                torch.cuda.synchronize()
+                return self.step(lrs)
             st.update(graph=g, key=key, ctr=ctr, ctr_t=None)
         if st["ctr_t"] != self.t:                            # (re)seed the device counter
             st["ctr"].fill_(self.t)
         st["graph"].replay()
         self.t += 1
         st["ctr_t"] = self.t
-        return self.G[self.n_params].clone()                 # the optimiser does not touch the loss slot
+        return self.G[self.n_params]                         # the optimiser does not touch the loss slot (see step())
 
     def step(self, lrs, rows=None, b_global=None, eps=None, num_particles=1):
         """loss_and_grads + optimiser, the body of SVI.step (vi.py:505-516).  `rows` (and `eps`) may be
         lists with one entry per particle: every particle draws its own subsample.
-        Returns the loss as a 0-d device tensor (no host sync)."""
+        Returns the loss as a 0-d device tensor (no host sync, no copy: a view of the step's loss slot, valid until the next
+        loss_and_grads / step of this engine -- `.clone()` it to keep it)."""
         S = int(num_particles)
         if (S == 1 and rows is None and eps is None and (b_global is None or int(b_global) == self.N)
                 and self._graphable()):
@@ -580,10 +604,9 @@ class _EngineBase(object):
                 self.GP.copy_(accP)
         with self._phase("allreduce"):
             self.allreduce()
-        loss = self.G[self.n_params].clone()
         with self._phase("optimizer"):
             self.apply_optim(lrs)
-        return loss
+        return self.G[self.n_params]                         # (the optimiser does not touch the loss slot)
 
 
 class IrtEngine(_EngineBase):
@@ -593,12 +616,24 @@ class IrtEngine(_EngineBase):
 
     def __init__(self, y_u8, model="irt_2pl", D=1, Dc=1.0, n_global=None, gid0=0, amortized=False, H=64,
                  share_cov=False, a_free=None, a0=None, b0=None, encoder_init=None, seed=1234, group=None,
-                 backend=None, observed_lists=True):
+                 backend=None, observed_lists=True, estimator="pathwise", baseline="none", baseline_beta=0.9):
         """group: the torch.distributed process group whose ranks SHARE this problem (each holds a contiguous shard of
         persons: y_u8 = rows gid0 .. gid0 + n_local of the n_global); None = this process owns the whole problem.
-        observed_lists: D = 1, full batch, >= 50 % missing -> step on compacted lists of observed cells."""
+        observed_lists: D = 1, full batch, >= 50 % missing -> step on compacted lists of observed cells.
+        estimator: 'pathwise' = what pyro's Trace_ELBO does for the reference's Normal guides (vi.py:684,705);
+        'score' (D = 1 only; BASELINE.json north_star) = the score-function (REINFORCE) gradient of the
+        guide, (log_r_i - baseline_i) d log q / d phi, with baseline 'none', 'avg' (per-person decaying average of log_r, rate
+        baseline_beta) or 'loo' (leave-one-out mean over the particles of a step, num_particles >= 2; the particles then share
+        the step's subsample).  The item gradients are the pathwise ones in every mode."""
+        if estimator not in ("pathwise", "score"):
+            raise ValueError("estimator must be 'pathwise' or 'score'")
+        if baseline not in ("none", "avg", "loo"):
+            raise ValueError("baseline must be 'none', 'avg' or 'loo'")
+        if estimator == "score" and int(D) != 1:
+            raise NotImplementedError("the score-function estimator is built for the D = 1 Normal guides")
+        self.estimator, self.baseline, self.baseline_beta = estimator, baseline, float(baseline_beta)
         self.be = backend if backend is not None else HipBackend()
-        self.observed_lists = bool(observed_lists)
+        self.observed_lists = bool(observed_lists) and estimator == "pathwise"
         self.y = y_u8.contiguous()
         assert self.y.dtype == torch.uint8 and self.y.dim() == 2
         self.dev = self.y.device
@@ -658,6 +693,8 @@ class IrtEngine(_EngineBase):
                 encoder_init = default_encoder_init(J, Dd, self.H, seed)
             for k in ENC_KEYS:
                 self.view("encoder$$$" + k).copy_(torch.as_tensor(encoder_init[k], dtype=torch.float32).reshape(-1))
+        self.base = (torch.zeros(max(self.n_local, 1), dtype=torch.float32, device=self.dev)
+                     if (estimator == "score" and baseline == "avg") else None)
 
     # -- parameter access (constrained values as pyro.param(name) returns them) -----------------
     def names(self):
@@ -689,9 +726,10 @@ class IrtEngine(_EngineBase):
         return u.clone()
 
     # -- one ELBO-gradient step ------------------------------------------------------------------
-    def loss_and_grads(self, rows=None, b_global=None, eps=None, stream_id=0):
+    def loss_and_grads(self, rows=None, b_global=None, eps=None, stream_id=0, baseline_buf=None, guide_grads=True):
         """Fills self.G (flat grads + loss slot) and per-person grads for ONE particle.
-        rows: int64 device tensor of LOCAL row indices (None = all local rows, i.e. full batch)."""
+        rows: int64 device tensor of LOCAL row indices (None = all local rows, i.e. full batch).
+        baseline_buf / guide_grads: the 'loo' mode of the score-function estimator (step())."""
         be = self.be
         nb = self.n_local if rows is None else int(rows.numel())
         Bg = int(b_global) if b_global is not None else (self.N if rows is None else nb)
@@ -788,6 +826,25 @@ class IrtEngine(_EngineBase):
                 else:
                     be.irt1d_grad(cfg, self.y, rows, nb, self.gid0, loc, raw, eps, a, self.view("b"), c_un, d_un,
                                   gloc, graw, elbo, g1d, i1d_ws, loss=lossslot, **sdk)
+            if self.estimator == "score":
+                # score-function gradient of the guide in place of the pathwise one (the step kernel's item gradients and
+                # loss stand); the draws are the step's own Philox normals, keyed by the global person id
+                with self._phase("irt1d_score"):
+                    if eps is None:
+                        eps_sf = self._buf("sf_eps", nb)
+                        gids = None if rows is None else (rows + self.gid0)
+                        be.philox_normals(eps_sf, gids, self.gid0, nb, 1, self.seed, self.t, stream_id)
+                    else:
+                        eps_sf = eps
+                    log_r = self._buf("sf_lr%d" % stream_id if not guide_grads else "sf_lr", nb)
+                    if baseline_buf is not None:
+                        base, beta, by_row = baseline_buf, -1.0, 0
+                    elif self.baseline == "avg":
+                        base, beta, by_row = self.base, (self.baseline_beta if guide_grads else -1.0), 1
+                    else:
+                        base, beta, by_row = None, -1.0, 0
+                    be.irt1d_score_grad(nb, scale, elbo, eps_sf, raw, rows, base, beta, by_row, log_r, gloc, graw)
+                    self.last_log_r = log_r
             if self.amortized:
                 with self._phase("guide_backward"):
                     be.norm_enc_backward(cfg, self.y, rows, nb, enc, fw["h"], gloc, graw,
@@ -796,6 +853,41 @@ class IrtEngine(_EngineBase):
             else:
                 self._scatter_pp(rows, nb, gloc, graw)
             self.last = {"elbo": elbo, "nb": nb}                # the loss itself came out of the kernel's reduction
+
+
+def _irt_step(self, lrs, rows=None, b_global=None, eps=None, num_particles=1):
+    """IrtEngine.step: the leave-one-out control variate of the score-function estimator needs two passes over the
+    particles (log_r of every particle first; the same Philox draws both times: the particle index is the Philox stream);
+    everything else is the common step."""
+    S = int(num_particles)
+    if self.estimator != "score" or self.baseline != "loo" or S < 2:
+        return _EngineBase.step(self, lrs, rows=rows, b_global=b_global, eps=eps, num_particles=S)
+    r = rows[0] if isinstance(rows, (list, tuple)) else rows
+    nb = self.n_local if r is None else int(r.numel())
+    lr_all = self._buf("sf_lr_all", S * nb)
+    for sidx in range(S):
+        e = eps[sidx] if isinstance(eps, (list, tuple)) else eps
+        self.loss_and_grads(r, b_global, e, sidx, guide_grads=False)
+        lr_all[sidx * nb:(sidx + 1) * nb].copy_(self.last_log_r[:nb])
+    accG = torch.zeros_like(self.G)
+    accP = torch.zeros_like(self.GP) if self.per_person else None
+    loo = self._buf("sf_loo", nb)
+    for sidx in range(S):
+        e = eps[sidx] if isinstance(eps, (list, tuple)) else eps
+        self.be.loo_baseline(lr_all, S, nb, sidx, loo)
+        self.loss_and_grads(r, b_global, e, sidx, baseline_buf=loo)
+        accG.add_(self.G, alpha=1.0 / S)
+        if accP is not None:
+            accP.add_(self.GP, alpha=1.0 / S)
+    self.G.copy_(accG)
+    if accP is not None:
+        self.GP.copy_(accP)
+    self.allreduce()
+    self.apply_optim(lrs)
+    return self.G[self.n_params]
+
+
+IrtEngine.step = _irt_step
 
 
 class HoDinaEngine(_EngineBase):
@@ -1206,9 +1298,8 @@ class CdmSfEngine(_EngineBase):
         if accP is not None:
             self.GP.copy_(accP)
         self.allreduce()
-        loss = self.G[self.n_params].clone()
         self.apply_optim(lrs)
-        return loss
+        return self.G[self.n_params]
 
 
 def default_bin_encoder_init(J, K, H, seed):

@@ -187,16 +187,29 @@ class BaseIRT(BasePsy):
                                 H=hidden_dim, share_cov=share_cov, a_free=self.kwargs.get("a_free"),
                                 a0=self.kwargs.get("a0"), b0=self.kwargs.get("b0"),
                                 encoder_init=self.kwargs.get("encoder_init"),
-                                observed_lists=self.kwargs.get("observed_lists", True), **self._eng_kw)
+                                observed_lists=self.kwargs.get("observed_lists", True),
+                                estimator=self.kwargs.get("estimator", "pathwise"),      # 'score': north_star's REINFORCE mode
+                                baseline=self.kwargs.get("baseline", "none"),
+                                baseline_beta=self.kwargs.get("baseline_beta", 0.9), **self._eng_kw)
         self._register()
         self._ri = None
+        self._S, self._loo_left = 1, 0
 
     def fit(self, optim=None, loss=None, max_iter=5000, random_instance=None, progress=True):
         """vi.py:627-656 (defaults Adam lr 5e-2, Trace_ELBO(1), 5000 iterations).  Returns the last loss."""
         optim = optim if optim is not None else Adam({"lr": 5e-2})
         loss = loss if loss is not None else Trace_ELBO(num_particles=1)
         self._ri = random_instance
+        self._S, self._loo_left = max(1, getattr(loss, "num_particles", 1)), 0
         return self._loop(optim, loss, max_iter, progress)
+
+    def _subsample(self):
+        if self.engine.estimator == "score" and self.engine.baseline == "loo":   # the particles of a step share one subsample
+            if self._loo_left == 0:
+                self._loo_cache, self._loo_left = super()._subsample(), self._S
+            self._loo_left -= 1
+            return self._loo_cache
+        return super()._subsample()
 
     def _postfix(self):
         ri, out = self._ri, {}
