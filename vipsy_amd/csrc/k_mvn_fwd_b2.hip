@@ -15,6 +15,9 @@
 
 #define FB2_THREADS 256
 #define FB2_WAVES 4
+#ifndef FB2_LB
+#define FB2_LB 1
+#endif
 #define FB2_NS 2                                                     // person sets of 32 per wave
 #define FB2_WP (32 * FB2_NS)
 
@@ -26,7 +29,7 @@ __host__ __device__ inline size_t fb2_lds_bytes(int D, int J) {
     return FB2_WAVES * fb2_wave_floats(D, J) * sizeof(float) + (size_t)(pk_off_total(D) / 8 + 4) / 4 * 16;
 }
 
-__global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
+__global__ __launch_bounds__(FB2_THREADS, FB2_LB) void k_mvn_enc_fwd_b2(
     EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, int64_t gid0,
     const uint8_t* __restrict__ w1img, const float* __restrict__ b1, const uint8_t* __restrict__ img,
     const uint32_t* __restrict__ gt2, const float* __restrict__ sc /*k_enc_scales*/, const float* __restrict__ eps_in,
@@ -334,6 +337,7 @@ __global__ __launch_bounds__(FB2_THREADS, 1) void k_mvn_enc_fwd_b2(
     };
 
     __syncthreads();                                           // the group table in LDS is complete
+    // (two tiles ahead with a third register set: no change, tools/fwd2_bench.hip -- the loop does not wait for the L2)
     TileRegs RA, RB;
     pull(RA, 0);
     f32x16 accP[NS];
