@@ -51,7 +51,9 @@ int main(int argc, char** argv) {
     k_fill<<<1024, 256>>>(W22, (int64_t)T * 64, 0.125f, 5); k_fill<<<32, 256>>>(b22, T, 0.125f, 6);
     k_fill_y<<<4096, 256>>>(y, nb * J);
     hipLaunchKernelGGL(k_pack_heads, dim3(Rp), dim3(64), 0, 0, D, 64, W21, b21, W22, b22, Wp, bp, gtab, WpT);
-    hipLaunchKernelGGL(k_enc_scales, dim3(1), dim3(1024), 0, 0, D, J, W1, b1, W21, b21, W22, b22, sc);
+    CK(hipMemset(sc, 0, 64));
+    hipLaunchKernelGGL(k_enc_scales_max, dim3(FB_SC_BLOCKS), dim3(256), 0, 0, D, J, W1, b1, W21, b21, W22, b22, sc);
+    hipLaunchKernelGGL(k_enc_scales, dim3(1), dim3(64), 0, 0, sc);
     hipLaunchKernelGGL(k_pack_w1_b, dim3((J + 15) / 16), dim3(256), 0, 0, J, W1, (const float*)sc, w1img);
     hipLaunchKernelGGL(k_pack_heads_b, dim3(n_tiles), dim3(256), 0, 0, n_tiles, pk_off_total(D) / 8, Wp, bp, gtab, (const float*)sc, img, gt2);
     EncDims dm; dm.D = D; dm.J = J; dm.H = 64; dm.Hp = 64; dm.DS = enc_ds(D); dm.T = T; dm.nb = nb;

@@ -89,7 +89,8 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
     const float* __restrict__ eps_in, const float* __restrict__ gxT, const float* __restrict__ gdT /*DIAG-row operand [D][nb]*/,
     float* __restrict__ ghpre_out /*[nb][64] or null*/, const float* __restrict__ hT /*[64][nb], with ghpreT_out*/,
     float* __restrict__ ghpreT_out /*[64][nb] or null*/,
-    uint32_t* __restrict__ maxw /*float bits: largest |gx|, |gd|, |eps|, |ghpre| of the launch, or null*/) {
+    uint32_t* __restrict__ maxw /*float bits: largest |gx|, |gd|, |eps|, |ghpre| of the launch, or null*/,
+    int64_t i_base = 0 /*first person of this launch (a multiple of 32): the persons before it belong to another launch*/) {
     extern __shared__ __attribute__((aligned(16))) char smem_hb[];
     constexpr int H = 64;
     const int D = dm.D;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
     float* gx_lds = (float*)smem_hb + (size_t)wave * D * 32;           // [D][32] of this wave
     const char* ring = smem_hb + (size_t)HB_WAVES * D * 32 * sizeof(float);
     const uint32_t ring_lds = lds_addr_uniform(ring);
-    const int64_t i0 = SPLIT ? (int64_t)blockIdx.x * 32 : ((int64_t)blockIdx.x * HB_WAVES + wave) * 32;
+    const int64_t i0 = i_base + (SPLIT ? (int64_t)blockIdx.x * 32 : ((int64_t)blockIdx.x * HB_WAVES + wave) * 32);
     const int64_t i = i0 + l31;
     const int64_t ic = i < nb ? i : nb - 1;                            // absent persons: a valid one, never stored
     const int n_units = hb_units(D);

@@ -40,42 +40,48 @@ __host__ __device__ inline size_t fb_lds_bytes(int D, int J) {
 // bound cannot overflow, and a bound a few binades above the values costs nothing (fp16 pairs keep 2^-22 relative down
 // to 2^-3 and 2^-25 absolute below it).
 #define FB_NSCALES 16
-__global__ __launch_bounds__(1024) void k_enc_scales(int D, int J, const float* __restrict__ W1, const float* __restrict__ b1,
-                                                     const float* __restrict__ W21, const float* __restrict__ b21,
-                                                     const float* __restrict__ W22, const float* __restrict__ b22,
-                                                     float* __restrict__ sc) {
-    __shared__ float red[4][16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// two launches: FB_SC_BLOCKS blocks take the maxima (integer atomicMax on the bit patterns of non-negative floats:
+// order-independent) into sc[11..14] (cleared by k_pack_heads, which runs first), one thread turns them into the powers of
+// two.  (One block over the 0.36 M parameters took 72 us a step.)
+#define FB_SC_BLOCKS 64
+__global__ __launch_bounds__(256) void k_enc_scales_max(int D, int J, const float* __restrict__ W1, const float* __restrict__ b1,
+                                                        const float* __restrict__ W21, const float* __restrict__ b21,
+                                                        const float* __restrict__ W22, const float* __restrict__ b22,
+                                                        float* __restrict__ sc) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
     const int T = D * (D + 1) / 2;
+    const int gt = blk * 256 + tid, gn = FB_SC_BLOCKS * 256;
     float mw = 0.f, mb = 0.f, m1 = 0.f, l1 = 0.f;
-    for (int e = tid; e < D * 64; e += 1024) mw = fmaxf(mw, fabsf(W21[e]));
-    for (int e = tid; e < T * 64; e += 1024) mw = fmaxf(mw, fabsf(W22[e]));
-    for (int e = tid; e < D; e += 1024) mb = fmaxf(mb, fabsf(b21[e]));
-    for (int e = tid; e < T; e += 1024) mb = fmaxf(mb, fabsf(b22[e]));
-    for (int u = wave; u < 64; u += 16) {                      // hidden unit u: |W1[u, :]|_1 + |b1[u]|
+    for (int e = gt; e < D * 64; e += gn) mw = fmaxf(mw, fabsf(W21[e]));
+    for (int e = gt; e < T * 64; e += gn) mw = fmaxf(mw, fabsf(W22[e]));
+    for (int e = gt; e < D; e += gn) mb = fmaxf(mb, fabsf(b21[e]));
+    for (int e = gt; e < T; e += gn) mb = fmaxf(mb, fabsf(b22[e]));
+    for (int u = blk * 4 + wave; u < 64; u += FB_SC_BLOCKS * 4) {          // hidden unit u: |W1[u, :]|_1 + |b1[u]|
         float sacc = 0.f;
         for (int j = lane; j < J; j += 64) { const float w = fabsf(W1[(int64_t)u * J + j]); sacc += w; m1 = fmaxf(m1, w); }
         sacc = wave_sum(sacc) + fabsf(b1[u]);
         l1 = fmaxf(l1, sacc);
     }
     mw = wave_max_dpp(mw); mb = wave_max_dpp(mb); m1 = wave_max_dpp(m1);
-    if (lane == 0) { red[0][wave] = mw; red[1][wave] = mb; red[2][wave] = m1; red[3][wave] = l1; }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < 16; ++w) {
-            mw = fmaxf(mw, red[0][w]); mb = fmaxf(mb, red[1][w]); m1 = fmaxf(m1, red[2][w]); l1 = fmaxf(l1, red[3][w]);
-        }
-        const float hbound = 1.001f * (fmaxf(l1, 0.f) + log1pf(expf(-fabsf(l1)))) + 1e-30f;     // softplus(l1), a hair over
-        const int sw1 = f16_scale_exp(m1), sh = f16_scale_exp(hbound);
-        int sw = f16_scale_exp(mw), sb = f16_scale_exp(mb), eb = sw + sh - sb;
-        // the bias enters the accumulator chain as one more product, (b 2^sb) x 2^eb: the constant must be an fp16 normal
-        if (eb > 15) { sw -= eb - 15; eb = 15; }                // a bias far above |W| |h|: the weights give up headroom
-        if (eb < -14) { sb = sw + sh + 14; eb = -14; }          // a bias far below: it sits lower in the fp16 range
-        sc[0] = ldexpf(1.f, sw1); sc[1] = ldexpf(1.f, -sw1);
-        sc[2] = ldexpf(1.f, sw); sc[3] = ldexpf(1.f, sh); sc[4] = ldexpf(1.f, -(sw + sh));
-        sc[5] = ldexpf(1.f, sb); sc[6] = ldexpf(1.f, eb);
-        sc[7] = hbound; sc[8] = mw; sc[9] = mb; sc[10] = m1;
+    if (lane == 0) {
+        uint32_t* w = (uint32_t*)(sc + 11);
+        atomicMax(w + 0, __builtin_bit_cast(uint32_t, mw)); atomicMax(w + 1, __builtin_bit_cast(uint32_t, mb));
+        atomicMax(w + 2, __builtin_bit_cast(uint32_t, m1)); atomicMax(w + 3, __builtin_bit_cast(uint32_t, l1));
     }
+}
+__global__ void k_enc_scales(float* __restrict__ sc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float mw = sc[11], mb = sc[12], m1 = sc[13], l1 = sc[14];
+    const float hbound = 1.001f * (fmaxf(l1, 0.f) + log1pf(expf(-fabsf(l1)))) + 1e-30f;     // softplus(l1), a hair over
+    const int sw1 = f16_scale_exp(m1), sh = f16_scale_exp(hbound);
+    int sw = f16_scale_exp(mw), sb = f16_scale_exp(mb), eb = sw + sh - sb;
+    // the bias enters the accumulator chain as one more product, (b 2^sb) x 2^eb: the constant must be an fp16 normal
+    if (eb > 15) { sw -= eb - 15; eb = 15; }                // a bias far above |W| |h|: the weights give up headroom
+    if (eb < -14) { sb = sw + sh + 14; eb = -14; }          // a bias far below: it sits lower in the fp16 range
+    sc[0] = ldexpf(1.f, sw1); sc[1] = ldexpf(1.f, -sw1);
+    sc[2] = ldexpf(1.f, sw); sc[3] = ldexpf(1.f, sh); sc[4] = ldexpf(1.f, -(sw + sh));
+    sc[5] = ldexpf(1.f, sb); sc[6] = ldexpf(1.f, eb);
+    sc[7] = hbound; sc[8] = mw; sc[9] = mb; sc[10] = m1;
 }
 
 // tile image: fragment (term sp, k-step s) at byte (sp * 4 + s) * 1024 + lane * 16, lane = 32 half + row; sp = 0: heads, 1:

@@ -151,6 +151,23 @@ struct ProfScope {
     }
 };
 
+// A second stream for work that is independent of what the launch stream does next (the fc1 weight gradient beside the head
+// weight gradient of vx_mvn_enc_backward): forked and joined with events, so the caller still sees ONE ordered stream.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool ok = false;
+    SideStream() {
+        ok = hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess;
+    }
+};
+SideStream& side_stream() {
+    static thread_local SideStream ss;                     // (one per host thread: events are re-recorded per call)
+    return ss;
+}
+
 }  // namespace
 
 extern "C" {
@@ -351,8 +368,10 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
         // the powers of two of the f16x2 operands (the backward kernels read them too: pack_scales below)
         float* sc = packws + vx_mvn_pack_floats(cfg) - FB_NSCALES;
         hs_after.hscale = sc + 3;
-        hipLaunchKernelGGL(k_enc_scales, dim3(1), dim3(1024), 0, (hipStream_t)hs, (int)dm.D, (int)dm.J, W1, b1, W21, b21, W22,
-                           b22, sc);
+        hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(64), 0, (hipStream_t)hs, (uint32_t*)(sc + 11), 4);
+        hipLaunchKernelGGL(k_enc_scales_max, dim3(FB_SC_BLOCKS), dim3(256), 0, (hipStream_t)hs, (int)dm.D, (int)dm.J, W1, b1, W21,
+                           b21, W22, b22, sc);
+        hipLaunchKernelGGL(k_enc_scales, dim3(1), dim3(64), 0, (hipStream_t)hs, sc);
         VX_CHECK_LAUNCH();
         if (fwb_shape(cfg)) {
             uint8_t* img = (uint8_t*)(WpT + (int64_t)Rp * 64);
@@ -845,6 +864,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     int rc;
     bool f1t = false;                                      // fc1 gradient on the dimension-major kernel (ghpre holds ghpreT)
     bool maxw_ready = false;                               // k_mvn_enc_bwd_h_b ran: the operand maxima of the step are collected
+    bool f1_done = false;                                  // the fc1 gradient (and its slab sum) went out on the side stream
     if (packed) {
         const float* Wp = packws;
         const uint32_t* gtab = (const uint32_t*)(packws + Rp * 64 + Rp);
@@ -880,9 +900,22 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                     const size_t lds2 = hb2_lds_bytes(dm.D);
                     rc = set_lds(k_mvn_enc_bwd_h_b2<7>, lds2);
                     if (rc) return rc;
-                    hipLaunchKernelGGL(k_mvn_enc_bwd_h_b2<7>, dim3((unsigned)((nb + HB2_WAVES * HB2_WP - 1) / (HB2_WAVES * HB2_WP))),
+                    // its workgroups take 256 persons: a last round that fills less than half the chip goes to the 32-persons-
+                    // per-wave kernel instead (1M persons: 15 full rounds + 16 960 persons), as in the forward
+                    const int64_t round2 = (int64_t)HB2_WAVES * HB2_WP * num_cu();
+                    const int64_t rem = nb % round2;
+                    const int64_t n_done = (rem > 0 && 2 * rem <= round2 && nb > round2) ? nb - rem : nb;
+                    hipLaunchKernelGGL(k_mvn_enc_bwd_h_b2<7>, dim3((unsigned)((n_done + HB2_WAVES * HB2_WP - 1) / (HB2_WAVES * HB2_WP))),
                                        dim3(HB2_THREADS), lds2, st, dm, (const uint8_t*)himg, sc, h, eps, gxT, (const float*)gdT1,
                                        f1t ? (float*)nullptr : ghpre, hT, f1t ? ghpre : (float*)nullptr, maxw);
+                    if (n_done < nb) {
+                        VX_CHECK_LAUNCH();
+                        rc = set_lds(k_mvn_enc_bwd_h_b<false>, ldsh);
+                        if (rc) return rc;
+                        hipLaunchKernelGGL(k_mvn_enc_bwd_h_b<false>, dim3((unsigned)((nb - n_done + 32 * HB_WAVES - 1) / (32 * HB_WAVES))),
+                                           dim3(HB_THREADS), ldsh, st, dm, (const uint8_t*)himg, sc, h, eps, gxT, (const float*)gdT1,
+                                           f1t ? (float*)nullptr : ghpre, hT, f1t ? ghpre : (float*)nullptr, maxw, n_done);
+                    }
                 } else {
                     rc = set_lds(k_mvn_enc_bwd_h_b<false>, ldsh);
                     if (rc) return rc;
@@ -906,6 +939,22 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
             hipLaunchKernelGGL(k_mvn_enc_bwd_h_p, dim3((unsigned)((nb + ENC_P - 1) / ENC_P)), dim3(ENC_THREADS), lds, st,
                                dm, cfg->scale, Wp, gtab, h, eps, ldT, gx, ghpre);
             VX_CHECK_LAUNCH();
+        }
+        if (nb > 0 && f1t && (mfma16_mode() & 8) && side_stream().ok) {
+            // the fc1 weight gradient needs ghpre only: it runs on a second stream beside the head weight gradient below
+            // (0.33 ms of a 1M step that used to follow it) and is joined before this call returns
+            SideStream& ss = side_stream();
+            if (hipEventRecord(ss.fork, st) != hipSuccess || hipStreamWaitEvent(ss.s, ss.fork, 0) != hipSuccess) return VX_EINVAL;
+            {
+                ProfScope ps("k_fc1_bwd_b", ss.s);
+                hipLaunchKernelGGL(k_fc1_bwd_b, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0, ss.s,
+                                   dm, yT, yT_stride, ghpre, slabs_f, lenf);
+                VX_CHECK_LAUNCH();
+            }
+            rc = vx_reduce_slabs(slabs_f, n_prf, lenf, -1.0f, genc, (void*)ss.s);
+            if (rc) return rc;
+            if (hipEventRecord(ss.join, ss.s) != hipSuccess) return VX_EINVAL;
+            f1_done = true;
         }
         if (use_t && bwb_shape(cfg, nb)) {
             float* gdT = slabs_f + (int64_t)n_prf * lenf;
@@ -991,7 +1040,9 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
             VX_CHECK_LAUNCH();
         }
     }
-    if (nb > 0 && f1t && (mfma16_mode() & 8)) {
+    if (f1_done) {
+        // (joined below)
+    } else if (nb > 0 && f1t && (mfma16_mode() & 8)) {
         ProfScope ps("k_fc1_bwd_b", st);
         hipLaunchKernelGGL(k_fc1_bwd_b, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0, st, dm,
                            yT, yT_stride, ghpre, slabs_f, lenf);
@@ -1021,8 +1072,12 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
         if (he != hipSuccess) return (int)he;
     }
     // flat encoder-gradient layout = nn.Linear order: [W1 | b1 | W21 | b21 | W22 | b22]; loss grads = -dELBO
-    rc = vx_reduce_slabs(slabs_f, n_prf, lenf, -1.0f, genc, hs);
-    if (rc) return rc;
+    if (f1_done) {
+        if (hipStreamWaitEvent(st, side_stream().join, 0) != hipSuccess) return VX_EINVAL;   // the fc1 gradient is in genc
+    } else {
+        rc = vx_reduce_slabs(slabs_f, n_prf, lenf, -1.0f, genc, hs);
+        if (rc) return rc;
+    }
     if (packed) {
         hipLaunchKernelGGL(k_unpack_head_grads, dim3((unsigned)((Rp + 3) / 4)), dim3(256), 0, st, (int)D, (int)H, slabs_w, n_prw,
                            Rp * (H + 1), -1.0f, genc + lenf);
