@@ -91,15 +91,17 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y /*[n_local][J]*/,
                        float* hT /*[H][nb] or NULL*/, float* epsT /*[D][nb] or NULL*/,
                        float* packws /*vx_mvn_pack_floats(cfg) floats or NULL*/,
                        uint8_t* ximg /*vx_irt_lik_ximg_bytes(cfg, nb) bytes or NULL*/,
-                       uint16_t* hs /*[3][64][nb] bf16 or NULL*/, void* hip_stream);
-/* hs (optional, with hT, hidden_dim 64): the three bf16 terms of hT, the operand of the head weight-gradient kernel --
- * point it at workspace + vx_mvn_enc_bwd_hs_offset(cfg, nb) of the backward call and set bit 1 of its gd_ready. */
+                       uint16_t* hs /*[2][64][nb] fp16 or NULL*/, void* hip_stream);
+/* hs (optional, with hT, hidden_dim 64): the two fp16 terms of hT 2^sh (the power of two that `packws` carries for h), the
+ * operand of the head weight-gradient kernel -- point it at workspace + vx_mvn_enc_bwd_hs_offset(cfg, nb) of the backward
+ * call and set bit 1 of its gd_ready. */
 /* ximg (optional): x once more, as the pre-split operand image of the bf16-MFMA likelihood kernel (three bf16 terms per
  * value in that kernel's LDS tile order); hand the same buffer to vx_irt_lik_grad, which otherwise makes it itself. */
 /* hT / epsT: optional dimension-major copies of h and eps (person-contiguous rows) for the weight-gradient kernel
  * of vx_mvn_enc_backward; written only by the packed fast path (H == 64, D % 4 == 0, J % 4 == 0). */
 /* `packws` holds this step's packed copy of the head weights (a re-ordering of fc22 | fc21 rows that the
- * fast kernels use, see vipsy_amd/csrc/k_pack.hip); forward fills it, the matching backward call reads it. */
+ * fast kernels use, see vipsy_amd/csrc/k_pack.hip), their fp16-pair operand images and the powers of two of the
+ * f16x2 operands; forward fills it, the matching backward call of the SAME step reads it. */
 int64_t vx_mvn_pack_floats(const vx_irt_cfg* cfg);
 
 /* ---- model likelihood + gradients for D >= 2 (irt_2pl..4pl + _get_p_data mask + Bernoulli
@@ -149,7 +151,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                                            vx_mvn_enc_forward already wrote hs there*/, void* hip_stream);
 /* float offset of gdT[D][nb] inside the backward workspace, or -1 when this (cfg, nb) has no such operand */
 int64_t vx_mvn_enc_bwd_gd_offset(const vx_irt_cfg* cfg, int64_t nb);
-/* float offset of hs[3][64][nb] (bf16) inside the backward workspace, or -1 when this (cfg, nb) does not use it */
+/* float offset of hs[2][64][nb] (fp16) inside the backward workspace, or -1 when this (cfg, nb) does not use it */
 int64_t vx_mvn_enc_bwd_hs_offset(const vx_irt_cfg* cfg, int64_t nb);
 /* With hT, epsT and gxT (the dimension-major copies made by the forward / likelihood calls) the head weight
  * gradients run on the DMA-staged kernel of k_mvn_bwd_t.hip; without them on the person-major one.
