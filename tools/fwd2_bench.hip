@@ -57,21 +57,32 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(k_pack_w1_b, dim3((J + 15) / 16), dim3(256), 0, 0, J, W1, (const float*)sc, w1img);
     hipLaunchKernelGGL(k_pack_heads_b, dim3(n_tiles), dim3(256), 0, 0, n_tiles, pk_off_total(D) / 8, Wp, bp, gtab, (const float*)sc, img, gt2);
     EncDims dm; dm.D = D; dm.J = J; dm.H = 64; dm.Hp = 64; dm.DS = enc_ds(D); dm.T = T; dm.nb = nb;
-    const size_t lds = fb2_lds_bytes(D, J);
-    CK(hipFuncSetAttribute((const void*)k_mvn_enc_fwd_b2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int rep = 0; rep < 4; ++rep) {
-        hipEventRecord(e0);
-        hipLaunchKernelGGL(k_mvn_enc_fwd_b2, dim3((unsigned)((nb + 255) / 256)), dim3(FB2_THREADS), lds, 0, dm, (const uint8_t*)y,
-                           (const int64_t*)nullptr, (int64_t)0, (const uint8_t*)w1img, (const float*)b1, (const uint8_t*)img,
-                           (const uint32_t*)gt2, (const float*)sc, (const float*)nullptr, (uint64_t)1234, 0u, 0u, h, x, eps, ldT, ent, hT,
-                           epsT, ximg, hs);
-        hipEventRecord(e1); CK(hipEventSynchronize(e1));
-        float ms; hipEventElapsedTime(&ms, e0, e1);
-        printf("k_mvn_enc_fwd_b2 nb=%lld: %.3f ms (lds %zu)\n", (long long)nb, ms, lds);
-    }
-    std::vector<float> out(4);
-    CK(hipMemcpy(out.data(), x + 1000, 16, hipMemcpyDeviceToHost));
-    printf("check %g %g %g %g\n", out[0], out[1], out[2], out[3]);
+    auto run = [&](auto nsc) -> int {
+        constexpr int NS = decltype(nsc)::value;
+        const size_t lds = fb2_lds_bytes(D, J, NS);
+        CK(hipFuncSetAttribute((const void*)k_mvn_enc_fwd_b2<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int wg = FB2_WAVES * 32 * NS;
+        for (int rep = 0; rep < 4; ++rep) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(k_mvn_enc_fwd_b2<NS>, dim3((unsigned)((nb + wg - 1) / wg)), dim3(FB2_THREADS), lds, 0, dm, (const uint8_t*)y,
+                               (const int64_t*)nullptr, (int64_t)0, (const uint8_t*)w1img, (const float*)b1, (const uint8_t*)img,
+                               (const uint32_t*)gt2, (const float*)sc, (const float*)nullptr, (uint64_t)1234, 0u, 0u, h, x, eps, ldT, ent, hT,
+                               epsT, ximg, hs);
+            hipEventRecord(e1); CK(hipEventSynchronize(e1));
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("k_mvn_enc_fwd_b2<%d> nb=%lld: %.3f ms (lds %zu)\n", NS, (long long)nb, ms, lds);
+        }
+        std::vector<float> o(4);
+        CK(hipMemcpy(o.data(), x + 1000, 16, hipMemcpyDeviceToHost));
+        float hv, ev, lv; uint16_t hsv; uint8_t xb;
+        CK(hipMemcpy(&hv, hT + 3 * nb + 777, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&ev, epsT + 5 * nb + 4321, 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(&lv, ldT + 7 * nb + 99, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&hsv, hs + 64 * nb + 2 * nb + 55, 2, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(&xb, ximg + 123457, 1, hipMemcpyDeviceToHost));
+        printf("check x %g %g %g %g  hT %g epsT %g ldT %g hs %u ximg %u\n", o[0], o[1], o[2], o[3], hv, ev, lv, (unsigned)hsv, (unsigned)xb);
+        return 0;
+    };
+    if (run(std::integral_constant<int, 2>{})) return 1;
+    if (run(std::integral_constant<int, 1>{})) return 1;
     return 0;
 }

@@ -15,21 +15,23 @@
 
 #define FB2_THREADS 256
 #define FB2_WAVES 4
-#ifndef FB2_LB
-#define FB2_LB 1
-#endif
-#define FB2_NS 2                                                     // person sets of 32 per wave
-#define FB2_WP (32 * FB2_NS)
+// NS person sets of 32 per wave.  NS = 2 (64 persons, one workgroup a CU: 135 KB of LDS at the headline shape) is the form
+// described above.  NS = 1 (round 3) is the same code with one set: 66 KB of LDS and under 256 registers, so TWO workgroups
+// share a CU -- two waves per SIMD, from different workgroups and therefore out of step: the serial phases of one (y
+// staging, fc1 outputs, eps, sections, x image: 40 % of the NS = 2 kernel) run under the head loop of the other, and the
+// MFMAs take the VGPR form (no accumulator reads from AGPRs in the epilogue).
+#define FB2_WP_OF(NS) (32 * (NS))
 
-__host__ __device__ inline size_t fb2_wave_floats(int D, int J) {
-    const size_t a = (size_t)FB2_WP * ef_ys(J) / 4, b = (size_t)FB2_WP * pk_dse(D);   // response bytes | eps tile
+__host__ __device__ inline size_t fb2_wave_floats(int D, int J, int NS = 2) {
+    const size_t a = (size_t)FB2_WP_OF(NS) * ef_ys(J) / 4, b = (size_t)FB2_WP_OF(NS) * pk_dse(D);   // response bytes | eps tile
     return ((a > b ? a : b) + 3) & ~(size_t)3;
 }
-__host__ __device__ inline size_t fb2_lds_bytes(int D, int J) {
-    return FB2_WAVES * fb2_wave_floats(D, J) * sizeof(float) + (size_t)(pk_off_total(D) / 8 + 4) / 4 * 16;
+__host__ __device__ inline size_t fb2_lds_bytes(int D, int J, int NS = 2) {
+    return FB2_WAVES * fb2_wave_floats(D, J, NS) * sizeof(float) + (size_t)(pk_off_total(D) / 8 + 4) / 4 * 16;
 }
 
-__global__ __launch_bounds__(FB2_THREADS, FB2_LB) void k_mvn_enc_fwd_b2(
+template <int NS>
+__global__ __launch_bounds__(FB2_THREADS, (NS == 1 ? 2 : 1)) void k_mvn_enc_fwd_b2(
     EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, int64_t gid0,
     const uint8_t* __restrict__ w1img, const float* __restrict__ b1, const uint8_t* __restrict__ img,
     const uint32_t* __restrict__ gt2, const float* __restrict__ sc /*k_enc_scales*/, const float* __restrict__ eps_in,
@@ -39,16 +41,16 @@ __global__ __launch_bounds__(FB2_THREADS, FB2_LB) void k_mvn_enc_fwd_b2(
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2w __attribute__((ext_vector_type(2)));
-    constexpr int H = 64, NS = FB2_NS;
+    constexpr int H = 64, FB2_WP = FB2_WP_OF(NS);
     const int D = dm.D, J = dm.J;
     const int DS = pk_dse(D);
     const int YS = ef_ys(J);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    float* R1 = smem + wave * fb2_wave_floats(D, J);
+    float* R1 = smem + wave * fb2_wave_floats(D, J, NS);
     int8_t* Yi = (int8_t*)R1;                                 // phase A: [64][ysr] response bytes
     float* eps_lds = R1;                                      // phase B: [64][DS]
-    uint32_t* gt_lds = (uint32_t*)(smem + FB2_WAVES * fb2_wave_floats(D, J));
+    uint32_t* gt_lds = (uint32_t*)(smem + FB2_WAVES * fb2_wave_floats(D, J, NS));
     const int64_t i0 = ((int64_t)blockIdx.x * FB2_WAVES + wave) * FB2_WP;
     const int p = l31;
     int64_t iu[NS];                                           // this lane's person of set u
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(FB2_THREADS, FB2_LB) void k_mvn_enc_fwd_b2(
     // ---------------------------------------------------------------- response rows of the wave's 64 persons
     const int n_ydma = (FB2_WP * J + 1023) / 1024;
     const bool ydense = !rows && ((J >> 2) & 1) && i0 + FB2_WP <= dm.nb && (i0 * J + (int64_t)n_ydma * 1024 <= dm.nb * (int64_t)J) &&
-                        (size_t)n_ydma * 1024 <= fb2_wave_floats(D, J) * sizeof(float);
+                        (size_t)n_ydma * 1024 <= fb2_wave_floats(D, J, NS) * sizeof(float);
     const int ysr = ydense ? J : YS;
     if (ydense) {
         const uint8_t* src = y + i0 * J + 16 * lane;
@@ -138,11 +140,13 @@ __global__ __launch_bounds__(FB2_THREADS, FB2_LB) void k_mvn_enc_fwd_b2(
         // 128 of them per person set, and the phase is bound by store issue.  A whole wave on 16-byte aligned rows
         // transposes through the LDS region the response bytes have left instead: 16 bytes per lane, 20 instructions.
         constexpr int ST_T = 36, ST_S = 40;                   // row strides of the stages: [64][36] f32 | [2 * 64][40] u16
+        // (NS = 1: the region holds one stage at a time -- the hs stage takes the place of the hT stage once that is stored)
+        constexpr bool SEQ = NS == 1;
         const bool coal = i0 + FB2_WP <= dm.nb && (dm.nb & 7) == 0 && hT_out && hs_out &&
                           (((uintptr_t)hT_out | (uintptr_t)hs_out) & 15) == 0 &&
-                          fb2_wave_floats(D, J) * sizeof(float) >= 64 * ST_T * 4 + 128 * ST_S * 2;   // wave-uniform
+                          fb2_wave_floats(D, J, NS) * sizeof(float) >= (SEQ ? 128 * ST_S * 2 : 64 * ST_T * 4 + 128 * ST_S * 2);   // wave-uniform
         float* stT = R1;
-        uint16_t* stS = (uint16_t*)(R1 + 64 * ST_T);
+        uint16_t* stS = SEQ ? (uint16_t*)R1 : (uint16_t*)(R1 + 64 * ST_T);
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
             const int64_t i = iu[u];
@@ -177,6 +181,16 @@ __global__ __launch_bounds__(FB2_THREADS, FB2_LB) void k_mvn_enc_fwd_b2(
                 for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) stT[(32 * ht + crow32(r, half)) * ST_T + p] = hreg[ht][r];
+                const int64_t c0 = i0 + 32 * u;
+                if constexpr (SEQ) {
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {              // hT: 64 rows x 8 pieces of 4 persons
+                        const int e = lane + 64 * it, hh = e >> 3, g = e & 7;
+                        *(f32x4*)(hT_out + (int64_t)hh * dm.nb + c0 + 4 * g) = *(const f32x4*)(stT + hh * ST_T + 4 * g);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
                 // the hs planes (operand of k_mvn_enc_bwd_w_b) take the fragments' two fp16 terms of h 2^sh
 #pragma unroll
                 for (int t2 = 0; t2 < 2; ++t2)
@@ -190,11 +204,12 @@ __global__ __launch_bounds__(FB2_THREADS, FB2_LB) void k_mvn_enc_fwd_b2(
                         }
                     }
                 __builtin_amdgcn_wave_barrier();
-                const int64_t c0 = i0 + 32 * u;
+                if constexpr (!SEQ) {
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {                  // hT: 64 rows x 8 pieces of 4 persons
-                    const int e = lane + 64 * it, hh = e >> 3, g = e & 7;
-                    *(f32x4*)(hT_out + (int64_t)hh * dm.nb + c0 + 4 * g) = *(const f32x4*)(stT + hh * ST_T + 4 * g);
+                    for (int it = 0; it < 8; ++it) {              // hT: 64 rows x 8 pieces of 4 persons
+                        const int e = lane + 64 * it, hh = e >> 3, g = e & 7;
+                        *(f32x4*)(hT_out + (int64_t)hh * dm.nb + c0 + 4 * g) = *(const f32x4*)(stT + hh * ST_T + 4 * g);
+                    }
                 }
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {                  // hs: 2 x 64 rows x 4 pieces of 8 persons
@@ -246,8 +261,9 @@ __global__ __launch_bounds__(FB2_THREADS, FB2_LB) void k_mvn_enc_fwd_b2(
     // instead of D
     const bool coalE = i0 + FB2_WP <= dm.nb && (dm.nb & 3) == 0 && epsT_out && ((uintptr_t)epsT_out & 15) == 0;
     if (coalE) {
-        for (int e = lane; e < D * 16; e += 64) {
-            const int k = e >> 4, g = e & 15;
+        constexpr int PG = FB2_WP / 4;                         // groups of four persons
+        for (int e = lane; e < D * PG; e += 64) {
+            const int k = e / PG, g = e - k * PG;
             const float* ec = eps_lds + 4 * g * DS + k;
             *(f32x4*)(epsT_out + (int64_t)k * dm.nb + i0 + 4 * g) = f32x4{ec[0], ec[DS], ec[2 * DS], ec[3 * DS]};
         }
@@ -298,7 +314,7 @@ __global__ __launch_bounds__(FB2_THREADS, FB2_LB) void k_mvn_enc_fwd_b2(
     float* xrow[NS];
     float* xst[NS];                                           // staging of the OFF sums: element k at xst + (k << st_sh)
     const bool whole = i0 + FB2_WP <= dm.nb;                  // wave-uniform
-    const int st_sh = whole ? 6 : 0;
+    const int st_sh = whole ? (NS == 2 ? 6 : 5) : 0;
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
         cur_part[u] = 0.f;
@@ -467,6 +483,7 @@ __global__ __launch_bounds__(FB2_THREADS, FB2_LB) void k_mvn_enc_fwd_b2(
     STAMP();                                                  // 5: sections + eps_out
     // ---------------------------------------------------------------- the likelihood kernel's operand image of x
     if (ximg_out && i0 < (dm.nb + 63) / 64 * 64) {
+        const int pbase = (int)(i0 & 63);                      // NS = 1: this wave's 32 persons are one half of a 64-person tile
         vx_wait_vmem();                                        // x of this wave is complete in memory
         __builtin_amdgcn_wave_barrier();
         // x_aug = [x, 1, 0..] as three bf16 terms in the LDS tile order of k_irt_lik_b (lb_xoff): the wave's 64 persons are
@@ -497,7 +514,7 @@ __global__ __launch_bounds__(FB2_THREADS, FB2_LB) void k_mvn_enc_fwd_b2(
                     ch = 12 + (r & 1);
                 }
                 pp += 32 * hs2;
-                off[w] = lb_xoff(pp, ch);
+                off[w] = lb_xoff(pbase + pp, ch);
                 const float* xr = x_out + (i0 + (pp < pvi ? pp : 0)) * D;
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {               // D % 4 == 0: a quad is inside the row, or at k == D, or past it

@@ -399,21 +399,25 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
                 VX_CHECK_LAUNCH();
                 return VX_OK;
             }
-            int64_t n_done = 0;                                     // persons taken by the 64-per-wave kernel
-            if (fb2_lds_bytes(dm.D, dm.J) <= 160 * 1024) {
-                // large batch: 64 persons per wave, every head-tile fragment feeds two MFMA chains (k_mvn_fwd_b2.hip).  Its
-                // workgroups take 256 persons: a last round that fills less than half the chip goes to the 128-person
-                // kernel instead (1M persons: 15 full rounds + 16 960 persons)
-                const int64_t round2 = (int64_t)FB2_WAVES * FB2_WP * num_cu();
+            int64_t n_done = 0;                                     // persons taken by k_mvn_enc_fwd_b2
+            // large batch: k_mvn_fwd_b2.hip with ONE person set per wave -- 128-person workgroups, two of them on a CU (two
+            // waves per SIMD, out of step): 2.74 against 2.86-2.97 ms for the 64-persons-per-wave form on the same box
+            // (tools/fwd2_bench.hip).  A chip round is 65 536 persons either way: a last round that fills less than half the
+            // chip goes to the 128-person kernel of k_mvn_fwd_b.hip (1M persons: 15 full rounds + 16 960 persons)
+            constexpr int FNS = 1;
+            if (fb2_lds_bytes(dm.D, dm.J, FNS) <= 80 * 1024) {
+                const int64_t round2 = (int64_t)FB2_WAVES * 64 * num_cu();
                 const int64_t rem = nb % round2;
                 n_done = (rem > 0 && 2 * rem <= round2) ? nb - rem : nb;
+                n_done -= n_done % (FB2_WAVES * 64);            // whole 64-person tiles of the x image, whole workgroups
             }
             if (n_done > 0) {
-                const size_t lds2 = fb2_lds_bytes(dm.D, dm.J);
-                rc = set_lds(k_mvn_enc_fwd_b2, lds2);
+                const size_t lds2 = fb2_lds_bytes(dm.D, dm.J, FNS);
+                rc = set_lds(k_mvn_enc_fwd_b2<FNS>, lds2);
                 if (rc) return rc;
                 ProfScope ps("k_mvn_enc_fwd_b2", (hipStream_t)hs, n_done);
-                hipLaunchKernelGGL(k_mvn_enc_fwd_b2, dim3((unsigned)((n_done + FB2_WAVES * FB2_WP - 1) / (FB2_WAVES * FB2_WP))),
+                const int wg = FB2_WAVES * 32 * FNS;
+                hipLaunchKernelGGL(k_mvn_enc_fwd_b2<FNS>, dim3((unsigned)((n_done + wg - 1) / wg)),
                                    dim3(FB2_THREADS), lds2, (hipStream_t)hs, dm, y, rows, gid0, (const uint8_t*)w1img, b1,
                                    (const uint8_t*)img, (const uint32_t*)gt2, (const float*)sc, eps_in, cfg->seed, cfg->step,
                                    cfg->stream, h, x, eps, ldT, ent, hT, epsT, ximg, hs_out);      // the grid stops at n_done
