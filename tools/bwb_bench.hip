@@ -47,7 +47,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k_mvn_enc_bwd_w_b, dim3(n_rowslabs, n_prw), dim3(BT_THREADS), lds, 0, dm, hs, epsT, gdT, gxT, gtab,
+        hipLaunchKernelGGL(k_mvn_enc_bwd_w_b, dim3(n_rowslabs, n_prw), dim3(BWB_THREADS), lds, 0, dm, hs, epsT, gdT, gxT, gtab,
                            (const float*)sc, (const uint32_t*)maxw, slabs, (int64_t)Rp * 65);
         hipEventRecord(e1); CK(hipEventSynchronize(e1));
         float ms; hipEventElapsedTime(&ms, e0, e1);

@@ -52,7 +52,21 @@ __global__ void k_absmax3(const float* __restrict__ a, const float* __restrict__
 __global__ void k_clear_words(uint32_t* __restrict__ w, int n) { if ((int)threadIdx.x < n) w[threadIdx.x] = 0u; }
 
 
-__global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
+// BWB_WAVES waves of BWB_RT row tiles each (BWB_WAVES * BWB_RT * 32 = BT_ROWS rows a workgroup, as k_mvn_bwd_t.hip).  Round 3:
+// EIGHT waves of two row tiles instead of four of four -- 64 accumulator registers a wave, the kernel fits 256 registers
+// (the MFMAs take the VGPR form) and two waves share a SIMD: one wave's products / split / LDS waits run under the other's
+// MFMAs.  (BWB_WAVES 4 / BWB_RT 4 is the round-2 form.)
+#ifndef BWB_WAVES
+#define BWB_WAVES 8
+#endif
+#ifndef BWB_PRESCALE
+#define BWB_PRESCALE 0                                                  // 1: the E rows take V's power of two in LDS instead of a multiply per
+                                                                       // product -- 8 vector instructions a group less, and no faster
+                                                                       // (2.88-2.91 against 2.83-2.84 ms on one box, tools/bwb_bench.hip)
+#endif
+#define BWB_RT (16 / BWB_WAVES)
+#define BWB_THREADS (64 * BWB_WAVES)
+__global__ __launch_bounds__(BWB_THREADS, 1) void k_mvn_enc_bwd_w_b(
     EncDims dm, const uint16_t* __restrict__ hs /*[2][64][nb] fp16 terms of h 2^sh*/, const float* __restrict__ epsT,
     const float* __restrict__ gdT, const float* __restrict__ gxT, const uint32_t* __restrict__ gtab,
     const float* __restrict__ sc /*k_enc_scales*/, const uint32_t* __restrict__ maxw /*float bits: max |gx|, |gd|, |eps|*/,
@@ -66,7 +80,7 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
     const int Rp = pk_rows(D);
     int rb_, blk_pr;
     bt_decode(rb_, blk_pr);
-    const int64_t rbase = (int64_t)rb_ * BT_ROWS + (int64_t)wave * BT_RT * 32;
+    const int64_t rbase = (int64_t)rb_ * BT_ROWS + (int64_t)wave * BWB_RT * 32;
     const int rE = bt_row_E(D), rH = bb_row_H(D), rGD = bb_row_GD(D), rOnes = bb_row_ones(D), rZero = rOnes + 1;
     const bool need_gd = (int64_t)(rb_ + 1) * BT_ROWS > pk_off_total(D);
     // one power of two for every V of the launch: |V| <= max(|gx|max |eps|max, |gd|max, |gx|max)
@@ -79,9 +93,9 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
     }
 
     // ---- per-lane LDS addresses: fp32 rows, persons 16 c + 8 half + 0..7 = chunks 4c + 2 half and + 1
-    uint32_t aG[BT_RT][2], aE[BT_RT][2], aHf[2][2][2];                 // [..][chunk c]; H: [term][hidden tile][chunk]
+    uint32_t aG[BWB_RT][2], aE[BWB_RT][2], aHf[2][2][2];                 // [..][chunk c]; H: [term][hidden tile][chunk]
 #pragma unroll
-    for (int t = 0; t < BT_RT; ++t) {
+    for (int t = 0; t < BWB_RT; ++t) {
         const int64_t pr = rbase + 32 * t + l31;
         int g = rZero, e = rOnes;
         if (pr < Rp) {
@@ -103,17 +117,18 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
             for (int c = 0; c < 2; ++c) aHf[s3][ht][c] = (uint32_t)rH * 128u + bb_haddr(s3, 32 * ht + l31, 2 * c + half);
 
     for (int b = 0; b < 2; ++b) {
-        if (tid < 64) *(float*)(smem_bb + b * BUF + bt_addr(rOnes + (tid >> 5), (tid & 31) >> 2) + 4 * (tid & 3)) = (tid < 32) ? 1.0f : 0.f;
+        // the "ones" row holds the power of two of V (the E rows are multiplied by it as they land: scale_own below)
+        if (tid < 64) *(float*)(smem_bb + b * BUF + bt_addr(rOnes + (tid >> 5), (tid & 31) >> 2) + 4 * (tid & 3)) = (tid < 32) ? (BWB_PRESCALE ? v_scale : 1.0f) : 0.f;
     }
-    f32x16 acc[BT_RT][2];
-    float bsum[BT_RT];
+    f32x16 acc[BWB_RT][2];
+    float bsum[BWB_RT];
 #pragma unroll
-    for (int t = 0; t < BT_RT; ++t) { bsum[t] = 0.f; acc[t][0] = zero16(); acc[t][1] = zero16(); }
+    for (int t = 0; t < BWB_RT; ++t) { bsum[t] = 0.f; acc[t][0] = zero16(); acc[t][1] = zero16(); }
 
     const int64_t n_ptiles = (nb + BT_P - 1) / BT_P;
     // DMA transfers of 1 KB (see k_mvn_bwd_t.hip): d < rH / 8: G / E rows; the next 8: the H area (4 per term);
     // then GD rows.  Per-lane global addresses are fixed; only the person offset of the tile is added.
-    constexpr int BB_MAXD = 14;
+    constexpr int BB_MAXD = (56 + BWB_WAVES - 1) / BWB_WAVES;
     const int dH0 = rH / 8, dGD0 = rGD / 8;
     const int n_dma = need_gd ? rOnes / 8 : dGD0;
     // per-lane 64-bit source address of transfer u at person 0, and the shift of a person index to bytes (bf16 planes 1,
@@ -124,7 +139,7 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
     uint32_t voff[BB_MAXD];
 #pragma unroll
     for (int u = 0; u < BB_MAXD; ++u) {
-        const int d = wave + 4 * u;
+        const int d = wave + BWB_WAVES * u;
         if (d >= dH0 && d < dGD0) {                                    // H area: 16 hidden rows of one term
             const int dd = d - dH0, s3 = dd >> 2;
             const int hh = 16 * (dd & 3) + 4 * (lane >> 4) + ((lane & 15) >> 2);
@@ -148,7 +163,7 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
         const int pv = (int)((nb - i0) < BT_P ? (nb - i0) : BT_P);
         const uint32_t lbase = lds_addr_uniform(smem_bb + b * BUF) + (uint32_t)wave * 1024u;
         if (pv < BT_P) {                                               // the last tile: absent persons are zeros
-            for (int e = tid; e < bb_rows(D) * 32; e += BT_THREADS) {
+            for (int e = tid; e < bb_rows(D) * 32; e += BWB_THREADS) {
                 const int row = e >> 5;
                 if (row != rOnes) ((float*)(smem_bb + b * BUF))[e] = 0.f;
             }
@@ -156,12 +171,12 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
         }
 #pragma unroll
         for (int u = 0; u < BB_MAXD; ++u) {
-            const int d = wave + 4 * u;
+            const int d = wave + BWB_WAVES * u;
             if (d < n_dma) {
                 const bool isH = d >= dH0 && d < dGD0;
                 const char* src = vbase[u] + ((uint64_t)i0 << vsh[u]);
                 if (pv == BT_P) {
-                    dma16(src, lbase + (uint32_t)u * 4096u);
+                    dma16(src, lbase + (uint32_t)u * (1024u * BWB_WAVES));
                 } else {                                               // persons of this lane's 16 bytes: 8 (H) or 4 (fp32)
                     int p0;
                     if (isH) {
@@ -170,13 +185,30 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
                     } else {
                         p0 = 4 * ((lane & 7) ^ (4 * (d & 1) + (lane >> 4)));
                     }
-                    if (p0 < pv) dma16(src, lbase + (uint32_t)u * 4096u);
+                    if (p0 < pv) dma16(src, lbase + (uint32_t)u * (1024u * BWB_WAVES));
                 }
             }
         }
     };
 
-    // ---- compute: 2 chunks x BT_RT row tiles = 8 groups per tile, 6 MFMAs per group.  The fragments of group g + 1
+    // V = G * E is formed in fp16 range: the E rows (and the "ones" row) carry the launch's power of two.  Each wave multiplies
+    // the E transfers it moved itself, in place, once they have landed and before the barrier that publishes the tile (8
+    // multiplies a group less in the loop; the bias sums carry the power of two as well and lose it at the end).
+    const int dE0 = rE / 8;
+    auto scale_own = [&](int b) __attribute__((always_inline)) {
+        char* lb = smem_bb + b * BUF + wave * 1024 + lane * 16;
+#pragma unroll
+        for (int u = 0; u < BB_MAXD; ++u) {
+            const int d = wave + BWB_WAVES * u;
+            if (d >= dE0 && d < dH0) {
+                f32x4 v = *(f32x4*)(lb + u * (1024 * BWB_WAVES));
+                v[0] *= v_scale; v[1] *= v_scale; v[2] *= v_scale; v[3] *= v_scale;
+                *(f32x4*)(lb + u * (1024 * BWB_WAVES)) = v;
+            }
+        }
+    };
+
+    // ---- compute: 2 chunks x BWB_RT row tiles = 2 BWB_RT groups per tile and wave, 6 MFMAs per group.  The fragments of group g + 1
     // (4 LDS reads, 8 products, their scaling, 4 x (split of an element pair), the bias sum) are made in the shadow of the
     // MFMAs of group g, a few vector instructions after each MFMA; every slice is a pinned scheduling region.  The barrier
     // of a tile sits before its LAST group, whose operands are in registers already: behind it the buffer is free for the
@@ -196,26 +228,20 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
     f32x4 rg0, rg1, re0, re1;
     float pv_[8], ps_[8], pr_[8], s0, s1, s2, s3;
     auto amul = [](float x, float y) -> float { float d; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; };
-    auto amuls = [](float x, float y) -> float { float d; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(d) : "s"(x), "v"(y)); return d; };
     auto aadd = [](float x, float y) -> float { float d; asm volatile("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; };
-    const float vsc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v_scale)));
     auto read_raw = [&](const char* rb, uint32_t ag, uint32_t ae) __attribute__((always_inline)) {
         rg0 = *(const f32x4*)(rb + ag); rg1 = *(const f32x4*)(rb + (ag ^ 16u));
         re0 = *(const f32x4*)(rb + ae); re1 = *(const f32x4*)(rb + (ae ^ 16u));
     };
     auto products0 = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pv_[j] = amul(rg0[j], re0[j]);
+        for (int j = 0; j < 4; ++j) { pv_[j] = amul(rg0[j], re0[j]); ps_[j] = BWB_PRESCALE ? pv_[j] : amul(pv_[j], v_scale); }
         s0 = aadd(pv_[0], pv_[1]); s1 = aadd(pv_[2], pv_[3]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ps_[j] = amuls(vsc, pv_[j]);
     };
     auto products1 = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pv_[4 + j] = amul(rg1[j], re1[j]);
+        for (int j = 0; j < 4; ++j) { pv_[4 + j] = amul(rg1[j], re1[j]); ps_[4 + j] = BWB_PRESCALE ? pv_[4 + j] : amul(pv_[4 + j], v_scale); }
         s2 = aadd(pv_[4], pv_[5]); s3 = aadd(pv_[6], pv_[7]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ps_[4 + j] = amuls(vsc, pv_[4 + j]);
     };
     auto asub = [](float x, float y) -> float { float d; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; };
     float th[2][2];                                                    // [pair parity][element]: the heads as floats
@@ -248,12 +274,13 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
     };
     auto tile_body = [&](auto bc, bool has_next, int64_t stage_tile) {
         constexpr int b = decltype(bc)::value;
-        static_for<2 * BT_RT>([&](auto gc) {
-            constexpr int gi = decltype(gc)::value, c = gi / BT_RT, t = gi % BT_RT, cur = gi & 1, nxt = cur ^ 1;
-            constexpr int gn = (gi + 1) % (2 * BT_RT), cn = gn / BT_RT, tn = gn % BT_RT;
-            constexpr bool last = gi == 2 * BT_RT - 1;
+        static_for<2 * BWB_RT>([&](auto gc) {
+            constexpr int gi = decltype(gc)::value, c = gi / BWB_RT, t = gi % BWB_RT, cur = gi & 1, nxt = cur ^ 1;
+            constexpr int gn = (gi + 1) % (2 * BWB_RT), cn = gn / BWB_RT, tn = gn % BWB_RT;
+            constexpr bool last = gi == 2 * BWB_RT - 1;
             if constexpr (last) {
                 vx_wait_vmem();
+                if (BWB_PRESCALE) scale_own(1 - b);                     // this wave's E rows of the next tile, in place
                 __syncthreads();                                       // next tile landed; this tile's buffer is free
                 if (stage_tile >= 0) stage(stage_tile, b);
             }
@@ -269,7 +296,7 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
             acc[t][0] = mfma_f16(vl, hf[c][0][0], acc[t][0]);
             __builtin_amdgcn_sched_barrier(0);
             read_raw(rb, aG[tn][cn], aE[tn][cn]);
-            if constexpr (t == BT_RT - 1) {
+            if constexpr (t == BWB_RT - 1) {
 #pragma unroll
                 for (int s3 = 0; s3 < 2; ++s3)
 #pragma unroll
@@ -305,8 +332,9 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
     const int64_t t0 = blk_pr, GS = gridDim.y;
     if (t0 < n_ptiles) {
         stage(t0, 0);
-        if (t0 + GS < n_ptiles) stage(t0 + GS, 1);
         vx_wait_vmem();
+        if (BWB_PRESCALE) scale_own(0);
+        if (t0 + GS < n_ptiles) stage(t0 + GS, 1);
         __syncthreads();
         // fragments of the first group, outside the pipeline
         read_raw(smem_bb, aG[0][0], aE[0][0]);
@@ -340,7 +368,7 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
 
     float* slab = slabs + (int64_t)blk_pr * slab_len;
 #pragma unroll
-    for (int t = 0; t < BT_RT; ++t) {
+    for (int t = 0; t < BWB_RT; ++t) {
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht) {
             const int hh = 32 * ht + l31;
@@ -350,7 +378,7 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_b(
                 if (row < Rp) slab[row * 64 + hh] = acc[t][ht][r] * out_inv;
             }
         }
-        const float bt = half_sum32(bsum[t]);
+        const float bt = half_sum32(bsum[t]) * (BWB_PRESCALE ? out_inv * sc[3] : 1.0f);   // 2^-sv: the bias sums carry V's power of two
         const int64_t row = rbase + 32 * t + l31;
         if (half == 0 && row < Rp) slab[(int64_t)Rp * 64 + row] = bt;
     }

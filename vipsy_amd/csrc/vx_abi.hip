@@ -976,7 +976,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
             rc = set_lds(k_mvn_enc_bwd_w_b, lds);
             if (rc) return rc;
             ProfScope ps("k_mvn_enc_bwd_w_b", st);
-            hipLaunchKernelGGL(k_mvn_enc_bwd_w_b, dim3((unsigned)n_rowslabs, (unsigned)n_prw), dim3(BT_THREADS), lds, st,
+            hipLaunchKernelGGL(k_mvn_enc_bwd_w_b, dim3((unsigned)n_rowslabs, (unsigned)n_prw), dim3(BWB_THREADS), lds, st,
                                dm, hs3, epsT, gdT, gxT, gtab, sc, (const uint32_t*)maxw, slabs_w, Rp * (H + 1));
             VX_CHECK_LAUNCH();
         } else if (use_t) {
