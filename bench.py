@@ -107,6 +107,32 @@ def physical_bytes(workload):
     return best
 
 
+def _usable_cpus():
+    """The cores this process may really use: the cgroup CPU quota when there is one (a GPU box hands out a share of a
+    256-thread host; a torch pool of 256 threads on a 16-core share runs 70x slower than one thread), else the affinity
+    mask, never more than 32."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:                                  # pragma: no cover
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            quota = int(parts[0]) if parts[0] != "max" else -1
+            period = int(parts[1]) if len(parts) > 1 else 100000
+            if path.endswith("cfs_quota_us"):
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read())
+            if quota > 0:
+                n = min(n, max(1, -(-quota // period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, 32))
+
+
 def cpu_baseline(J, D, H, n_sample, min_seconds=6.0):
     """The CPU restatement of the reference step (oracle/vi_oracle.py, numpy float32) on a bounded sample of the same
     workload: full step (loss, all gradients, Adam).  Three figures: all host threads numpy's
@@ -147,15 +173,18 @@ def cpu_baseline(J, D, H, n_sample, min_seconds=6.0):
     # materialised as the reference does) under torch.set_num_threads, on one thread and on all
     from oracle import torch_step
     n_torch = min(n_sample, 1000)
-    try:
-        n_cpu = len(os.sched_getaffinity(0))               # the cores this process may use (a GPU box hands out a share)
-    except AttributeError:                                  # pragma: no cover
-        n_cpu = os.cpu_count()
+    n_cpu = _usable_cpus()
     torch_sec = {1: torch_step.time_step(J, D, H, n_torch, 1, min_seconds / 2),
                  n_cpu: torch_step.time_step(J, D, H, n_torch, n_cpu, min_seconds / 2)}
     torch_b100 = torch_step.time_step(J, D, H, 100, n_cpu, min_seconds / 3)
-    sec_all = timed(n_sample, min_seconds)
-    sec_b100 = timed(100, min_seconds / 3)
+    if threadpool_limits is not None:                      # numpy's BLAS pool sized to the usable cores as well
+        with threadpool_limits(limits=n_cpu):
+            sec_all = timed(n_sample, min_seconds)
+            sec_b100 = timed(100, min_seconds / 3)
+        threads = min(threads, n_cpu)
+    else:                                                   # pragma: no cover
+        sec_all = timed(n_sample, min_seconds)
+        sec_b100 = timed(100, min_seconds / 3)
     if threadpool_limits is not None:
         with threadpool_limits(limits=1):
             sec_one = timed(n_sample, min_seconds)

@@ -13,31 +13,38 @@
 //   * one wave per SIMD (the kernel takes ~400 registers); nothing but MFMAs, LDS reads and the epilogue in the loop.
 // (included by vx_abi.hip after k_mvn_bwd_hb.hip, whose unit images, scales and helpers it uses)
 
-#define HB2_THREADS 256
-#define HB2_WAVES 4
-#define HB2_WP 64
+// NSET person sets of 32 per wave, 8 / NSET waves per workgroup (256 persons either way).  NSET = 2: four waves of 64
+// persons, one per SIMD, accumulators in AGPRs (the form described above).  NSET = 1 (round 3, after the same change paid in
+// k_mvn_enc_bwd_w_b): eight waves of 32 persons, two per SIMD, under 256 registers -- the MFMAs take the VGPR form, so the
+// epilogue reads its accumulators directly (32 FMAs a row and wave, no AGPR reads), and one wave's epilogue / LDS waits run
+// under its SIMD partner's MFMAs.
+#define HB2_WAVES_OF(NSET) (8 / (NSET))
+#define HB2_WP_OF(NSET) (32 * (NSET))
 #define HB2_NSLOT 12                                                   // three batches of four units
 #define HB2_BATCH 4
 
-__host__ __device__ inline size_t hb2_lds_bytes(int D) {
-    return (size_t)HB2_WAVES * D * HB2_WP * sizeof(float) + (size_t)HB2_NSLOT * HB_UNIT_BYTES;
+__host__ __device__ inline size_t hb2_lds_bytes(int D) {      // operand tiles [roundup8(D)][256 persons] | ring
+    return (size_t)((D + 7) & ~7) * 256 * sizeof(float) + (size_t)HB2_NSLOT * HB_UNIT_BYTES;
 }
 
-template <int NS>
-__global__ __launch_bounds__(HB2_THREADS, 1) void k_mvn_enc_bwd_h_b2(
+template <int NS, int NSET>
+__global__ __launch_bounds__(64 * HB2_WAVES_OF(NSET), 1) void k_mvn_enc_bwd_h_b2(
     EncDims dm, const uint8_t* __restrict__ img, const float* __restrict__ sc /*k_enc_scales*/, const float* __restrict__ h_in,
     const float* __restrict__ eps_in, const float* __restrict__ gxT, const float* __restrict__ gdT /*DIAG-row operand [D][nb]*/,
     float* __restrict__ ghpre_out /*[nb][64] or null*/, const float* __restrict__ hT /*[64][nb], with ghpreT_out*/,
     float* __restrict__ ghpreT_out /*[64][nb] or null*/,
     uint32_t* __restrict__ maxw /*float bits: largest |gx|, |gd|, |eps|, |ghpre| of the launch, or null*/) {
     extern __shared__ __attribute__((aligned(16))) char smem_h2[];
-    constexpr int H = 64, NSET = 2;
+    constexpr int H = 64, HB2_WAVES = HB2_WAVES_OF(NSET), HB2_WP = HB2_WP_OF(NSET);
+    constexpr int VM_OWN = 16 / HB2_WAVES;                             // ring transfers of one wave per batch
+    constexpr int TROWS = 256 / HB2_WP;                                // operand rows per 1 KB tile transfer
     const int D = dm.D;
     const int64_t nb = dm.nb;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    float* gx_lds = (float*)smem_h2 + (size_t)wave * D * HB2_WP;       // [D][64] of this wave
-    const char* ring = smem_h2 + (size_t)HB2_WAVES * D * HB2_WP * sizeof(float);
+    const int DR = (D + 7) & ~7;                                       // tile rows (whole transfers)
+    float* gx_lds = (float*)smem_h2 + (size_t)wave * DR * HB2_WP;      // [DR][WP] of this wave
+    const char* ring = smem_h2 + (size_t)DR * 256 * sizeof(float);
     const uint32_t ring_lds = lds_addr_uniform(ring);
     const int64_t i0 = ((int64_t)blockIdx.x * HB2_WAVES + wave) * HB2_WP;
     int64_t iu[NSET], ic[NSET];
@@ -64,11 +71,12 @@ __global__ __launch_bounds__(HB2_THREADS, 1) void k_mvn_enc_bwd_h_b2(
     int st_u = 0;                                                      // its first unit
     auto stage_next = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int c = 0; c < HB2_BATCH; ++c) {
+        for (int j = 0; j < VM_OWN; ++j) {                              // transfer t = (unit c, fragment f) of the batch
+            const int t = wave + HB2_WAVES * j, c = t >> 2, f = t & 3;
             int u = st_u + c;
-            const uint32_t dst = ring_lds + (uint32_t)(4 * st_b3 + c) * HB_UNIT_BYTES + (uint32_t)wave * 1024u;
+            const uint32_t dst = ring_lds + (uint32_t)(4 * st_b3 + c) * HB_UNIT_BYTES + (uint32_t)f * 1024u;
             if (u >= n_units) u = n_units - 1;                         // past the end: a harmless duplicate
-            dma16s(img + (int64_t)u * HB_UNIT_BYTES, (uint32_t)(wave * 1024 + lane * 16), dst);
+            dma16s(img + (int64_t)u * HB_UNIT_BYTES, (uint32_t)(f * 1024 + lane * 16), dst);
         }
         st_u += HB2_BATCH;
         st_b3 = (st_b3 == 2) ? 0 : st_b3 + 1;
@@ -77,11 +85,15 @@ __global__ __launch_bounds__(HB2_THREADS, 1) void k_mvn_enc_bwd_h_b2(
     // ---- an operand tile [D][64] (lanes = persons: 256-byte rows of a dimension-major array) into this wave's region by
     // DMA, as it stands: one transfer = four rows (lane: row lane / 16, persons 4 (lane % 16) .. + 3; D % 4 == 0, nb % 4 == 0).
     auto tile_dma = [&](const float* __restrict__ srcT) __attribute__((always_inline)) {
-        int64_t ig = i0 + 4 * (lane & 15);
+        constexpr int LPR = HB2_WP / 4;                                // lanes per row
+        int64_t ig = i0 + 4 * (lane % LPR);
         if (ig + 4 > nb) ig = nb - 4;                                  // absent persons: valid ones, never stored
-        const float* src = srcT + (int64_t)(lane >> 4) * nb + ig;
+        const int r0 = lane / LPR;
         const uint32_t dst = lds_addr_uniform(gx_lds);
-        for (int k = 0; k < D; k += 4) dma16(src + (int64_t)k * nb, dst + (uint32_t)k * (HB2_WP * 4));
+        for (int k = 0; k < D; k += TROWS) {
+            const int kr = (k + r0 < D) ? k + r0 : D - 1;              // rows past D (tile padding): a harmless duplicate
+            dma16(srcT + (int64_t)kr * nb + ig, dst + (uint32_t)k * (HB2_WP * 4));
+        }
     };
     // The ring's first two batches and the gx tile are requested before anything else: they land while the eps fragments
     // are made.  (The powers of two that U_k carries are folded into gx when it is read: epilogue.)
@@ -168,7 +180,7 @@ __global__ __launch_bounds__(HB2_THREADS, 1) void k_mvn_enc_bwd_h_b2(
         ++un;
         slot = (slot + 1 == HB2_NSLOT) ? 0 : slot + 1;
         if ((un & (HB2_BATCH - 1)) == 0) {
-            __builtin_amdgcn_s_waitcnt(0x0F74);                        // vmcnt(4): only the batch after it may be in flight
+            __builtin_amdgcn_s_waitcnt(0x0F70 | VM_OWN);               // vmcnt(own transfers of one batch): only the batch after it may be in flight
             __syncthreads();
             stage_next();
         }
@@ -182,16 +194,24 @@ __global__ __launch_bounds__(HB2_THREADS, 1) void k_mvn_enc_bwd_h_b2(
     // reads, beyond the wait states the hardware needs between an MFMA and a read of its result.
     float gk[NSET];
     auto epi_piece = [&](const f32x16 (&U)[NSET][2], int e0, int e1) __attribute__((always_inline)) {
-        float t[12];                                                   // the reads of a piece first, then its FMAs (a read
-#pragma unroll                                                         // followed by its own use costs a wait state each)
-        for (int e = e0; e < e1; ++e) {
-            const int u = e >> 5, ht = (e >> 4) & 1, r = e & 15;
-            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t[e - e0]) : "a"(U[u][ht][r]));
-        }
+        if constexpr (NSET == 1) {                                     // VGPR-form accumulators: read in place
 #pragma unroll
-        for (int e = e0; e < e1; ++e) {
-            const int u = e >> 5, ht = (e >> 4) & 1, r = e & 15;
-            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(gh[u][ht][r]) : "v"(gk[u]), "v"(t[e - e0]));
+            for (int e = e0; e < e1; ++e) {
+                const int ht = (e >> 4) & 1, r = e & 15;
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(gh[0][ht][r]) : "v"(gk[0]), "v"(U[0][ht][r]));
+            }
+        } else {
+            float t[12];                                               // the reads of a piece first, then its FMAs (a read
+#pragma unroll                                                         // followed by its own use costs a wait state each)
+            for (int e = e0; e < e1; ++e) {
+                const int u = e >> 5, ht = (e >> 4) & 1, r = e & 15;
+                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t[e - e0]) : "a"(U[u][ht][r]));
+            }
+#pragma unroll
+            for (int e = e0; e < e1; ++e) {
+                const int u = e >> 5, ht = (e >> 4) & 1, r = e & 15;
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(gh[u][ht][r]) : "v"(gk[u]), "v"(t[e - e0]));
+            }
         }
     };
     // one unit: 3 products per hidden tile and person set.  ONE fragment set: a fragment is re-read (for the next unit) right
@@ -207,7 +227,7 @@ __global__ __launch_bounds__(HB2_THREADS, 1) void k_mvn_enc_bwd_h_b2(
         constexpr int P0 = E0, P1 = E0 + (EN * 1 + 5) / 6, P2 = E0 + (EN * 2 + 5) / 6, P3 = E0 + (EN * 3 + 5) / 6,
                       P4 = E0 + (EN * 4 + 5) / 6, P5 = E0 + (EN * 5 + 5) / 6, P6 = E0 + EN;
         if constexpr (EPI == 1 || EPI == 3) gk[0] = gx_lds[kp * HB2_WP + l31] * u_inv;
-        if constexpr (EPI == 2 || EPI == 3) gk[1] = gx_lds[kp * HB2_WP + 32 + l31] * u_inv;
+        if constexpr (NSET == 2 && (EPI == 2 || EPI == 3)) gk[NSET - 1] = gx_lds[kp * HB2_WP + 32 + l31] * u_inv;
 #pragma unroll
         for (int u = 0; u < NSET; ++u) U[u][0] = mfma_f16(A[0], bf[u][1][s], FIRST ? zero16() : U[u][0]);
         if constexpr (EPI != 0) { __builtin_amdgcn_sched_barrier(0); epi_piece(Up, P0, P1); __builtin_amdgcn_sched_barrier(0); }
@@ -267,7 +287,7 @@ __global__ __launch_bounds__(HB2_THREADS, 1) void k_mvn_enc_bwd_h_b2(
             constexpr bool EP = decltype(epic)::value;
             static_for<kb + 1>([&](auto sc_) {
                 constexpr int s = decltype(sc_)::value;
-                constexpr int part = !EP ? 0 : (kb == 0 ? 3 : (s == 0 ? 1 : (s == 1 ? 2 : 0)));
+                constexpr int part = !EP ? 0 : NSET == 1 ? (s == 0 ? 1 : 0) : (kb == 0 ? 3 : (s == 0 ? 1 : (s == 1 ? 2 : 0)));
                 if constexpr (s == 0) unit(sc_, T_, std::integral_constant<int, part>{}, Uc, Up, k - 1);
                 else unit(sc_, F_, std::integral_constant<int, part>{}, Uc, Up, k - 1);
             });

@@ -902,15 +902,16 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                 } else if (dm.D <= 112 && hb2_lds_bytes(dm.D) <= 160 * 1024) {
                     // large batch: 64 persons per wave, batches of four units per barrier (k_mvn_bwd_hb2.hip)
                     const size_t lds2 = hb2_lds_bytes(dm.D);
-                    rc = set_lds(k_mvn_enc_bwd_h_b2<7>, lds2);
+                    constexpr int HNSET = 1;                              // eight waves of 32 persons (k_mvn_bwd_hb2.hip)
+                    rc = set_lds((k_mvn_enc_bwd_h_b2<7, HNSET>), lds2);
                     if (rc) return rc;
                     // its workgroups take 256 persons: a last round that fills less than half the chip goes to the 32-persons-
                     // per-wave kernel instead (1M persons: 15 full rounds + 16 960 persons), as in the forward
-                    const int64_t round2 = (int64_t)HB2_WAVES * HB2_WP * num_cu();
+                    const int64_t round2 = (int64_t)256 * num_cu();
                     const int64_t rem = nb % round2;
                     const int64_t n_done = (rem > 0 && 2 * rem <= round2 && nb > round2) ? nb - rem : nb;
-                    hipLaunchKernelGGL(k_mvn_enc_bwd_h_b2<7>, dim3((unsigned)((n_done + HB2_WAVES * HB2_WP - 1) / (HB2_WAVES * HB2_WP))),
-                                       dim3(HB2_THREADS), lds2, st, dm, (const uint8_t*)himg, sc, h, eps, gxT, (const float*)gdT1,
+                    hipLaunchKernelGGL((k_mvn_enc_bwd_h_b2<7, HNSET>), dim3((unsigned)((n_done + 255) / 256)),
+                                       dim3(64 * HB2_WAVES_OF(HNSET)), lds2, st, dm, (const uint8_t*)himg, sc, h, eps, gxT, (const float*)gdT1,
                                        f1t ? (float*)nullptr : ghpre, hT, f1t ? ghpre : (float*)nullptr, maxw);
                     if (n_done < nb) {
                         VX_CHECK_LAUNCH();
