@@ -68,6 +68,7 @@ def kernel_model(name, J, D, H):
         "k_irt_lik_r": (2.0 * 3 * (D + 1) * J, PEAK_F32_MFMA_TFLOPS, "f32 MFMA"),        # Z, gx, GA
         "k_irt_lik_b": (2.0 * 3 * (D + 1) * J, PEAK_BF16_MFMA_TFLOPS * 3.0 / 16.0,
                         "f32 via bf16 terms on the bf16 MFMA (Z: six products, gx and GA: five)"),
+        "k_irt_lik_h": (2.0 * 3 * (D + 1) * J, PEAK_F16X2_TFLOPS, f16x2),               # Z, gx, GA
     }
     return table.get(name)
 
@@ -347,9 +348,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "persons": N, "items": J, "dims": D, "hidden": H,
-                       "arithmetic": ("results f32; the guide's GEMMs (fc1, heads, their gradients) from two fp16 terms per operand "
-                                      "(2^-22 relative, three products, fp32 accumulate); the likelihood's from bf16 terms (x, a: three; "
-                                      "dlogp/dz: two, 2^-17)") if (D > 1 and amortized) else "f32",
+                       "arithmetic": ("results f32; every large GEMM (the guide's fc1, heads and their gradients; the likelihood's "
+                                      "x.a, dlogp/dz.a, x.dlogp/dz) from two fp16 terms per operand (2^-22 relative, three "
+                                      "products on the fp16 MFMA, fp32 accumulate)") if (D > 1 and amortized) else "f32",
                        "guide": "amortized MvnEncoder" if amortized else "BBVI per-person", "batch": "full (B=N)",
                        "particles": 1, "missing_rate": missing, "persons_per_rank": per,
                        "parallelism": "persons sharded x%d, 1 all-reduce/step" % world,

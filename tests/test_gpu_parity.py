@@ -196,6 +196,12 @@ def _random_problem(N, J, D, H, model, miss, seed):
     (136, 100, 124, 64, "irt_2pl", 0.1, None),
     (300, 260, 112, 64, "irt_4pl", 0.3, 104),
     (264, 36, 36, 64, "irt_2pl", 0.0, None),
+    # the MFMA likelihood kernels (96 <= D <= 111, full batch): f16x2 (k_irt_lik_h, 1PL / 2PL link) at the ends of its D
+    # range, ragged item chunks and person tiles; bf16x3 (k_irt_lik_b) for the 3PL / 4PL links, which make their own image
+    (1104, 260, 96, 64, "irt_2pl", 0.1, None),
+    (464, 132, 108, 64, "irt_2pl", 0.2, None),
+    (320, 500, 100, 64, "irt_4pl", 0.1, None),
+    (208, 260, 104, 64, "irt_3pl", 0.2, None),
 ])
 def test_mvn_amortized_step_vs_oracle(N, J, D, H, model, miss, B):
     from vipsy_amd.engine import IrtEngine, ENC_KEYS

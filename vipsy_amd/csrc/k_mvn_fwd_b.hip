@@ -196,7 +196,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     uint32_t step, uint32_t stream, float* __restrict__ h_out,
     float* __restrict__ x_out, float* __restrict__ eps_out, float* __restrict__ ldT, float* __restrict__ ent_out,
     float* __restrict__ hT_out /*[64][nb] or null*/, float* __restrict__ epsT_out /*[D][nb] or null*/,
-    uint8_t* __restrict__ ximg_out /*bf16x3 tile images of x for k_irt_lik_b (k_irt_lik_b.hip), or null*/,
+    uint8_t* __restrict__ ximg_out /*f16x2 tile images of x for k_irt_lik_h (k_irt_lik_h.hip), or null*/,
     uint16_t* __restrict__ hs_out /*[2][64][nb] fp16 terms of h 2^sh for k_mvn_enc_bwd_w_b (what k_split2_f16 makes), or null*/,
     int64_t i_base = 0 /*first person of this launch (a multiple of 64): the persons before it belong to another launch*/) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -572,10 +572,10 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     __builtin_amdgcn_wave_barrier();
     // ---------------------------------------------------------------- write x, entropy part
     if (writer && ximg_out && i0 < (dm.nb + 63) / 64 * 64) {
-        // the likelihood kernel's operand: x_aug = [x, 1, 0..] as three bf16 terms, in its LDS tile order (lb_xoff): this
+        // the likelihood kernel's operand: x_aug = [x, 1, 0..] 2^LH_XEXP as two fp16 terms (k_irt_lik_h.hip), in its LDS tile order (lb_xoff): this
         // wave's 32 persons are one half of a 64-person tile (absent persons: all-zero rows); 14 chunks of 8 columns each
         const int pvi = (int)((dm.nb - i0) < FB_WP ? (dm.nb - i0) : FB_WP);       // may be <= 0
-        uint8_t* out = ximg_out + (i0 >> 6) * LB_XT_BYTES;
+        uint8_t* out = ximg_out + (i0 >> 6) * LH_XT_BYTES;
         const int pbase = (int)(i0 & 63);
         for (int e = lane; e < FB_WP * 2 * LB_NKS; e += 64) {
             // order of the image bytes: 32 consecutive lanes fill one 512-byte subtile (8 persons x 4 chunks), then the
@@ -596,12 +596,11 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
                 const int k = 8 * ch + j;
                 v[j] = (pp < pvi) ? (k < D ? x_lds[pp * DX + k] : (k == D ? 1.0f : 0.f)) : 0.f;
             }
-            bf16x8 fh, fm, fl;
-            split3_frag(v, fh, fm, fl);
+            f16x8 fh, fl;
+            lh_split_x(v, fh, fl);
             const uint32_t o = lb_xoff(pbase + pp, ch);
-            *(bf16x8*)(out + o) = fh;
-            *(bf16x8*)(out + LB_PLANE + o) = fm;
-            *(bf16x8*)(out + 2 * LB_PLANE + o) = fl;
+            *(f16x8*)(out + o) = fh;
+            *(f16x8*)(out + LB_PLANE + o) = fl;
         }
     }
     if (writer && wave_live) {

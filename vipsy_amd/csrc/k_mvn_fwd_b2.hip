@@ -486,10 +486,10 @@ __global__ __launch_bounds__(FB2_THREADS, (NS == 1 ? 2 : 1)) void k_mvn_enc_fwd_
         const int pbase = (int)(i0 & 63);                      // NS = 1: this wave's 32 persons are one half of a 64-person tile
         vx_wait_vmem();                                        // x of this wave is complete in memory
         __builtin_amdgcn_wave_barrier();
-        // x_aug = [x, 1, 0..] as three bf16 terms in the LDS tile order of k_irt_lik_b (lb_xoff): the wave's 64 persons are
+        // x_aug = [x, 1, 0..] 2^LH_XEXP as two fp16 terms in the LDS tile order of k_irt_lik_h (lb_xoff): the wave's 64 persons are
         // one whole tile; absent persons: all-zero rows
         const int pvi = (int)((dm.nb - i0) < FB2_WP ? (dm.nb - i0) : FB2_WP);
-        uint8_t* out = ximg_out + (i0 >> 6) * LB_XT_BYTES;
+        uint8_t* out = ximg_out + (i0 >> 6) * LH_XT_BYTES;
         // seven work items per lane in flight (loads of all, then splits and stores): one at a time is a chain of L2
         // latencies
         constexpr int XU = 7;
@@ -532,11 +532,10 @@ __global__ __launch_bounds__(FB2_THREADS, (NS == 1 ? 2 : 1)) void k_mvn_enc_fwd_
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = q[w][j >> 2][j & 3];
-                bf16x8 fh, fm, fl;
-                split3_frag(v, fh, fm, fl);
-                *(bf16x8*)(out + off[w]) = fh;
-                *(bf16x8*)(out + LB_PLANE + off[w]) = fm;
-                *(bf16x8*)(out + 2 * LB_PLANE + off[w]) = fl;
+                f16x8 fh, fl;
+                lh_split_x(v, fh, fl);
+                *(f16x8*)(out + off[w]) = fh;
+                *(f16x8*)(out + LB_PLANE + off[w]) = fl;
             }
         }
     }

@@ -10,6 +10,7 @@
 #include "k_irt_lik.hip"
 #include "k_irt_lik_r.hip"
 #include "k_irt_lik_b.hip"
+#include "k_irt_lik_h.hip"
 #include "k_irt1d.hip"
 #include "k_irt1d_sparse.hip"
 #include "k_hodina.hip"
@@ -326,35 +327,23 @@ int vx_adam_step2(float* pA, const float* gA, float* mA, float* vA, const float*
 }
 
 // ------------------------------------------------------------------------------------------------
-int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, int64_t gid0,
-                       const float* W1, const float* b1, const float* W21, const float* b21, const float* W22,
-                       const float* b22, const float* eps_in, float* h, float* x, float* eps, float* ldT,
-                       float* ent, float* hT, float* epsT, float* packws, uint8_t* ximg, uint16_t* hs_out, void* hs) {
-    if (!enc_cfg_ok(cfg) || !y || !W1 || !b1 || !W21 || !b21 || !W22 || !b22 || !h || !x || !eps || !ldT || !ent ||
-        nb < 0)
-        return VX_EINVAL;
-    if (nb == 0) return VX_OK;
-    if (ximg && !(cfg->D >= 96 && cfg->D <= 16 * LB_NKS - 1 && aligned16(ximg))) return VX_EINVAL;
+// the f16x2 likelihood kernel (k_irt_lik_h.hip): D + 1 in (96, 112], 1PL / 2PL link
+static bool lik_h_shape(const vx_irt_cfg* cfg) {
+    return !force_generic() && cfg->D >= 96 && cfg->D <= 16 * LB_NKS - 1 && cfg->model <= VX_IRT_2PL;
+}
+
+// The kernels of the forward; what they leave undone is reported to the entry point below, which finishes it once the
+// kernels have been launched without an error: ximg_done (the likelihood operand image: every forward kernel but
+// k_mvn_enc_fwd_b / _b2 leaves it to a pass over x), hs_done (the fp16 terms of hT, the head weight-gradient kernel's
+// operand: a pass over hT, scaled by *hscale).
+static int mvn_enc_forward_kernels(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, int64_t gid0,
+                                   const float* W1, const float* b1, const float* W21, const float* b21, const float* W22,
+                                   const float* b22, const float* eps_in, float* h, float* x, float* eps, float* ldT,
+                                   float* ent, float* hT, float* epsT, float* packws, uint8_t* ximg, uint16_t* hs_out, void* hs,
+                                   bool& ximg_done, bool& hs_done, const float*& hscale) {
     EncDims dm = make_enc_dims(cfg, nb);
     const dim3 grid((unsigned)((nb + ENC_P - 1) / ENC_P));
     int rc;
-    // every forward kernel but k_mvn_enc_fwd_b leaves the likelihood operand image to this pass over x
-    struct XimgAfter {
-        uint8_t* img; const vx_irt_cfg* cfg; int64_t nb; const float* x; hipStream_t st; bool done;
-        ~XimgAfter() {
-            if (img && !done)
-                hipLaunchKernelGGL(k_lik_ximg, dim3((unsigned)((nb + LB_P - 1) / LB_P)), dim3(256), 0, st, (int)cfg->D, nb, x, img);
-        }
-    } ximg_after{ximg, cfg, nb, x, (hipStream_t)hs, false};
-    // ... and the bf16 terms of hT (the head weight-gradient kernel's operand) to this pass over hT
-    if (hs_out && (!hT || cfg->H != 64)) return VX_EINVAL;
-    struct HsAfter {
-        uint16_t* out; const float* hT; int64_t nb; hipStream_t st; bool done; const float* hscale;
-        ~HsAfter() {
-            if (out && !done && hscale)
-                hipLaunchKernelGGL(k_split2_f16, dim3(num_cu() * 8), dim3(256), 0, st, hT, nb * 64, hscale, out);
-        }
-    } hs_after{hs_out, hT, nb, (hipStream_t)hs, false, nullptr};
     if (packed_ok(cfg) && packws && aligned16(packws) && aligned16(y) && aligned16(W1) && aligned16(b1) &&
         aligned16(W21) && aligned16(W22) && aligned16(h)) {
         const int Rp = pk_rows(cfg->D);
@@ -367,7 +356,7 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
         VX_CHECK_LAUNCH();
         // the powers of two of the f16x2 operands (the backward kernels read them too: pack_scales below)
         float* sc = packws + vx_mvn_pack_floats(cfg) - FB_NSCALES;
-        hs_after.hscale = sc + 3;
+        hscale = sc + 3;
         hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(64), 0, (hipStream_t)hs, (uint32_t*)(sc + 11), 4);
         hipLaunchKernelGGL(k_enc_scales_max, dim3(FB_SC_BLOCKS), dim3(256), 0, (hipStream_t)hs, (int)dm.D, (int)dm.J, W1, b1, W21,
                            b21, W22, b22, sc);
@@ -384,8 +373,8 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
                                pk_off_total(dm.D) / 8, Wp, bp, gtab, (const float*)sc, img, gt2);
             VX_CHECK_LAUNCH();
             const size_t ldsb = fb_lds_bytes(dm.D, dm.J);
-            ximg_after.done = true;
-            hs_after.done = true;
+            ximg_done = true;
+            hs_done = true;
             if (nb <= FB_SPLIT_MAX) {
                 // small batch: one 32-person tile per workgroup, its four waves share the head tiles
                 ProfScope ps("k_mvn_enc_fwd_b", (hipStream_t)hs);
@@ -469,6 +458,33 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
     return VX_OK;
 }
 
+int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, int64_t gid0,
+                       const float* W1, const float* b1, const float* W21, const float* b21, const float* W22,
+                       const float* b22, const float* eps_in, float* h, float* x, float* eps, float* ldT,
+                       float* ent, float* hT, float* epsT, float* packws, uint8_t* ximg, uint16_t* hs_out, void* hs) {
+    if (!enc_cfg_ok(cfg) || !y || !W1 || !b1 || !W21 || !b21 || !W22 || !b22 || !h || !x || !eps || !ldT || !ent ||
+        nb < 0)
+        return VX_EINVAL;
+    if (nb == 0) return VX_OK;
+    if (ximg && !(lik_h_shape(cfg) && aligned16(ximg))) return VX_EINVAL;     // vx_irt_lik_ximg_bytes(cfg, nb) == 0: no image
+    if (hs_out && (!hT || cfg->H != 64)) return VX_EINVAL;
+    bool ximg_done = false, hs_done = false;
+    const float* hscale = nullptr;
+    const int rc = mvn_enc_forward_kernels(cfg, y, rows, nb, gid0, W1, b1, W21, b21, W22, b22, eps_in, h, x, eps, ldT, ent, hT,
+                                           epsT, packws, ximg, hs_out, hs, ximg_done, hs_done, hscale);
+    if (rc) return rc;                                               // nothing is launched on buffers an error left unwritten
+    if (ximg && !ximg_done) {
+        hipLaunchKernelGGL(k_lik_ximg_h, dim3((unsigned)((nb + LB_P - 1) / LB_P)), dim3(256), 0, (hipStream_t)hs, (int)cfg->D, nb,
+                           (const float*)x, ximg);
+        VX_CHECK_LAUNCH();
+    }
+    if (hs_out && !hs_done && hscale) {
+        hipLaunchKernelGGL(k_split2_f16, dim3(num_cu() * 8), dim3(256), 0, (hipStream_t)hs, (const float*)hT, nb * 64, hscale, hs_out);
+        VX_CHECK_LAUNCH();
+    }
+    return VX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 static void lik_plan(const vx_irt_cfg* cfg, int64_t nb, int& kt, int& nch, int& groups, int& n_pr) {
     const int dk = cfg->D + 1;
@@ -529,7 +545,7 @@ static bool lik_cfg_ok(const vx_irt_cfg* cfg) {
 
 int64_t vx_irt_lik_ximg_bytes(const vx_irt_cfg* cfg, int64_t nb) {
     if (!lik_cfg_ok(cfg) || nb < 0) return VX_EINVAL;
-    return lik_b_shape(cfg) ? ((nb + LB_P - 1) / LB_P) * (int64_t)LB_XT_BYTES : 0;
+    return lik_h_shape(cfg) ? ((nb + LB_P - 1) / LB_P) * (int64_t)LH_XT_BYTES : 0;
 }
 
 int64_t vx_irt_lik_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
@@ -548,26 +564,11 @@ int64_t vx_irt_lik_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
     return w;
 }
 
-int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* x,
-                    const float* a, const float* b, const float* c_un, const float* d_un, float* gx, float* gxT,
-                    float* ll, float* gitem, float* workspace, const uint8_t* yT, int64_t yT_stride, const uint8_t* ximg_in,
-                    const float* epsT, const float* ldT, float* gdT, void* hs) {
-    if (gdT && (!gxT || !epsT || !ldT || (nb * (int64_t)(cfg ? cfg->D : 0)) % 4 != 0 || !aligned16(gdT) || !aligned16(gxT) ||
-                !aligned16(epsT) || !aligned16(ldT)))
-        return VX_EINVAL;
-    // the fused DIAG-row operand of the guide backward, for the paths that do not make it themselves
-    struct GdAfter {
-        const vx_irt_cfg* cfg; int64_t nb; const float *gxT, *epsT, *ldT; float* gdT; hipStream_t st; bool done;
-        ~GdAfter() {
-            if (gdT && !done && nb > 0)
-                hipLaunchKernelGGL(k_mvn_gd, dim3(num_cu() * 8), dim3(256), 0, st, (const float4*)gxT, (const float4*)epsT,
-                                   (const float4*)ldT, cfg->scale, nb * cfg->D / 4, (float4*)gdT);
-        }
-    } gd_after{cfg, nb, gxT, epsT, ldT, gdT, (hipStream_t)hs, false};
-    if (!lik_cfg_ok(cfg) || !y || !x || !a || !b || (!gx && !gxT) || !ll || !gitem || !workspace || nb < 0)
-        return VX_EINVAL;
-    if (cfg->model >= VX_IRT_3PL && !c_un) return VX_EINVAL;
-    if (cfg->model == VX_IRT_4PL && !d_un) return VX_EINVAL;
+// The kernels of vx_irt_lik_grad (arguments validated by the entry point below); gd_done: the path wrote gdT itself.
+static int irt_lik_grad_kernels(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* x,
+                                const float* a, const float* b, const float* c_un, const float* d_un, float* gx, float* gxT,
+                                float* ll, float* gitem, float* workspace, const uint8_t* yT, int64_t yT_stride,
+                                const uint8_t* ximg_in, const float* epsT, const float* ldT, float* gdT, void* hs, bool& gd_done) {
     if (lik_b_ok(cfg, rows, nb, yT, yT_stride, gxT) && aligned16(workspace) && aligned16(gxT)) {
         int groups, n_pr;
         lik_b_plan(cfg, nb, groups, n_pr);
@@ -579,18 +580,28 @@ int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows
         float* slabs = workspace;
         uint8_t* ximg_ws = (uint8_t*)(workspace + (((int64_t)n_pr * dm.slab_len + 3) & ~(int64_t)3));
         float* gx_part = (float*)(ximg_ws + n_ptiles * LB_XT_BYTES);
-        const uint8_t* ximg = (ximg_in && aligned16(ximg_in)) ? ximg_in : ximg_ws;
+        // 1PL / 2PL link: the f16x2 kernel and its image (the forward's, or made here); its gx stores address 16 nbp bytes
+        // with 32 bits.  3PL / 4PL: the bf16x3 kernel on its own three-term image (the forward writes none for them).
+        const bool f16 = lik_h_shape(cfg) && nbp < ((int64_t)1 << 27);
+        const uint8_t* ximg = (f16 && ximg_in && aligned16(ximg_in)) ? ximg_in : ximg_ws;
         float* ll_part = gx_part + (int64_t)groups * LB_DP * nbp;
         hipStream_t st = (hipStream_t)hs;
         hipError_t he = hipMemsetAsync(slabs, 0, sizeof(float) * (size_t)n_pr * dm.slab_len, st);
         if (he != hipSuccess) return (int)he;
         if (ximg == ximg_ws) {
-            hipLaunchKernelGGL(k_lik_ximg, dim3((unsigned)n_ptiles), dim3(256), 0, st, (int)cfg->D, nb, x, ximg_ws);
+            if (f16) hipLaunchKernelGGL(k_lik_ximg_h, dim3((unsigned)n_ptiles), dim3(256), 0, st, (int)cfg->D, nb, x, ximg_ws);
+            else hipLaunchKernelGGL(k_lik_ximg, dim3((unsigned)n_ptiles), dim3(256), 0, st, (int)cfg->D, nb, x, ximg_ws);
             VX_CHECK_LAUNCH();
         }
         int rc;
         const dim3 grid((unsigned)(groups * n_pr));
-        if (cfg->model >= VX_IRT_3PL) {
+        if (f16) {
+            rc = set_lds(k_irt_lik_h<0>, LH_LDS_BYTES);
+            if (rc) return rc;
+            ProfScope ps("k_irt_lik_h", st);
+            hipLaunchKernelGGL((k_irt_lik_h<0>), grid, dim3(LH_THREADS), LH_LDS_BYTES, st, dm, yT, yT_stride, ximg, a, b,
+                               gx_part, ll_part, slabs);
+        } else if (cfg->model >= VX_IRT_3PL) {
             rc = set_lds(k_irt_lik_b<1>, LB_LDS_BYTES);
             if (rc) return rc;
             ProfScope ps("k_irt_lik_b", st);
@@ -604,7 +615,7 @@ int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows
                                a, b, c_un, d_un, gx_part, ll_part, slabs, (long long*)nullptr);
         }
         VX_CHECK_LAUNCH();
-        gd_after.done = true;
+        gd_done = true;
         hipLaunchKernelGGL(k_lik_reduce_parts, dim3((unsigned)n_ptiles), dim3(256), 0, st, (const float*)gx_part, (const float*)ll_part,
                            x, groups, (int)cfg->D, nb, nbp, cfg->scale, gxT, ll, epsT, ldT, gdT);
         VX_CHECK_LAUNCH();
@@ -730,6 +741,30 @@ int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows
     }
     // loss gradients = -(d ELBO / d .)
     return vx_reduce_slabs(slabs, n_pr, dm.slab_len, -1.0f, gitem, hs);
+}
+
+int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* x,
+                    const float* a, const float* b, const float* c_un, const float* d_un, float* gx, float* gxT,
+                    float* ll, float* gitem, float* workspace, const uint8_t* yT, int64_t yT_stride, const uint8_t* ximg_in,
+                    const float* epsT, const float* ldT, float* gdT, void* hs) {
+    if (!lik_cfg_ok(cfg) || !y || !x || !a || !b || (!gx && !gxT) || !ll || !gitem || !workspace || nb < 0)
+        return VX_EINVAL;
+    if (gdT && (!gxT || !epsT || !ldT || (nb * (int64_t)cfg->D) % 4 != 0 || !aligned16(gdT) || !aligned16(gxT) ||
+                !aligned16(epsT) || !aligned16(ldT)))
+        return VX_EINVAL;
+    if (cfg->model >= VX_IRT_3PL && !c_un) return VX_EINVAL;
+    if (cfg->model == VX_IRT_4PL && !d_un) return VX_EINVAL;
+    bool gd_done = false;
+    const int rc = irt_lik_grad_kernels(cfg, y, rows, nb, x, a, b, c_un, d_un, gx, gxT, ll, gitem, workspace, yT, yT_stride, ximg_in,
+                                        epsT, ldT, gdT, hs, gd_done);
+    if (rc) return rc;
+    // the fused DIAG-row operand of the guide backward, for the paths that do not make it themselves
+    if (gdT && !gd_done && nb > 0) {
+        hipLaunchKernelGGL(k_mvn_gd, dim3(num_cu() * 8), dim3(256), 0, (hipStream_t)hs, (const float4*)gxT, (const float4*)epsT,
+                           (const float4*)ldT, cfg->scale, nb * cfg->D / 4, (float4*)gdT);
+        VX_CHECK_LAUNCH();
+    }
+    return VX_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
