@@ -193,6 +193,24 @@ int vx_irt1d_score_grad(int64_t nb, float scale, const float* elbo, const float*
                         float* baseline, float base_beta, int32_t base_by_row, float* log_r, float* gloc, float* graw,
                         void* hip_stream);
 
+/* Score-function estimator for the multivariate Normal guides, x_feature > 1 (same standing as vx_irt1d_score_grad: an opt-in
+ * of this build, IrtEngine(estimator="score"); oracle/vi_oracle.py::irt_particle).  With u_i = L_i^-T eps_i the score of the
+ * guide has the pathwise gradient's shape -- d log q / d loc = u, / d L_kc = u_k eps_c, / d M_kk = u_k eps_k L_kk - 1 -- so
+ * this call, made AFTER the forward and the likelihood of the same batch (whose item gradients and loss stand), only writes
+ * the operands the guide-backward kernels take in place of d ELBO / d x:
+ *     w[i] = log_r_i - baseline_i,  log_r_i = cfg->scale (ll[i] + ent[i])        (baseline arguments as vx_irt1d_score_grad)
+ *     gx[nb][D], gxT[D][nb] = w_i u_i;   gdT[D][nb] = w_i (u_ik eps_ik L_kk - 1)   (the DIAG-row operand; any may be NULL)
+ * kind 0: L from the encoder heads (h [nb][H], W22 [T][H], b22 [T]); hand gxT / gdT to vx_mvn_enc_backward (gd_ready bit 0),
+ * which must be on the dimension-major kernels (vx_mvn_enc_bwd_layout == 1).  kind 1 / 2: L from M [n_local][D][D] (rows
+ * index it) / the shared M [D][D]; run vx_mvn_bbvi_backward on gx with cfg->scale = 0, then vx_mvn_score_diag adds the
+ * diagonal term (+ w_i on the person's own M_kk, + sum_i w_i on the shared one). */
+int vx_mvn_score_operands(const vx_irt_cfg* cfg, int64_t nb, const int64_t* rows, int32_t kind, const float* h,
+                          const float* W22, const float* b22, const float* M, const float* eps, const float* ll,
+                          const float* ent, float* baseline, float base_beta, int32_t base_by_row, float* log_r, float* w,
+                          float* gx, float* gxT, float* gdT, void* hip_stream);
+int vx_mvn_score_diag(const vx_irt_cfg* cfg, int64_t nb, const int64_t* rows, const float* w, int32_t shared, float* gM,
+                      void* hip_stream);
+
 /* ---- black-box MVN guide with per-person or shared Cholesky rows (VIRT.guide, x_feature > 1, vi.py:706-723).
  *   loc: [n_local][D];  M: [n_local][D][D] unconstrained (shared == 0) or [D][D] (shared == 1, share_cov=True)
  *   forward : x[nb][D] = loc[row] + L eps, eps[nb][D], ent[nb] = 0.5|eps|^2 + sum_k M_kk

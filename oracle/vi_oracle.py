@@ -252,14 +252,28 @@ ENC_KEYS = ("fc1.weight", "fc1.bias", "fc21.weight", "fc21.bias", "fc22.weight",
 # ------------------------------------------------------------------------------------------------
 # One particle of the IRT ELBO -> loss and grads w.r.t. unconstrained leaves
 # ------------------------------------------------------------------------------------------------
+def mvn_score_terms(L, eps):
+    """d log q(x) / d loc (B, D) and / d M (B, D, D; M the unconstrained matrix: strict lower part = L's, diagonal = log L_kk)
+    of q = MultivariateNormal(loc, scale_tril = L) at the FIXED point x = loc + L eps:
+    log q = -sum_k log L_kk - 0.5 |L^-1 (x - loc)|^2 + const  =>  u = L^-T eps, d/d loc = u, d/d L_kc = u_k eps_c (c <= k)
+    - [k == c] / L_kk, and through L_kk = exp(M_kk): d/d M_kk = u_k eps_k L_kk - 1."""
+    B, D = eps.shape
+    u = np.stack([np.linalg.solve(L[i].T, eps[i]) for i in range(B)])
+    sM = np.tril(np.einsum("bi,bj->bij", u, eps), -1)
+    dg = u * eps * np.einsum("bii->bi", L) - 1.0
+    sM = sM + np.einsum("bi,ij->bij", dg, np.eye(D, dtype=eps.dtype))
+    return u, sM
+
+
 def irt_particle(spec, params, y_u8_full, idx, eps, baseline=None, want_log_r=False):
     """spec: dict(model, D, Dc, N, amortized, share_cov, a_free (D,J bool or None)[, estimator]).
     params: unconstrained leaves keyed by the reference's param-store names.
     idx: (B,) int64 rows of the plate subsample; eps: (B,D) standard normal draws.
-    spec["estimator"] == "score" (D = 1 only; SURVEY.md App. A.5 -- NOT what the reference does for its Normal guides,
-    vi.py:684,705 are reparameterised): the guide's gradient is the score-function one, (log_r_i - baseline_i) d log q / d phi
+    spec["estimator"] == "score" (SURVEY.md App. A.5 -- NOT what the reference does for its Normal guides, vi.py:684,693,
+    705,715,723 are reparameterised): the guide's gradient is the score-function one, (log_r_i - baseline_i) d log q / d phi
     with log_r_i = scale (ll_i + log p(x_i) - log q(x_i)) detached and the score term unscaled; the item gradients stay
-    pathwise.  baseline: (B,) control variate or None.
+    pathwise.  For D > 1, x = loc + L eps held fixed: d log q / d loc = u = L^-T eps, d log q / d L_kc = u_k eps_c (c < k),
+    d log q / d M_kk = u_k eps_k L_kk - 1 (mvn_score_terms).  baseline: (B,) control variate or None.
     Returns (loss, grads) for ONE particle (not yet divided by num_particles); with want_log_r also log_r (B,)."""
     model, D, Dc, N = spec["model"], spec["D"], spec["Dc"], spec["N"]
     dt = params["b"].dtype
@@ -323,9 +337,12 @@ def irt_particle(spec, params, y_u8_full, idx, eps, baseline=None, want_log_r=Fa
     gx = scale * (g["x"] - x)                                    # d ELBO / d x (likelihood + prior)
     g_loc = gx
     log_r = scale * (ll + logp_x - logq)
-    if spec.get("estimator", "pathwise") == "score":
-        if D != 1:
-            raise NotImplementedError("score-function mode: D = 1 Normal guides")
+    if spec.get("estimator", "pathwise") == "score" and D > 1:
+        f = (log_r - (0.0 if baseline is None else np.asarray(baseline, dt)))
+        s_loc, s_M = mvn_score_terms(L, eps)
+        g_loc = f[:, None] * s_loc
+        g_raw = f[:, None, None] * s_M
+    elif spec.get("estimator", "pathwise") == "score":
         f = (log_r - (0.0 if baseline is None else np.asarray(baseline, dt)))[:, None]
         g_loc = f * eps / sig                                    # d log q / d loc = (x - loc) / sigma^2 = eps / sigma
         g_raw = f * (eps ** 2 - 1.0)                             # d log q / d raw (sigma = exp(raw))

@@ -693,6 +693,63 @@ def test_irt_score_function_step_vs_oracle(amort, model, B, baseline):
             assert np.abs(gh - go).max() / sc < 3e-4, (name, t, np.abs(gh - go).max() / sc)
 
 
+@pytest.mark.parametrize("guide,N,J,D,model,B,baseline", [
+    ("amortized", 264, 36, 8, "irt_2pl", None, "none"),              # encoder heads: dimension-major backward kernels
+    ("amortized", 640, 40, 12, "irt_3pl", 128, "avg"),               # ... subsample, decaying-average baseline by row
+    ("amortized", 320, 500, 100, "irt_2pl", None, "avg"),            # the headline's guide shape
+    ("shared", 300, 30, 3, "irt_2pl", None, "none"),                 # VIRT share_cov (vi.py:706-715)
+    ("person", 257, 33, 4, "irt_4pl", 100, "avg"),                   # VIRT per-person Cholesky rows (vi.py:716-723)
+])
+def test_mvn_score_function_step_vs_oracle(guide, N, J, D, model, B, baseline):
+    """estimator='score' for the multivariate Normal guides (x_feature > 1): w_i L_i^-T eps_i and the DIAG-row operand from
+    k_mvn_score.hip through the unchanged guide-backward kernels, against the oracle's score mode (mvn_score_terms) on the
+    same Philox draws; two steps so that the decaying-average baseline is carried over."""
+    from vipsy_amd.engine import IrtEngine
+    amort = guide == "amortized"
+    rng = np.random.RandomState(N + J + D)
+    if amort:
+        y, enc, rng = _random_problem(N, J, D, 64, model, 0.1, seed=N + J + D)
+        kw = {"encoder_init": {k: v.astype(np.float32) for k, v in enc.items()}}
+    else:
+        y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+        y[rng.rand(N, J) < 0.1] = 255
+        kw = {"share_cov": guide == "shared"}
+    eng = IrtEngine(torch.from_numpy(y).to(_dev()), model=model, D=D, amortized=amort, H=64, seed=5, estimator="score",
+                    baseline=baseline, baseline_beta=0.8, **kw)
+    eng.unconstrained("b").copy_(torch.from_numpy(0.5 * rng.randn(1, J)).float())
+    a0 = eng.unconstrained("a") * torch.from_numpy(1 + 0.3 * rng.randn(D, J)).float().to(_dev())
+    eng.unconstrained("a").copy_((0.05 if D >= 64 else 1.0) * a0 * eng.unconstrained("a", eng.free))
+    if not amort:
+        eng.unconstrained("x_local").copy_(torch.from_numpy(0.5 * rng.randn(N, D)).float())
+        Ms = 0.3 * rng.randn(*((D, D) if guide == "shared" else (N, D, D)))
+        eng.unconstrained("x_scale").copy_(torch.from_numpy(Ms).float())
+    spec = {"family": "irt", "model": model, "D": D, "Dc": 1.0, "N": N, "amortized": amort, "share_cov": guide == "shared",
+            "a_free": vo.default_a_free(D, J), "estimator": "score"}
+    base = np.zeros(N)
+    for t in range(2):
+        idx = np.arange(N) if B is None else np.sort(rng.permutation(N)[:B])
+        rows = None if B is None else torch.from_numpy(idx).to(_dev())
+        eng.t = t
+        eps = vo.philox_normals(5, t, 0, idx, D)
+        eng.loss_and_grads(rows, len(idx))
+        torch.cuda.synchronize()
+        names = eng.names() + ([] if amort else ["x_local"] + ([] if guide == "shared" else ["x_scale"]))
+        params = {n: eng.unconstrained(n).cpu().numpy().astype(np.float64) for n in dict.fromkeys(names)}
+        bl = base[idx] if baseline == "avg" else None
+        loss_o, g_o, log_r = vo.irt_particle(spec, params, y, idx, eps, baseline=bl, want_log_r=True)
+        if baseline == "avg":
+            base[idx] = 0.8 * base[idx] + 0.2 * log_r
+            np.testing.assert_allclose(eng.base.cpu().numpy(), base, rtol=3e-5, atol=1e-3 * max(1.0, np.abs(log_r).max() * 1e-2))
+        assert float(eng.G[eng.n_params].item()) == pytest.approx(loss_o, rel=3e-5)
+        for name, go in g_o.items():
+            src = eng.GP if (eng.per_person and name in eng.pp_off) else eng.G
+            gh = eng.unconstrained(name, src).cpu().numpy()
+            if name == "a":
+                gh = gh * eng.unconstrained("a", eng.free).cpu().numpy()
+            sc = max(1e-6, float(np.abs(go).max()))
+            assert np.abs(gh.reshape(go.shape) - go).max() / sc < 3e-4, (name, t, np.abs(gh.reshape(go.shape) - go).max() / sc)
+
+
 def test_irt_score_function_loo_baseline_through_step():
     """baseline='loo' through IrtEngine.step: three particles share the batch, each with the leave-one-out mean of the others'
     log_r as its control variate (lr = 0 keeps the parameters, so the averaged gradient can be checked)."""

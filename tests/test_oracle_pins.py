@@ -147,3 +147,34 @@ def test_irt_score_function_estimator_is_unbiased_and_baseline_cuts_its_variance
     l0, g0 = vo.irt_particle(spec, params, y, idx, eps[0])
     l1, g1 = vo.irt_particle(sc, params, y, idx, eps[0])
     assert l0 == l1 and all(np.array_equal(g0[k], g1[k]) for k in ("a", "b"))
+
+
+def test_mvn_score_terms_are_the_gradient_of_log_q():
+    """The score of MultivariateNormal(loc, scale_tril = L(M)) at a fixed point, as the oracle's score mode for x_feature > 1
+    uses it (L as vi.py:452-454 / :711-714 build it): central differences of log q itself."""
+    rng = np.random.RandomState(0)
+    B, D = 3, 5
+    M, loc, eps = 0.3 * rng.randn(B, D, D), rng.randn(B, D), rng.randn(B, D)
+
+    def l_of(m):
+        return np.tril(m, -1) + np.einsum("bi,ij->bij", np.exp(np.einsum("bii->bi", m)), np.eye(D))
+
+    x = loc + np.einsum("bij,bj->bi", l_of(M), eps)
+
+    def logq(lc, m):
+        L = l_of(m)
+        e = np.stack([np.linalg.solve(L[i], x[i] - lc[i]) for i in range(B)])
+        return -np.log(np.einsum("bii->bi", L)).sum(1) - 0.5 * (e ** 2).sum(1)
+
+    s_loc, s_m = vo.mvn_score_terms(l_of(M), eps)
+    h = 1e-6
+    for i in range(B):
+        for k in range(D):
+            d = np.zeros_like(loc)
+            d[i, k] = h
+            assert s_loc[i, k] == pytest.approx((logq(loc + d, M)[i] - logq(loc - d, M)[i]) / (2 * h), abs=1e-6)
+            for c in range(D):
+                dm = np.zeros_like(M)
+                dm[i, k, c] = h
+                fd = (logq(loc, M + dm)[i] - logq(loc, M - dm)[i]) / (2 * h)
+                assert s_m[i, k, c] == pytest.approx(fd, abs=1e-6), (i, k, c)

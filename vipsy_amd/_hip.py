@@ -83,6 +83,8 @@ SIGNATURES = {
     "vx_cdm_sf_grad": (ctypes.c_int, [ctypes.POINTER(HoDinaCfg), _I32, _I32, _F, _P, _P, _I64, _I64] + [_P] * 3 + [_P, _P, _P, _F, _I32] + [_P] * 3 + [_P, _P, _P]),
     "vx_loo_baseline": (ctypes.c_int, [_P, _I32, _I64, _I32, _P, _P]),
     "vx_irt1d_score_grad": (ctypes.c_int, [_I64, ctypes.c_float, _P, _P, _P, _P, _P, ctypes.c_float, _I32, _P, _P, _P, _P]),
+    "vx_mvn_score_operands": (ctypes.c_int, [_CFG, _I64, _P, _I32] + [_P] * 8 + [_F, _I32] + [_P] * 6),
+    "vx_mvn_score_diag": (ctypes.c_int, [_CFG, _I64, _P, _P, _I32, _P, _P]),
     "vx_bin_enc_param_floats": (_I64, [ctypes.POINTER(HoDinaCfg)]),
     "vx_bin_enc_forward": (ctypes.c_int, [ctypes.POINTER(HoDinaCfg), _P, _P, _I64] + [_P] * 4 + [_P, _P, _P]),
     "vx_bin_enc_bwd_workspace_floats": (_I64, [ctypes.POINTER(HoDinaCfg), _I64]),

@@ -17,6 +17,7 @@
 #include "k_hodina_m.hip"
 #include "k_norm_enc.hip"
 #include "k_mvn_bbvi.hip"
+#include "k_mvn_score.hip"
 #include "k_mvn_bwd_t.hip"
 #include "k_mvn_bwd_b.hip"
 #include "k_mvn_fwd_b.hip"
@@ -1198,6 +1199,42 @@ int vx_irt1d_score_grad(int64_t nb, float scale, const float* elbo, const float*
     if (nb == 0) return VX_OK;
     hipLaunchKernelGGL(k_irt1d_score, dim3(grid_1d(nb, 256)), dim3(256), 0, (hipStream_t)hs, nb, scale, elbo, eps, raw, rows,
                        baseline, base_beta, (int)base_by_row, log_r, gloc, graw);
+    VX_CHECK_LAUNCH();
+    return VX_OK;
+}
+
+// ---- score-function operands of the multivariate Normal guides (k_mvn_score.hip)
+int vx_mvn_score_operands(const vx_irt_cfg* cfg, int64_t nb, const int64_t* rows, int32_t kind, const float* h,
+                          const float* W22, const float* b22, const float* M, const float* eps, const float* ll,
+                          const float* ent, float* baseline, float base_beta, int32_t base_by_row, float* log_r, float* w,
+                          float* gx, float* gxT, float* gdT, void* hs) {
+    if (!cfg || cfg->D < 2 || cfg->D > 127 || nb < 0 || kind < 0 || kind > 2 || !eps || !ll || !ent || (!gx && !gxT && !w))
+        return VX_EINVAL;
+    if (kind == 0 && (!h || !W22 || !b22 || cfg->H < 1)) return VX_EINVAL;
+    if (kind != 0 && !M) return VX_EINVAL;
+    if (nb == 0) return VX_OK;
+    const size_t lds = ms_lds_bytes(cfg->D, cfg->H, kind);
+    if (lds > 160 * 1024) return VX_EINVAL;
+    const dim3 grid((unsigned)((nb + MS_THREADS - 1) / MS_THREADS));
+    hipStream_t st = (hipStream_t)hs;
+    int rc;
+#define LAUNCH_MS(K)                                                                                               \
+    rc = set_lds(k_mvn_score_operands<K>, lds);                                                                    \
+    if (rc) return rc;                                                                                             \
+    hipLaunchKernelGGL(k_mvn_score_operands<K>, grid, dim3(MS_THREADS), lds, st, (int)cfg->D, (int)cfg->H, nb,     \
+                       cfg->scale, rows, h, W22, b22, M, eps, ll, ent, baseline, base_beta, (int)base_by_row, log_r, w, gx, gxT, gdT)
+    if (kind == 0) { LAUNCH_MS(0); } else if (kind == 1) { LAUNCH_MS(1); } else { LAUNCH_MS(2); }
+#undef LAUNCH_MS
+    VX_CHECK_LAUNCH();
+    return VX_OK;
+}
+
+int vx_mvn_score_diag(const vx_irt_cfg* cfg, int64_t nb, const int64_t* rows, const float* w, int32_t shared, float* gM,
+                      void* hs) {
+    if (!cfg || cfg->D < 2 || cfg->D > 127 || nb < 0 || !w || !gM) return VX_EINVAL;
+    if (nb == 0) return VX_OK;
+    const unsigned blocks = shared ? 1u : (unsigned)grid_1d(nb * cfg->D, 256);
+    hipLaunchKernelGGL(k_mvn_score_diag, dim3(blocks), dim3(256), 0, (hipStream_t)hs, (int)cfg->D, nb, rows, w, (int)shared, gM);
     VX_CHECK_LAUNCH();
     return VX_OK;
 }

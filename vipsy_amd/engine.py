@@ -217,6 +217,18 @@ class HipBackend(object):
                                         _hip.ptr(gloc), _hip.ptr(graw), _hip.stream_ptr())
         _hip.check(rc, "vx_irt1d_score_grad")
 
+    def mvn_score_operands(self, cfg, nb, rows, kind, h, W22, b22, M, eps, ll, ent, baseline, base_beta, base_by_row, log_r, w,
+                           gx, gxT, gdT):
+        rc = self.L.vx_mvn_score_operands(ctypes.byref(cfg), nb, _hip.ptr(rows), int(kind), _hip.ptr(h), _hip.ptr(W22),
+                                          _hip.ptr(b22), _hip.ptr(M), _hip.ptr(eps), _hip.ptr(ll), _hip.ptr(ent),
+                                          _hip.ptr(baseline), float(base_beta), int(base_by_row), _hip.ptr(log_r), _hip.ptr(w),
+                                          _hip.ptr(gx), _hip.ptr(gxT), _hip.ptr(gdT), _hip.stream_ptr())
+        _hip.check(rc, "vx_mvn_score_operands")
+
+    def mvn_score_diag(self, cfg, nb, rows, w, shared, gM):
+        _hip.check(self.L.vx_mvn_score_diag(ctypes.byref(cfg), nb, _hip.ptr(rows), _hip.ptr(w), int(bool(shared)), _hip.ptr(gM),
+                                            _hip.stream_ptr()), "vx_mvn_score_diag")
+
     def loo_baseline(self, lr_all, S, nb, s, out):
         _hip.check(self.L.vx_loo_baseline(_hip.ptr(lr_all), int(S), nb, int(s), _hip.ptr(out), _hip.stream_ptr()),
                    "vx_loo_baseline")
@@ -620,8 +632,8 @@ class IrtEngine(_EngineBase):
         """group: the torch.distributed process group whose ranks SHARE this problem (each holds a contiguous shard of
         persons: y_u8 = rows gid0 .. gid0 + n_local of the n_global); None = this process owns the whole problem.
         observed_lists: D = 1, full batch, >= 50 % missing -> step on compacted lists of observed cells.
-        estimator: 'pathwise' = what pyro's Trace_ELBO does for the reference's Normal guides (vi.py:684,705);
-        'score' (D = 1 only; BASELINE.json north_star) = the score-function (REINFORCE) gradient of the
+        estimator: 'pathwise' = what pyro's Trace_ELBO does for the reference's Normal guides (vi.py:684,693,705,715,723);
+        'score' (BASELINE.json north_star; every guide of this engine) = the score-function (REINFORCE) gradient of the
         guide, (log_r_i - baseline_i) d log q / d phi, with baseline 'none', 'avg' (per-person decaying average of log_r, rate
         baseline_beta) or 'loo' (leave-one-out mean over the particles of a step, num_particles >= 2; the particles then share
         the step's subsample).  The item gradients are the pathwise ones in every mode."""
@@ -629,8 +641,6 @@ class IrtEngine(_EngineBase):
             raise ValueError("estimator must be 'pathwise' or 'score'")
         if baseline not in ("none", "avg", "loo"):
             raise ValueError("baseline must be 'none', 'avg' or 'loo'")
-        if estimator == "score" and int(D) != 1:
-            raise NotImplementedError("the score-function estimator is built for the D = 1 Normal guides")
         self.estimator, self.baseline, self.baseline_beta = estimator, baseline, float(baseline_beta)
         self.be = backend if backend is not None else HipBackend()
         self.observed_lists = bool(observed_lists) and estimator == "pathwise"
@@ -726,6 +736,14 @@ class IrtEngine(_EngineBase):
         return u.clone()
 
     # -- one ELBO-gradient step ------------------------------------------------------------------
+    def _score_baseline(self, baseline_buf, guide_grads):
+        """(control variate, decay rate or -1, indexed-by-row flag) of the score-function estimator for this pass."""
+        if baseline_buf is not None:
+            return baseline_buf, -1.0, 0
+        if self.baseline == "avg":
+            return self.base, (self.baseline_beta if guide_grads else -1.0), 1
+        return None, -1.0, 0
+
     def loss_and_grads(self, rows=None, b_global=None, eps=None, stream_id=0, baseline_buf=None, guide_grads=True):
         """Fills self.G (flat grads + loss slot) and per-person grads for ONE particle.
         rows: int64 device tensor of LOCAL row indices (None = all local rows, i.e. full batch).
@@ -754,12 +772,25 @@ class IrtEngine(_EngineBase):
                 be.mvn_bbvi_forward(cfg, nb, rows, self.gid0, loc, Mq, self.share_cov, eps, fw["x"], fw["eps"], fw["ent"])
             with self._phase("likelihood"):
                 be.lik_grad(cfg, self.y, rows, nb, fw["x"], a, self.view("b"), c_un, d_un, gx, ll, gitem, lik_ws)
+            cfg_b = cfg
+            if self.estimator == "score":
+                # the guide's score-function gradient in place of the pathwise one: gx <- w_i L_i^-T eps_i, and the diagonal
+                # term -w_i in place of the entropy's +scale (k_mvn_score.hip); item gradients and loss stand
+                with self._phase("mvn_score"):
+                    w_sf, log_r = self._buf("sf_w", nb), self._buf("sf_lr%d" % stream_id if not guide_grads else "sf_lr", nb)
+                    base, beta, by_row = self._score_baseline(baseline_buf, guide_grads)
+                    be.mvn_score_operands(cfg, nb, rows, 2 if self.share_cov else 1, None, None, None, Mq, fw["eps"], ll,
+                                          fw["ent"], base, beta, by_row, log_r, w_sf, gx, None, None)
+                    self.last_log_r = log_r
+                cfg_b = be.cfg(self.model, self.D, self.J, self.H, self.Dc, 0.0, self.seed, self.t, stream_id)
             with self._phase("guide_backward"):
                 self.GP.zero_()                                       # dense per-person grads: zero off the batch
                 if self.share_cov:
                     gM.zero_()
-                be.mvn_bbvi_backward(cfg, nb, rows, Mq, self.share_cov, gx, fw["eps"], self.GP[:n * D], gM,
+                be.mvn_bbvi_backward(cfg_b, nb, rows, Mq, self.share_cov, gx, fw["eps"], self.GP[:n * D], gM,
                                      self._buf("bbvi_ws", be.mvn_bbvi_bwd_workspace(cfg, nb, self.share_cov)))
+                if self.estimator == "score":
+                    be.mvn_score_diag(cfg, nb, rows, w_sf, self.share_cov, gM)
             be.sum2_into(ll, fw["ent"], nb, -scale, lossslot, self.sum_ws)        # loss = -scale * sum_i (ll_i + ent_i)
             self.last = {"fw": fw, "gx": gx, "ll": ll, "nb": nb}
         elif self.D > 1:
@@ -793,6 +824,18 @@ class IrtEngine(_EngineBase):
                 be.lik_grad(cfg, self.y, rows, nb, fw["x"], a, self.view("b"), c_un, d_un, gx, ll, gitem, lik_ws,
                             gxT=gxT, yT=yT, ximg=fw.get("ximg"), epsT=fw["epsT"] if gdT is not None else None,
                             ldT=fw["ldT"] if gdT is not None else None, gdT=gdT)
+            if self.estimator == "score":
+                # gxT, gdT <- the score-function operands (k_mvn_score.hip); item gradients and loss stand
+                if gx is not None or gdT is None:
+                    raise NotImplementedError("the score-function estimator of the amortized multivariate guide runs on the "
+                                              "dimension-major backward kernels: hidden_dim 64, x_feature % 4 == 0 (<= 124), "
+                                              "item_size % 4 == 0, batch % 4 == 0")
+                with self._phase("mvn_score"):
+                    log_r = self._buf("sf_lr%d" % stream_id if not guide_grads else "sf_lr", nb)
+                    base, beta, by_row = self._score_baseline(baseline_buf, guide_grads)
+                    be.mvn_score_operands(cfg, nb, rows, 0, fw["h"], enc["fc22.weight"], enc["fc22.bias"], None, fw["eps"], ll,
+                                          fw["ent"], base, beta, by_row, log_r, None, None, gxT, gdT)
+                    self.last_log_r = log_r
             with self._phase("guide_backward"):
                 be.mvn_enc_backward(cfg, self.y, rows, nb, enc, fw, gx,
                                     self.G[self.enc_off0:self.enc_off0 + self.n_enc], encb_ws, gxT=gxT,
@@ -837,12 +880,7 @@ class IrtEngine(_EngineBase):
                     else:
                         eps_sf = eps
                     log_r = self._buf("sf_lr%d" % stream_id if not guide_grads else "sf_lr", nb)
-                    if baseline_buf is not None:
-                        base, beta, by_row = baseline_buf, -1.0, 0
-                    elif self.baseline == "avg":
-                        base, beta, by_row = self.base, (self.baseline_beta if guide_grads else -1.0), 1
-                    else:
-                        base, beta, by_row = None, -1.0, 0
+                    base, beta, by_row = self._score_baseline(baseline_buf, guide_grads)
                     be.irt1d_score_grad(nb, scale, elbo, eps_sf, raw, rows, base, beta, by_row, log_r, gloc, graw)
                     self.last_log_r = log_r
             if self.amortized:

@@ -50,9 +50,21 @@ class _RandomIrtBase(RandomPsyData):
         x_in = None
         if getattr(self, "_x_host", None) is not None:                 # latent draws the host made (correlated traits)
             x_in = self._x_host.to(dev).float().contiguous()
+        loc, sc = getattr(self, "_x_affine", (0.0, 1.0))
+        if (loc, sc) != (0.0, 1.0):
+            # x = loc + sc z with z ~ N(0, 1) drawn by the kernel: the response law is that of z with a' = sc a,
+            # b' = b + loc sum_k a_k (1PL: a = 1)
+            a_eff = dv["a"] if "a" in dv else torch.ones((D, J), dtype=torch.float32, device=dev)
+            dv["b"] = (dv["b"] + loc * a_eff.sum(0, keepdim=True)).contiguous()
+            if "a" in dv:
+                dv["a"] = (sc * dv["a"]).contiguous()
+            elif sc != 1.0:
+                raise NotImplementedError("RandomIrt1PL with x_scale != 1 (the kernel's 1PL link has no slope)")
         _hip.check(L.vx_synth_irt(ctypes.byref(cfg), n, self.gid0, _hip.ptr(x_in), _hip.ptr(dv.get("a")), _hip.ptr(dv["b"]),
                                   _hip.ptr(dv.get("c")), _hip.ptr(dv.get("d")), 0.0, _hip.ptr(y), _hip.ptr(x),
                                   _hip.stream_ptr()), "vx_synth_irt")
+        if (loc, sc) != (0.0, 1.0):
+            x.mul_(sc).add_(loc)
         self._y, self._x = y, (x_in if x_in is not None else x)
 
     @property
@@ -69,8 +81,8 @@ class _RandomIrtBase(RandomPsyData):
 
 
 class RandomIrt1PL(_RandomIrtBase):
-    """vi.py:202-233: x ~ N(x_local, x_scale) (drawn on the device as N(0, 1) and shifted only through the defaults),
-    b ~ N(b_local, b_scale)."""
+    """vi.py:202-233: x ~ N(x_local, x_scale) (drawn on the device as N(0, 1); a location / scale is folded into the item
+    parameters the kernel sees and applied to `.x`), b ~ N(b_local, b_scale)."""
     name = "irt_1pl"
 
     def __init__(self, x_feature=1, x_local=0, x_scale=1, b_local=0, b_scale=1, D=1, *args, **kwargs):
@@ -79,8 +91,7 @@ class RandomIrt1PL(_RandomIrtBase):
         self.b = torch.empty(1, self.item_size).normal_(b_local, b_scale)
         self.D = D
         self._x_host = None
-        if x_local != 0 or x_scale != 1:
-            self._x_host = torch.empty(self.sample_size, x_feature).normal_(x_local, x_scale)
+        self._x_affine = (float(x_local), float(x_scale))
 
 
 class RandomIrt2PL(RandomIrt1PL):
@@ -199,6 +210,11 @@ class RandomDina(RandomPsyData):
         attr = torch.empty((n, K), dtype=torch.uint8, device=dev)
         theta = torch.empty(n, dtype=torch.float32, device=dev) if self._hodina else None
         dv = {k: getattr(self, k).to(dev).float().contiguous() for k in ("q", "g", "s", "lam0", "lam1") if hasattr(self, k)}
+        t_loc, t_sc = getattr(self, "_theta_affine", (0.0, 1.0))
+        if self._hodina and (t_loc, t_sc) != (0.0, 1.0):
+            # theta = loc + sc z, z ~ N(0, 1) drawn by the kernel: sigmoid(theta lam1 + lam0) = sigmoid(z (sc lam1) + (lam0 + loc lam1))
+            dv["lam0"] = (dv["lam0"] + t_loc * dv["lam1"]).contiguous()
+            dv["lam1"] = (t_sc * dv["lam1"]).contiguous()
         _hip.check(L.vx_synth_cdm(ctypes.byref(cfg), int(self._dino), int(self._hodina), float(self.attr_p), n, self.gid0,
                                   _hip.ptr(dv["q"]), _hip.ptr(dv["g"]), _hip.ptr(dv["s"]), _hip.ptr(dv.get("lam0")),
                                   _hip.ptr(dv.get("lam1")), 0.0, _hip.ptr(y), _hip.ptr(attr), _hip.ptr(theta),
@@ -206,6 +222,8 @@ class RandomDina(RandomPsyData):
         self._y, self._attr = y, attr
         if theta is not None:
             self._theta = theta.reshape(n, 1)
+            if (t_loc, t_sc) != (0.0, 1.0):
+                self._theta.mul_(t_sc).add_(t_loc)
 
     @property
     def y(self):
@@ -227,14 +245,14 @@ class RandomDino(RandomDina):
 
 
 class RandomHoDina(RandomDina):
-    """vi.py:175-199: theta ~ N(0, 1), lam0 ~ N, lam1 ~ U(.5, 3); attributes ~ Bern(sigmoid(theta lam1 + lam0))."""
+    """vi.py:175-199: theta ~ N(theta_local, theta_scale), lam0 ~ N, lam1 ~ U(.5, 3); attributes ~
+    Bern(sigmoid(theta lam1 + lam0))."""
     name = "ho_dina"
     _hodina = True
 
     def __init__(self, theta_local=0, theta_scale=1, lam0_local=0, lam0_scale=1, lam1_lower=0.5, lam1_upper=3, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        if theta_local != 0 or theta_scale != 1:
-            raise NotImplementedError("theta is drawn on the device as N(0, 1)")
+        self._theta_affine = (float(theta_local), float(theta_scale))
         self.lam0 = torch.empty(1, self.q_size).normal_(lam0_local, lam0_scale)
         self.lam1 = torch.empty(1, self.q_size).uniform_(lam1_lower, lam1_upper)
 

@@ -1,16 +1,51 @@
 """Synthetic response data with the distributions of the reference's Random* generators
-(vi.py:120-412), produced on the device in uint8 (0 / 1 / 255 = missing).
+(vi.py:120-412) in uint8 (0 / 1 / 255 = missing), from explicit item parameters and a seed -- what bench.py and
+the tests feed the engines.  Benchmark / test INPUT only, never inside a timed region.
 
-Benchmark / test INPUT only; torch ops are used as plumbing for setup work that
-is never inside a timed region.  Item-side draws (J or D x J values) are made on the host exactly as
-the reference does; the N x J Bernoulli draws are made on the device in row chunks so 1M x 500 never
-needs an fp32 N x J host matrix.
+Item-side draws (J or D x J values) are made on the host exactly as the reference does.  The N x J responses and the
+latent draws behind them come from ONE generator per device: on a GPU the HIP kernels of vipsy_amd/csrc/k_synth.hip
+(vx_synth_irt / vx_synth_cdm, Philox keyed by the global person id: a data set does not depend on the sharding); on the
+CPU -- the `-m "not gpu"` tests only -- torch ops with the same distributions.
 """
 import math
 import random
 
+import ctypes
+
 import numpy as np
 import torch
+
+
+def _on_gpu(device):
+    return torch.device(device).type == "cuda"
+
+
+def _device_irt(n, gid0, items, model, device, seed, missing, Dc):
+    from . import _hip
+    from .engine import MODEL_CODE
+    J = items["b"].shape[1]
+    D = items["a"].shape[0] if "a" in items else 1
+    cfg = _hip.IrtCfg(MODEL_CODE[model], D, J, 0, float(Dc), 1.0, int(seed), 0, 0)
+    dv = {k: items[k].to(device).float().contiguous() for k in ("a", "b", "c", "d") if k in items}
+    y = torch.empty((n, J), dtype=torch.uint8, device=device)
+    with torch.cuda.device(device):
+        _hip.check(_hip.lib().vx_synth_irt(ctypes.byref(cfg), n, int(gid0), None, _hip.ptr(dv.get("a")), _hip.ptr(dv["b"]),
+                                           _hip.ptr(dv.get("c")), _hip.ptr(dv.get("d")), float(missing), _hip.ptr(y), None,
+                                           _hip.stream_ptr()), "vx_synth_irt")
+    return y
+
+
+def _device_cdm(n, gid0, prm, device, seed, missing, dino, hodina, attr_p):
+    from . import _hip
+    K, J = prm["q"].shape
+    cfg = _hip.HoDinaCfg(K, J, 0, 0, 1.0, 0.0, int(seed), 0, 0)
+    dv = {k: prm[k].to(device).float().contiguous() for k in ("q", "g", "s", "lam0", "lam1") if k in prm}
+    y = torch.empty((n, J), dtype=torch.uint8, device=device)
+    with torch.cuda.device(device):
+        _hip.check(_hip.lib().vx_synth_cdm(ctypes.byref(cfg), int(dino), int(hodina), float(attr_p), n, int(gid0), _hip.ptr(dv["q"]),
+                                           _hip.ptr(dv["g"]), _hip.ptr(dv["s"]), _hip.ptr(dv.get("lam0")), _hip.ptr(dv.get("lam1")),
+                                           float(missing), _hip.ptr(y), None, None, _hip.stream_ptr()), "vx_synth_cdm")
+    return y
 
 
 def _gen_omega(n, rnd):
@@ -67,6 +102,8 @@ def irt_item_params(J, model, seed, D=1):
 def simulate_responses(n, gid0, items, model, device, seed, missing=0.0, chunk=65536, Dc=1.0):
     """y[i, j] ~ Bernoulli(P_ij) for persons gid0 .. gid0+n-1 with x_i ~ N(0, I) (vi.py:228, 335);
     MCAR missingness at rate `missing`.  Deterministic per (seed, global person id chunk)."""
+    if _on_gpu(device):
+        return _device_irt(n, gid0, items, model, device, seed, missing, Dc)
     J = items["b"].shape[1]
     D = items["a"].shape[0] if "a" in items else 1
     a = items["a"].to(device) if "a" in items else torch.ones(1, J, device=device)
@@ -102,6 +139,8 @@ def hodina_params(J, K, seed):
 
 def simulate_hodina(n, gid0, prm, device, seed, missing=0.0, chunk=262144):
     """theta ~ N(0,1); attr_k ~ Bern(sigmoid(theta lam1_k + lam0_k)); DINA response (vi.py:69-83, 103-116)."""
+    if _on_gpu(device):
+        return _device_cdm(n, gid0, prm, device, seed, missing, False, True, 0.5)
     q = prm["q"].to(device)
     K, J = q.shape
     need = (q ** 2).sum(0)
@@ -135,8 +174,11 @@ def dina_params(J, K, seed, q_p=0.5):
 
 
 def simulate_dina(n, gid0, prm, device, seed, cdm="dina", attr_p=0.5, missing=0.0, chunk=262144):
-    """attr_k ~ Bern(attr_p); DINA / DINO response (vi.py:69-100, 158-172; DINO without the reference's in-place quirk of
-    dino(): this is the data-generating model, eta = 1 iff at least one required attribute is mastered)."""
+    """attr_k ~ Bern(attr_p); DINA / DINO response (vi.py:69-100, 158-172).  DINO is the reference's dino() INCLUDING its
+    in-place sequencing (vi.py:96-100; oracle/vi_oracle.py::dino_eta): eta = 1 iff the item needs more than one attribute
+    and at least one of them is mastered -- the definition the kernels, random_data.RandomDino and the fitted models use."""
+    if _on_gpu(device):
+        return _device_cdm(n, gid0, prm, device, seed, missing, cdm == "dino", False, attr_p)
     q = prm["q"].to(device)
     K, J = q.shape
     need = (q ** 2).sum(0)
@@ -146,7 +188,7 @@ def simulate_dina(n, gid0, prm, device, seed, cdm="dina", attr_p=0.5, missing=0.
         g = torch.Generator(device=device).manual_seed(seed * 1000003 + (gid0 + s))
         attr = (torch.rand(e - s, K, generator=g, device=device) < attr_p).float()
         if cdm == "dino":
-            eta = (((1 - attr) @ q) < need).float()
+            eta = ((((1 - attr) @ q) < need) & (need > 1)).float()
         else:
             eta = ((attr @ q) == need).float()
         p = eta * (1 - prm["s"].to(device)) + (1 - eta) * prm["g"].to(device)
