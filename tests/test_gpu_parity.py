@@ -11,6 +11,11 @@ from tests import golden_util as gu
 pytestmark = pytest.mark.gpu
 
 
+# every gradient against the oracle, as a fraction of its tensor's largest magnitude: the tolerance of the golden replays
+# (round 3: the largest value any case of this file reaches is 2.2e-6; rounds 1-2 accepted 2e-4 to 3e-4 here)
+GRAD_TOL = 3e-5
+
+
 def _dev():
     return torch.device("cuda:0")
 
@@ -235,7 +240,7 @@ def test_mvn_amortized_step_vs_oracle(N, J, D, H, model, miss, B):
         gh = eng.unconstrained(name, eng.G).cpu().numpy() * eng.unconstrained(name, eng.free).cpu().numpy()
         sc = max(1e-6, float(np.abs(go).max()))
         err = np.abs(gh - go).max() / sc
-        assert err < 2e-4, (name, err)
+        assert err < GRAD_TOL, (name, err)
 
 
 def _oracle_headline_chunked(eng, y, eps, model="irt_2pl", chunk=2048):
@@ -367,7 +372,7 @@ def test_irt1d_step_vs_oracle(N, J, model, miss, B):
     for name, go in g_o.items():
         gh = eng.unconstrained(name, eng.GP if (eng.per_person and name in eng.pp_off) else eng.G).cpu().numpy()
         sc = max(1e-6, float(np.abs(go).max()))
-        assert np.abs(gh - go).max() / sc < 2e-4, name
+        assert np.abs(gh - go).max() / sc < GRAD_TOL, name
 
 
 def test_entry_points_reject_bad_arguments():
@@ -496,7 +501,7 @@ def test_irt1d_amortized_step_vs_oracle(N, J, model, miss, B, H=64):
     for name, go in g_o.items():
         gh = eng.unconstrained(name, eng.G).cpu().numpy()
         sc = max(1e-6, float(np.abs(go).max()))
-        assert np.abs(gh - go).max() / sc < 3e-4, (name, np.abs(gh - go).max() / sc)
+        assert np.abs(gh - go).max() / sc < GRAD_TOL, (name, np.abs(gh - go).max() / sc)
 
 
 @pytest.mark.parametrize("N,J,D,share,B", [(300, 64, 20, False, None), (257, 40, 100, False, 50), (200, 33, 9, True, 64)])
@@ -526,7 +531,7 @@ def test_mvn_bbvi_step_vs_oracle(N, J, D, share, B):
         if name == "a":
             gh = gh * spec["a_free"]
         sc = max(1e-6, float(np.abs(go).max()))
-        assert np.abs(gh - go).max() / sc < 3e-4, (name, np.abs(gh - go).max() / sc)
+        assert np.abs(gh - go).max() / sc < GRAD_TOL, (name, np.abs(gh - go).max() / sc)
 
 
 @pytest.mark.parametrize("N,J,K,cdm,miss,B", [
@@ -557,7 +562,7 @@ def test_ccdm_step_vs_oracle(N, J, K, cdm, miss, B):
     for name, go in g_o.items():
         gh = eng.unconstrained(name, eng.G).cpu().numpy()
         sc = max(1e-6, float(np.abs(go).max()))
-        assert np.abs(gh - go).max() / sc < 2e-4, (name, np.abs(gh - go).max() / sc)
+        assert np.abs(gh - go).max() / sc < GRAD_TOL, (name, np.abs(gh - go).max() / sc)
 
 
 @pytest.mark.parametrize("amortized,D,model", [(True, 4, "irt_2pl"), (False, 1, "irt_2pl"), (False, 1, "irt_4pl")])
@@ -690,7 +695,7 @@ def test_irt_score_function_step_vs_oracle(amort, model, B, baseline):
         for name, go in g_o.items():
             gh = eng.unconstrained(name, eng.GP if (eng.per_person and name in eng.pp_off) else eng.G).cpu().numpy()
             sc = max(1e-6, float(np.abs(go).max()))
-            assert np.abs(gh - go).max() / sc < 3e-4, (name, t, np.abs(gh - go).max() / sc)
+            assert np.abs(gh - go).max() / sc < GRAD_TOL, (name, t, np.abs(gh - go).max() / sc)
 
 
 @pytest.mark.parametrize("guide,N,J,D,model,B,baseline", [
@@ -747,7 +752,7 @@ def test_mvn_score_function_step_vs_oracle(guide, N, J, D, model, B, baseline):
             if name == "a":
                 gh = gh * eng.unconstrained("a", eng.free).cpu().numpy()
             sc = max(1e-6, float(np.abs(go).max()))
-            assert np.abs(gh.reshape(go.shape) - go).max() / sc < 3e-4, (name, t, np.abs(gh.reshape(go.shape) - go).max() / sc)
+            assert np.abs(gh.reshape(go.shape) - go).max() / sc < GRAD_TOL, (name, t, np.abs(gh.reshape(go.shape) - go).max() / sc)
 
 
 def test_irt_score_function_loo_baseline_through_step():
@@ -773,4 +778,4 @@ def test_irt_score_function_loo_baseline_through_step():
         go = np.mean([o[1][name] for o in outs], axis=0)
         gh = eng.unconstrained(name, eng.GP if name in eng.pp_off else eng.G).cpu().numpy()
         sc = max(1e-6, float(np.abs(go).max()))
-        assert np.abs(gh - go).max() / sc < 3e-4, (name, np.abs(gh - go).max() / sc)
+        assert np.abs(gh - go).max() / sc < GRAD_TOL, (name, np.abs(gh - go).max() / sc)
