@@ -84,11 +84,14 @@ __global__ __launch_bounds__(256) void k_lik_ximg_h(int D, int64_t nb, const flo
 #define LH_LDS_BYTES (3 * LH_XT_BYTES + 2 * LH_R_BYTES + 4 * LH_Y_BYTES + 2 * LH_LP_BYTES)   // 143360
 #define LH_VM_HALF 5                                                // transfers of one half per cell wave (4 x + 1 y)
 
-// LDS writes of this wave done, then the workgroup barrier -- without the release fence of __syncthreads(), which would
-// also wait for the gradient waves' global stores
+// LDS accesses of this wave done, then the workgroup barrier -- without the release fence of __syncthreads(), which would
+// also wait for the gradient waves' global stores (the intrinsic alone is "no memory" to the compiler: the empty asm
+// statements keep its own scheduling from carrying an LDS access across)
 __device__ __forceinline__ void lh_barrier() {
+    asm volatile("" ::: "memory");                                   // the compiler moves no LDS access across the barrier either
     __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 
 template <int ABL = 0>
