@@ -53,11 +53,12 @@ __global__ void k_clear_words(uint32_t* __restrict__ w, int n) { if ((int)thread
 
 
 // BWB_WAVES waves of BWB_RT row tiles each (BWB_WAVES * BWB_RT * 32 = BT_ROWS rows a workgroup, as k_mvn_bwd_t.hip).  Round 3:
-// EIGHT waves of two row tiles instead of four of four -- 64 accumulator registers a wave, the kernel fits 256 registers
+// eight waves of two row tiles instead of four of four -- 64 accumulator registers a wave, the kernel fits 256 registers
 // (the MFMAs take the VGPR form) and two waves share a SIMD: one wave's products / split / LDS waits run under the other's
-// MFMAs.  (BWB_WAVES 4 / BWB_RT 4 is the round-2 form.)
+// MFMAs: 3.12 -> 2.77 ms; then SIXTEEN waves of one row tile (128 registers, four waves a SIMD): 2.82 -> 2.72 ms on one box
+// (tools/bwb_bench.hip).  (BWB_WAVES 4 / BWB_RT 4 is the round-2 form.)
 #ifndef BWB_WAVES
-#define BWB_WAVES 8
+#define BWB_WAVES 16
 #endif
 #ifndef BWB_PRESCALE
 #define BWB_PRESCALE 0                                                  // 1: the E rows take V's power of two in LDS instead of a multiply per
