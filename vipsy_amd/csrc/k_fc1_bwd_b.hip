@@ -9,7 +9,13 @@
 // k-step ahead (consecutive k-steps of a lane continue in the same cache lines); no LDS.
 // (included by vx_abi.hip after k_mvn_fwd_b.hip)
 
-#define F1B_THREADS 256
+// F1B_NT item tiles a wave, 512 / (32 F1B_NT) waves a workgroup (512 items either way).  Four tiles and four waves; two tiles
+// and eight waves (64 accumulator registers, two waves per SIMD) were slower beside k_mvn_enc_bwd_w_b (the pair 3.04 instead of
+// 2.82 ms): the split of ghpre is then shared by half as many MFMAs.
+#ifndef F1B_NT
+#define F1B_NT 4
+#endif
+#define F1B_THREADS (64 * (16 / F1B_NT))
 #define F1B_NS 6                                                     // operand stages in registers (k-steps of look-ahead + 1)
 
 __global__ __launch_bounds__(F1B_THREADS, 1) void k_fc1_bwd_b(
@@ -21,23 +27,23 @@ __global__ __launch_bounds__(F1B_THREADS, 1) void k_fc1_bwd_b(
     const int64_t nb = dm.nb;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int jw0 = blockIdx.x * 512 + 128 * wave;                     // items of this wave: jw0 .. jw0 + 127 (item J = bias)
+    const int jw0 = blockIdx.x * 512 + 32 * F1B_NT * wave;             // items of this wave: jw0 .. jw0 + 32 F1B_NT - 1 (item J = bias)
     if (jw0 > J) return;                                               // waves share nothing
-    const uint8_t* yrow[4];
-    int kind[4];                                                       // 0: response row, 1: ones (the bias column), 2: nothing
+    const uint8_t* yrow[F1B_NT];
+    int kind[F1B_NT];                                                       // 0: response row, 1: ones (the bias column), 2: nothing
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < F1B_NT; ++t) {
         const int j = jw0 + 32 * t + l31;
         kind[t] = j < J ? 0 : (j == J ? 1 : 2);
         yrow[t] = yT + (int64_t)(j < J ? j : 0) * ystride + 8 * half;
     }
     const float* grow[2] = {ghpreT + (int64_t)l31 * nb + 8 * half, ghpreT + (int64_t)(32 + l31) * nb + 8 * half};
 
-    f32x16 acc[4][2];
+    f32x16 acc[F1B_NT][2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { acc[t][0] = zero16(); acc[t][1] = zero16(); }
+    for (int t = 0; t < F1B_NT; ++t) { acc[t][0] = zero16(); acc[t][1] = zero16(); }
 
-    struct Ops { f32x4 g[2][2]; u32x2w y[4]; };
+    struct Ops { f32x4 g[2][2]; u32x2w y[F1B_NT]; };
     auto load = [&](Ops& o, int64_t ks) __attribute__((always_inline)) {
         const int64_t p0 = 16 * ks;                                    // this lane: persons p0 + 8 half + 0..7
 #pragma unroll
@@ -49,7 +55,7 @@ __global__ __launch_bounds__(F1B_THREADS, 1) void k_fc1_bwd_b(
                 o.g[ht][q] = v;
             }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) o.y[t] = *(const u32x2w*)(yrow[t] + p0);     // ystride % 16 == 0, >= nb rounded to 16
+        for (int t = 0; t < F1B_NT; ++t) o.y[t] = *(const u32x2w*)(yrow[t] + p0);     // ystride % 16 == 0, >= nb rounded to 16
     };
     auto compute = [&](const Ops& o) __attribute__((always_inline)) {
         bf16x8 a[2][3];
@@ -60,7 +66,7 @@ __global__ __launch_bounds__(F1B_THREADS, 1) void k_fc1_bwd_b(
             fb_split8(v, a[ht][0], a[ht][1], a[ht][2]);
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < F1B_NT; ++t) {
             u32x4w q;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {                              // byte b in {0, 1, 255} -> bf16 {0, 1, -1}
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(F1B_THREADS, 1) void k_fc1_bwd_b(
     // slab: [W1-grad: 64 * J | b1-grad: 64]
     float* slab = slabs + (int64_t)blockIdx.y * slab_len;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < F1B_NT; ++t) {
         const int j = jw0 + 32 * t + l31;
         if (j <= J) {
 #pragma unroll
