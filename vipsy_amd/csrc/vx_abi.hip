@@ -988,8 +988,12 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
             if (hipEventRecord(ss.fork, st) != hipSuccess || hipStreamWaitEvent(ss.s, ss.fork, 0) != hipSuccess) return VX_EINVAL;
             {
                 ProfScope ps("k_fc1_bwd_b", ss.s);
-                hipLaunchKernelGGL(k_fc1_bwd_b, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0, ss.s,
-                                   dm, yT, yT_stride, ghpre, slabs_f, lenf);
+                if (maxw_ready)
+                    hipLaunchKernelGGL(k_fc1_bwd_b<true>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0,
+                                       ss.s, dm, yT, yT_stride, ghpre, slabs_f, lenf, (const uint32_t*)maxw);
+                else
+                    hipLaunchKernelGGL(k_fc1_bwd_b<false>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0,
+                                       ss.s, dm, yT, yT_stride, ghpre, slabs_f, lenf, (const uint32_t*)nullptr);
                 VX_CHECK_LAUNCH();
             }
             rc = vx_reduce_slabs(slabs_f, n_prf, lenf, -1.0f, genc, (void*)ss.s);
@@ -1085,8 +1089,12 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
         // (joined below)
     } else if (nb > 0 && f1t && (mfma16_mode() & 8)) {
         ProfScope ps("k_fc1_bwd_b", st);
-        hipLaunchKernelGGL(k_fc1_bwd_b, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0, st, dm,
-                           yT, yT_stride, ghpre, slabs_f, lenf);
+        if (maxw_ready)
+            hipLaunchKernelGGL(k_fc1_bwd_b<true>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0, st, dm,
+                               yT, yT_stride, ghpre, slabs_f, lenf, (const uint32_t*)maxw);
+        else
+            hipLaunchKernelGGL(k_fc1_bwd_b<false>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0, st, dm,
+                               yT, yT_stride, ghpre, slabs_f, lenf, (const uint32_t*)nullptr);
         VX_CHECK_LAUNCH();
     } else if (nb > 0 && f1t) {
         const size_t lds = f1_lds_bytes(cfg->J);
@@ -1434,8 +1442,8 @@ int vx_norm_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t*
             hipLaunchKernelGGL(k_norm_enc_bwd_t64, dim3(nblk), dim3(256), 0, st, nb, W21, W22, h, gloc, graw, ghpreT, slabs_h);
             VX_CHECK_LAUNCH();
             if (mfma16_mode() & 8) {
-                hipLaunchKernelGGL(k_fc1_bwd_b, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0,
-                                   st, dm, yT, yT_stride, ghpreT, slabs_f, lenf);
+                hipLaunchKernelGGL(k_fc1_bwd_b<false>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0,
+                                   st, dm, yT, yT_stride, ghpreT, slabs_f, lenf, (const uint32_t*)nullptr);
             } else {
                 const size_t ldst = f1_lds_bytes(cfg->J);
                 rc = set_lds(k_fc1_bwd_t, ldst);
