@@ -7,6 +7,7 @@
 #include "../vipsy_amd/csrc/k_irt_lik.hip"
 #include "../vipsy_amd/csrc/k_irt_lik_r.hip"
 #include "../vipsy_amd/csrc/k_irt_lik_b.hip"
+#include "../vipsy_amd/csrc/k_irt_lik_h.hip"
 #include "../vipsy_amd/csrc/k_mvn_bwd_t.hip"
 #include "../vipsy_amd/csrc/k_mvn_bwd_b.hip"
 #include "../vipsy_amd/csrc/k_mvn_fwd_b.hip"
