@@ -135,8 +135,8 @@ struct ProfScope {
     hipStream_t st;
     const char* name;
     int64_t units;                                                    // persons of this launch when it is not the whole batch (else 0)
-    ProfScope(const char* nm, hipStream_t s, int64_t u = 0) : st(s), name(nm), units(u) {
-        if (!g_prof) return;
+    ProfScope(const char* nm, hipStream_t s, int64_t u = 0, bool on = true) : st(s), name(nm), units(u) {
+        if (!g_prof || !on) return;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = nullptr; return; }
         (void)hipEventRecord(a, st);
     }
@@ -401,6 +401,31 @@ static int mvn_enc_forward_kernels(const vx_irt_cfg* cfg, const uint8_t* y, cons
                 n_done = (rem > 0 && 2 * rem <= round2) ? nb - rem : nb;
                 n_done -= n_done % (FB2_WAVES * 64);            // whole 64-person tiles of the x image, whole workgroups
             }
+            // the short last round runs on a second stream BESIDE the whole rounds (launched first: its workgroups take their
+            // CUs at once, the whole rounds fill the rest), not after them: its 133 workgroups then cost their share of the
+            // chip's time instead of a round of their own
+            bool tail_beside = false;
+            auto launch_tail = [&](hipStream_t ts) -> int {
+                int r = set_lds(k_mvn_enc_fwd_b<false>, ldsb);
+                if (r) return r;
+                // (timed only when it runs alone: beside the whole rounds its bracket spans theirs)
+                ProfScope ps("k_mvn_enc_fwd_b", ts, nb - n_done, ts == (hipStream_t)hs);
+                const dim3 gridb((unsigned)((nb - n_done + FB_WAVES * FB_WP - 1) / (FB_WAVES * FB_WP)));
+                hipLaunchKernelGGL(k_mvn_enc_fwd_b<false>, gridb, dim3(FB_THREADS), ldsb, ts, dm, y, rows, gid0,
+                                   (const uint8_t*)w1img, b1, (const uint8_t*)img, (const uint32_t*)gt2, (const float*)sc, eps_in, cfg->seed,
+                                   cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT, ximg, hs_out, n_done);
+                VX_CHECK_LAUNCH();
+                return VX_OK;
+            };
+            if (n_done > 0 && n_done < nb && (mfma16_mode() & 8) && side_stream().ok) {
+                SideStream& ss = side_stream();
+                if (hipEventRecord(ss.fork, (hipStream_t)hs) != hipSuccess || hipStreamWaitEvent(ss.s, ss.fork, 0) != hipSuccess)
+                    return VX_EINVAL;
+                rc = launch_tail(ss.s);
+                if (rc) return rc;
+                if (hipEventRecord(ss.join, ss.s) != hipSuccess) return VX_EINVAL;
+                tail_beside = true;
+            }
             if (n_done > 0) {
                 const size_t lds2 = fb2_lds_bytes(dm.D, dm.J, FNS);
                 rc = set_lds(k_mvn_enc_fwd_b2<FNS>, lds2);
@@ -414,15 +439,11 @@ static int mvn_enc_forward_kernels(const vx_irt_cfg* cfg, const uint8_t* y, cons
                 VX_CHECK_LAUNCH();
                 if (n_done == nb) return VX_OK;
             }
-            rc = set_lds(k_mvn_enc_fwd_b<false>, ldsb);
-            if (rc) return rc;
-            ProfScope ps("k_mvn_enc_fwd_b", (hipStream_t)hs, nb - n_done);
-            const dim3 gridb((unsigned)((nb - n_done + FB_WAVES * FB_WP - 1) / (FB_WAVES * FB_WP)));
-            hipLaunchKernelGGL(k_mvn_enc_fwd_b<false>, gridb, dim3(FB_THREADS), ldsb, (hipStream_t)hs, dm, y, rows, gid0,
-                               (const uint8_t*)w1img, b1, (const uint8_t*)img, (const uint32_t*)gt2, (const float*)sc, eps_in, cfg->seed,
-                               cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT, ximg, hs_out, n_done);
-            VX_CHECK_LAUNCH();
-            return VX_OK;
+            if (tail_beside) {
+                if (hipStreamWaitEvent((hipStream_t)hs, side_stream().join, 0) != hipSuccess) return VX_EINVAL;
+                return VX_OK;
+            }
+            return launch_tail((hipStream_t)hs);
         }
         const size_t ldsp = enc_p_lds_floats(dm.D, dm.J) * sizeof(float);
         rc = set_lds(k_mvn_enc_fwd_p, ldsp);
@@ -946,16 +967,38 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                     const int64_t round2 = (int64_t)256 * num_cu();
                     const int64_t rem = nb % round2;
                     const int64_t n_done = (rem > 0 && 2 * rem <= round2 && nb > round2) ? nb - rem : nb;
+                    // the short last round on the second stream beside the whole rounds (launched first), as in the forward
+                    const bool beside = n_done < nb && (mfma16_mode() & 8) && side_stream().ok;
+                    hipStream_t ts = st;
+                    if (beside) {
+                        SideStream& ss = side_stream();
+                        if (hipEventRecord(ss.fork, st) != hipSuccess || hipStreamWaitEvent(ss.s, ss.fork, 0) != hipSuccess) return VX_EINVAL;
+                        ts = ss.s;
+                    }
+                    auto launch_tail = [&]() -> int {
+                        int r = set_lds(k_mvn_enc_bwd_h_b<false>, ldsh);
+                        if (r) return r;
+                        hipLaunchKernelGGL(k_mvn_enc_bwd_h_b<false>, dim3((unsigned)((nb - n_done + 32 * HB_WAVES - 1) / (32 * HB_WAVES))),
+                                           dim3(HB_THREADS), ldsh, ts, dm, (const uint8_t*)himg, sc, h, eps, gxT, (const float*)gdT1,
+                                           f1t ? (float*)nullptr : ghpre, hT, f1t ? ghpre : (float*)nullptr, maxw, n_done);
+                        VX_CHECK_LAUNCH();
+                        return VX_OK;
+                    };
+                    if (beside) {
+                        rc = launch_tail();
+                        if (rc) return rc;
+                        if (hipEventRecord(side_stream().join, ts) != hipSuccess) return VX_EINVAL;
+                    }
                     hipLaunchKernelGGL((k_mvn_enc_bwd_h_b2<7, HNSET>), dim3((unsigned)((n_done + 255) / 256)),
                                        dim3(64 * HB2_WAVES_OF(HNSET)), lds2, st, dm, (const uint8_t*)himg, sc, h, eps, gxT, (const float*)gdT1,
                                        f1t ? (float*)nullptr : ghpre, hT, f1t ? ghpre : (float*)nullptr, maxw);
-                    if (n_done < nb) {
+                    if (beside) {
                         VX_CHECK_LAUNCH();
-                        rc = set_lds(k_mvn_enc_bwd_h_b<false>, ldsh);
+                        if (hipStreamWaitEvent(st, side_stream().join, 0) != hipSuccess) return VX_EINVAL;
+                    } else if (n_done < nb) {
+                        VX_CHECK_LAUNCH();
+                        rc = launch_tail();
                         if (rc) return rc;
-                        hipLaunchKernelGGL(k_mvn_enc_bwd_h_b<false>, dim3((unsigned)((nb - n_done + 32 * HB_WAVES - 1) / (32 * HB_WAVES))),
-                                           dim3(HB_THREADS), ldsh, st, dm, (const uint8_t*)himg, sc, h, eps, gxT, (const float*)gdT1,
-                                           f1t ? (float*)nullptr : ghpre, hT, f1t ? ghpre : (float*)nullptr, maxw, n_done);
                     }
                 } else {
                     rc = set_lds(k_mvn_enc_bwd_h_b<false>, ldsh);
