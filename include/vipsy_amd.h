@@ -96,8 +96,9 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y /*[n_local][J]*/,
  * operand of the head weight-gradient kernel -- point it at workspace + vx_mvn_enc_bwd_hs_offset(cfg, nb) of the backward
  * call and set bit 1 of its gd_ready. */
 /* ximg (optional, vx_irt_lik_ximg_bytes(cfg, nb) > 0 only: 96 <= D <= 111, 1PL / 2PL link): x once more, as the pre-split
- * operand image of the fp16-MFMA likelihood kernel (two fp16 terms of x 2^7 per value, in that kernel's LDS tile order);
- * hand the same buffer to vx_irt_lik_grad, which otherwise makes it itself. */
+ * operand image of the fp16-MFMA likelihood kernel (two fp16 terms of x 2^7 per value, in that kernel's LDS tile order,
+ * followed by one overflow word that the writers raise for a latent of |x| >= 511.75); hand the same buffer to
+ * vx_irt_lik_grad, which otherwise makes it itself. */
 /* hT / epsT: optional dimension-major copies of h and eps (person-contiguous rows) for the weight-gradient kernel
  * of vx_mvn_enc_backward; written only by the packed fast path (H == 64, D % 4 == 0, J % 4 == 0). */
 /* `packws` holds this step's packed copy of the head weights (a re-ordering of fc22 | fc21 rows that the
@@ -132,7 +133,8 @@ int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows
  * yT (optional, full batches only: rows == NULL): the responses item-major -- row j = item j over the batch rows, row J
  * and every column past nb filled with 254 ("outside the problem"), yT_stride % 64 == 0 and >= nb rounded up to 64.
  * With it, 96 <= D <= 111 runs on the MFMA kernels -- 1PL / 2PL: k_irt_lik_h.hip (fp32 results from two fp16 terms per
- * operand, three products; |x| < 511.75), 3PL / 4PL: k_irt_lik_b.hip (three bf16 terms, six products); the same buffer serves vx_mvn_enc_backward / vx_norm_enc_backward (which read rows 0..J-1). */
+ * operand, three products; a batch with a latent of |x| >= 511.75 is taken by k_irt_lik_b.hip instead, decided on the
+ * device), 3PL / 4PL: k_irt_lik_b.hip (three bf16 terms, six products); the same buffer serves vx_mvn_enc_backward / vx_norm_enc_backward (which read rows 0..J-1). */
 
 /* ---- amortized MVN guide, backward: encoder weight gradients of the LOSS from gx.
  * genc = d LOSS / d encoder parameters, flat in the nn.Linear order of vi.py:442-444:

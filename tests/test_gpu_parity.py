@@ -706,6 +706,74 @@ def test_irt_score_function_step_vs_oracle(amort, model, B, baseline):
             assert np.abs(gh - go).max() / sc < GRAD_TOL, (name, t, np.abs(gh - go).max() / sc)
 
 
+def test_latent_outside_the_f16_image_range_through_the_step():
+    """A guide whose location head puts one latent dimension at 700 (> 511.75, the range of the fp16 x image the forward writes
+    for k_irt_lik_h) with items that discriminate weakly on it (slope 0.01: the true z moves by 7, a saturated image would
+    make it 5.1): the forward raises the image's overflow word, k_irt_lik_h stands down and the bf16x3 kernel does the step --
+    loss and every gradient as the oracle's."""
+    from vipsy_amd.engine import IrtEngine
+    N, J, D, H = 320, 500, 100, 64
+    y, enc, rng = _random_problem(N, J, D, H, "irt_2pl", 0.1, seed=77)
+    enc["fc21.bias"][3] = 700.0
+    eng = IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_2pl", D=D, amortized=True, H=H,
+                    encoder_init={k: v.astype(np.float32) for k, v in enc.items()}, seed=11)
+    a0 = 0.05 * eng.unconstrained("a") * torch.from_numpy(1 + 0.3 * rng.randn(D, J)).float().to(_dev())
+    a0[3, :] = 0.01
+    eng.unconstrained("a").copy_(a0 * eng.unconstrained("a", eng.free))
+    eng.unconstrained("b").copy_(torch.from_numpy(0.5 * rng.randn(1, J)).float())
+    eng.loss_and_grads(None, N)
+    torch.cuda.synchronize()
+    fw = eng.last["fw"]
+    assert float(fw["x"][:N * D].reshape(N, D)[:, 3].min()) > 600.0
+    eps = fw["eps"][:N * D].reshape(N, D).cpu().numpy()
+    spec = {"family": "irt", "model": "irt_2pl", "D": D, "Dc": 1.0, "N": N, "amortized": True, "share_cov": False,
+            "a_free": vo.default_a_free(D, J)}
+    params = {n: eng.unconstrained(n).cpu().numpy().astype(np.float64) for n in eng.names()}
+    loss_o, g_o = vo.loss_and_grads(spec, params, y, [np.arange(N)], [eps])
+    assert float(eng.G[eng.n_params].item()) == pytest.approx(loss_o, rel=3e-5)
+    for name, go in g_o.items():
+        gh = eng.unconstrained(name, eng.G).cpu().numpy() * eng.unconstrained(name, eng.free).cpu().numpy()
+        sc = max(1e-6, float(np.abs(go).max()))
+        assert np.abs(gh - go).max() / sc < GRAD_TOL, (name, np.abs(gh - go).max() / sc)
+
+
+def test_f16x2_likelihood_entry_with_extreme_latents():
+    """vx_irt_lik_grad called directly, without the forward's operand image, on latents that leave the fixed range of
+    k_irt_lik_h's x operand (|x| 2^7 beyond the largest fp16): the image made inside the call raises its overflow word and
+    the bf16x3 kernel, launched behind the fp16 one, does the work -- every output as the oracle's."""
+    from vipsy_amd.engine import HipBackend
+    N, J, D, scale = 192, 260, 100, 3.0
+    rng = np.random.RandomState(5)
+    y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+    y[rng.rand(N, J) < 0.1] = 255
+    x = rng.randn(N, D).astype(np.float32)
+    x[5, 3], x[17, 40], x[100, 99] = 900.0, -2000.0, 511.9
+    a = (0.05 * (1 + 0.3 * rng.randn(D, J))).astype(np.float32)
+    b = (0.5 * rng.randn(1, J)).astype(np.float32)
+    be, dev = HipBackend(), _dev()
+    cfg = be.cfg("irt_2pl", D, J, 64, 1.0, scale, 1, 0, 0)
+    t = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(dev)
+    stride = (N + 63) // 64 * 64
+    yT = torch.full((J + 1, stride), 254, dtype=torch.uint8, device=dev)
+    yT[:J, :N] = t(y).t()
+    gxT = torch.empty(D * N, dtype=torch.float32, device=dev)
+    ll = torch.empty(N, dtype=torch.float32, device=dev)
+    gitem = torch.zeros(D * J + 3 * J, dtype=torch.float32, device=dev)
+    ws = torch.empty(be.lik_workspace(cfg, N), dtype=torch.float32, device=dev)
+    be.lik_grad(cfg, t(y), None, N, t(x), t(a), t(b), None, None, None, ll, gitem, ws, gxT=gxT, yT=yT.contiguous())
+    torch.cuda.synchronize()
+    x64 = x.astype(np.float64)
+    ll_o, g = vo.irt_loglik("irt_2pl", x64, a.astype(np.float64), b.astype(np.float64), None, None, 1.0, y)
+    for name, got, want in (("ll", ll.cpu().numpy(), ll_o - 0.5 * (x64 ** 2).sum(1)),
+                            ("gx", gxT.cpu().numpy().reshape(D, N).T, scale * (g["x"] - x64)),
+                            ("ga", gitem[:D * J].cpu().numpy().reshape(D, J), -scale * g["a"]),
+                            ("gb", gitem[D * J:D * J + J].cpu().numpy().reshape(1, J), -scale * g["b"])):
+        assert np.isfinite(got).all(), name
+        err = np.abs(got - want)
+        w = np.unravel_index(err.argmax(), err.shape)
+        assert err.max() / np.abs(want).max() < GRAD_TOL, (name, err.max() / np.abs(want).max(), w, got[w], want[w])
+
+
 @pytest.mark.parametrize("guide,N,J,D,model,B,baseline", [
     ("amortized", 264, 36, 8, "irt_2pl", None, "none"),              # encoder heads: dimension-major backward kernels
     ("amortized", 640, 40, 12, "irt_3pl", 128, "avg"),               # ... subsample, decaying-average baseline by row

@@ -24,7 +24,7 @@ static float run(int D, int J, int64_t nb, int model, int n_pr_req, bool check, 
     CK(hipMalloc(&c, J * 4)); CK(hipMalloc(&d, J * 4));
     const int64_t nbp = n_ptiles * LB_P;
     CK(hipMalloc(&gxp, (size_t)dm.groups * LB_DP * nbp * 4)); CK(hipMalloc(&llp, (size_t)dm.groups * nbp * 4));
-    CK(hipMalloc(&slabs, (size_t)dm.n_pr * dm.slab_len * 4)); CK(hipMalloc(&img, (size_t)n_ptiles * LH_XT_BYTES));
+    CK(hipMalloc(&slabs, (size_t)dm.n_pr * dm.slab_len * 4)); CK(hipMalloc(&img, (size_t)n_ptiles * LH_XT_BYTES + LH_FLAG_BYTES)); CK(hipMemset(img + (size_t)n_ptiles * LH_XT_BYTES, 0, LH_FLAG_BYTES));
     CK(hipMalloc(&gxT, (size_t)nb * D * 4)); CK(hipMalloc(&llo, nb * 4));
     std::vector<uint8_t> hy(nb * J);
     std::vector<float> hx(nb * D), ha(D * J), hb(J), hc(J), hd(J);
@@ -53,12 +53,12 @@ static float run(int D, int J, int64_t nb, int model, int n_pr_req, bool check, 
     float ms_img = 0, ms = 0;
     for (int r = 0; r < reps + 1; ++r) {
         if (r == 1) hipEventRecord(e0);
-        hipLaunchKernelGGL(k_lik_ximg_h, dim3((unsigned)n_ptiles), dim3(256), 0, 0, D, nb, x, img);
+        hipLaunchKernelGGL(k_lik_ximg_h, dim3((unsigned)n_ptiles), dim3(256), 0, 0, D, nb, x, img, (uint32_t*)(img + n_ptiles * LH_XT_BYTES));
     }
     hipEventRecord(e1);
     for (int r = 0; r < reps + 1; ++r) {
         if (r == 1) hipEventRecord(e1);
-        hipLaunchKernelGGL((k_irt_lik_h<ABL>), grid, dim3(LH_THREADS), LH_LDS_BYTES, 0, dm, y, ystride, img, a, b, gxp, llp, slabs);
+        hipLaunchKernelGGL((k_irt_lik_h<ABL>), grid, dim3(LH_THREADS), LH_LDS_BYTES, 0, dm, y, ystride, img, a, b, gxp, llp, slabs, (const uint32_t*)(img + n_ptiles * LH_XT_BYTES));
     }
     hipEventRecord(e2);
     CK(hipEventSynchronize(e2));

@@ -68,8 +68,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 #endif
 
 // x fp32 [nb][D] -> tile images (the three bf16 terms of x_aug); persons past nb: all-zero rows
-__global__ __launch_bounds__(256) void k_lik_ximg(int D, int64_t nb, const float* __restrict__ x, uint8_t* __restrict__ img) {
-    const int64_t tile = blockIdx.x;
+// only_if (or null): the launch is the stand-by of the fp16 kernel (k_irt_lik_h.hip) and returns unless that word is set
+__global__ __launch_bounds__(256) void k_lik_ximg(int D, int64_t nb, const float* __restrict__ x, uint8_t* __restrict__ img,
+                                                  const uint32_t* __restrict__ only_if = nullptr) {
+    if (only_if && *only_if == 0u) return;
+    const int64_t n_tiles = (nb + LB_P - 1) / LB_P;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {      // (a stand-by launch keeps its grid small)
     uint8_t* out = img + tile * LB_XT_BYTES;
     for (int e = threadIdx.x; e < LB_P * 2 * LB_NKS; e += blockDim.x) {
         const int p = e / (2 * LB_NKS), ch = e - p * (2 * LB_NKS);
@@ -86,6 +90,7 @@ __global__ __launch_bounds__(256) void k_lik_ximg(int D, int64_t nb, const float
         *(bf16x8*)(out + o) = fh;
         *(bf16x8*)(out + LB_PLANE + o) = fm;
         *(bf16x8*)(out + 2 * LB_PLANE + o) = fl;
+    }
     }
 }
 
@@ -151,8 +156,9 @@ __global__ __launch_bounds__(LB_THREADS, 1) void k_irt_lik_b(
     LikBDims dm, const uint8_t* __restrict__ yT, int64_t yT_stride, const uint8_t* __restrict__ ximg,
     const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c_un,
     const float* __restrict__ d_un, float* __restrict__ gx_part, float* __restrict__ ll_part, float* __restrict__ slabs,
-    long long* __restrict__ stamps = nullptr /*ABL & 32 only*/) {
+    long long* __restrict__ stamps = nullptr /*ABL & 32 only*/, const uint32_t* __restrict__ only_if = nullptr /*as k_lik_ximg*/) {
     extern __shared__ __attribute__((aligned(16))) char smem_lb[];
+    if (only_if && *only_if == 0u) return;                          // uniform: no barrier has been passed
     const int D = dm.D, J = dm.J;
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
     auto stamp = [&](int idx) {

@@ -6,8 +6,11 @@
 //
 // Powers of two (all exact, taken off the fp32 accumulators):
 //   x     2^LH_XEXP, fixed: the image is written by the guide-forward kernel before the largest |x| of the launch is known.
-//         |x| 2^7 saturates at the largest fp16 (|x| >= 511.75 reads as 511.75: far outside the link's clamp |z| <= 15.94 for any
-//         item that discriminates at all); small |x| keep an absolute error of 2^-32 (fp16 subnormals are honoured by the MFMA).
+//         Small |x| keep an absolute error of 2^-32 (fp16 subnormals are honoured by the MFMA).  |x| 2^7 beyond the largest
+//         fp16 (|x| >= 511.75) cannot be represented: the image writers saturate the value AND raise the overflow word behind
+//         the image (the forward's image: byte offset tiles * LH_XT_BYTES, LH_FLAG_BYTES of its own); k_irt_lik_h returns at once when it is set, and the bf16x3
+//         kernel (k_irt_lik_b, no range limit), launched behind it every time, runs instead of returning at once -- one
+//         weakly discriminating item would otherwise see a latent of 2 000 as 511.75 and leave the link's clamp.
 //   a, b  by the largest |a|, |b| of the workgroup's own 128-item chunk (its Z, gx partial and GA slab are its own results).
 //   R     = scale Dc dlogp/dz with |dlogp/dz| <= 1 for this link: by |scale Dc|.  (The 3PL / 4PL links keep k_irt_lik_b:
 //         with d < c their dlogp/dz is only bounded by 1 / eps.)
@@ -24,16 +27,23 @@ __device__ __forceinline__ f16x8 lh_frag(lb_u32x2 lo, lb_u32x2 hi) {
 }
 __device__ __forceinline__ f16x8 lh_read128(lb_lds* p) { return *(__attribute__((address_space(3))) const f16x8*)p; }
 
-// eight values of x_aug -> the two fp16 fragments of x 2^LH_XEXP, saturated
-__device__ __forceinline__ void lh_split_x(const float (&v)[8], f16x8& fh, f16x8& fl) {
-    float w[8];
+#define LH_FLAG_BYTES 64                           // the overflow word behind the tile images (its own 64 bytes)
+// eight values of x_aug -> the two fp16 fragments of x 2^LH_XEXP, saturated; true when a value was out of range
+__device__ __forceinline__ bool lh_split_x(const float (&v)[8], f16x8& fh, f16x8& fl) {
+    float w[8], m = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) w[j] = __builtin_amdgcn_fmed3f(v[j] * (float)(1 << LH_XEXP), -65504.0f, 65504.0f);
+    for (int j = 0; j < 8; ++j) {
+        const float t = v[j] * (float)(1 << LH_XEXP);
+        m = fmaxf(m, fabsf(t));
+        w[j] = __builtin_amdgcn_fmed3f(t, -65504.0f, 65504.0f);
+    }
     split2h_frag(w, 1.0f, fh, fl);
+    return !(m <= 65504.0f);                                         // (NaN counts as out of range)
 }
 
 // x fp32 [nb][D] -> tile images (the two fp16 terms of x_aug 2^LH_XEXP); persons past nb: all-zero rows
-__global__ __launch_bounds__(256) void k_lik_ximg_h(int D, int64_t nb, const float* __restrict__ x, uint8_t* __restrict__ img) {
+__global__ __launch_bounds__(256) void k_lik_ximg_h(int D, int64_t nb, const float* __restrict__ x, uint8_t* __restrict__ img,
+                                                    uint32_t* __restrict__ ovf /*the overflow word (cleared by the caller)*/) {
     const int64_t tile = blockIdx.x;
     uint8_t* out = img + tile * LH_XT_BYTES;
     for (int e = threadIdx.x; e < LB_P * 2 * LB_NKS; e += blockDim.x) {
@@ -46,7 +56,7 @@ __global__ __launch_bounds__(256) void k_lik_ximg_h(int D, int64_t nb, const flo
             v[j] = (i < nb) ? (k < D ? x[i * D + k] : (k == D ? 1.0f : 0.f)) : 0.f;
         }
         f16x8 fh, fl;
-        lh_split_x(v, fh, fl);
+        if (lh_split_x(v, fh, fl)) atomicOr(ovf, 1u);
         const uint32_t o = lb_xoff(p, ch);
         *(f16x8*)(out + o) = fh;
         *(f16x8*)(out + LB_PLANE + o) = fl;
@@ -98,9 +108,11 @@ template <int ABL = 0>
 __global__ __launch_bounds__(LH_THREADS, 1) void k_irt_lik_h(
     LikBDims dm, const uint8_t* __restrict__ yT, int64_t yT_stride, const uint8_t* __restrict__ ximg,
     const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ gx_part, float* __restrict__ ll_part,
-    float* __restrict__ slabs) {
+    float* __restrict__ slabs, const uint32_t* __restrict__ ovf /*the image's overflow word*/) {
     extern __shared__ __attribute__((aligned(16))) char smem_lh[];
     const int D = dm.D, J = dm.J;
+    // a latent out of the image's range: k_irt_lik_b, launched behind this kernel, does the work (uniform: no barrier is passed)
+    if (*ovf != 0u) return;
     lb_lds* const Xb = (lb_lds*)smem_lh;                            // [3 tiles][2 planes][64 persons] (lb_xoff)
     lb_lds* const Rb = Xb + 3 * LH_XT_BYTES;                         // [2 slots][2 terms][128 items][64 B]
     lb_lds* const Yb = Rb + 2 * LH_R_BYTES;                         // [4 slots][128 items][32 B]

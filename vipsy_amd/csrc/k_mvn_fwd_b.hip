@@ -597,7 +597,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
                 v[j] = (pp < pvi) ? (k < D ? x_lds[pp * DX + k] : (k == D ? 1.0f : 0.f)) : 0.f;
             }
             f16x8 fh, fl;
-            lh_split_x(v, fh, fl);
+            if (lh_split_x(v, fh, fl)) atomicOr((uint32_t*)(ximg_out + (dm.nb + 63) / 64 * (int64_t)LH_XT_BYTES), 1u);
             const uint32_t o = lb_xoff(pbase + pp, ch);
             *(f16x8*)(out + o) = fh;
             *(f16x8*)(out + LB_PLANE + o) = fl;

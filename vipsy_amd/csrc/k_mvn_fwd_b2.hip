@@ -533,7 +533,7 @@ __global__ __launch_bounds__(FB2_THREADS, (NS == 1 ? 2 : 1)) void k_mvn_enc_fwd_
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = q[w][j >> 2][j & 3];
                 f16x8 fh, fl;
-                lh_split_x(v, fh, fl);
+                if (lh_split_x(v, fh, fl)) atomicOr((uint32_t*)(ximg_out + (dm.nb + 63) / 64 * (int64_t)LH_XT_BYTES), 1u);
                 *(f16x8*)(out + off[w]) = fh;
                 *(f16x8*)(out + LB_PLANE + off[w]) = fl;
             }

@@ -492,12 +492,14 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
     if (hs_out && (!hT || cfg->H != 64)) return VX_EINVAL;
     bool ximg_done = false, hs_done = false;
     const float* hscale = nullptr;
+    uint32_t* ovf = ximg ? (uint32_t*)(ximg + (nb + LB_P - 1) / LB_P * (int64_t)LH_XT_BYTES) : nullptr;   // k_irt_lik_h.hip
+    if (ovf && hipMemsetAsync(ovf, 0, sizeof(uint32_t), (hipStream_t)hs) != hipSuccess) return VX_EINVAL;
     const int rc = mvn_enc_forward_kernels(cfg, y, rows, nb, gid0, W1, b1, W21, b21, W22, b22, eps_in, h, x, eps, ldT, ent, hT,
                                            epsT, packws, ximg, hs_out, hs, ximg_done, hs_done, hscale);
     if (rc) return rc;                                               // nothing is launched on buffers an error left unwritten
     if (ximg && !ximg_done) {
         hipLaunchKernelGGL(k_lik_ximg_h, dim3((unsigned)((nb + LB_P - 1) / LB_P)), dim3(256), 0, (hipStream_t)hs, (int)cfg->D, nb,
-                           (const float*)x, ximg);
+                           (const float*)x, ximg, ovf);
         VX_CHECK_LAUNCH();
     }
     if (hs_out && !hs_done && hscale) {
@@ -557,7 +559,7 @@ static int64_t lik_b_ws_floats(const vx_irt_cfg* cfg, int64_t nb) {
     const int64_t n_ptiles = (nb + LB_P - 1) / LB_P, nbp = n_ptiles * LB_P;
     const int64_t slab_len = (int64_t)cfg->D * cfg->J + 3 * (int64_t)cfg->J;
     return (((int64_t)n_pr * slab_len + 3) & ~(int64_t)3) + n_ptiles * (LB_XT_BYTES / 4) + (int64_t)groups * LB_DP * nbp +
-           (int64_t)groups * nbp;
+           (int64_t)groups * nbp + 16;                    // + the overflow word of an x image made here
 }
 
 static bool lik_cfg_ok(const vx_irt_cfg* cfg) {
@@ -567,7 +569,7 @@ static bool lik_cfg_ok(const vx_irt_cfg* cfg) {
 
 int64_t vx_irt_lik_ximg_bytes(const vx_irt_cfg* cfg, int64_t nb) {
     if (!lik_cfg_ok(cfg) || nb < 0) return VX_EINVAL;
-    return lik_h_shape(cfg) ? ((nb + LB_P - 1) / LB_P) * (int64_t)LH_XT_BYTES : 0;
+    return lik_h_shape(cfg) ? ((nb + LB_P - 1) / LB_P) * (int64_t)LH_XT_BYTES + LH_FLAG_BYTES : 0;   // tile images | overflow word
 }
 
 int64_t vx_irt_lik_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
@@ -607,12 +609,19 @@ static int irt_lik_grad_kernels(const vx_irt_cfg* cfg, const uint8_t* y, const i
         const bool f16 = lik_h_shape(cfg) && nbp < ((int64_t)1 << 27);
         const uint8_t* ximg = (f16 && ximg_in && aligned16(ximg_in)) ? ximg_in : ximg_ws;
         float* ll_part = gx_part + (int64_t)groups * LB_DP * nbp;
+        // the overflow word of the f16 image: behind the forward's image, or -- an image made here -- at the end of the workspace
+        uint32_t* ovf = (ximg == ximg_ws) ? (uint32_t*)(ll_part + (int64_t)groups * nbp)
+                                          : (uint32_t*)(const_cast<uint8_t*>(ximg_in) + n_ptiles * (int64_t)LH_XT_BYTES);
         hipStream_t st = (hipStream_t)hs;
         hipError_t he = hipMemsetAsync(slabs, 0, sizeof(float) * (size_t)n_pr * dm.slab_len, st);
         if (he != hipSuccess) return (int)he;
         if (ximg == ximg_ws) {
-            if (f16) hipLaunchKernelGGL(k_lik_ximg_h, dim3((unsigned)n_ptiles), dim3(256), 0, st, (int)cfg->D, nb, x, ximg_ws);
-            else hipLaunchKernelGGL(k_lik_ximg, dim3((unsigned)n_ptiles), dim3(256), 0, st, (int)cfg->D, nb, x, ximg_ws);
+            if (f16) {
+                if (hipMemsetAsync(ovf, 0, sizeof(uint32_t), st) != hipSuccess) return VX_EINVAL;
+                hipLaunchKernelGGL(k_lik_ximg_h, dim3((unsigned)n_ptiles), dim3(256), 0, st, (int)cfg->D, nb, x, ximg_ws, ovf);
+            } else {
+                hipLaunchKernelGGL(k_lik_ximg, dim3((unsigned)n_ptiles), dim3(256), 0, st, (int)cfg->D, nb, x, ximg_ws, (const uint32_t*)nullptr);
+            }
             VX_CHECK_LAUNCH();
         }
         int rc;
@@ -622,7 +631,17 @@ static int irt_lik_grad_kernels(const vx_irt_cfg* cfg, const uint8_t* y, const i
             if (rc) return rc;
             ProfScope ps("k_irt_lik_h", st);
             hipLaunchKernelGGL((k_irt_lik_h<0>), grid, dim3(LH_THREADS), LH_LDS_BYTES, st, dm, yT, yT_stride, ximg, a, b,
-                               gx_part, ll_part, slabs);
+                               gx_part, ll_part, slabs, (const uint32_t*)ovf);
+            VX_CHECK_LAUNCH();
+            // the stand-by for a latent outside the f16 image's range (|x| >= 511.75): the bf16x3 kernel on its own image, both
+            // returning at once unless the overflow word is set -- two empty launches a step otherwise.  Its image takes the
+            // workspace's image region (an f16 image made here is dead by then; the overflow word is not in that region).
+            rc = set_lds(k_irt_lik_b<0>, LB_LDS_BYTES);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_lik_ximg, dim3((unsigned)(n_ptiles < 4 * num_cu() ? n_ptiles : 4 * num_cu())), dim3(256), 0, st, (int)cfg->D,
+                               nb, x, ximg_ws, (const uint32_t*)ovf);
+            hipLaunchKernelGGL((k_irt_lik_b<0>), grid, dim3(LB_THREADS), LB_LDS_BYTES, st, dm, yT, yT_stride, (const uint8_t*)ximg_ws,
+                               a, b, c_un, d_un, gx_part, ll_part, slabs, (long long*)nullptr, (const uint32_t*)ovf);
         } else if (cfg->model >= VX_IRT_3PL) {
             rc = set_lds(k_irt_lik_b<1>, LB_LDS_BYTES);
             if (rc) return rc;
