@@ -831,6 +831,35 @@ def test_mvn_score_function_step_vs_oracle(guide, N, J, D, model, B, baseline):
             assert np.abs(gh.reshape(go.shape) - go).max() / sc < GRAD_TOL, (name, t, np.abs(gh.reshape(go.shape) - go).max() / sc)
 
 
+def test_mvn_score_function_loo_baseline_through_step():
+    """baseline='loo' for a multivariate guide (per-person Cholesky rows, D = 3) through IrtEngine.step: three particles share
+    the batch, each with the leave-one-out mean of the others' log_r as its control variate (lr = 0 keeps the parameters)."""
+    from vipsy_amd.engine import IrtEngine, LrSpec
+    N, J, D, S = 256, 30, 3, 3
+    rng = np.random.RandomState(21)
+    y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+    eng = IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_2pl", D=D, seed=9, estimator="score", baseline="loo")
+    eng.unconstrained("x_local").copy_(torch.from_numpy(0.5 * rng.randn(N, D)).float())
+    eng.unconstrained("x_scale").copy_(torch.from_numpy(0.3 * rng.randn(N, D, D)).float())
+    spec = {"family": "irt", "model": "irt_2pl", "D": D, "Dc": 1.0, "N": N, "amortized": False, "share_cov": False,
+            "a_free": vo.default_a_free(D, J), "estimator": "score"}
+    params = {n: eng.unconstrained(n).cpu().numpy().astype(np.float64) for n in eng.names() + ["x_local", "x_scale"]}
+    idx = np.arange(N)
+    eps = [vo.philox_normals(9, 0, s, idx, D) for s in range(S)]        # the particle index is the Philox stream
+    lrs = [vo.irt_particle(spec, params, y, idx, e, want_log_r=True)[2] for e in eps]
+    outs = [vo.irt_particle(spec, params, y, idx, e, baseline=(sum(lrs) - lrs[s]) / (S - 1)) for s, e in enumerate(eps)]
+    loss_h = float(eng.step(LrSpec(0.0), num_particles=S).item())
+    torch.cuda.synchronize()
+    assert loss_h == pytest.approx(np.mean([o[0] for o in outs]), rel=3e-5)
+    for name in ("a", "b", "x_local", "x_scale"):
+        go = np.mean([o[1][name] for o in outs], axis=0)
+        gh = eng.unconstrained(name, eng.GP if name in eng.pp_off else eng.G).cpu().numpy().reshape(go.shape)
+        if name == "a":
+            gh = gh * eng.unconstrained("a", eng.free).cpu().numpy()
+        sc = max(1e-6, float(np.abs(go).max()))
+        assert np.abs(gh - go).max() / sc < GRAD_TOL, (name, np.abs(gh - go).max() / sc)
+
+
 def test_irt_score_function_loo_baseline_through_step():
     """baseline='loo' through IrtEngine.step: three particles share the batch, each with the leave-one-out mean of the others'
     log_r as its control variate (lr = 0 keeps the parameters, so the averaged gradient can be checked)."""
