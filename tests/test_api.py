@@ -144,3 +144,29 @@ def test_vccdm_dina_recovers_guess_and_slip():
     assert l1 < l0
     assert float((vi.param("g").cpu() - RI.g).abs().mean()) < 0.03
     assert float((vi.param("s").cpu() - RI.s).abs().mean()) < 0.04
+
+
+@pytest.mark.gpu
+def test_score_function_estimator_through_the_class_surface():
+    """estimator='score' (north_star's REINFORCE mode; no reference counterpart) through the reference-style classes, for the
+    1-D guide, the amortized multivariate guide and the shared-covariance guide, with each baseline: the fits run, stay finite
+    and move the item parameters."""
+    from vipsy_amd import vi, synth
+    dev = torch.device("cuda:0")
+    a, b = synth.mirt_item_params(40, 4, seed=5)
+    y4 = synth.simulate_responses(2000, 0, {"a": a, "b": b}, "irt_2pl", dev, seed=6)
+    items = synth.irt_item_params(24, "irt_2pl", seed=7)
+    y1 = synth.simulate_responses(2000, 0, items, "irt_2pl", dev, seed=8)
+    for make, loss in ((lambda: vi.VaeIRT(data=y4, model="irt_2pl", x_feature=4, subsample_size=200, estimator="score", baseline="avg"),
+                        vi.Trace_ELBO(num_particles=1)),
+                       (lambda: vi.VIRT(data=y4, model="irt_2pl", x_feature=4, share_cov=True, estimator="score", baseline="loo"),
+                        vi.Trace_ELBO(num_particles=3)),
+                       (lambda: vi.VIRT(data=y1, model="irt_2pl", subsample_size=500, estimator="score", baseline="none"),
+                        vi.Trace_ELBO(num_particles=1))):
+        vi.clear_param_store()
+        m = make()
+        b0 = vi.param("b").clone()
+        l = m.fit(optim=vi.Adam({"lr": 1e-2}), loss=loss, max_iter=30, progress=False)
+        assert np.isfinite(float(l))
+        bb = vi.param("b")
+        assert torch.isfinite(bb).all() and float((bb - b0).abs().max()) > 1e-3
