@@ -36,7 +36,7 @@ extern "C" {
 #define VX_OK 0
 #define VX_EINVAL (-1)       /* bad argument / unsupported shape */
 #define VX_EUNIMPL (-2)
-#define VX_ABI_VERSION 2
+#define VX_ABI_VERSION 3
 
 enum vx_model { VX_IRT_1PL = 1, VX_IRT_2PL = 2, VX_IRT_3PL = 3, VX_IRT_4PL = 4 }; /* vi.py:538-543 */
 
@@ -368,17 +368,22 @@ int vx_sum2(const float* v1, const float* v2, int64_t n, float alpha, float* out
  * learning rate (pyro.optim.Adam with callable optim_args; vi.py:514, test.py:345-350), optional
  * 0/1 `free` mask multiplied into the gradient first (vi.py:511-512).
  * t: the 1-based step count of the bias corrections; t_dev (or NULL): the same count in DEVICE memory, read by the
- * kernel instead of t (captured steps, see vx_irt1d_grad). */
+ * kernel instead of t (captured steps, see vx_irt1d_grad).
+ * loss_src / loss_ring (or NULL): the launch also copies *loss_src (the step's loss slot, all-reduced by then) into
+ * loss_ring[t % VX_LOSS_RING] -- the value `svi.step` returns (vi.py:516) then stays readable for VX_LOSS_RING - 1 further
+ * steps without a copy launch of its own, in eager and in replayed steps alike. */
+#define VX_LOSS_RING 64
 typedef struct vx_adam_seg { int64_t begin, end; float lr; float _pad; } vx_adam_seg;
 int vx_adam_step(float* p, const float* g, float* m, float* v, const float* free_mask /*or NULL*/,
                  int64_t n, const vx_adam_seg* segs /*host*/, int32_t n_segs, int32_t t, const uint32_t* t_dev,
-                 float beta1, float beta2, float eps, void* hip_stream);
+                 float beta1, float beta2, float eps, const float* loss_src, float* loss_ring /*[VX_LOSS_RING]*/,
+                 void* hip_stream);
 /* the same for TWO buffers in one launch: A with its free mask (the replicated leaves), B without (the per-person rows
  * of a BBVI guide); same t, betas and eps for both */
 int vx_adam_step2(float* pA, const float* gA, float* mA, float* vA, const float* freeA /*or NULL*/, int64_t nA,
                   const vx_adam_seg* segsA, int32_t n_segsA, float* pB, const float* gB, float* mB, float* vB, int64_t nB,
                   const vx_adam_seg* segsB, int32_t n_segsB, int32_t t, const uint32_t* t_dev, float beta1, float beta2,
-                  float eps, void* hip_stream);
+                  float eps, const float* loss_src, float* loss_ring /*[VX_LOSS_RING]*/, void* hip_stream);
 
 
 #ifdef __cplusplus

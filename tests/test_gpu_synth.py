@@ -34,6 +34,22 @@ def test_random_irt_classes_match_the_restated_draw_rule(cls_name, kw):
             assert float(ri.a[i, 37 - i:].abs().sum()) == 0            # identification zeros (vi.py:257-258, 378-379)
 
 
+def test_random_irt_1pl_with_a_latent_location_and_scale():
+    """vi.py:202-233 with x_local / x_scale: the 1PL link has no slope to carry the scale, so the class draws through the 2PL
+    link with a = x_scale; x = x_local + x_scale z, responses ~ Bernoulli(sigmoid(x + b))."""
+    from vipsy_amd import random_data as rd
+    torch.manual_seed(9)
+    ri = rd.RandomIrt1PL(sample_size=400, item_size=21, device=_dev(), seed=78, x_local=0.3, x_scale=1.7)
+    y = ri.y.cpu().numpy()
+    gids = np.arange(400)
+    b = ri.b.numpy().astype(np.float64)
+    a_eff = 1.7 * np.ones((1, 21))
+    yo, zo, P, u = vo.synth_irt("irt_2pl", 78, gids, a_eff, b + 0.3, None, None)
+    np.testing.assert_allclose(ri.x.cpu().numpy(), 0.3 + 1.7 * zo, atol=5e-5)
+    clear = np.abs(u - P) > 1e-5
+    assert clear.mean() > 0.999 and np.array_equal(y[clear], yo[clear])
+
+
 def test_random_cdm_classes_and_sharding_independence():
     from vipsy_amd import random_data as rd
     torch.manual_seed(6)

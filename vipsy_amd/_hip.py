@@ -103,9 +103,9 @@ SIGNATURES = {
     "vx_sum_workspace_floats": (_I64, []),
     "vx_sum": (ctypes.c_int, [_P, _I64, _F, _P, _P, _P]),
     "vx_sum2": (ctypes.c_int, [_P, _P, _I64, _F, _P, _P, _P]),
-    "vx_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, ctypes.POINTER(AdamSeg), _I32, _I32, _P, _F, _F, _F, _P]),
+    "vx_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, ctypes.POINTER(AdamSeg), _I32, _I32, _P, _F, _F, _F, _P, _P, _P]),
     "vx_adam_step2": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, ctypes.POINTER(AdamSeg), _I32, _P, _P, _P, _P, _I64,
-                                     ctypes.POINTER(AdamSeg), _I32, _I32, _P, _F, _F, _F, _P]),
+                                     ctypes.POINTER(AdamSeg), _I32, _I32, _P, _F, _F, _F, _P, _P, _P]),
 }
 
 _lib = None

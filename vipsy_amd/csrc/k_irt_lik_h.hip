@@ -30,15 +30,16 @@ __device__ __forceinline__ f16x8 lh_read128(lb_lds* p) { return *(__attribute__(
 #define LH_FLAG_BYTES 64                           // the overflow word behind the tile images (its own 64 bytes)
 // eight values of x_aug -> the two fp16 fragments of x 2^LH_XEXP, saturated; true when a value was out of range
 __device__ __forceinline__ bool lh_split_x(const float (&v)[8], f16x8& fh, f16x8& fl) {
-    float w[8], m = 0.f;
+    float w[8];
+    bool bad = false;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float t = v[j] * (float)(1 << LH_XEXP);
-        m = fmaxf(m, fabsf(t));
+        bad |= !(fabsf(t) <= 65504.0f);                              // per element: a NaN is out of range too (fmaxf would drop it)
         w[j] = __builtin_amdgcn_fmed3f(t, -65504.0f, 65504.0f);
     }
     split2h_frag(w, 1.0f, fh, fl);
-    return !(m <= 65504.0f);                                         // (NaN counts as out of range)
+    return bad;
 }
 
 // x fp32 [nb][D] -> tile images (the two fp16 terms of x_aug 2^LH_XEXP); persons past nb: all-zero rows

@@ -132,7 +132,11 @@ struct AdamSegs { int64_t begin[VX_MAX_SEGS]; int64_t end[VX_MAX_SEGS]; float lr
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                        float* __restrict__ v, const float* __restrict__ free_mask, int64_t n, AdamSegs segs,
                        float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
-                       const uint32_t* __restrict__ t_dev) {
+                       const uint32_t* __restrict__ t_dev, uint32_t t_host = 0, const float* __restrict__ loss_src = nullptr,
+                       float* __restrict__ loss_ring = nullptr) {
+    // the step's loss (all-reduced by now) into slot t of the ring: what step() returns stays valid for VX_LOSS_RING - 1
+    // further steps, eager or replayed, without a launch of its own
+    if (loss_ring && blockIdx.x == 0 && threadIdx.x == 0) loss_ring[(t_dev ? *t_dev : t_host) & (VX_LOSS_RING - 1)] = *loss_src;
     if (t_dev) {
         // replayed from a HIP graph: the step count lives in device memory; the bias corrections are made here, in
         // double like the host makes them, once per block
@@ -165,7 +169,9 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
 // [0, nA) -> buffer A (with its free mask), [nA, nA + nB) -> buffer B
 struct AdamBuf { float* p; const float* g; float* m; float* v; const float* free_mask; int64_t n; };
 __global__ void k_adam2(AdamBuf A, AdamSegs sA, AdamBuf B, AdamSegs sB, float beta1, float beta2, float eps, float bc1,
-                        float bc2_sqrt, const uint32_t* __restrict__ t_dev) {
+                        float bc2_sqrt, const uint32_t* __restrict__ t_dev, uint32_t t_host = 0,
+                        const float* __restrict__ loss_src = nullptr, float* __restrict__ loss_ring = nullptr) {
+    if (loss_ring && blockIdx.x == 0 && threadIdx.x == 0) loss_ring[(t_dev ? *t_dev : t_host) & (VX_LOSS_RING - 1)] = *loss_src;
     if (t_dev) {
         __shared__ float bc[2];
         if (threadIdx.x == 0) {

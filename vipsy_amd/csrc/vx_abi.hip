@@ -155,20 +155,48 @@ struct ProfScope {
 
 // A second stream for work that is independent of what the launch stream does next (the fc1 weight gradient beside the head
 // weight gradient of vx_mvn_enc_backward): forked and joined with events, so the caller still sees ONE ordered stream.
+// One per host thread AND device: a process that drives a second GPU gets a stream of that device, not device 0's.
 struct SideStream {
     hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
-    bool ok = false;
-    SideStream() {
-        ok = hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess;
-    }
+    bool init = false, ok = false;
 };
 SideStream& side_stream() {
-    static thread_local SideStream ss;                     // (one per host thread: events are re-recorded per call)
+    constexpr int MAXDEV = 16;
+    static thread_local SideStream per_dev[MAXDEV];        // (events are re-recorded per call)
+    static thread_local SideStream none;                   // ok == false: the single-stream paths
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return none;
+    SideStream& ss = per_dev[dev];
+    if (!ss.init) {
+        ss.init = true;
+        ss.ok = hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
+                hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess;
+    }
     return ss;
 }
+// fork() orders the side stream behind the launch stream; join() orders the launch stream behind the side stream.  A scope
+// that ends between the two (an error return) still joins: the caller's stream never runs ahead of side work in flight.
+struct ForkScope {
+    SideStream* ss = nullptr;
+    hipStream_t main_st = nullptr;
+    bool fork(SideStream& s, hipStream_t st) {
+        if (!s.ok || hipEventRecord(s.fork, st) != hipSuccess || hipStreamWaitEvent(s.s, s.fork, 0) != hipSuccess) return false;
+        ss = &s; main_st = st;
+        return true;
+    }
+    bool active() const { return ss != nullptr; }
+    hipStream_t side() const { return ss->s; }
+    int join() {
+        if (!ss) return VX_OK;
+        SideStream* s = ss;
+        ss = nullptr;
+        if (hipEventRecord(s->join, s->s) != hipSuccess || hipStreamWaitEvent(main_st, s->join, 0) != hipSuccess) return VX_EINVAL;
+        return VX_OK;
+    }
+    ~ForkScope() { (void)join(); }
+};
 
 }  // namespace
 
@@ -286,8 +314,9 @@ int vx_sum2(const float* v1, const float* v2, int64_t n, float alpha, float* out
 
 int vx_adam_step(float* p, const float* g, float* m, float* v, const float* free_mask, int64_t n,
                  const vx_adam_seg* segs, int32_t n_segs, int32_t t, const uint32_t* t_dev, float beta1, float beta2,
-                 float eps, void* hs) {
-    if (!p || !g || !m || !v || !segs || n_segs < 1 || n_segs > VX_MAX_SEGS || (t < 1 && !t_dev)) return VX_EINVAL;
+                 float eps, const float* loss_src, float* loss_ring, void* hs) {
+    if (!p || !g || !m || !v || !segs || n_segs < 1 || n_segs > VX_MAX_SEGS || (t < 1 && !t_dev) || (loss_ring && !loss_src))
+        return VX_EINVAL;
     AdamSegs s;
     s.n = n_segs;
     for (int i = 0; i < n_segs; ++i) {
@@ -297,16 +326,17 @@ int vx_adam_step(float* p, const float* g, float* m, float* v, const float* free
     const double bc1 = 1.0 - pow((double)beta1, (double)(t_dev ? 1 : t));
     const double bc2 = 1.0 - pow((double)beta2, (double)(t_dev ? 1 : t));
     hipLaunchKernelGGL(k_adam, dim3(grid_1d(n, 256)), dim3(256), 0, (hipStream_t)hs, p, g, m, v, free_mask, n, s,
-                       beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), t_dev);
+                       beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), t_dev, (uint32_t)t, loss_src, loss_ring);
     VX_CHECK_LAUNCH();
     return VX_OK;
 }
 
 int vx_adam_step2(float* pA, const float* gA, float* mA, float* vA, const float* freeA, int64_t nA, const vx_adam_seg* segsA,
                   int32_t n_segsA, float* pB, const float* gB, float* mB, float* vB, int64_t nB, const vx_adam_seg* segsB,
-                  int32_t n_segsB, int32_t t, const uint32_t* t_dev, float beta1, float beta2, float eps, void* hs) {
+                  int32_t n_segsB, int32_t t, const uint32_t* t_dev, float beta1, float beta2, float eps, const float* loss_src,
+                  float* loss_ring, void* hs) {
     if (!pA || !gA || !mA || !vA || !segsA || !pB || !gB || !mB || !vB || !segsB || n_segsA < 1 || n_segsA > VX_MAX_SEGS ||
-        n_segsB < 1 || n_segsB > VX_MAX_SEGS || nA < 0 || nB < 0 || (t < 1 && !t_dev))
+        n_segsB < 1 || n_segsB > VX_MAX_SEGS || nA < 0 || nB < 0 || (t < 1 && !t_dev) || (loss_ring && !loss_src))
         return VX_EINVAL;
     AdamSegs sa, sb;
     sa.n = n_segsA; sb.n = n_segsB;
@@ -322,7 +352,7 @@ int vx_adam_step2(float* pA, const float* gA, float* mA, float* vA, const float*
     const double bc1 = 1.0 - pow((double)beta1, (double)(t_dev ? 1 : t));
     const double bc2 = 1.0 - pow((double)beta2, (double)(t_dev ? 1 : t));
     hipLaunchKernelGGL(k_adam2, dim3(grid_1d(nA + nB, 256)), dim3(256), 0, (hipStream_t)hs, A, sa, B, sb, beta1, beta2, eps,
-                       (float)bc1, (float)sqrt(bc2), t_dev);
+                       (float)bc1, (float)sqrt(bc2), t_dev, (uint32_t)t, loss_src, loss_ring);
     VX_CHECK_LAUNCH();
     return VX_OK;
 }
@@ -404,7 +434,7 @@ static int mvn_enc_forward_kernels(const vx_irt_cfg* cfg, const uint8_t* y, cons
             // the short last round runs on a second stream BESIDE the whole rounds (launched first: its workgroups take their
             // CUs at once, the whole rounds fill the rest), not after them: its 133 workgroups then cost their share of the
             // chip's time instead of a round of their own
-            bool tail_beside = false;
+            ForkScope tail_fork;
             auto launch_tail = [&](hipStream_t ts) -> int {
                 int r = set_lds(k_mvn_enc_fwd_b<false>, ldsb);
                 if (r) return r;
@@ -417,14 +447,9 @@ static int mvn_enc_forward_kernels(const vx_irt_cfg* cfg, const uint8_t* y, cons
                 VX_CHECK_LAUNCH();
                 return VX_OK;
             };
-            if (n_done > 0 && n_done < nb && (mfma16_mode() & 8) && side_stream().ok) {
-                SideStream& ss = side_stream();
-                if (hipEventRecord(ss.fork, (hipStream_t)hs) != hipSuccess || hipStreamWaitEvent(ss.s, ss.fork, 0) != hipSuccess)
-                    return VX_EINVAL;
-                rc = launch_tail(ss.s);
-                if (rc) return rc;
-                if (hipEventRecord(ss.join, ss.s) != hipSuccess) return VX_EINVAL;
-                tail_beside = true;
+            if (n_done > 0 && n_done < nb && (mfma16_mode() & 8) && tail_fork.fork(side_stream(), (hipStream_t)hs)) {
+                rc = launch_tail(tail_fork.side());
+                if (rc) return rc;                                  // (the scope joins)
             }
             if (n_done > 0) {
                 const size_t lds2 = fb2_lds_bytes(dm.D, dm.J, FNS);
@@ -439,10 +464,7 @@ static int mvn_enc_forward_kernels(const vx_irt_cfg* cfg, const uint8_t* y, cons
                 VX_CHECK_LAUNCH();
                 if (n_done == nb) return VX_OK;
             }
-            if (tail_beside) {
-                if (hipStreamWaitEvent((hipStream_t)hs, side_stream().join, 0) != hipSuccess) return VX_EINVAL;
-                return VX_OK;
-            }
+            if (tail_fork.active()) return tail_fork.join();
             return launch_tail((hipStream_t)hs);
         }
         const size_t ldsp = enc_p_lds_floats(dm.D, dm.J) * sizeof(float);
@@ -490,6 +512,10 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
     if (nb == 0) return VX_OK;
     if (ximg && !(lik_h_shape(cfg) && aligned16(ximg))) return VX_EINVAL;     // vx_irt_lik_ximg_bytes(cfg, nb) == 0: no image
     if (hs_out && (!hT || cfg->H != 64)) return VX_EINVAL;
+    // hs and the powers of two behind it exist on the packed path only (checked BEFORE anything is launched)
+    if (hs_out && !(packed_ok(cfg) && packws && aligned16(packws) && aligned16(y) && aligned16(W1) && aligned16(b1) &&
+                    aligned16(W21) && aligned16(W22) && aligned16(h)))
+        return VX_EINVAL;
     bool ximg_done = false, hs_done = false;
     const float* hscale = nullptr;
     uint32_t* ovf = ximg ? (uint32_t*)(ximg + (nb + LB_P - 1) / LB_P * (int64_t)LH_XT_BYTES) : nullptr;   // k_irt_lik_h.hip
@@ -502,7 +528,10 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
                            (const float*)x, ximg, ovf);
         VX_CHECK_LAUNCH();
     }
-    if (hs_out && !hs_done && hscale) {
+    if (hs_out && !hs_done) {
+        // the caller will hand hs to vx_mvn_enc_backward (gd_ready bit 1), which reads it and the powers of two in packws
+        // unconditionally: a path that wrote neither (no packed layout: unaligned weights, H != 64 ...) must not return VX_OK
+        if (!hscale) return VX_EINVAL;
         hipLaunchKernelGGL(k_split2_f16, dim3(num_cu() * 8), dim3(256), 0, (hipStream_t)hs, (const float*)hT, nb * 64, hscale, hs_out);
         VX_CHECK_LAUNCH();
     }
@@ -945,6 +974,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     bool f1t = false;                                      // fc1 gradient on the dimension-major kernel (ghpre holds ghpreT)
     bool maxw_ready = false;                               // k_mvn_enc_bwd_h_b ran: the operand maxima of the step are collected
     bool f1_done = false;                                  // the fc1 gradient (and its slab sum) went out on the side stream
+    ForkScope f1_fork;                                     // ... joined below, or by the scope on an error return
     if (packed) {
         const float* Wp = packws;
         const uint32_t* gtab = (const uint32_t*)(packws + Rp * 64 + Rp);
@@ -987,13 +1017,9 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                     const int64_t rem = nb % round2;
                     const int64_t n_done = (rem > 0 && 2 * rem <= round2 && nb > round2) ? nb - rem : nb;
                     // the short last round on the second stream beside the whole rounds (launched first), as in the forward
-                    const bool beside = n_done < nb && (mfma16_mode() & 8) && side_stream().ok;
-                    hipStream_t ts = st;
-                    if (beside) {
-                        SideStream& ss = side_stream();
-                        if (hipEventRecord(ss.fork, st) != hipSuccess || hipStreamWaitEvent(ss.s, ss.fork, 0) != hipSuccess) return VX_EINVAL;
-                        ts = ss.s;
-                    }
+                    ForkScope tail_fork;
+                    const bool beside = n_done < nb && (mfma16_mode() & 8) && tail_fork.fork(side_stream(), st);
+                    const hipStream_t ts = beside ? tail_fork.side() : st;
                     auto launch_tail = [&]() -> int {
                         int r = set_lds(k_mvn_enc_bwd_h_b<false>, ldsh);
                         if (r) return r;
@@ -1005,15 +1031,15 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                     };
                     if (beside) {
                         rc = launch_tail();
-                        if (rc) return rc;
-                        if (hipEventRecord(side_stream().join, ts) != hipSuccess) return VX_EINVAL;
+                        if (rc) return rc;                                  // (the scope joins)
                     }
                     hipLaunchKernelGGL((k_mvn_enc_bwd_h_b2<7, HNSET>), dim3((unsigned)((n_done + 255) / 256)),
                                        dim3(64 * HB2_WAVES_OF(HNSET)), lds2, st, dm, (const uint8_t*)himg, sc, h, eps, gxT, (const float*)gdT1,
                                        f1t ? (float*)nullptr : ghpre, hT, f1t ? ghpre : (float*)nullptr, maxw);
                     if (beside) {
                         VX_CHECK_LAUNCH();
-                        if (hipStreamWaitEvent(st, side_stream().join, 0) != hipSuccess) return VX_EINVAL;
+                        rc = tail_fork.join();
+                        if (rc) return rc;
                     } else if (n_done < nb) {
                         VX_CHECK_LAUNCH();
                         rc = launch_tail();
@@ -1043,24 +1069,22 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                                dm, cfg->scale, Wp, gtab, h, eps, ldT, gx, ghpre);
             VX_CHECK_LAUNCH();
         }
-        if (nb > 0 && f1t && (mfma16_mode() & 8) && side_stream().ok) {
+        if (nb > 0 && f1t && (mfma16_mode() & 8) && f1_fork.fork(side_stream(), st)) {
             // the fc1 weight gradient needs ghpre only: it runs on a second stream beside the head weight gradient below
-            // (0.33 ms of a 1M step that used to follow it) and is joined before this call returns
-            SideStream& ss = side_stream();
-            if (hipEventRecord(ss.fork, st) != hipSuccess || hipStreamWaitEvent(ss.s, ss.fork, 0) != hipSuccess) return VX_EINVAL;
+            // (0.33 ms of a 1M step that used to follow it) and is joined before this call returns (also on an error return)
+            const hipStream_t fs = f1_fork.side();
             {
-                ProfScope ps("k_fc1_bwd_b", ss.s);
+                ProfScope ps("k_fc1_bwd_b", fs);
                 if (maxw_ready)
                     hipLaunchKernelGGL(k_fc1_bwd_b<true>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0,
-                                       ss.s, dm, yT, yT_stride, ghpre, slabs_f, lenf, (const uint32_t*)maxw);
+                                       fs, dm, yT, yT_stride, ghpre, slabs_f, lenf, (const uint32_t*)maxw);
                 else
                     hipLaunchKernelGGL(k_fc1_bwd_b<false>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0,
-                                       ss.s, dm, yT, yT_stride, ghpre, slabs_f, lenf, (const uint32_t*)nullptr);
+                                       fs, dm, yT, yT_stride, ghpre, slabs_f, lenf, (const uint32_t*)nullptr);
                 VX_CHECK_LAUNCH();
             }
-            rc = vx_reduce_slabs(slabs_f, n_prf, lenf, -1.0f, genc, (void*)ss.s);
+            rc = vx_reduce_slabs(slabs_f, n_prf, lenf, -1.0f, genc, (void*)fs);
             if (rc) return rc;
-            if (hipEventRecord(ss.join, ss.s) != hipSuccess) return VX_EINVAL;
             f1_done = true;
         }
         if (use_t && bwb_shape(cfg, nb)) {
@@ -1184,7 +1208,8 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     }
     // flat encoder-gradient layout = nn.Linear order: [W1 | b1 | W21 | b21 | W22 | b22]; loss grads = -dELBO
     if (f1_done) {
-        if (hipStreamWaitEvent(st, side_stream().join, 0) != hipSuccess) return VX_EINVAL;   // the fc1 gradient is in genc
+        rc = f1_fork.join();                               // the fc1 gradient is in genc
+        if (rc) return rc;
     } else {
         rc = vx_reduce_slabs(slabs_f, n_prf, lenf, -1.0f, genc, hs);
         if (rc) return rc;
@@ -1439,6 +1464,7 @@ int vx_norm_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
         const size_t ldsb = nb_lds_bytes(cfg->J);                       // fc1 on the bf16 MFMA, W1 shared by the workgroup
         rc = set_lds(k_norm_enc_fwd_b, ldsb);
         if (rc) return rc;
+        ProfScope ps("k_norm_enc_fwd_b", (hipStream_t)hs);
         hipLaunchKernelGGL(k_norm_enc_fwd_b, dim3((unsigned)((nb + NB_WAVES * EP_WP - 1) / (NB_WAVES * EP_WP))),
                            dim3(NB_THREADS), ldsb, (hipStream_t)hs, dm, y, rows, W1, b1, W21, b21, W22, b22, h, loc, raw);
         VX_CHECK_LAUNCH();
@@ -1504,6 +1530,7 @@ int vx_norm_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t*
             hipLaunchKernelGGL(k_norm_enc_bwd_t64, dim3(nblk), dim3(256), 0, st, nb, W21, W22, h, gloc, graw, ghpreT, slabs_h);
             VX_CHECK_LAUNCH();
             if (mfma16_mode() & 8) {
+                ProfScope ps("k_fc1_bwd_b", st);
                 hipLaunchKernelGGL(k_fc1_bwd_b<false>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0,
                                    st, dm, yT, yT_stride, ghpreT, slabs_f, lenf, (const uint32_t*)nullptr);
             } else {

@@ -16,6 +16,7 @@ import torch
 from . import _hip
 
 MODEL_CODE = {"irt_1pl": 1, "irt_2pl": 2, "irt_3pl": 3, "irt_4pl": 4}       # vi.py:538-543
+LOSS_RING = 64                                                               # VX_LOSS_RING (include/vipsy_amd.h)
 ENC_KEYS = ("fc1.weight", "fc1.bias", "fc21.weight", "fc21.bias", "fc22.weight", "fc22.bias")
 
 
@@ -291,22 +292,25 @@ class HipBackend(object):
         rc = self.L.vx_sum(_hip.ptr(v), n, alpha, _hip.ptr(out), _hip.ptr(ws), _hip.stream_ptr())
         _hip.check(rc, "vx_sum")
 
-    def adam2(self, bufA, free, nA, segsA, bufB, nB, segsB, t, betas=(0.9, 0.999), eps=1e-8, t_dev=None):
+    def adam2(self, bufA, free, nA, segsA, bufB, nB, segsB, t, betas=(0.9, 0.999), eps=1e-8, t_dev=None, loss=None):
         arrA = (_hip.AdamSeg * len(segsA))(*[_hip.AdamSeg(b, e, lr, 0.0) for (b, e, lr) in segsA])
         arrB = (_hip.AdamSeg * len(segsB))(*[_hip.AdamSeg(b, e, lr, 0.0) for (b, e, lr) in segsB])
+        src, ring = loss if loss is not None else (None, None)
         rc = self.L.vx_adam_step2(*[_hip.ptr(x) for x in bufA], _hip.ptr(free), nA, arrA, len(segsA),
                                   *[_hip.ptr(x) for x in bufB], nB, arrB, len(segsB), t, _hip.ptr(t_dev), betas[0], betas[1],
-                                  eps, _hip.stream_ptr())
+                                  eps, _hip.ptr(src), _hip.ptr(ring), _hip.stream_ptr())
         _hip.check(rc, "vx_adam_step2")
 
     def sum2_into(self, v1, v2, n, alpha, out, ws):
         rc = self.L.vx_sum2(_hip.ptr(v1), _hip.ptr(v2), n, alpha, _hip.ptr(out), _hip.ptr(ws), _hip.stream_ptr())
         _hip.check(rc, "vx_sum2")
 
-    def adam(self, p, g, m, v, free, n, segs, t, betas=(0.9, 0.999), eps=1e-8, t_dev=None):
+    def adam(self, p, g, m, v, free, n, segs, t, betas=(0.9, 0.999), eps=1e-8, t_dev=None, loss=None):
         arr = (_hip.AdamSeg * len(segs))(*[_hip.AdamSeg(b, e, lr, 0.0) for (b, e, lr) in segs])
+        src, ring = loss if loss is not None else (None, None)
         rc = self.L.vx_adam_step(_hip.ptr(p), _hip.ptr(g), _hip.ptr(m), _hip.ptr(v), _hip.ptr(free), n, arr,
-                                 len(segs), t, _hip.ptr(t_dev), betas[0], betas[1], eps, _hip.stream_ptr())
+                                 len(segs), t, _hip.ptr(t_dev), betas[0], betas[1], eps, _hip.ptr(src), _hip.ptr(ring),
+                                 _hip.stream_ptr())
         _hip.check(rc, "vx_adam_step")
 
     def philox_normals(self, out, gids, gid0, n, D, seed, step, stream):
@@ -393,6 +397,8 @@ class _EngineBase(object):
             self.MP = torch.zeros(self.pp_len, **f32)
             self.VP = torch.zeros(self.pp_len, **f32)
         self._ws = {}
+        # the losses of the last LOSS_RING steps: what step() returns is slot t % LOSS_RING, written by the optimiser launch
+        self.loss_ring = torch.zeros(LOSS_RING, **f32)
         self.sum_ws = torch.empty(1024, **f32)
         self.last = {}
         self.events = None               # bench.py: list collecting (phase, start_event, end_event)
@@ -510,6 +516,9 @@ class _EngineBase(object):
                 (o, o + int(np.prod(self.shape[name])), float(lrs.lr_of(name))))
         sd = getattr(self, "_step_dev", None)
         kw = {"t_dev": sd} if sd is not None else {}         # captured step: Adam's t = the (already advanced) device counter
+        hip = isinstance(self.be, HipBackend)
+        if hip:                                              # the first optimiser launch also files the step's loss in the ring
+            kw["loss"] = (self.G[self.n_params:self.n_params + 1], self.loss_ring)
         pp_hyper = {}
         if self.per_person:
             for nme, o in self.pp_off.items():
@@ -520,11 +529,20 @@ class _EngineBase(object):
             self.be.adam2((self.P, self.G, self.M, self.V), self.free, self.n_params, _merge_segments(segs),
                           (self.PP, self.GP, self.MP, self.VP), self.pp_len, _merge_segments(pp_hyper[(betas, eps)]),
                           self.t, betas, eps, **kw)
-            return
-        for (betas, eps), segs in by_hyper.items():         # one launch per distinct (betas, eps): normally one
-            self.be.adam(self.P, self.G, self.M, self.V, self.free, self.n_params, _merge_segments(segs), self.t, betas, eps, **kw)
-        for (betas, eps), segs in pp_hyper.items():
-            self.be.adam(self.PP, self.GP, self.MP, self.VP, None, self.pp_len, _merge_segments(segs), self.t, betas, eps, **kw)
+        else:
+            for (betas, eps), segs in by_hyper.items():     # one launch per distinct (betas, eps): normally one
+                self.be.adam(self.P, self.G, self.M, self.V, self.free, self.n_params, _merge_segments(segs), self.t, betas, eps, **kw)
+                kw.pop("loss", None)
+            for (betas, eps), segs in pp_hyper.items():
+                self.be.adam(self.PP, self.GP, self.MP, self.VP, None, self.pp_len, _merge_segments(segs), self.t, betas, eps, **kw)
+                kw.pop("loss", None)
+        if not hip:                                          # (the CPU rehearsal backends of tests/)
+            self.loss_ring[self.t % LOSS_RING] = self.G[self.n_params]
+
+    def step_loss(self):
+        """The loss of the step just taken as a 0-d device tensor (no host sync): its slot of the ring, not overwritten for
+        the next LOSS_RING - 1 steps -- a list of returned losses holds distinct values."""
+        return self.loss_ring[self.t % LOSS_RING]
 
     # -- the whole step as one HIP graph ---------------------------------------------------------
     # A D = 1 full-batch step is a handful of 10-100 us kernels: launched one by one the host (Python + ctypes, ~10 us a
@@ -585,13 +603,13 @@ class _EngineBase(object):
         st["graph"].replay()
         self.t += 1
         st["ctr_t"] = self.t
-        return self.G[self.n_params]                         # the optimiser does not touch the loss slot (see step())
+        return self.step_loss()
 
     def step(self, lrs, rows=None, b_global=None, eps=None, num_particles=1):
         """loss_and_grads + optimiser, the body of SVI.step (vi.py:505-516).  `rows` (and `eps`) may be
         lists with one entry per particle: every particle draws its own subsample.
-        Returns the loss as a 0-d device tensor (no host sync, no copy: a view of the step's loss slot, valid until the next
-        loss_and_grads / step of this engine -- `.clone()` it to keep it)."""
+        Returns the loss as a 0-d device tensor (no host sync, no launch of its own: the optimiser launch files it in a ring of
+        LOSS_RING slots, see step_loss())."""
         S = int(num_particles)
         if (S == 1 and rows is None and eps is None and (b_global is None or int(b_global) == self.N)
                 and self._graphable()):
@@ -618,7 +636,7 @@ class _EngineBase(object):
             self.allreduce()
         with self._phase("optimizer"):
             self.apply_optim(lrs)
-        return self.G[self.n_params]                         # (the optimiser does not touch the loss slot)
+        return self.step_loss()
 
 
 class IrtEngine(_EngineBase):
@@ -922,7 +940,7 @@ def _irt_step(self, lrs, rows=None, b_global=None, eps=None, num_particles=1):
         self.GP.copy_(accP)
     self.allreduce()
     self.apply_optim(lrs)
-    return self.G[self.n_params]
+    return self.step_loss()
 
 
 IrtEngine.step = _irt_step
@@ -1337,7 +1355,7 @@ class CdmSfEngine(_EngineBase):
             self.GP.copy_(accP)
         self.allreduce()
         self.apply_optim(lrs)
-        return self.G[self.n_params]
+        return self.step_loss()
 
 
 def default_bin_encoder_init(J, K, H, seed):

@@ -43,7 +43,7 @@ class _RandomIrtBase(RandomPsyData):
         _hip.require_gpu()
         L, dev = _hip.lib(), self.device
         n, J, D = self.sample_size, self.item_size, self.x_feature
-        cfg = _hip.IrtCfg(MODEL_CODE[self.name], D, J, 0, float(self.D), 1.0, self.seed, 0, 0)
+        model = self.name
         y = torch.empty((n, J), dtype=torch.uint8, device=dev)
         x = torch.empty((n, D), dtype=torch.float32, device=dev)
         dv = {k: getattr(self, k).to(dev).float().contiguous() for k in ("a", "b", "c", "d") if hasattr(self, k)}
@@ -59,7 +59,9 @@ class _RandomIrtBase(RandomPsyData):
             if "a" in dv:
                 dv["a"] = (sc * dv["a"]).contiguous()
             elif sc != 1.0:
-                raise NotImplementedError("RandomIrt1PL with x_scale != 1 (the kernel's 1PL link has no slope)")
+                # the 1PL link has no slope to fold the scale into: the same response law through the 2PL link with a = sc
+                model, dv["a"] = "irt_2pl", (sc * a_eff).contiguous()
+        cfg = _hip.IrtCfg(MODEL_CODE[model], D, J, 0, float(self.D), 1.0, self.seed, 0, 0)
         _hip.check(L.vx_synth_irt(ctypes.byref(cfg), n, self.gid0, _hip.ptr(x_in), _hip.ptr(dv.get("a")), _hip.ptr(dv["b"]),
                                   _hip.ptr(dv.get("c")), _hip.ptr(dv.get("d")), 0.0, _hip.ptr(y), _hip.ptr(x),
                                   _hip.stream_ptr()), "vx_synth_irt")
