@@ -51,6 +51,9 @@ typedef struct vx_irt_cfg {
     uint64_t seed;       /* Philox key */
     uint32_t step;       /* Philox counter word 2: optimisation step */
     uint32_t stream;     /* Philox counter word 3 high half: particle index */
+    const uint32_t* step_dev; /* or NULL: the step counter in DEVICE memory -- vx_mvn_enc_forward reads the Philox step from it
+                            instead of `step`, so that a whole step can be captured once in a HIP graph and replayed
+                            (vx_sum2 advances it, vx_adam_step reads it; the D = 1 entry points take it as an argument) */
 } vx_irt_cfg;
 
 int vx_abi_version(void);
@@ -361,8 +364,11 @@ int vx_reduce_slabs(const float* slabs, int64_t n_slabs, int64_t len, float alph
  * workspace: vx_sum_workspace_floats() floats */
 int64_t vx_sum_workspace_floats(void);
 int vx_sum(const float* v, int64_t n, float alpha, float* out, float* workspace, void* hip_stream);
-/* out[0] = alpha * (sum v1 + sum v2), both of length n, in one pass (the loss of the MVN guides: log-lik + entropy) */
-int vx_sum2(const float* v1, const float* v2, int64_t n, float alpha, float* out, float* workspace, void* hip_stream);
+/* out[0] = alpha * (sum v1 + sum v2), both of length n, in one pass (the loss of the MVN guides: log-lik + entropy).
+ * step_dev (or NULL): the device step counter of a captured step (vx_irt_cfg.step_dev): advanced by one here, the last
+ * launch of loss-and-gradients, so that vx_adam_step's t_dev may point at the same word (Adam's count is the step + 1). */
+int vx_sum2(const float* v1, const float* v2, int64_t n, float alpha, float* out, float* workspace, uint32_t* step_dev,
+            void* hip_stream);
 
 /* ---- optimiser: torch.optim.Adam on a flat float32 buffer split into segments with their own
  * learning rate (pyro.optim.Adam with callable optim_args; vi.py:514, test.py:345-350), optional

@@ -55,7 +55,7 @@ def main():
                         amortized=(case == "mvn"), H=H, seed=77, group=group)
     lrs = LrSpec(lambda m, n: {"lr": 1e-2 if n in ("a", "b", "g", "s") else 3e-3})
     losses = []
-    for t in range(4):
+    for t in range(6):
         if t == 2:                                      # one subsampled step: the same global draw on every rank
             idx = np.sort(np.random.RandomState(1000 + t).permutation(N)[:N // 2])
             mine = idx[(idx >= lo) & (idx < hi)] - lo

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     from vipsy_amd import _hip
-    assert ctypes.sizeof(_hip.IrtCfg) == 40          # 4*int32 + 2*float + uint64 + 2*uint32
+    assert ctypes.sizeof(_hip.IrtCfg) == 48          # 4*int32 + 2*float + uint64 + 2*uint32 + the device step pointer
     assert ctypes.sizeof(_hip.AdamSeg) == 24
 
 

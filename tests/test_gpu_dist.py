@@ -36,13 +36,12 @@ def test_hip_two_ranks_match_one_rank(case, port, tmp_path):
     one = _run(case, 1, tmp_path, port)[0]
     two = _run(case, 2, tmp_path, port + 1)
     if torch.cuda.device_count() >= 2:
-        # a multi-GPU box must not rehearse on gloo: the transport under test is RCCL, and the D = 1 per-person step must
-        # have been replayed from a HIP graph WITH its all-reduce captured (engine.py::_graphable)
+        # a multi-GPU box must not rehearse on gloo: the transport under test is RCCL
         assert all(r["backend"] == "nccl" for r in two), [r["backend"] for r in two]
-        if case == "irt1d":
-            assert all(r["graphed"] for r in two)
-    if case == "irt1d":
-        assert one["graphed"]                                                  # (single rank: always captured)
+    if case in ("irt1d", "mvn"):
+        # replayed from HIP graphs: one for a single rank, two around the eager all-reduce when the persons are sharded
+        # (engine.py::_step_graph; the gloo rehearsal replays the same two graphs around its host reduction)
+        assert one["graphed"] and all(r["graphed"] for r in two)
     for r in two:
         np.testing.assert_allclose(r["loss"], one["loss"], rtol=2e-5)
         np.testing.assert_allclose(r["P"], one["P"], rtol=2e-4, atol=2e-6)    # fp32 summation order differs by shard

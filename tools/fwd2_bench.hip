@@ -68,7 +68,7 @@ int main(int argc, char** argv) {
             hipEventRecord(e0);
             hipLaunchKernelGGL(k_mvn_enc_fwd_b2<NS>, dim3((unsigned)((nb + wg - 1) / wg)), dim3(FB2_THREADS), lds, 0, dm, (const uint8_t*)y,
                                (const int64_t*)nullptr, (int64_t)0, (const uint8_t*)w1img, (const float*)b1, (const uint8_t*)img,
-                               (const uint32_t*)gt2, (const float*)sc, (const float*)nullptr, (uint64_t)1234, 0u, 0u, h, x, eps, ldT, ent, hT,
+                               (const uint32_t*)gt2, (const float*)sc, (const float*)nullptr, (uint64_t)1234, 0u, (const uint32_t*)nullptr, 0u, h, x, eps, ldT, ent, hT,
                                epsT, ximg, hs);
             hipEventRecord(e1); CK(hipEventSynchronize(e1));
             float ms; hipEventElapsedTime(&ms, e0, e1);

@@ -20,7 +20,7 @@ class IrtCfg(ctypes.Structure):
     """struct vx_irt_cfg (include/vipsy_amd.h)."""
     _fields_ = [("model", ctypes.c_int32), ("D", ctypes.c_int32), ("J", ctypes.c_int32), ("H", ctypes.c_int32),
                 ("Dc", ctypes.c_float), ("scale", ctypes.c_float), ("seed", ctypes.c_uint64),
-                ("step", ctypes.c_uint32), ("stream", ctypes.c_uint32)]
+                ("step", ctypes.c_uint32), ("stream", ctypes.c_uint32), ("step_dev", ctypes.c_void_p)]
 
 
 class AdamSeg(ctypes.Structure):
@@ -102,7 +102,7 @@ SIGNATURES = {
     "vx_reduce_slabs": (ctypes.c_int, [_P, _I64, _I64, _F, _P, _P]),
     "vx_sum_workspace_floats": (_I64, []),
     "vx_sum": (ctypes.c_int, [_P, _I64, _F, _P, _P, _P]),
-    "vx_sum2": (ctypes.c_int, [_P, _P, _I64, _F, _P, _P, _P]),
+    "vx_sum2": (ctypes.c_int, [_P, _P, _I64, _F, _P, _P, _P, _P]),
     "vx_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, ctypes.POINTER(AdamSeg), _I32, _I32, _P, _F, _F, _F, _P, _P, _P]),
     "vx_adam_step2": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, ctypes.POINTER(AdamSeg), _I32, _P, _P, _P, _P, _I64,
                                      ctypes.POINTER(AdamSeg), _I32, _I32, _P, _F, _F, _F, _P, _P, _P]),

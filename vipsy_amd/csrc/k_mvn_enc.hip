@@ -51,9 +51,10 @@ __global__ __launch_bounds__(ENC_THREADS) void k_mvn_enc_fwd(
     EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, int64_t gid0,
     const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W21,
     const float* __restrict__ b21, const float* __restrict__ W22, const float* __restrict__ b22,
-    const float* __restrict__ eps_in, uint64_t seed, uint32_t step, uint32_t stream,
+    const float* __restrict__ eps_in, uint64_t seed, uint32_t step, const uint32_t* __restrict__ step_dev, uint32_t stream,
     float* __restrict__ h_out, float* __restrict__ x_out, float* __restrict__ eps_out,
     float* __restrict__ ldT, float* __restrict__ ent_out) {
+    if (step_dev) step = *step_dev;                              // captured step: the Philox step lives in device memory
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int D = dm.D, J = dm.J, H = dm.H, Hp = dm.Hp, DS = dm.DS, T = dm.T;
     const int HS = Hp + 1;

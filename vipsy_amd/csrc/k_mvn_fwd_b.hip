@@ -193,12 +193,13 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, int64_t gid0,
     const uint8_t* __restrict__ w1img, const float* __restrict__ b1, const uint8_t* __restrict__ img,
     const uint32_t* __restrict__ gt2, const float* __restrict__ sc /*k_enc_scales*/, const float* __restrict__ eps_in, uint64_t seed,
-    uint32_t step, uint32_t stream, float* __restrict__ h_out,
+    uint32_t step, const uint32_t* __restrict__ step_dev, uint32_t stream, float* __restrict__ h_out,
     float* __restrict__ x_out, float* __restrict__ eps_out, float* __restrict__ ldT, float* __restrict__ ent_out,
     float* __restrict__ hT_out /*[64][nb] or null*/, float* __restrict__ epsT_out /*[D][nb] or null*/,
     uint8_t* __restrict__ ximg_out /*f16x2 tile images of x for k_irt_lik_h (k_irt_lik_h.hip), or null*/,
     uint16_t* __restrict__ hs_out /*[2][64][nb] fp16 terms of h 2^sh for k_mvn_enc_bwd_w_b (what k_split2_f16 makes), or null*/,
     int64_t i_base = 0 /*first person of this launch (a multiple of 64): the persons before it belong to another launch*/) {
+    if (step_dev) step = *step_dev;                              // captured step: the Philox step lives in device memory
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
     constexpr int H = 64;

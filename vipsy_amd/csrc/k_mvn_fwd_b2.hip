@@ -35,9 +35,10 @@ __global__ __launch_bounds__(FB2_THREADS, (NS == 1 ? 2 : 1)) void k_mvn_enc_fwd_
     EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, int64_t gid0,
     const uint8_t* __restrict__ w1img, const float* __restrict__ b1, const uint8_t* __restrict__ img,
     const uint32_t* __restrict__ gt2, const float* __restrict__ sc /*k_enc_scales*/, const float* __restrict__ eps_in,
-    uint64_t seed, uint32_t step, uint32_t stream, float* __restrict__ h_out, float* __restrict__ x_out, float* __restrict__ eps_out, float* __restrict__ ldT,
+    uint64_t seed, uint32_t step, const uint32_t* __restrict__ step_dev, uint32_t stream, float* __restrict__ h_out, float* __restrict__ x_out, float* __restrict__ eps_out, float* __restrict__ ldT,
     float* __restrict__ ent_out, float* __restrict__ hT_out, float* __restrict__ epsT_out, uint8_t* __restrict__ ximg_out,
     uint16_t* __restrict__ hs_out) {
+    if (step_dev) step = *step_dev;                              // captured step: the Philox step lives in device memory
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2w __attribute__((ext_vector_type(2)));

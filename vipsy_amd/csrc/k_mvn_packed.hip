@@ -36,9 +36,10 @@ __global__ __launch_bounds__(EP_THREADS, 1) void k_mvn_enc_fwd_p(
     EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, int64_t gid0,
     const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ Wp,
     const float* __restrict__ bp, const uint32_t* __restrict__ gtab, const float* __restrict__ eps_in,
-    uint64_t seed, uint32_t step, uint32_t stream, float* __restrict__ h_out, float* __restrict__ x_out,
+    uint64_t seed, uint32_t step, const uint32_t* __restrict__ step_dev, uint32_t stream, float* __restrict__ h_out, float* __restrict__ x_out,
     float* __restrict__ eps_out, float* __restrict__ ldT, float* __restrict__ ent_out,
     float* __restrict__ hT_out /*[64][nb] or null*/, float* __restrict__ epsT_out /*[D][nb] or null*/) {
+    if (step_dev) step = *step_dev;                              // captured step: the Philox step lives in device memory
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int H = 64;
     const int D = dm.D, J = dm.J;

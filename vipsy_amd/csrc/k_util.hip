@@ -111,7 +111,8 @@ __global__ void k_sum_stage1(const float* __restrict__ v, int64_t n, float* __re
         partial[blockIdx.x] = t;
     }
 }
-__global__ void k_sum_stage2(const float* __restrict__ partial, int n, float alpha, float* __restrict__ out) {
+__global__ void k_sum_stage2(const float* __restrict__ partial, int n, float alpha, float* __restrict__ out,
+                             uint32_t* __restrict__ tick = nullptr /*the device step counter: advanced by one*/) {
     __shared__ float red[256 / VX_WAVE];
     float acc = 0.f;
     for (int i = threadIdx.x; i < n; i += blockDim.x) acc += partial[i];
@@ -122,6 +123,7 @@ __global__ void k_sum_stage2(const float* __restrict__ partial, int n, float alp
         float t = 0.f;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
         out[0] = alpha * t;
+        if (tick) *tick += 1u;                                 // (every kernel that reads it as the Philox step ran before this one)
     }
 }
 

@@ -300,14 +300,14 @@ int vx_sum(const float* v, int64_t n, float alpha, float* out, float* workspace,
     return VX_OK;
 }
 
-int vx_sum2(const float* v1, const float* v2, int64_t n, float alpha, float* out, float* workspace, void* hs) {
+int vx_sum2(const float* v1, const float* v2, int64_t n, float alpha, float* out, float* workspace, uint32_t* step_dev, void* hs) {
     if (!v1 || !v2 || !out || !workspace || n < 0) return VX_EINVAL;
     int nblk = (int)((n + 4095) / 4096);
     if (nblk < 1) nblk = 1;
     if (nblk > 1024) nblk = 1024;
     hipLaunchKernelGGL(k_sum_stage1, dim3(nblk), dim3(256), 0, (hipStream_t)hs, v1, n, workspace, v2);
     VX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_sum_stage2, dim3(1), dim3(256), 0, (hipStream_t)hs, workspace, nblk, alpha, out);
+    hipLaunchKernelGGL(k_sum_stage2, dim3(1), dim3(256), 0, (hipStream_t)hs, workspace, nblk, alpha, out, step_dev);
     VX_CHECK_LAUNCH();
     return VX_OK;
 }
@@ -415,7 +415,7 @@ static int mvn_enc_forward_kernels(const vx_irt_cfg* cfg, const uint8_t* y, cons
                 const unsigned gs = ximg ? (unsigned)(((nb + 63) / 64) * 2) : (unsigned)((nb + FB_WP - 1) / FB_WP);
                 hipLaunchKernelGGL(k_mvn_enc_fwd_b<true>, dim3(gs), dim3(FB_THREADS), ldsb,
                                    (hipStream_t)hs, dm, y, rows, gid0, (const uint8_t*)w1img, b1, (const uint8_t*)img,
-                                   (const uint32_t*)gt2, (const float*)sc, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT, ximg, hs_out);
+                                   (const uint32_t*)gt2, (const float*)sc, eps_in, cfg->seed, cfg->step, cfg->step_dev, cfg->stream, h, x, eps, ldT, ent, hT, epsT, ximg, hs_out);
                 VX_CHECK_LAUNCH();
                 return VX_OK;
             }
@@ -443,7 +443,7 @@ static int mvn_enc_forward_kernels(const vx_irt_cfg* cfg, const uint8_t* y, cons
                 const dim3 gridb((unsigned)((nb - n_done + FB_WAVES * FB_WP - 1) / (FB_WAVES * FB_WP)));
                 hipLaunchKernelGGL(k_mvn_enc_fwd_b<false>, gridb, dim3(FB_THREADS), ldsb, ts, dm, y, rows, gid0,
                                    (const uint8_t*)w1img, b1, (const uint8_t*)img, (const uint32_t*)gt2, (const float*)sc, eps_in, cfg->seed,
-                                   cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT, ximg, hs_out, n_done);
+                                   cfg->step, cfg->step_dev, cfg->stream, h, x, eps, ldT, ent, hT, epsT, ximg, hs_out, n_done);
                 VX_CHECK_LAUNCH();
                 return VX_OK;
             };
@@ -460,7 +460,7 @@ static int mvn_enc_forward_kernels(const vx_irt_cfg* cfg, const uint8_t* y, cons
                 hipLaunchKernelGGL(k_mvn_enc_fwd_b2<FNS>, dim3((unsigned)((n_done + wg - 1) / wg)),
                                    dim3(FB2_THREADS), lds2, (hipStream_t)hs, dm, y, rows, gid0, (const uint8_t*)w1img, b1,
                                    (const uint8_t*)img, (const uint32_t*)gt2, (const float*)sc, eps_in, cfg->seed, cfg->step,
-                                   cfg->stream, h, x, eps, ldT, ent, hT, epsT, ximg, hs_out);      // the grid stops at n_done
+                                   cfg->step_dev, cfg->stream, h, x, eps, ldT, ent, hT, epsT, ximg, hs_out);      // the grid stops at n_done
                 VX_CHECK_LAUNCH();
                 if (n_done == nb) return VX_OK;
             }
@@ -473,7 +473,7 @@ static int mvn_enc_forward_kernels(const vx_irt_cfg* cfg, const uint8_t* y, cons
         const dim3 gridp((unsigned)((nb + EP_WAVES * EP_WP - 1) / (EP_WAVES * EP_WP)));
         ProfScope ps("k_mvn_enc_fwd_p", (hipStream_t)hs);
         hipLaunchKernelGGL(k_mvn_enc_fwd_p, gridp, dim3(EP_THREADS), ldsp, (hipStream_t)hs, dm, y, rows, gid0, W1, b1, Wp,
-                           bp, gtab, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent, hT, epsT);
+                           bp, gtab, eps_in, cfg->seed, cfg->step, cfg->step_dev, cfg->stream, h, x, eps, ldT, ent, hT, epsT);
         VX_CHECK_LAUNCH();
         return VX_OK;
     }
@@ -485,7 +485,7 @@ static int mvn_enc_forward_kernels(const vx_irt_cfg* cfg, const uint8_t* y, cons
             if (rc) return rc;
             const dim3 gridr((unsigned)((nb + ER_WAVES * ER_WP - 1) / (ER_WAVES * ER_WP)));
             hipLaunchKernelGGL(k_mvn_enc_fwd_r, gridr, dim3(ER_THREADS), ldsr, (hipStream_t)hs, dm, y, rows, gid0, W1, b1,
-                               W21, b21, W22, b22, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent);
+                               W21, b21, W22, b22, eps_in, cfg->seed, cfg->step, cfg->step_dev, cfg->stream, h, x, eps, ldT, ent);
             VX_CHECK_LAUNCH();
             return VX_OK;
         }
@@ -495,7 +495,7 @@ static int mvn_enc_forward_kernels(const vx_irt_cfg* cfg, const uint8_t* y, cons
     rc = set_lds(k_mvn_enc_fwd<HT>, lds);                                                                    \
     if (rc) return rc;                                                                                       \
     hipLaunchKernelGGL(k_mvn_enc_fwd<HT>, grid, dim3(ENC_THREADS), lds, (hipStream_t)hs, dm, y, rows, gid0, W1, \
-                       b1, W21, b21, W22, b22, eps_in, cfg->seed, cfg->step, cfg->stream, h, x, eps, ldT, ent)
+                       b1, W21, b21, W22, b22, eps_in, cfg->seed, cfg->step, cfg->step_dev, cfg->stream, h, x, eps, ldT, ent)
     if (dm.Hp == 32) { LAUNCH_FWD(1); } else if (dm.Hp == 64) { LAUNCH_FWD(2); } else if (dm.Hp == 96) { LAUNCH_FWD(3); } else { LAUNCH_FWD(4); }
 #undef LAUNCH_FWD
     VX_CHECK_LAUNCH();

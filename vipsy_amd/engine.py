@@ -36,8 +36,10 @@ class HipBackend(object):
 
     # -- helpers -----------------------------------------------------------------------------
     @staticmethod
-    def cfg(model, D, J, H, Dc, scale, seed, step, stream):
-        return _hip.IrtCfg(MODEL_CODE[model], D, J, H, Dc, scale, seed, step, stream)
+    def cfg(model, D, J, H, Dc, scale, seed, step, stream, step_dev=None):
+        """step_dev: the device step counter of a captured step (vx_irt_cfg.step_dev) or None."""
+        return _hip.IrtCfg(MODEL_CODE[model], D, J, H, Dc, scale, seed, step, stream,
+                           None if step_dev is None else step_dev.data_ptr())
 
     def mvn_enc_forward(self, cfg, y, rows, nb, gid0, enc, eps_in, out):
         rc = self.L.vx_mvn_enc_forward(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb, gid0,
@@ -301,8 +303,9 @@ class HipBackend(object):
                                   eps, _hip.ptr(src), _hip.ptr(ring), _hip.stream_ptr())
         _hip.check(rc, "vx_adam_step2")
 
-    def sum2_into(self, v1, v2, n, alpha, out, ws):
-        rc = self.L.vx_sum2(_hip.ptr(v1), _hip.ptr(v2), n, alpha, _hip.ptr(out), _hip.ptr(ws), _hip.stream_ptr())
+    def sum2_into(self, v1, v2, n, alpha, out, ws, step_dev=None):
+        rc = self.L.vx_sum2(_hip.ptr(v1), _hip.ptr(v2), n, alpha, _hip.ptr(out), _hip.ptr(ws), _hip.ptr(step_dev),
+                            _hip.stream_ptr())
         _hip.check(rc, "vx_sum2")
 
     def adam(self, p, g, m, v, free, n, segs, t, betas=(0.9, 0.999), eps=1e-8, t_dev=None, loss=None):
@@ -545,21 +548,48 @@ class _EngineBase(object):
         return self.loss_ring[self.t % LOSS_RING]
 
     # -- the whole step as one HIP graph ---------------------------------------------------------
-    # A D = 1 full-batch step is a handful of 10-100 us kernels: launched one by one the host (Python + ctypes, ~10 us a
-    # launch) is slower than the GPU.  Nothing in such a step changes from call to call except the step count (Philox
-    # counter, Adam bias corrections), which the kernels can read from device memory -- so the step is captured once
-    # and replayed.  A new learning rate (scheduler milestone) captures again.
+    # A D = 1 full-batch step is a handful of 10-100 us kernels, a subsampled amortized step (the reference's own usage:
+    # subsample_size = 100, test.py:338) ~25 launches around kernels of 5-80 us, and a 125 k-person shard of the headline ~25
+    # launches around 1.3 ms of large kernels: launched one by one the host (Python + ctypes, ~10 us a launch) and the gaps
+    # between short kernels are a fixed cost per step.  Nothing in such a step changes from call to call except the step count
+    # (Philox counter, Adam bias corrections) -- read from a device word that the step's last reduction advances -- and, for a
+    # subsample, the row indices -- copied into a fixed device buffer before the replay.  So the step is captured once per
+    # FORM (full batch; or a subsample of nb rows out of b_global) and replayed.  A new learning rate (scheduler milestone)
+    # or a re-allocated workspace captures again.
+    #
+    # Sharded persons (a process group): by default the step is TWO replays around the eager all-reduce -- loss_and_grads |
+    # all_reduce(G) | optimiser -- three host calls instead of ~30, and no collective inside a capture.  VX_GRAPH_COLLECTIVE=1
+    # captures the RCCL all-reduce into ONE graph (RCCL collectives are capturable); that form has not run on any hardware this
+    # build could reach, so it is opt-in, and a capture that fails with a collective inside it RAISES: the communicator may be
+    # unusable after a half-recorded collective, so the process must not carry on (no eager retry).
     use_graph = True
 
+    def _graph_mode(self, rows, b_global, eps, S):
+        """The captured form this call can replay -- ('full' | 'rows', nb, b_global) -- or None for an eager step."""
+        if not (self.use_graph and S == 1 and eps is None and self.events is None and isinstance(self.be, HipBackend)
+                and getattr(self, "estimator", "pathwise") == "pathwise"):
+            return None
+        D, amort = getattr(self, "D", 0), getattr(self, "amortized", True)
+        full = rows is None and (b_global is None or int(b_global) == self.N)
+        if D == 1 and not amort and isinstance(self, IrtEngine):
+            return ("full", self.n_local, self.N) if full else None       # per-person rows: a subsample scatters dense gradients
+        if D > 1 and amort and isinstance(self, IrtEngine):
+            if full:
+                return ("full", self.n_local, self.N)
+            if rows is not None and not isinstance(rows, (list, tuple)) and self.n_local > 0:
+                nb = int(rows.numel())
+                return ("rows", nb, int(b_global) if b_global is not None else nb)
+        return None
+
     def _graphable(self):
-        """The D = 1 per-person step is a handful of short kernels: replayed from ONE HIP graph.  With a process group the
-        all-reduce is captured with it (RCCL collectives are capturable on the capture stream: loss_and_grads -> all_reduce(G)
-        -> Adam stay one replay per step); a gloo group (CPU rehearsal) reduces through the host and cannot be captured."""
-        if not (self.use_graph and getattr(self, "D", 0) == 1 and not getattr(self, "amortized", True)
-                and getattr(self, "estimator", "pathwise") == "pathwise"
-                and self.events is None and isinstance(self.be, HipBackend)):
-            return False
-        return self.group is None or torch.distributed.get_backend(self.group) == "nccl"
+        """Whether the full-batch step of this engine replays a graph (tests, bench.py)."""
+        return self._graph_mode(None, None, None, 1) is not None
+
+    def _one_graph(self):
+        """One graph for the whole step (no group, or the opt-in captured RCCL all-reduce) or two around an eager all-reduce."""
+        if self.group is None:
+            return True
+        return (torch.distributed.get_backend(self.group) == "nccl" and os.environ.get("VX_GRAPH_COLLECTIVE", "0") == "1")
 
     def _graph_key(self, lrs):
         """Everything a captured step bakes into its kernel arguments: the (begin, end, lr) segments and (betas, eps) of
@@ -568,54 +598,103 @@ class _EngineBase(object):
         _buf() has re-allocated since the capture would leave the graph writing into the old one)."""
         hyp = tuple((name, float(lrs.lr_of(name))) + lrs.hyper_of(name) for name in self.all_names())
         ptrs = tuple(sorted((k, t.data_ptr()) for k, t in self._ws.items()))
-        return hyp, ptrs
+        return hyp, ptrs, self._one_graph()
 
-    def _step_graph(self, lrs):
-        st = self._graph
+    def _stage_rows(self, rows, buf):
+        """The step's row indices into the fixed device buffer the captured kernels read.  Host indices (what the fit loop
+        draws) go through a small ring of pinned buffers: one asynchronous copy, no staging allocation, no sync unless the
+        GPU is a whole ring behind."""
+        nb = buf.numel()
+        if rows.is_cuda:
+            buf.copy_(rows)
+            return
+        ring = getattr(self, "_pin_ring", None)
+        if ring is None or ring[0][0].numel() < nb:
+            ring = self._pin_ring = [[torch.empty(max(nb, 1024), dtype=torch.int64).pin_memory(), None] for _ in range(8)]
+            self._pin_i = 0
+        slot = ring[self._pin_i]
+        self._pin_i = (self._pin_i + 1) % len(ring)
+        if slot[1] is not None:
+            slot[1].synchronize()                            # the copy that last read this slot has run
+        else:
+            slot[1] = torch.cuda.Event()
+        slot[0][:nb].copy_(rows.reshape(-1))
+        buf.copy_(slot[0][:nb], non_blocking=True)
+        slot[1].record()
+
+    def _step_graph(self, lrs, mode, rows):
+        st = self._graphs[mode]
+        self._graph = st                                     # (the form last replayed: what tests / bench.py look at)
         key = self._graph_key(lrs)
         if st["graph"] is None or st["key"] != key:
-            ctr = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            if getattr(self, "_ctr", None) is None:
+                self._ctr, self._ctr_t = torch.zeros(1, dtype=torch.int32, device=self.dev), None
+            rows_buf = None
+            if mode[0] == "rows":
+                rows_buf = st.get("rows")
+                if rows_buf is None:
+                    rows_buf = torch.zeros(mode[1], dtype=torch.int64, device=self.dev)
+                self._stage_rows(rows, rows_buf)             # valid indices while the capture records
+            one = self._one_graph()
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
+            gA, gB = torch.cuda.CUDAGraph(), None
             t0 = self.t
-            self._step_dev = ctr
-            captured = True
+            self._step_dev = self._ctr
             try:
-                with torch.cuda.graph(g):
-                    self.loss_and_grads(None, None, None, 0)  # reads the counter as the Philox step, then advances it
-                    self.allreduce()                          # (a no-op without a group)
-                    self.apply_optim(lrs)                     # reads it as Adam's t
-            except Exception:
-                if self.group is None:
-                    raise
-                captured = False                             # a collective this stack cannot capture
+                with torch.cuda.graph(gA):
+                    # reads the counter as the Philox step, then advances it
+                    self.loss_and_grads(rows_buf, mode[2] if mode[0] == "rows" else None, None, 0)
+                    if one:
+                        self.allreduce()                      # (a no-op without a group)
+                        self.apply_optim(lrs)                 # reads it as Adam's t
+                if not one:
+                    gB = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gB, pool=gA.pool()):
+                        self.apply_optim(lrs)
+            except Exception as e:
+                if one and self.group is not None:
+                    raise RuntimeError("capturing the step with its RCCL all-reduce failed; the communicator may be unusable "
+                                       "after a half-recorded collective, so this process must not carry on -- run again "
+                                       "without VX_GRAPH_COLLECTIVE=1 (two replays around an eager all-reduce)") from e
+                raise
             finally:
                 self._step_dev = None
                 self.t = t0                                  # capture records, it does not run
-            if not captured:                                 # the sharded step stays correct, launched kernel by kernel
-                self.use_graph = False
-                self._graph = None
-                torch.cuda.synchronize()
-                return self.step(lrs)
-            st.update(graph=g, key=key, ctr=ctr, ctr_t=None)
-        if st["ctr_t"] != self.t:                            # (re)seed the device counter
-            st["ctr"].fill_(self.t)
+            st.update(graph=gA, tail=gB, key=key, rows=rows_buf)
+        if mode[0] == "rows":
+            self._stage_rows(rows, st["rows"])
+        if self._ctr_t != self.t:                            # (re)seed the device counter
+            self._ctr.fill_(self.t)
         st["graph"].replay()
+        if st["tail"] is not None:
+            self.allreduce()
+            st["tail"].replay()
         self.t += 1
-        st["ctr_t"] = self.t
+        self._ctr_t = self.t
         return self.step_loss()
+
+    def _rows_on_device(self, rows):
+        """Host row indices (the fit loop's draw) for an eager step."""
+        if rows is None or isinstance(rows, (list, tuple)):
+            return [self._rows_on_device(r) for r in rows] if isinstance(rows, (list, tuple)) else None
+        return rows if rows.device == self.dev else rows.to(self.dev)
 
     def step(self, lrs, rows=None, b_global=None, eps=None, num_particles=1):
         """loss_and_grads + optimiser, the body of SVI.step (vi.py:505-516).  `rows` (and `eps`) may be
         lists with one entry per particle: every particle draws its own subsample.
+        rows: int64 LOCAL row indices, on the device or on the host (a captured step copies host indices itself).
         Returns the loss as a 0-d device tensor (no host sync, no launch of its own: the optimiser launch files it in a ring of
         LOSS_RING slots, see step_loss())."""
         S = int(num_particles)
-        if (S == 1 and rows is None and eps is None and (b_global is None or int(b_global) == self.N)
-                and self._graphable()):
-            if getattr(self, "_graph", None) is not None:
-                return self._step_graph(lrs)
-            self._graph = {"graph": None}                    # the first step runs eagerly: workspaces and lists get built
+        mode = self._graph_mode(rows, b_global, eps, S)
+        if mode is not None:
+            if not hasattr(self, "_graphs"):
+                self._graphs = {}
+            if mode in self._graphs:
+                return self._step_graph(lrs, mode, rows)
+            self._graphs[mode] = {"graph": None}             # the first step of a form runs eagerly: workspaces and lists get built
+            self._graph = self._graphs[mode]
+        rows = self._rows_on_device(rows)
         if S == 1:
             self.loss_and_grads(rows[0] if isinstance(rows, (list, tuple)) else rows, b_global,
                                 eps[0] if isinstance(eps, (list, tuple)) else eps, 0)
@@ -770,7 +849,9 @@ class IrtEngine(_EngineBase):
         nb = self.n_local if rows is None else int(rows.numel())
         Bg = int(b_global) if b_global is not None else (self.N if rows is None else nb)
         scale = float(self.N) / float(Bg)
-        cfg = be.cfg(self.model, self.D, self.J, self.H, self.Dc, scale, self.seed, self.t, stream_id)
+        sd = getattr(self, "_step_dev", None)               # captured step: the step count lives in device memory
+        sdc = {"step_dev": sd} if sd is not None else {}
+        cfg = be.cfg(self.model, self.D, self.J, self.H, self.Dc, scale, self.seed, self.t, stream_id, **sdc)
         c_un = self.view("c") if self.model in ("irt_3pl", "irt_4pl") else None
         d_un = self.view("d") if self.model == "irt_4pl" else None
         a = self.view("a") if self.model != "irt_1pl" else None
@@ -858,8 +939,8 @@ class IrtEngine(_EngineBase):
                 be.mvn_enc_backward(cfg, self.y, rows, nb, enc, fw, gx,
                                     self.G[self.enc_off0:self.enc_off0 + self.n_enc], encb_ws, gxT=gxT,
                                     gd_ready=gdT is not None)
-            # loss = -scale * sum_i (ll_i + ent_i)
-            be.sum2_into(ll, fw["ent"], nb, -scale, lossslot, self.sum_ws)        # loss = -scale * sum_i (ll_i + ent_i)
+            # loss = -scale * sum_i (ll_i + ent_i); a captured step's counter advances here, behind every kernel that read it
+            be.sum2_into(ll, fw["ent"], nb, -scale, lossslot, self.sum_ws, **sdc)
             self.last = {"fw": fw, "gx": gx, "gxT": gxT, "ll": ll, "nb": nb}
         else:
             # D = 1: the flat item layout [a: J | b: J | c: J | d: J] IS the kernels' gradient layout -> written in place
@@ -877,8 +958,7 @@ class IrtEngine(_EngineBase):
             else:
                 loc, raw, gloc, graw = self._gather_pp(rows, nb)
             lists = self._sparse_lists(rows)
-            sd = getattr(self, "_step_dev", None)
-            sdk = {"step_dev": sd} if sd is not None else {}          # captured step: the step count lives in device memory
+            sdk = sdc                                              # captured step: the step count lives in device memory
             with self._phase("irt1d"):
                 if lists is not None:                      # mostly-missing responses: observed cells only
                     sp_ws = self._buf("i1d_sp_ws", be.irt1d_sparse_workspace(cfg, lists["n_groups"]))
@@ -918,6 +998,7 @@ def _irt_step(self, lrs, rows=None, b_global=None, eps=None, num_particles=1):
     S = int(num_particles)
     if self.estimator != "score" or self.baseline != "loo" or S < 2:
         return _EngineBase.step(self, lrs, rows=rows, b_global=b_global, eps=eps, num_particles=S)
+    rows = self._rows_on_device(rows)
     r = rows[0] if isinstance(rows, (list, tuple)) else rows
     nb = self.n_local if r is None else int(r.numel())
     lr_all = self._buf("sf_lr_all", S * nb)
@@ -1333,6 +1414,7 @@ class CdmSfEngine(_EngineBase):
             return super().step(lrs, rows=rows, b_global=b_global, eps=eps, num_particles=S)
         # leave-one-out control variate: a first pass records log_r of every particle (same subsample, the same Philox
         # draws as the second pass: the particle index is the Philox stream), the second pass uses the means
+        rows = self._rows_on_device(rows)
         r = rows[0] if isinstance(rows, (list, tuple)) else rows
         nb = self.n_local if r is None else int(r.numel())
         lr_all = self._buf("cs_lr_all", S * nb)

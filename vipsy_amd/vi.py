@@ -139,8 +139,8 @@ class BasePsy(object):
             # a small subset of many rows: a full permutation on the device is a radix sort of n keys (0.25 ms at 1M, a
             # third of a B = 100 step).  numpy's Generator.choice draws b distinct rows in O(b); same distribution over
             # subsets, ordered like the first b of a random permutation (shuffle=True)
-            host = torch.from_numpy(self._np_gen.choice(n, size=b_local, replace=False, shuffle=True).astype(np.int64))
-            idx = host.to(self.device, non_blocking=True)
+            # (left on the host: the engine copies the indices into the fixed buffer its captured step reads, or moves them itself)
+            idx = torch.from_numpy(self._np_gen.choice(n, size=b_local, replace=False, shuffle=True).astype(np.int64))
         else:
             idx = torch.randperm(n, generator=self._gen, device=self.device)[:b_local].contiguous()
         return idx, b_local * self.world
