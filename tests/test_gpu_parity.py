@@ -535,7 +535,7 @@ def test_hodina_step_vs_oracle(N, J, K, miss, B, amort):
     assert max(errs.values()) < HODINA_TOL, errs
 
 
-HODINA_TOL = 5e-4
+HODINA_TOL = 3e-5        # (measured: <= 5.2e-6, theta_local of the K = 8 case)
 
 
 @pytest.mark.parametrize("N,J,model,miss,B", [

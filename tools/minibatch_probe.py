@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Where a B = 100 step of the headline model goes (the reference's own usage, test.py:338): eager against replayed, with the
+host-side cost of a step (rows drawn and staged, launches) separated from the device-side cost.
+    python tools/minibatch_probe.py [--persons N] [--B 100] [--steps 300]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vipsy_amd import synth                                   # noqa: E402
+from vipsy_amd.engine import IrtEngine, LrSpec                # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--persons", type=int, default=200000)
+    ap.add_argument("--B", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--modes", default="eager,graph")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    J, D, H = 500, 100, 64
+    a, b = synth.mirt_item_params(J, D, seed=20243)
+    y = synth.simulate_responses(args.persons, 0, {"a": a, "b": b}, "irt_2pl", dev, seed=20240, missing=0.0)
+    lrs = LrSpec(lambda m, p: {"lr": 1e-2 if p in ("a", "b") else 1e-3})
+    rg = np.random.Generator(np.random.PCG64(7))
+
+    def draw():
+        return torch.from_numpy(rg.choice(args.persons, size=args.B, replace=False).astype(np.int64))
+    for mode in args.modes.split(","):
+        eng = IrtEngine(y, model="irt_2pl", D=D, amortized=True, H=H, seed=1234)
+        eng.use_graph = mode == "graph"
+        for _ in range(10):
+            eng.step(lrs, rows=draw(), b_global=args.B)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.step(lrs, rows=draw(), b_global=args.B)
+        t_host = time.perf_counter() - t0                      # the host has enqueued everything
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+        # the same replays without a new draw (device-side cost of the step alone)
+        r = draw()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.step(lrs, rows=r.to(dev) if mode == "eager" else r, b_global=args.B)
+        torch.cuda.synchronize()
+        t_fixed = time.perf_counter() - t1
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            draw()
+        t_draw = time.perf_counter() - t2
+        print("%-6s B=%d: %.1f us/step (%.0f steps/s); host enqueue %.1f us/step; same rows re-used %.1f us/step; draw alone %.1f us"
+              % (mode, args.B, 1e6 * t_all / args.steps, args.steps / t_all, 1e6 * t_host / args.steps,
+                 1e6 * t_fixed / args.steps, 1e6 * t_draw / args.steps))
+
+
+if __name__ == "__main__":
+    main()

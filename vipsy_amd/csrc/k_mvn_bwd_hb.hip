@@ -44,13 +44,10 @@ __host__ __device__ inline size_t hb_lds_bytes(int D) {
 // in that order (the 64-person kernel replaces its gx tile by the gd tile while the LOC units run).
 // Block 0 also clears the words that collect the largest |gx|, |gd|, |eps| and |ghpre| of the step (the kernel below adds
 // its waves' maxima; k_mvn_enc_bwd_w_b and k_fc1_bwd_b scale by them).
-__global__ void k_pack_heads_hb(int D, const float* __restrict__ W21, const float* __restrict__ W22,
-                                const float* __restrict__ sc, uint8_t* __restrict__ img, uint32_t* __restrict__ maxw) {
+__device__ __forceinline__ void pack_heads_hb_unit(int u, int D, const float* __restrict__ W21, const float* __restrict__ W22,
+                                                   float w_scale, uint8_t* __restrict__ img) {
     const int n_off = hb_units_off(D), ns = (D + 15) / 16;
-    const int u = blockIdx.x;
-    if (u == 0 && threadIdx.x < 4 && maxw) maxw[threadIdx.x] = 0u;
     if (u >= n_off + 2 * ns) return;
-    const float w_scale = sc[2];
     int type = 0, k = 0, s = 0;                                        // 0 OFF, 1 DIAG, 2 LOC
     if (u < n_off) {
         int rem = u;
@@ -76,6 +73,11 @@ __global__ void k_pack_heads_hb(int D, const float* __restrict__ W21, const floa
         uint16_t* o = (uint16_t*)(out + (ht * 2) * 1024 + lane * 16) + j;
         split2h_bits(w_scale * v, o[0], o[512]);
     }
+}
+__global__ void k_pack_heads_hb(int D, const float* __restrict__ W21, const float* __restrict__ W22,
+                                const float* __restrict__ sc, uint8_t* __restrict__ img, uint32_t* __restrict__ maxw) {
+    if (blockIdx.x == 0 && threadIdx.x < 4 && maxw) maxw[threadIdx.x] = 0u;
+    pack_heads_hb_unit(blockIdx.x, D, W21, W22, sc[2], img);
 }
 
 // SPLIT (small batches, at most HB_SPLIT_MAX persons): a workgroup takes ONE 32-person tile and its eight waves share

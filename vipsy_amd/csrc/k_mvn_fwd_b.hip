@@ -39,19 +39,22 @@ __host__ __device__ inline size_t fb_lds_bytes(int D, int J) {
 // h = softplus(W1 y + b1) with y in {-1, 0, 1} is bounded by softplus(max_u (|W1[u, :]|_1 + |b1[u]|)): a scale from that
 // bound cannot overflow, and a bound a few binades above the values costs nothing (fp16 pairs keep 2^-22 relative down
 // to 2^-3 and 2^-25 absolute below it).
-#define FB_NSCALES 16
+#define FB_SC_BLOCKS 64
+#define FB_SC_PART 16                                                // sc[FB_SC_PART + 4 b + i]: block b's maxima (the fused pack launches)
+#define FB_NSCALES (FB_SC_PART + 4 * FB_SC_BLOCKS)
 // two launches: FB_SC_BLOCKS blocks take the maxima (integer atomicMax on the bit patterns of non-negative floats:
 // order-independent) into sc[11..14] (cleared by k_pack_heads, which runs first), one thread turns them into the powers of
 // two.  (One block over the 0.36 M parameters took 72 us a step.)
 #define FB_SC_BLOCKS 64
-__global__ __launch_bounds__(256) void k_enc_scales_max(int D, int J, const float* __restrict__ W1, const float* __restrict__ b1,
-                                                        const float* __restrict__ W21, const float* __restrict__ b21,
-                                                        const float* __restrict__ W22, const float* __restrict__ b22,
-                                                        float* __restrict__ sc) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
+// the maxima one block of FB_SC_BLOCKS sees (blk = its index; 256 threads): lane 0 of every wave holds the wave's four values
+__device__ __forceinline__ void enc_scales_block_max(int blk, int D, int J, const float* __restrict__ W1, const float* __restrict__ b1,
+                                                     const float* __restrict__ W21, const float* __restrict__ b21,
+                                                     const float* __restrict__ W22, const float* __restrict__ b22,
+                                                     float& mw, float& mb, float& m1, float& l1) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = D * (D + 1) / 2;
     const int gt = blk * 256 + tid, gn = FB_SC_BLOCKS * 256;
-    float mw = 0.f, mb = 0.f, m1 = 0.f, l1 = 0.f;
+    mw = 0.f; mb = 0.f; m1 = 0.f; l1 = 0.f;
     for (int e = gt; e < D * 64; e += gn) mw = fmaxf(mw, fabsf(W21[e]));
     for (int e = gt; e < T * 64; e += gn) mw = fmaxf(mw, fabsf(W22[e]));
     for (int e = gt; e < D; e += gn) mb = fmaxf(mb, fabsf(b21[e]));
@@ -63,15 +66,21 @@ __global__ __launch_bounds__(256) void k_enc_scales_max(int D, int J, const floa
         l1 = fmaxf(l1, sacc);
     }
     mw = wave_max_dpp(mw); mb = wave_max_dpp(mb); m1 = wave_max_dpp(m1);
-    if (lane == 0) {
+}
+__global__ __launch_bounds__(256) void k_enc_scales_max(int D, int J, const float* __restrict__ W1, const float* __restrict__ b1,
+                                                        const float* __restrict__ W21, const float* __restrict__ b21,
+                                                        const float* __restrict__ W22, const float* __restrict__ b22,
+                                                        float* __restrict__ sc) {
+    float mw, mb, m1, l1;
+    enc_scales_block_max(blockIdx.x, D, J, W1, b1, W21, b21, W22, b22, mw, mb, m1, l1);
+    if ((threadIdx.x & 63) == 0) {
         uint32_t* w = (uint32_t*)(sc + 11);
         atomicMax(w + 0, __builtin_bit_cast(uint32_t, mw)); atomicMax(w + 1, __builtin_bit_cast(uint32_t, mb));
         atomicMax(w + 2, __builtin_bit_cast(uint32_t, m1)); atomicMax(w + 3, __builtin_bit_cast(uint32_t, l1));
     }
 }
-__global__ void k_enc_scales(float* __restrict__ sc) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const float mw = sc[11], mb = sc[12], m1 = sc[13], l1 = sc[14];
+// the maxima -> the eleven scale words (one thread's arithmetic)
+__device__ __forceinline__ void enc_scales_from_max(float mw, float mb, float m1, float l1, float* __restrict__ sc) {
     const float hbound = 1.001f * (fmaxf(l1, 0.f) + log1pf(expf(-fabsf(l1)))) + 1e-30f;     // softplus(l1), a hair over
     const int sw1 = f16_scale_exp(m1), sh = f16_scale_exp(hbound);
     int sw = f16_scale_exp(mw), sb = f16_scale_exp(mb), eb = sw + sh - sb;
@@ -83,17 +92,18 @@ __global__ void k_enc_scales(float* __restrict__ sc) {
     sc[5] = ldexpf(1.f, sb); sc[6] = ldexpf(1.f, eb);
     sc[7] = hbound; sc[8] = mw; sc[9] = mb; sc[10] = m1;
 }
+__global__ void k_enc_scales(float* __restrict__ sc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    enc_scales_from_max(sc[11], sc[12], sc[13], sc[14], sc);
+}
 
 // tile image: fragment (term sp, k-step s) at byte (sp * 4 + s) * 1024 + lane * 16, lane = 32 half + row; sp = 0: heads, 1:
 // remainders of Wp 2^sw; element j of it = Wp[32 T + row][16 s + 8 (j >> 2) + 4 half + (j & 3)];  a 9th fragment at
 // FB_A_BYTES carries the bias
 // gt2[group] (OFF groups only): byte offset of eps[l0] | byte offset of x[k] << 12 | (last group of its k) << 31
-__global__ void k_pack_heads_b(int n_tiles, int n_off_groups, const float* __restrict__ Wp, const float* __restrict__ bp,
-                               const uint32_t* __restrict__ gtab, const float* __restrict__ sc, uint8_t* __restrict__ img,
-                               uint32_t* __restrict__ gt2) {
-    const int T = blockIdx.x;
-    if (T >= n_tiles) return;
-    const float w_scale = sc[2], b_scale = sc[5];
+__device__ __forceinline__ void pack_heads_b_tile(int T, int n_off_groups, const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                  const uint32_t* __restrict__ gtab, float w_scale, float b_scale,
+                                                  uint8_t* __restrict__ img, uint32_t* __restrict__ gt2) {
     uint8_t* out = img + (int64_t)T * FB_IMG_BYTES;
     if (threadIdx.x < 4 && 4 * T + (int)threadIdx.x < n_off_groups) {
         const int G = 4 * T + threadIdx.x;
@@ -121,15 +131,19 @@ __global__ void k_pack_heads_b(int n_tiles, int n_off_groups, const float* __res
         ((uint16_t*)(out + FB_A_BYTES))[e] = w;
     }
 }
+__global__ void k_pack_heads_b(int n_tiles, int n_off_groups, const float* __restrict__ Wp, const float* __restrict__ bp,
+                               const uint32_t* __restrict__ gtab, const float* __restrict__ sc, uint8_t* __restrict__ img,
+                               uint32_t* __restrict__ gt2) {
+    if ((int)blockIdx.x >= n_tiles) return;
+    pack_heads_b_tile(blockIdx.x, n_off_groups, Wp, bp, gtab, sc[2], sc[5], img, gt2);
+}
 
 // fc1 weights as k-step images: k-step ks (items 16 ks .. + 15), fragment (hidden tile ht, term sp) at byte
 // ks * FB_W1_KS + (ht * 2 + sp) * 1024 + lane * 16, lane = 32 half + row; element j = W1[32 ht + row][16 ks + 8 half + j] 2^sw1
 // (zero past J)
 #define FB_W1_KS 4096
 __host__ __device__ inline int64_t fb_w1img_floats(int J) { return (int64_t)((J + 15) / 16) * (FB_W1_KS / 4); }
-__global__ void k_pack_w1_b(int J, const float* __restrict__ W1, const float* __restrict__ sc, uint8_t* __restrict__ w1img) {
-    const int ks = blockIdx.x;
-    const float w1_scale = sc[0];
+__device__ __forceinline__ void pack_w1_b_kstep(int ks, int J, const float* __restrict__ W1, float w1_scale, uint8_t* __restrict__ w1img) {
     uint8_t* out = w1img + (int64_t)ks * FB_W1_KS;
     for (int e = threadIdx.x; e < 2 * 64 * 8; e += blockDim.x) {       // (ht, lane, j)
         const int j = e & 7, lane = (e >> 3) & 63, ht = e >> 9;
@@ -139,6 +153,9 @@ __global__ void k_pack_w1_b(int J, const float* __restrict__ W1, const float* __
         uint16_t* o = (uint16_t*)(out + (ht * 2) * 1024 + lane * 16) + j;
         split2h_bits(v, o[0], o[512]);
     }
+}
+__global__ void k_pack_w1_b(int J, const float* __restrict__ W1, const float* __restrict__ sc, uint8_t* __restrict__ w1img) {
+    pack_w1_b_kstep(blockIdx.x, J, W1, sc[0], w1img);
 }
 
 // the response bytes of one B fragment (items 16 ks + 8 half + 0..7 of a person) as fp16: byte b in {0, 1, 255} ->

@@ -1,0 +1,71 @@
+// The per-step weight images of the f16x2 guide kernels in TWO launches instead of seven (k_pack_heads, k_clear_words,
+// k_enc_scales_max, k_enc_scales, k_pack_w1_b, k_pack_heads_b and -- in the backward call -- k_pack_heads_hb): a launch costs
+// a step 4-5 us however little it does (tools/minibatch_probe.py: 13 such launches were 61 of the 350 us of a B = 100 step,
+// 60 of the 1 480 us of a 125 k-person shard), and the first two kernels of the old chain ran one after the other for no
+// reason.  Same arithmetic, same images, bit for bit: the bodies are the ones the single kernels run.
+//   stage 1   blocks [0, Rp / 4): four packed rows each (k_pack_heads);  the next FB_SC_BLOCKS blocks: the partial maxima of
+//             the parameters (k_enc_scales_max), ONE set of four floats per block into sc[FB_SC_PART ..] -- no atomics,
+//             nothing to clear.
+//   stage 2   every block first turns the partial maxima into the scale words (a fixed-order maximum: identical in every
+//             block), block 0 files them in sc[0 .. 10] for the kernels of the step and clears sc[11 .. 14], the words that
+//             collect the step's largest |gx|, |gd|, |eps|, |ghpre| (k_mvn_enc_bwd_h_b*);  then by role: the fc1 k-step images
+//             (k_pack_w1_b), the head tile images (k_pack_heads_b), the unit images of the hidden gradient (k_pack_heads_hb).
+// (included by vx_abi.hip after k_mvn_bwd_hb.hip)
+#pragma once
+
+__global__ __launch_bounds__(256) void k_pack_stage1(int D, int J, const float* __restrict__ W1, const float* __restrict__ b1,
+                                                     const float* __restrict__ W21, const float* __restrict__ b21,
+                                                     const float* __restrict__ W22, const float* __restrict__ b22,
+                                                     float* __restrict__ Wp, float* __restrict__ bp, uint32_t* __restrict__ gtab,
+                                                     float* __restrict__ WpT /*or null: no kernel of this step reads it*/,
+                                                     float* __restrict__ sc) {
+    const int Rp = pk_rows(D), n_row_blocks = (Rp + 3) / 4;
+    const int blk = blockIdx.x, tid = threadIdx.x;
+    if (blk < n_row_blocks) {
+        const int T = D * (D + 1) / 2;
+        const int pr = 4 * blk + (tid >> 6), hh = tid & 63;
+        if (pr >= Rp) return;
+        int src;
+        uint32_t gcode;
+        pk_decode(pr, D, T, src, gcode);
+        const float v = (src < 0) ? 0.f : (src < T ? W22[(int64_t)src * 64 + hh] : W21[(int64_t)(src - T) * 64 + hh]);
+        Wp[(int64_t)pr * 64 + hh] = v;
+        if (WpT) WpT[(int64_t)hh * Rp + pr] = v;
+        if (hh == 0) {
+            bp[pr] = (src < 0) ? 0.f : (src < T ? b22[src] : b21[src - T]);
+            if ((pr & 7) == 0) gtab[pr >> 3] = gcode;
+        }
+        return;
+    }
+    const int b = blk - n_row_blocks;                                  // 0 .. FB_SC_BLOCKS - 1
+    __shared__ float red[4][4];
+    float mw, mb, m1, l1;
+    enc_scales_block_max(b, D, J, W1, b1, W21, b21, W22, b22, mw, mb, m1, l1);
+    if ((tid & 63) == 0) { red[tid >> 6][0] = mw; red[tid >> 6][1] = mb; red[tid >> 6][2] = m1; red[tid >> 6][3] = l1; }
+    __syncthreads();
+    if (tid < 4) sc[FB_SC_PART + 4 * b + tid] = fmaxf(fmaxf(red[0][tid], red[1][tid]), fmaxf(red[2][tid], red[3][tid]));
+}
+
+__global__ __launch_bounds__(256) void k_pack_stage2(int D, int J, int n_tiles, int n_off_groups, const float* __restrict__ W1,
+                                                     const float* __restrict__ W21, const float* __restrict__ W22,
+                                                     const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                     const uint32_t* __restrict__ gtab, float* __restrict__ sc,
+                                                     uint8_t* __restrict__ w1img, uint8_t* __restrict__ img, uint32_t* __restrict__ gt2,
+                                                     uint8_t* __restrict__ himg /*or null*/) {
+    __shared__ float scl[16];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    if (tid < 64) {
+        const f32x4 v = *(const f32x4*)(sc + FB_SC_PART + 4 * tid);    // FB_SC_BLOCKS == 64: one block's four maxima per lane
+        const float mw = wave_max_dpp(v[0]), mb = wave_max_dpp(v[1]), m1 = wave_max_dpp(v[2]), l1 = wave_max_dpp(v[3]);
+        if (tid == 0) enc_scales_from_max(mw, mb, m1, l1, scl);
+    }
+    __syncthreads();
+    if (blk == 0) {
+        if (tid < 11) sc[tid] = scl[tid];
+        else if (tid < 15) ((uint32_t*)sc)[tid] = 0u;                  // the step's operand maxima start from zero
+    }
+    const int n_w1 = (J + 15) / 16;
+    if (blk < n_w1) { pack_w1_b_kstep(blk, J, W1, scl[0], w1img); return; }
+    if (blk < n_w1 + n_tiles) { pack_heads_b_tile(blk - n_w1, n_off_groups, Wp, bp, gtab, scl[2], scl[5], img, gt2); return; }
+    if (himg) pack_heads_hb_unit(blk - n_w1 - n_tiles, D, W21, W22, scl[2], himg);
+}

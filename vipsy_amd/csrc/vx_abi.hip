@@ -24,6 +24,7 @@
 #include "k_mvn_fwd_b2.hip"
 #include "k_mvn_bwd_hb.hip"
 #include "k_mvn_bwd_hb2.hip"
+#include "k_pack_fused.hip"
 #include "k_fc1_bwd_b.hip"
 #include "k_cdm_sf.hip"
 #include "k_synth.hip"
@@ -363,6 +364,11 @@ static bool lik_h_shape(const vx_irt_cfg* cfg) {
     return !force_generic() && cfg->D >= 96 && cfg->D <= 16 * LB_NKS - 1 && cfg->model <= VX_IRT_2PL;
 }
 
+static bool bwhb_shape(const vx_irt_cfg* cfg, int64_t nb);
+// the f16x2 forward ran its fused pack launches AND the f16x2 hidden-gradient kernel will run in the backward call of the same
+// (cfg, nb): its unit images and the words that collect the step's operand maxima live in packws (k_pack_fused.hip)
+static bool hb_from_forward(const vx_irt_cfg* cfg, int64_t nb) { return fwb_shape(cfg) && bwhb_shape(cfg, nb); }
+
 // The kernels of the forward; what they leave undone is reported to the entry point below, which finishes it once the
 // kernels have been launched without an error: ximg_done (the likelihood operand image: every forward kernel but
 // k_mvn_enc_fwd_b / _b2 leaves it to a pass over x), hs_done (the fp16 terms of hT, the head weight-gradient kernel's
@@ -382,26 +388,36 @@ static int mvn_enc_forward_kernels(const vx_irt_cfg* cfg, const uint8_t* y, cons
         float* bp = Wp + (int64_t)Rp * 64;
         uint32_t* gtab = (uint32_t*)(bp + Rp);
         float* WpT = (float*)(gtab + Rp / 8 + 8);
-        hipLaunchKernelGGL(k_pack_heads, dim3(Rp), dim3(64), 0, (hipStream_t)hs, (int)cfg->D, 64, W21, b21, W22, b22, Wp,
-                           bp, gtab, WpT);
-        VX_CHECK_LAUNCH();
         // the powers of two of the f16x2 operands (the backward kernels read them too: pack_scales below)
         float* sc = packws + vx_mvn_pack_floats(cfg) - FB_NSCALES;
         hscale = sc + 3;
-        hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(64), 0, (hipStream_t)hs, (uint32_t*)(sc + 11), 4);
-        hipLaunchKernelGGL(k_enc_scales_max, dim3(FB_SC_BLOCKS), dim3(256), 0, (hipStream_t)hs, (int)dm.D, (int)dm.J, W1, b1, W21,
-                           b21, W22, b22, sc);
-        hipLaunchKernelGGL(k_enc_scales, dim3(1), dim3(64), 0, (hipStream_t)hs, sc);
-        VX_CHECK_LAUNCH();
+        if (!fwb_shape(cfg)) {
+            hipLaunchKernelGGL(k_pack_heads, dim3(Rp), dim3(64), 0, (hipStream_t)hs, (int)cfg->D, 64, W21, b21, W22, b22, Wp,
+                               bp, gtab, WpT);
+            VX_CHECK_LAUNCH();
+            hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(64), 0, (hipStream_t)hs, (uint32_t*)(sc + 11), 4);
+            hipLaunchKernelGGL(k_enc_scales_max, dim3(FB_SC_BLOCKS), dim3(256), 0, (hipStream_t)hs, (int)dm.D, (int)dm.J, W1, b1, W21,
+                               b21, W22, b22, sc);
+            hipLaunchKernelGGL(k_enc_scales, dim3(1), dim3(64), 0, (hipStream_t)hs, sc);
+            VX_CHECK_LAUNCH();
+        }
         if (fwb_shape(cfg)) {
             uint8_t* img = (uint8_t*)(WpT + (int64_t)Rp * 64);
             const int n_tiles = fb_tiles(dm.D);
             uint32_t* gt2 = (uint32_t*)(img + (int64_t)n_tiles * FB_IMG_BYTES);
             uint8_t* w1img = img + fb_img_floats(dm.D) * 4;
-            hipLaunchKernelGGL(k_pack_w1_b, dim3((dm.J + 15) / 16), dim3(256), 0, (hipStream_t)hs, dm.J, W1, (const float*)sc, w1img);
+            // every weight image of the step in two launches (k_pack_fused.hip).  The unit images of the hidden gradient are
+            // made here too when that kernel will run (hb_from_forward: the backward call then reads them from packws), and
+            // WpT only when a kernel of this step reads it (the fp32 hidden-gradient kernel)
+            const bool hb = hb_from_forward(cfg, nb);
+            uint8_t* himg = hb ? (uint8_t*)((float*)sc - hb_img_floats(dm.D)) : nullptr;
+            const int n_row_blocks = (Rp + 3) / 4, n_w1 = (dm.J + 15) / 16;
+            hipLaunchKernelGGL(k_pack_stage1, dim3(n_row_blocks + FB_SC_BLOCKS), dim3(256), 0, (hipStream_t)hs, (int)dm.D, (int)dm.J,
+                               W1, b1, W21, b21, W22, b22, Wp, bp, gtab, hb ? (float*)nullptr : WpT, sc);
             VX_CHECK_LAUNCH();
-            hipLaunchKernelGGL(k_pack_heads_b, dim3(n_tiles), dim3(256), 0, (hipStream_t)hs, n_tiles,
-                               pk_off_total(dm.D) / 8, Wp, bp, gtab, (const float*)sc, img, gt2);
+            hipLaunchKernelGGL(k_pack_stage2, dim3(n_w1 + n_tiles + (hb ? hb_units(dm.D) : 0)), dim3(256), 0, (hipStream_t)hs,
+                               (int)dm.D, (int)dm.J, n_tiles, pk_off_total(dm.D) / 8, W1, W21, W22, (const float*)Wp, (const float*)bp,
+                               (const uint32_t*)gtab, sc, w1img, img, gt2, himg);
             VX_CHECK_LAUNCH();
             const size_t ldsb = fb_lds_bytes(dm.D, dm.J);
             ximg_done = true;
@@ -908,8 +924,9 @@ int64_t vx_mvn_enc_bwd_hs_offset(const vx_irt_cfg* cfg, int64_t nb) {
 int64_t vx_mvn_pack_floats(const vx_irt_cfg* cfg) {
     if (!enc_cfg_ok(cfg)) return VX_EINVAL;
     const int64_t Rp = pk_rows(cfg->D);
-    // Wp | bp | gtab | WpT | f16x2 tile images of the heads | f16x2 k-step images of fc1 | the operands' powers of two
-    return Rp * 64 + Rp + Rp / 8 + 8 + Rp * 64 + fb_img_floats(cfg->D) + fb_w1img_floats(cfg->J) + FB_NSCALES;
+    // Wp | bp | gtab | WpT | f16x2 tile images of the heads | f16x2 k-step images of fc1 | f16x2 unit images of the hidden
+    // gradient | the operands' powers of two (and the words that collect the step's operand maxima)
+    return Rp * 64 + Rp + Rp / 8 + 8 + Rp * 64 + fb_img_floats(cfg->D) + fb_w1img_floats(cfg->J) + hb_img_floats(cfg->D) + FB_NSCALES;
 }
 
 int64_t vx_mvn_enc_param_floats(const vx_irt_cfg* cfg) {
@@ -965,8 +982,11 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     float* ghpre = workspace;
     // written by the forward call of this step (k_enc_scales): the powers of two of the f16x2 weight images
     const float* sc = packws ? packws + vx_mvn_pack_floats(cfg) - FB_NSCALES : nullptr;
-    // the step's largest |gx|, |gd|, |eps|, |ghpre| (float bits; the last words of the workspace)
-    uint32_t* maxw = (uint32_t*)(workspace + vx_mvn_enc_bwd_workspace_floats(cfg, nb) - 8);
+    // the step's largest |gx|, |gd|, |eps|, |ghpre| (float bits): words 11 .. 14 of the scale block when the forward call packed
+    // for this backward (cleared there), the last words of the workspace otherwise
+    const bool hb_fw = packws && hb_from_forward(cfg, nb);
+    uint32_t* maxw = hb_fw ? (uint32_t*)(const_cast<float*>(sc) + 11)
+                           : (uint32_t*)(workspace + vx_mvn_enc_bwd_workspace_floats(cfg, nb) - 8);
     float* slabs_w = ghpre + nb * H;
     float* slabs_f = slabs_w + (int64_t)n_prw_ws * lenw;
     hipStream_t st = (hipStream_t)hs;
@@ -994,8 +1014,12 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
             if (bwhb_shape(cfg, nb)) {
                 float* gdT1 = slabs_f + (int64_t)n_prf * lenf;
                 uint8_t* himg = (uint8_t*)(gdT1 + nb * D + 4 + (bwb_shape(cfg, nb) ? nb * 64 : 0));
-                hipLaunchKernelGGL(k_pack_heads_hb, dim3(hb_units(dm.D)), dim3(256), 0, st, dm.D, W21, W22, sc, himg, maxw);
-                VX_CHECK_LAUNCH();
+                if (hb_fw) {                                             // made by the forward call's pack launches (k_pack_fused.hip)
+                    himg = (uint8_t*)(const_cast<float*>(sc) - hb_img_floats(dm.D));
+                } else {
+                    hipLaunchKernelGGL(k_pack_heads_hb, dim3(hb_units(dm.D)), dim3(256), 0, st, dm.D, W21, W22, sc, himg, maxw);
+                    VX_CHECK_LAUNCH();
+                }
                 maxw_ready = true;
                 const size_t ldsh = hb_lds_bytes(dm.D);
                 ProfScope ps("k_mvn_enc_bwd_h_b", st);
