@@ -563,6 +563,7 @@ class _EngineBase(object):
     # build could reach, so it is opt-in, and a capture that fails with a collective inside it RAISES: the communicator may be
     # unusable after a half-recorded collective, so the process must not carry on (no eager retry).
     use_graph = True
+    graph_max_persons = int(os.environ.get("VX_GRAPH_MAX_PERSONS", "300000"))
 
     def _graph_mode(self, rows, b_global, eps, S):
         """The captured form this call can replay -- ('full' | 'rows', nb, b_global) -- or None for an eager step."""
@@ -575,7 +576,12 @@ class _EngineBase(object):
             return ("full", self.n_local, self.N) if full else None       # per-person rows: a subsample scatters dense gradients
         if D > 1 and amort and isinstance(self, IrtEngine):
             if full:
-                return ("full", self.n_local, self.N)
+                # a large shard runs short kernels BESIDE long ones on a second stream (the last chip round of the forward and
+                # the hidden gradient, the fc1 gradient); replayed from a graph the branches keep their dependencies but not
+                # their launch order, and the short kernel ends up behind the long one: measured 10.7 against 10.1 ms at 1M
+                # persons, 1.46 against 1.63 at 125 k (where the ~25 launch gaps dominate) -- so only shards up to
+                # GRAPH_MAX_PERSONS persons replay
+                return ("full", self.n_local, self.N) if self.n_local <= self.graph_max_persons else None
             if rows is not None and not isinstance(rows, (list, tuple)) and self.n_local > 0:
                 nb = int(rows.numel())
                 return ("rows", nb, int(b_global) if b_global is not None else nb)
@@ -641,7 +647,8 @@ class _EngineBase(object):
             t0 = self.t
             self._step_dev = self._ctr
             try:
-                with torch.cuda.graph(gA):
+                # (thread-local capture mode: a process group's watchdog thread may query its events while this thread records)
+                with torch.cuda.graph(gA, capture_error_mode="thread_local"):
                     # reads the counter as the Philox step, then advances it
                     self.loss_and_grads(rows_buf, mode[2] if mode[0] == "rows" else None, None, 0)
                     if one:
@@ -649,7 +656,7 @@ class _EngineBase(object):
                         self.apply_optim(lrs)                 # reads it as Adam's t
                 if not one:
                     gB = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gB, pool=gA.pool()):
+                    with torch.cuda.graph(gB, pool=gA.pool(), capture_error_mode="thread_local"):
                         self.apply_optim(lrs)
             except Exception as e:
                 if one and self.group is not None:
