@@ -108,6 +108,9 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y /*[n_local][J]*/,
  * fast kernels use, see vipsy_amd/csrc/k_pack.hip), their fp16-pair operand images and the powers of two of the
  * f16x2 operands; forward fills it, the matching backward call of the SAME step reads it. */
 int64_t vx_mvn_pack_floats(const vx_irt_cfg* cfg);
+/* float offset inside packws of the three words that collect the step's largest |gx|, |gd|, |eps| (vx_irt_lik_grad's opmax;
+ * cleared by vx_mvn_enc_forward), or -1 when this configuration does not run the f16x2 kernels that use them */
+int64_t vx_mvn_pack_opmax_offset(const vx_irt_cfg* cfg);
 
 /* ---- model likelihood + gradients for D >= 2 (irt_2pl..4pl + _get_p_data mask + Bernoulli
  * log-lik; vi.py:32-66, 596-625).  Consumes x, produces
@@ -128,11 +131,16 @@ int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows
                     const uint8_t* yT /*[J + 1][yT_stride] or NULL*/, int64_t yT_stride,
                     const uint8_t* ximg /*as written by vx_mvn_enc_forward, or NULL*/,
                     const float* epsT /*[D][nb] or NULL*/, const float* ldT /*[D][nb] or NULL*/,
-                    float* gdT /*[D][nb] or NULL: fused output gxT * epsT * ldT + scale*/, void* hip_stream);
+                    float* gdT /*[D][nb] or NULL: fused output gxT * epsT * ldT + scale*/,
+                    uint32_t* opmax /*[3] or NULL, with gdT*/, void* hip_stream);
 /* gx and gxT are the same gradient in person-major / dimension-major order; at least one must be given.
  * gdT (optional, with gxT, epsT, ldT; nb * D % 4 == 0): the DIAG-row operand of the dimension-major guide-backward kernels,
  * written in the same pass over gxT -- point it at workspace + vx_mvn_enc_bwd_gd_offset(cfg, nb) of the backward call and
  * hand that call gd_ready = 1.
+ * opmax (optional, with gdT): three words that receive, by integer atomicMax on the float bits, the largest |gx|, |gd| and
+ * |eps| of the batch -- what the f16x2 head weight-gradient kernel takes its power of two from.  Point it at packws +
+ * vx_mvn_pack_opmax_offset(cfg) (cleared by the forward call of the step) and set bit 2 of the backward call's gd_ready: the
+ * head weight gradient then starts beside the hidden gradient instead of behind it.
  * yT (optional, full batches only: rows == NULL): the responses item-major -- row j = item j over the batch rows, row J
  * and every column past nb filled with 254 ("outside the problem"), yT_stride % 64 == 0 and >= nb rounded up to 64.
  * With it, 96 <= D <= 111 runs on the MFMA kernels -- 1PL / 2PL: k_irt_lik_h.hip (fp32 results from two fp16 terms per
@@ -154,7 +162,8 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                         const uint8_t* yT /*[>= J][yT_stride] item-major copy of y (pad bytes 0 or 254), or NULL*/, int64_t yT_stride,
                         float* genc, float* workspace, const float* packws,
                         int32_t gd_ready /*bit 0: vx_irt_lik_grad already wrote gdT into the workspace; bit 1:
-                                           vx_mvn_enc_forward already wrote hs there*/, void* hip_stream);
+                                           vx_mvn_enc_forward already wrote hs there; bit 2: the operand maxima are in packws
+                                           (vx_irt_lik_grad's opmax)*/, void* hip_stream);
 /* float offset of gdT[D][nb] inside the backward workspace, or -1 when this (cfg, nb) has no such operand */
 int64_t vx_mvn_enc_bwd_gd_offset(const vx_irt_cfg* cfg, int64_t nb);
 /* float offset of hs[2][64][nb] (fp16) inside the backward workspace, or -1 when this (cfg, nb) does not use it */

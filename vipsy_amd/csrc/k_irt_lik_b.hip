@@ -579,7 +579,9 @@ __global__ __launch_bounds__(256) void k_lik_reduce_parts(const float* __restric
                                                          const float* __restrict__ x, int groups, int D, int64_t nb, int64_t nbp,
                                                          float scale, float* __restrict__ gxT, float* __restrict__ ll,
                                                          const float* __restrict__ epsT = nullptr, const float* __restrict__ ldT = nullptr,
-                                                         float* __restrict__ gdT = nullptr /*fused: gxT epsT ldT + scale*/) {
+                                                         float* __restrict__ gdT = nullptr /*fused: gxT epsT ldT + scale*/,
+                                                         uint32_t* __restrict__ opmax = nullptr /*with gdT: float bits of the largest
+                                                         |gx|, |gd|, |eps| (integer atomicMax: order-free); cleared by the caller*/) {
     __shared__ float xs[64 * 129];
     const int64_t i0 = (int64_t)blockIdx.x * 64;
     const int pv = (int)((nb - i0) < 64 ? (nb - i0) : 64);
@@ -600,6 +602,7 @@ __global__ __launch_bounds__(256) void k_lik_reduce_parts(const float* __restric
     __syncthreads();
     const int pq = tid & 15, kq = tid >> 4;                          // persons 4 pq .. 4 pq + 3, latent rows kq, kq + 16, ...
     const bool vec = (nb & 3) == 0 && 4 * pq + 4 <= pv;             // aligned full quad
+    float mg = 0.f, md = 0.f, me = 0.f;                              // this thread's largest |gx|, |gd|, |eps|
     for (int k = kq; k < D; k += 16) {
         const float* src = gx_part + (int64_t)k * nbp + i0 + 4 * pq;
         f32x4 acc = *(const f32x4*)src;                              // nbp % 64 == 0: always in bounds and aligned
@@ -614,16 +617,31 @@ __global__ __launch_bounds__(256) void k_lik_reduce_parts(const float* __restric
                 const f32x4 e = *(const f32x4*)(epsT + o), l = *(const f32x4*)(ldT + o);
                 f32x4 gdv;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) gdv[c] = fmaf(acc[c] * e[c], l[c], scale);
+                for (int c = 0; c < 4; ++c) {
+                    gdv[c] = fmaf(acc[c] * e[c], l[c], scale);
+                    mg = fmaxf(mg, fabsf(acc[c])); md = fmaxf(md, fabsf(gdv[c])); me = fmaxf(me, fabsf(e[c]));
+                }
                 *(f32x4*)(gdT + o) = gdv;
             }
         } else {
             for (int c = 0; c < 4; ++c)
                 if (4 * pq + c < pv) {
                     dst[c] = acc[c];
-                    if (gdT) gdT[o + c] = fmaf(acc[c] * epsT[o + c], ldT[o + c], scale);
+                    if (gdT) {
+                        const float ev = epsT[o + c], gdv = fmaf(acc[c] * ev, ldT[o + c], scale);
+                        gdT[o + c] = gdv;
+                        mg = fmaxf(mg, fabsf(acc[c])); md = fmaxf(md, fabsf(gdv)); me = fmaxf(me, fabsf(ev));
+                    }
                 }
         }
+    }
+    if (opmax && gdT) {
+        // the block's maxima through LDS, then one conditional atomic per word (atomic_max_raise, vx_common.h)
+        __shared__ float mred[4][3];
+        mg = wave_max_dpp(mg); md = wave_max_dpp(md); me = wave_max_dpp(me);
+        if ((tid & 63) == 0) { mred[tid >> 6][0] = mg; mred[tid >> 6][1] = md; mred[tid >> 6][2] = me; }
+        __syncthreads();
+        if (tid < 3) atomic_max_raise(opmax + tid, fmaxf(fmaxf(mred[0][tid], mred[1][tid]), fmaxf(mred[2][tid], mred[3][tid])));
     }
     if (tid < pv) {
         float acc = 0.f, sq = 0.f;

@@ -298,9 +298,9 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
         }
         __syncthreads();
         if (lane == 0 && maxw) {                                       // (before the partial waves leave)
-            atomicMax(maxw + 0, __builtin_bit_cast(uint32_t, fmaxf(g_max, x_max)));
-            atomicMax(maxw + 1, __builtin_bit_cast(uint32_t, d_max));
-            atomicMax(maxw + 2, __builtin_bit_cast(uint32_t, e_max));
+            atomic_max_raise(maxw + 0, fmaxf(g_max, x_max));
+            atomic_max_raise(maxw + 1, d_max);
+            atomic_max_raise(maxw + 2, e_max);
         }
         if (wave != 0) return;
 #pragma unroll
@@ -355,9 +355,9 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
     }
     vx_wait_vmem();                                                    // no DMA may be in flight when the LDS is released
     if (lane == 0 && maxw) {
-        atomicMax(maxw + 0, __builtin_bit_cast(uint32_t, fmaxf(g_max, x_max)));
-        atomicMax(maxw + 1, __builtin_bit_cast(uint32_t, d_max));
-        atomicMax(maxw + 2, __builtin_bit_cast(uint32_t, e_max));
+        atomic_max_raise(maxw + 0, fmaxf(g_max, x_max));
+        atomic_max_raise(maxw + 1, d_max);
+        atomic_max_raise(maxw + 2, e_max);
     }
     }
 
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
                 }
         }
         p_max = wave_max_dpp(p_max);
-        if (lane == 0 && maxw) atomicMax(maxw + 3, __builtin_bit_cast(uint32_t, p_max));
+        if (lane == 0 && maxw) atomic_max_raise(maxw + 3, p_max);
     } else if (i < nb) {
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht)

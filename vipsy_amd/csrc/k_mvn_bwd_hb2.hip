@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64 * HB2_WAVES_OF(NSET), 1) void k_mvn_enc_bwd_h_b2
     }
     HSTAMP();                                                          // 1: eps fragments
     const float u_inv = w_inv * ldexpf(1.0f, -f16_scale_exp(e_max));   // takes 2^(sw + se) off U_k, folded into gx[p][k]
-    if (lane == 0 && maxw) atomicMax(maxw + 2, __builtin_bit_cast(uint32_t, e_max));
+    if (lane == 0 && maxw) atomic_max_raise(maxw + 2, e_max);
     vx_wait_vmem();                                                    // the prologue's transfers are done: from here on
     HSTAMP();                                                          // 2: gx tile               vmcnt counts the ring alone
 
@@ -341,8 +341,8 @@ __global__ __launch_bounds__(64 * HB2_WAVES_OF(NSET), 1) void k_mvn_enc_bwd_h_b2
     vx_wait_vmem();                                                    // no DMA may be in flight when the LDS is released
     HSTAMP();                                                          // 5: sections
     if (lane == 0 && maxw) {
-        atomicMax(maxw + 0, __builtin_bit_cast(uint32_t, g_max));
-        atomicMax(maxw + 1, __builtin_bit_cast(uint32_t, d_max));
+        atomic_max_raise(maxw + 0, g_max);
+        atomic_max_raise(maxw + 1, d_max);
     }
 
     // ---- ghpre = gh * softplus'(pre) = gh * (1 - exp(-h));  C layout: rows hh = crow32(r, half), cols p
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(64 * HB2_WAVES_OF(NSET), 1) void k_mvn_enc_bwd_h_b2
     }
     if (ghpreT_out) {
         p_max = wave_max_dpp(p_max);
-        if (lane == 0 && maxw) atomicMax(maxw + 3, __builtin_bit_cast(uint32_t, p_max));
+        if (lane == 0 && maxw) atomic_max_raise(maxw + 3, p_max);
     }
 #ifdef HB2_STAMPS
     HSTAMP();                                                          // 6: output

@@ -162,15 +162,18 @@ struct SideStream {
     hipEvent_t fork = nullptr, join = nullptr;
     bool init = false, ok = false;
 };
-SideStream& side_stream() {
+SideStream& side_stream(int which = 0) {
     constexpr int MAXDEV = 16;
-    static thread_local SideStream per_dev[MAXDEV];        // (events are re-recorded per call)
+    static thread_local SideStream per_dev[2][MAXDEV];     // (events are re-recorded per call)
     static thread_local SideStream none;                   // ok == false: the single-stream paths
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return none;
-    SideStream& ss = per_dev[dev];
+    SideStream& ss = per_dev[which & 1][dev];
     if (!ss.init) {
         ss.init = true;
+        // (stream 1 carries the head weight gradient beside the launch stream's kernels.  A LOW-PRIORITY stream for it changed
+        // nothing at 1M persons -- 9.58 against 9.59 ms -- and its mere existence slowed every node of a replayed graph: 1.91
+        // against 1.38 ms for a 125 k-person shard)
         ss.ok = hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
                 hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess;
@@ -637,7 +640,8 @@ int64_t vx_irt_lik_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
 static int irt_lik_grad_kernels(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* x,
                                 const float* a, const float* b, const float* c_un, const float* d_un, float* gx, float* gxT,
                                 float* ll, float* gitem, float* workspace, const uint8_t* yT, int64_t yT_stride,
-                                const uint8_t* ximg_in, const float* epsT, const float* ldT, float* gdT, void* hs, bool& gd_done) {
+                                const uint8_t* ximg_in, const float* epsT, const float* ldT, float* gdT, uint32_t* opmax, void* hs,
+                                bool& gd_done) {
     if (lik_b_ok(cfg, rows, nb, yT, yT_stride, gxT) && aligned16(workspace) && aligned16(gxT)) {
         int groups, n_pr;
         lik_b_plan(cfg, nb, groups, n_pr);
@@ -703,7 +707,7 @@ static int irt_lik_grad_kernels(const vx_irt_cfg* cfg, const uint8_t* y, const i
         VX_CHECK_LAUNCH();
         gd_done = true;
         hipLaunchKernelGGL(k_lik_reduce_parts, dim3((unsigned)n_ptiles), dim3(256), 0, st, (const float*)gx_part, (const float*)ll_part,
-                           x, groups, (int)cfg->D, nb, nbp, cfg->scale, gxT, ll, epsT, ldT, gdT);
+                           x, groups, (int)cfg->D, nb, nbp, cfg->scale, gxT, ll, epsT, ldT, gdT, opmax);
         VX_CHECK_LAUNCH();
         if (gx) {                                          // both orders requested: gx[nb][D] = transpose(gxT[D][nb])
             hipLaunchKernelGGL(k_transpose, dim3(num_cu() * 8), dim3(256), 0, st, gxT, gx, (int64_t)cfg->D, nb);
@@ -832,9 +836,10 @@ static int irt_lik_grad_kernels(const vx_irt_cfg* cfg, const uint8_t* y, const i
 int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* x,
                     const float* a, const float* b, const float* c_un, const float* d_un, float* gx, float* gxT,
                     float* ll, float* gitem, float* workspace, const uint8_t* yT, int64_t yT_stride, const uint8_t* ximg_in,
-                    const float* epsT, const float* ldT, float* gdT, void* hs) {
+                    const float* epsT, const float* ldT, float* gdT, uint32_t* opmax, void* hs) {
     if (!lik_cfg_ok(cfg) || !y || !x || !a || !b || (!gx && !gxT) || !ll || !gitem || !workspace || nb < 0)
         return VX_EINVAL;
+    if (opmax && !gdT) return VX_EINVAL;
     if (gdT && (!gxT || !epsT || !ldT || (nb * (int64_t)cfg->D) % 4 != 0 || !aligned16(gdT) || !aligned16(gxT) ||
                 !aligned16(epsT) || !aligned16(ldT)))
         return VX_EINVAL;
@@ -842,12 +847,17 @@ int vx_irt_lik_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows
     if (cfg->model == VX_IRT_4PL && !d_un) return VX_EINVAL;
     bool gd_done = false;
     const int rc = irt_lik_grad_kernels(cfg, y, rows, nb, x, a, b, c_un, d_un, gx, gxT, ll, gitem, workspace, yT, yT_stride, ximg_in,
-                                        epsT, ldT, gdT, hs, gd_done);
+                                        epsT, ldT, gdT, opmax, hs, gd_done);
     if (rc) return rc;
     // the fused DIAG-row operand of the guide backward, for the paths that do not make it themselves
     if (gdT && !gd_done && nb > 0) {
         hipLaunchKernelGGL(k_mvn_gd, dim3(num_cu() * 8), dim3(256), 0, (hipStream_t)hs, (const float4*)gxT, (const float4*)epsT,
                            (const float4*)ldT, cfg->scale, nb * cfg->D / 4, (float4*)gdT);
+        VX_CHECK_LAUNCH();
+    }
+    if (opmax && !gd_done && nb > 0) {                     // (the fused pass collects the maxima itself)
+        hipLaunchKernelGGL(k_absmax3, dim3(num_cu() * 8), dim3(256), 0, (hipStream_t)hs, (const float*)gxT, (const float*)gdT, epsT,
+                           nb * cfg->D, opmax);
         VX_CHECK_LAUNCH();
     }
     return VX_OK;
@@ -929,6 +939,11 @@ int64_t vx_mvn_pack_floats(const vx_irt_cfg* cfg) {
     return Rp * 64 + Rp + Rp / 8 + 8 + Rp * 64 + fb_img_floats(cfg->D) + fb_w1img_floats(cfg->J) + hb_img_floats(cfg->D) + FB_NSCALES;
 }
 
+int64_t vx_mvn_pack_opmax_offset(const vx_irt_cfg* cfg) {
+    if (!enc_cfg_ok(cfg)) return VX_EINVAL;
+    return fwb_shape(cfg) ? vx_mvn_pack_floats(cfg) - FB_NSCALES + 11 : -1;
+}
+
 int64_t vx_mvn_enc_param_floats(const vx_irt_cfg* cfg) {
     if (!enc_cfg_ok(cfg)) return VX_EINVAL;
     const int64_t D = cfg->D, J = cfg->J, H = cfg->H, T = tril_len(cfg->D);
@@ -995,6 +1010,8 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     bool maxw_ready = false;                               // k_mvn_enc_bwd_h_b ran: the operand maxima of the step are collected
     bool f1_done = false;                                  // the fc1 gradient (and its slab sum) went out on the side stream
     ForkScope f1_fork;                                     // ... joined below, or by the scope on an error return
+    ForkScope bwb_fork;
+    bool bwb_done = false;
     if (packed) {
         const float* Wp = packws;
         const uint32_t* gtab = (const uint32_t*)(packws + Rp * 64 + Rp);
@@ -1003,6 +1020,25 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
             hipLaunchKernelGGL(k_mvn_gd, dim3(num_cu() * 8), dim3(256), 0, st, (const float4*)gxT, (const float4*)epsT,
                                (const float4*)ldT, cfg->scale, nb * D / 4, (float4*)gdT0);
             VX_CHECK_LAUNCH();
+        }
+        if ((gd_ready & 4) && (gd_ready & 2) && (gd_ready & 1) && hb_fw && use_t && bwb_shape(cfg, nb) && nb >= 4 &&
+            bh_lds_bytes(dm.D) <= 160 * 1024 && (mfma16_mode() & 8) && bwb_fork.fork(side_stream(1), st)) {
+            // The head weight gradient needs nothing the hidden gradient makes once the step's operand maxima are there (bit 2:
+            // vx_irt_lik_grad collected them): it starts NOW on a second, low-priority stream, and the hidden gradient and then
+            // the fc1 gradient run beside it on the launch stream.  The two large kernels each fill the chip alone; side by
+            // side their workgroups interleave and neither leaves CUs idle in its last round or behind its barriers: 5.30 ->
+            // 4.93 ms for the backward phase of the 1M step.  (The hidden-gradient kernels still add their waves' maxima to
+            // the same words: values that are already there, so the words do not change under the reader.)
+            float* gdT = slabs_f + (int64_t)n_prf * lenf;
+            uint16_t* hs3 = (uint16_t*)(gdT + nb * D + 4);
+            const size_t lds = bb_lds_bytes(dm.D);
+            rc = set_lds(k_mvn_enc_bwd_w_b, lds);
+            if (rc) return rc;
+            ProfScope ps("k_mvn_enc_bwd_w_b", bwb_fork.side(), 0, false);      // (beside other kernels: no duration of its own)
+            hipLaunchKernelGGL(k_mvn_enc_bwd_w_b, dim3((unsigned)n_rowslabs, (unsigned)n_prw), dim3(BWB_THREADS), lds, bwb_fork.side(),
+                               dm, hs3, epsT, gdT, gxT, gtab, sc, (const uint32_t*)maxw, slabs_w, Rp * (H + 1));
+            VX_CHECK_LAUNCH();
+            bwb_done = true;
         }
         if (use_t && nb >= 4 && bh_lds_bytes(dm.D) <= 160 * 1024) {
             const float* WpT = (const float*)(gtab + Rp / 8 + 8);
@@ -1111,7 +1147,10 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
             if (rc) return rc;
             f1_done = true;
         }
-        if (use_t && bwb_shape(cfg, nb)) {
+        if (bwb_done) {
+            rc = bwb_fork.join();
+            if (rc) return rc;
+        } else if (use_t && bwb_shape(cfg, nb)) {
             float* gdT = slabs_f + (int64_t)n_prf * lenf;
             uint16_t* hs3 = (uint16_t*)(gdT + nb * D + 4);
             if (!(gd_ready & 2)) {                             // bit 1: the forward call already wrote the fp16 terms of hT here

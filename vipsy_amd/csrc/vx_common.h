@@ -295,6 +295,14 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
     v = fmaxf(v, dpp_movv<0x143, 0xC>(v, v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// *w = max(*w, float bits of v) for a non-negative v, by integer atomicMax (order-free) -- but only when it would RAISE the
+// word: atomics on one address serialise in the L2 (15 625 blocks x 12 of them: +1.5 ms on a 0.7 ms kernel, measured), and
+// after the first few waves the word already holds a value no later wave exceeds.  The word is read first; a stale read can
+// only cost a redundant atomic.
+__device__ __forceinline__ void atomic_max_raise(uint32_t* w, float v) {
+    const uint32_t b = __builtin_bit_cast(uint32_t, v);
+    if (b > *(volatile const uint32_t*)w) atomicMax(w, b);
+}
 // v[lane & 31] + v[(lane & 31) + 32] in every lane: gfx950 v_permlane32_swap (VALU, no LDS round trip).
 // (the clang builtin for it mis-assigns its second result on this toolchain, hence the asm)
 __device__ __forceinline__ float half_sum32(float v) {

@@ -71,13 +71,16 @@ class HipBackend(object):
             raise _hip.VxError("vx_irt_lik_workspace_floats: unsupported configuration (code %d)" % n)
         return n
 
+    def mvn_pack_opmax_offset(self, cfg):
+        return int(self.L.vx_mvn_pack_opmax_offset(ctypes.byref(cfg)))
+
     def lik_grad(self, cfg, y, rows, nb, x, a, b, c_un, d_un, gx, ll, gitem, ws, gxT=None, yT=None, ximg=None,
-                 epsT=None, ldT=None, gdT=None):
+                 epsT=None, ldT=None, gdT=None, opmax=None):
         rc = self.L.vx_irt_lik_grad(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb, _hip.ptr(x), _hip.ptr(a),
                                     _hip.ptr(b), _hip.ptr(c_un), _hip.ptr(d_un), _hip.ptr(gx), _hip.ptr(gxT),
                                     _hip.ptr(ll), _hip.ptr(gitem), _hip.ptr(ws), _hip.ptr(yT),
                                     int(yT.shape[1]) if yT is not None else 0, _hip.ptr(ximg), _hip.ptr(epsT),
-                                    _hip.ptr(ldT), _hip.ptr(gdT), _hip.stream_ptr())
+                                    _hip.ptr(ldT), _hip.ptr(gdT), _hip.ptr(opmax), _hip.stream_ptr())
         _hip.check(rc, "vx_irt_lik_grad")
 
     def mvn_enc_bwd_workspace(self, cfg, nb):
@@ -95,14 +98,15 @@ class HipBackend(object):
     def mvn_enc_bwd_hs_offset(self, cfg, nb):
         return int(self.L.vx_mvn_enc_bwd_hs_offset(ctypes.byref(cfg), nb))
 
-    def mvn_enc_backward(self, cfg, y, rows, nb, enc, fw, gx, genc, ws, gxT=None, gd_ready=False):
+    def mvn_enc_backward(self, cfg, y, rows, nb, enc, fw, gx, genc, ws, gxT=None, gd_ready=False, opmax_ready=False):
         rc = self.L.vx_mvn_enc_backward(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb,
                                         _hip.ptr(enc["fc21.weight"]), _hip.ptr(enc["fc22.weight"]),
                                         _hip.ptr(fw["h"]), _hip.ptr(fw["eps"]), _hip.ptr(fw["ldT"]), _hip.ptr(gx),
                                         _hip.ptr(fw.get("hT")), _hip.ptr(fw.get("epsT")), _hip.ptr(gxT),
                                         _hip.ptr(fw.get("yT")), int(fw["yT"].shape[1]) if fw.get("yT") is not None else 0,
                                         _hip.ptr(genc), _hip.ptr(ws), _hip.ptr(fw.get("packws")),
-                                        int(bool(gd_ready)) | (2 if fw.get("hs") is not None else 0), _hip.stream_ptr())
+                                        int(bool(gd_ready)) | (2 if fw.get("hs") is not None else 0) | (4 if opmax_ready else 0),
+                                        _hip.stream_ptr())
         _hip.check(rc, "vx_mvn_enc_backward")
 
     def irt1d_workspace(self, cfg, nb):
@@ -926,10 +930,17 @@ class IrtEngine(_EngineBase):
                 be.mvn_enc_forward(cfg, self.y, rows, nb, self.gid0, enc, eps, fw)
             gd_off = be.mvn_enc_bwd_gd_offset(cfg, nb)     # the backward's DIAG-row operand, made in the likelihood's last pass
             gdT = encb_ws[gd_off:gd_off + nb * D] if gd_off >= 0 else None
+            # the step's largest |gx|, |gd|, |eps| (the head weight gradient's power of two), collected by the likelihood's last
+            # pass into words of packws that the forward call cleared -- unless the score-function mode replaces gxT / gdT below
+            opmax = None
+            if gdT is not None and self.estimator == "pathwise" and isinstance(be, HipBackend):
+                om = be.mvn_pack_opmax_offset(cfg)
+                if om >= 0:
+                    opmax = fw["packws"][om:om + 3]
             with self._phase("likelihood"):
                 be.lik_grad(cfg, self.y, rows, nb, fw["x"], a, self.view("b"), c_un, d_un, gx, ll, gitem, lik_ws,
                             gxT=gxT, yT=yT, ximg=fw.get("ximg"), epsT=fw["epsT"] if gdT is not None else None,
-                            ldT=fw["ldT"] if gdT is not None else None, gdT=gdT)
+                            ldT=fw["ldT"] if gdT is not None else None, gdT=gdT, **({"opmax": opmax} if opmax is not None else {}))
             if self.estimator == "score":
                 # gxT, gdT <- the score-function operands (k_mvn_score.hip); item gradients and loss stand
                 if gx is not None or gdT is None:
@@ -945,7 +956,7 @@ class IrtEngine(_EngineBase):
             with self._phase("guide_backward"):
                 be.mvn_enc_backward(cfg, self.y, rows, nb, enc, fw, gx,
                                     self.G[self.enc_off0:self.enc_off0 + self.n_enc], encb_ws, gxT=gxT,
-                                    gd_ready=gdT is not None)
+                                    gd_ready=gdT is not None, **({"opmax_ready": True} if opmax is not None else {}))
             # loss = -scale * sum_i (ll_i + ent_i); a captured step's counter advances here, behind every kernel that read it
             be.sum2_into(ll, fw["ent"], nb, -scale, lossslot, self.sum_ws, **sdc)
             self.last = {"fw": fw, "gx": gx, "gxT": gxT, "ll": ll, "nb": nb}
