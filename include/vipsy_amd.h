@@ -109,8 +109,8 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y /*[n_local][J]*/,
  * f16x2 operands; forward fills it, the matching backward call of the SAME step reads it. */
 int64_t vx_mvn_pack_floats(const vx_irt_cfg* cfg);
 /* float offset inside packws of the three words that collect the step's largest |gx|, |gd|, |eps| (vx_irt_lik_grad's opmax;
- * cleared by vx_mvn_enc_forward), or -1 when this configuration does not run the f16x2 kernels that use them */
-int64_t vx_mvn_pack_opmax_offset(const vx_irt_cfg* cfg);
+ * cleared by vx_mvn_enc_forward), or -1 when this (cfg, nb) does not run the f16x2 kernels that use them */
+int64_t vx_mvn_pack_opmax_offset(const vx_irt_cfg* cfg, int64_t nb);
 
 /* ---- model likelihood + gradients for D >= 2 (irt_2pl..4pl + _get_p_data mask + Bernoulli
  * log-lik; vi.py:32-66, 596-625).  Consumes x, produces

@@ -55,7 +55,7 @@ SIGNATURES = {
     "vx_philox_raw": (ctypes.c_int, [_P, _I64, _I64, _U64, _U32, _U32, _P]),
     "vx_mvn_enc_forward": (ctypes.c_int, [_CFG, _P, _P, _I64, _I64] + [_P] * 6 + [_P] + [_P] * 5 + [_P, _P] + [_P, _P, _P, _P]),
     "vx_mvn_pack_floats": (_I64, [_CFG]),
-    "vx_mvn_pack_opmax_offset": (_I64, [_CFG]),
+    "vx_mvn_pack_opmax_offset": (_I64, [_CFG, _I64]),
     "vx_irt_lik_workspace_floats": (_I64, [_CFG, _I64]),
     "vx_irt_lik_ximg_bytes": (_I64, [_CFG, _I64]),
     "vx_irt_lik_grad": (ctypes.c_int, [_CFG, _P, _P, _I64] + [_P] * 5 + [_P] * 4 + [_P, _P, _I64, _P] + [_P] * 3 + [_P, _P]),

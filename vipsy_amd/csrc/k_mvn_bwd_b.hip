@@ -46,7 +46,7 @@ __global__ void k_absmax3(const float* __restrict__ a, const float* __restrict__
 #pragma unroll
     for (int w = 0; w < 3; ++w) {
         const float r = wave_max_dpp(m[w]);
-        if ((threadIdx.x & 63) == 0) atomicMax(out + w, __builtin_bit_cast(uint32_t, r));
+        if ((threadIdx.x & 63) == 0) atomic_max_raise(out + w, r);        // (conditional: atomics on one word serialise in the L2)
     }
 }
 __global__ void k_clear_words(uint32_t* __restrict__ w, int n) { if ((int)threadIdx.x < n) w[threadIdx.x] = 0u; }

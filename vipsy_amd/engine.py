@@ -71,8 +71,8 @@ class HipBackend(object):
             raise _hip.VxError("vx_irt_lik_workspace_floats: unsupported configuration (code %d)" % n)
         return n
 
-    def mvn_pack_opmax_offset(self, cfg):
-        return int(self.L.vx_mvn_pack_opmax_offset(ctypes.byref(cfg)))
+    def mvn_pack_opmax_offset(self, cfg, nb):
+        return int(self.L.vx_mvn_pack_opmax_offset(ctypes.byref(cfg), nb))
 
     def lik_grad(self, cfg, y, rows, nb, x, a, b, c_un, d_un, gx, ll, gitem, ws, gxT=None, yT=None, ximg=None,
                  epsT=None, ldT=None, gdT=None, opmax=None):
@@ -934,7 +934,7 @@ class IrtEngine(_EngineBase):
             # pass into words of packws that the forward call cleared -- unless the score-function mode replaces gxT / gdT below
             opmax = None
             if gdT is not None and self.estimator == "pathwise" and isinstance(be, HipBackend):
-                om = be.mvn_pack_opmax_offset(cfg)
+                om = be.mvn_pack_opmax_offset(cfg, nb)
                 if om >= 0:
                     opmax = fw["packws"][om:om + 3]
             with self._phase("likelihood"):
