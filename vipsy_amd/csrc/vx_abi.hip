@@ -162,13 +162,22 @@ struct SideStream {
     hipEvent_t fork = nullptr, join = nullptr;
     bool init = false, ok = false;
 };
-SideStream& side_stream(int which = 0) {
-    constexpr int MAXDEV = 16;
-    static thread_local SideStream per_dev[2][MAXDEV];     // (events are re-recorded per call)
+SideStream& side_stream(int which, hipStream_t main_st) {
+    // keyed by (host thread, device, launch stream): two call sequences that run side by side on two launch streams (the two
+    // person slices of a large batch, engine.py) must not share a side stream -- they would queue behind each other there
+    constexpr int MAXDEV = 16, MAXMAIN = 4;
+    struct Slot { hipStream_t main_st; SideStream ss[2]; bool used; };
+    static thread_local Slot slots[MAXDEV][MAXMAIN];
     static thread_local SideStream none;                   // ok == false: the single-stream paths
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return none;
-    SideStream& ss = per_dev[which & 1][dev];
+    Slot* sl = nullptr;
+    for (int i = 0; i < MAXMAIN && !sl; ++i)
+        if (slots[dev][i].used && slots[dev][i].main_st == main_st) sl = &slots[dev][i];
+    for (int i = 0; i < MAXMAIN && !sl; ++i)
+        if (!slots[dev][i].used) { sl = &slots[dev][i]; sl->used = true; sl->main_st = main_st; }
+    if (!sl) sl = &slots[dev][0];                          // more launch streams than slots: share the first (still correct)
+    SideStream& ss = sl->ss[which & 1];
     if (!ss.init) {
         ss.init = true;
         // (stream 1 carries the head weight gradient beside the launch stream's kernels.  A LOW-PRIORITY stream for it changed
@@ -467,7 +476,7 @@ static int mvn_enc_forward_kernels(const vx_irt_cfg* cfg, const uint8_t* y, cons
                 VX_CHECK_LAUNCH();
                 return VX_OK;
             };
-            if (n_done > 0 && n_done < nb && (mfma16_mode() & 8) && tail_fork.fork(side_stream(), (hipStream_t)hs)) {
+            if (n_done > 0 && n_done < nb && (mfma16_mode() & 8) && tail_fork.fork(side_stream(0, (hipStream_t)hs), (hipStream_t)hs)) {
                 rc = launch_tail(tail_fork.side());
                 if (rc) return rc;                                  // (the scope joins)
             }
@@ -1023,7 +1032,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
             VX_CHECK_LAUNCH();
         }
         if ((gd_ready & 4) && (gd_ready & 2) && (gd_ready & 1) && hb_fw && use_t && bwb_shape(cfg, nb) && nb >= 4 &&
-            bh_lds_bytes(dm.D) <= 160 * 1024 && (mfma16_mode() & 8) && bwb_fork.fork(side_stream(1), st)) {
+            bh_lds_bytes(dm.D) <= 160 * 1024 && (mfma16_mode() & 8) && bwb_fork.fork(side_stream(1, st), st)) {
             // The head weight gradient needs nothing the hidden gradient makes once the step's operand maxima are there (bit 2:
             // vx_irt_lik_grad collected them): it starts NOW on a second, low-priority stream, and the hidden gradient and then
             // the fc1 gradient run beside it on the launch stream.  The two large kernels each fill the chip alone; side by
@@ -1080,7 +1089,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                     const int64_t n_done = (rem > 0 && 2 * rem <= round2 && nb > round2) ? nb - rem : nb;
                     // the short last round on the second stream beside the whole rounds (launched first), as in the forward
                     ForkScope tail_fork;
-                    const bool beside = n_done < nb && (mfma16_mode() & 8) && tail_fork.fork(side_stream(), st);
+                    const bool beside = n_done < nb && (mfma16_mode() & 8) && tail_fork.fork(side_stream(0, st), st);
                     const hipStream_t ts = beside ? tail_fork.side() : st;
                     auto launch_tail = [&]() -> int {
                         int r = set_lds(k_mvn_enc_bwd_h_b<false>, ldsh);
@@ -1131,7 +1140,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                                dm, cfg->scale, Wp, gtab, h, eps, ldT, gx, ghpre);
             VX_CHECK_LAUNCH();
         }
-        if (nb > 0 && f1t && (mfma16_mode() & 8) && f1_fork.fork(side_stream(), st)) {
+        if (nb > 0 && f1t && (mfma16_mode() & 8) && f1_fork.fork(side_stream(0, st), st)) {
             // the fc1 weight gradient needs ghpre only: it runs on a second stream beside the head weight gradient below
             // (0.33 ms of a 1M step that used to follow it) and is joined before this call returns (also on an error return)
             const hipStream_t fs = f1_fork.side();
