@@ -1031,24 +1031,29 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                                (const float4*)ldT, cfg->scale, nb * D / 4, (float4*)gdT0);
             VX_CHECK_LAUNCH();
         }
-        if ((gd_ready & 4) && (gd_ready & 2) && (gd_ready & 1) && hb_fw && use_t && bwb_shape(cfg, nb) && nb >= 4 &&
-            bh_lds_bytes(dm.D) <= 160 * 1024 && (mfma16_mode() & 8) && bwb_fork.fork(side_stream(1, st), st)) {
-            // The head weight gradient needs nothing the hidden gradient makes once the step's operand maxima are there (bit 2:
-            // vx_irt_lik_grad collected them): it starts NOW on a second, low-priority stream, and the hidden gradient and then
-            // the fc1 gradient run beside it on the launch stream.  The two large kernels each fill the chip alone; side by
-            // side their workgroups interleave and neither leaves CUs idle in its last round or behind its barriers: 5.30 ->
-            // 4.93 ms for the backward phase of the 1M step.  (The hidden-gradient kernels still add their waves' maxima to
-            // the same words: values that are already there, so the words do not change under the reader.)
+        auto launch_bwb = [&]() -> int {
             float* gdT = slabs_f + (int64_t)n_prf * lenf;
             uint16_t* hs3 = (uint16_t*)(gdT + nb * D + 4);
             const size_t lds = bb_lds_bytes(dm.D);
-            rc = set_lds(k_mvn_enc_bwd_w_b, lds);
-            if (rc) return rc;
-            ProfScope ps("k_mvn_enc_bwd_w_b", bwb_fork.side(), 0, false);      // (beside other kernels: no duration of its own)
+            int r = set_lds(k_mvn_enc_bwd_w_b, lds);
+            if (r) return r;
             hipLaunchKernelGGL(k_mvn_enc_bwd_w_b, dim3((unsigned)n_rowslabs, (unsigned)n_prw), dim3(BWB_THREADS), lds, bwb_fork.side(),
                                dm, hs3, epsT, gdT, gxT, gtab, sc, (const uint32_t*)maxw, slabs_w, Rp * (H + 1));
             VX_CHECK_LAUNCH();
+            return VX_OK;
+        };
+        if ((gd_ready & 4) && (gd_ready & 2) && (gd_ready & 1) && hb_fw && use_t && bwb_shape(cfg, nb) && nb >= 4 &&
+            bh_lds_bytes(dm.D) <= 160 * 1024 && (mfma16_mode() & 8) && bwb_fork.fork(side_stream(1, st), st)) {
+            // The head weight gradient needs nothing the hidden gradient makes once the step's operand maxima are there (bit 2:
+            // vx_irt_lik_grad collected them): it starts NOW on a second stream, and the hidden gradient and then the fc1
+            // gradient run beside it on the launch stream.  The two large kernels each fill the chip alone; side by side
+            // their workgroups interleave and neither leaves CUs idle in its last round or behind its barriers: 5.2 -> 4.7 ms
+            // for the backward phase of the 1M step.  (The hidden-gradient kernels still add their waves' maxima to the same
+            // words: values that are already there, so the words do not change under the reader.)
+            // (launched before or behind the hidden gradient: 9.63 against 9.62 ms -- the order does not matter)
             bwb_done = true;
+            rc = launch_bwb();
+            if (rc) return rc;
         }
         if (use_t && nb >= 4 && bh_lds_bytes(dm.D) <= 160 * 1024) {
             const float* WpT = (const float*)(gtab + Rp / 8 + 8);
