@@ -30,7 +30,38 @@ __host__ __device__ inline size_t fb2_lds_bytes(int D, int J, int NS = 2) {
     return FB2_WAVES * fb2_wave_floats(D, J, NS) * sizeof(float) + (size_t)(pk_off_total(D) / 8 + 4) / 4 * 16;
 }
 
-template <int NS>
+// SH (NS = 1 only; round 4): the OFF tiles come to the four waves of a workgroup through ONE ring in LDS instead of four
+// register streams.  Every wave of the plain form pulls the whole 1.5 MB image of the packed heads out of the L2 for its 32
+// persons: 49 GB a launch at the headline shape, 17.6 TB/s over the kernel -- the rate at which this chip serves a table
+// shared by every workgroup out of its L2s (MI355X_MICROARCH.md, indexed rows: 16.8-18.8 TB/s), and the reason why neither
+// a third wave a SIMD nor a split of the roles over the waves moved the kernel (docs/NOTEBOOK.md).  Shared, a tile crosses
+// the L2 -> CU path once a workgroup: a quarter of the bytes; the 9 fragment reads a tile and wave then come from LDS
+// (256 B / clock / CU).
+//   ring   three slots of one tile image (9 KB); tile t lives in slot t % 3.  Wave w transfers fragments w and w + 4 (wave 0
+//          also the bias fragment) of a tile by LDS-DMA.
+//   turn   at the end of iteration t (tile t in the MFMAs, tile t + 1 read into the other register set): wait for the
+//          reads of tile t + 1 and for the own transfers of tile t + 2 (counted: those of tile t + 3 stay in flight),
+//          barrier, then transfer tile t + 4 into the slot of tile t + 1.  A transfer has two iterations to land.
+// Two workgroups a CU as before, so the ring has to fit beside them: the eps tile loses its row padding ([32][D] + 8 floats:
+// D / 4 odd keeps the 16-byte reads of 16 lanes on distinct banks as well as the padded stride does) and the response bytes
+// are staged in QUARTERS of 128 items (three 4 KB slots a wave, chunks XOR-swizzled over the row, the fourth quarter staged
+// while the second runs) instead of whole rows (16 KB): 81,680 bytes a workgroup.  Same arithmetic in the same order: every
+// output bit-identical to the plain form (tools/fwd2_bench.hip compares checksums of all nine).
+#define FB2_RING_SLOTS 3
+__host__ __device__ inline size_t fb2_tbl_bytes(int D) { return (size_t)(pk_off_total(D) / 8 + 4) / 4 * 16; }
+__host__ __device__ inline size_t fb2s_wave_floats(int D) {       // eps tile | 3 quarter slots | the hT / hs stages
+    size_t f = (size_t)32 * D + 8;
+    if (f < 3072) f = 3072;
+    return (f + 3) & ~(size_t)3;
+}
+__host__ __device__ inline size_t fb2s_lds_bytes(int D) {
+    return FB2_WAVES * fb2s_wave_floats(D) * sizeof(float) + fb2_tbl_bytes(D) + (size_t)FB2_RING_SLOTS * FB_IMG_BYTES;
+}
+__host__ __device__ inline bool fb2s_shape_ok(int D, int J) {
+    return D % 4 == 0 && ((D >> 2) & 1) && D >= 80 && J % 4 == 0 && J <= 512 && J > 384 && pk_off_total(D) / 32 >= 4 &&
+           2 * ((fb2s_lds_bytes(D) + 1279) / 1280 * 1280) <= 160 * 1024;
+}
+template <int NS, bool SH = false>
 __global__ __launch_bounds__(FB2_THREADS, (NS == 1 ? 2 : 1)) void k_mvn_enc_fwd_b2(
     EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, int64_t gid0,
     const uint8_t* __restrict__ w1img, const float* __restrict__ b1, const uint8_t* __restrict__ img,
@@ -44,14 +75,17 @@ __global__ __launch_bounds__(FB2_THREADS, (NS == 1 ? 2 : 1)) void k_mvn_enc_fwd_
     typedef uint32_t u32x2w __attribute__((ext_vector_type(2)));
     constexpr int H = 64, FB2_WP = FB2_WP_OF(NS);
     const int D = dm.D, J = dm.J;
-    const int DS = pk_dse(D);
+    static_assert(!SH || NS == 1, "shared ring: one person set a wave");
+    const int DS = SH ? D : pk_dse(D);
     const int YS = ef_ys(J);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    float* R1 = smem + wave * fb2_wave_floats(D, J, NS);
-    int8_t* Yi = (int8_t*)R1;                                 // phase A: [64][ysr] response bytes
+    const size_t WF = SH ? fb2s_wave_floats(D) : fb2_wave_floats(D, J, NS);
+    float* R1 = smem + wave * WF;
+    int8_t* Yi = (int8_t*)R1;                                 // phase A: [64][ysr] response bytes (SH: three quarter slots)
     float* eps_lds = R1;                                      // phase B: [64][DS]
-    uint32_t* gt_lds = (uint32_t*)(smem + FB2_WAVES * fb2_wave_floats(D, J, NS));
+    uint32_t* gt_lds = (uint32_t*)(smem + FB2_WAVES * WF);
+    uint8_t* ring = (uint8_t*)gt_lds + fb2_tbl_bytes(D);       // SH: FB2_RING_SLOTS tile images
     const int64_t i0 = ((int64_t)blockIdx.x * FB2_WAVES + wave) * FB2_WP;
     const int p = l31;
     int64_t iu[NS];                                           // this lane's person of set u
@@ -74,13 +108,53 @@ __global__ __launch_bounds__(FB2_THREADS, (NS == 1 ? 2 : 1)) void k_mvn_enc_fwd_
     const int t_end = n_off + 2 * n_sec;
     for (int e = tid; e < 4 * n_off; e += FB2_THREADS) gt_lds[e] = gt2[e];
     const float w1_inv = sc[1], h_scale = sc[3], acc_inv = sc[4];
+    // SH: this wave's fragments of tile t -> slot (tiles past the end: a harmless reload of the last one, so that the counted
+    // wait of a turn always has the transfers of one tile behind the ones it waits for)
+    const uint32_t ring_lb = SH ? lds_addr_uniform(ring) : 0u;
+    auto ring_dma = [&](int t, int slot) __attribute__((always_inline)) {
+        const int tc = t < t_end ? t : t_end - 1;
+        const uint8_t* gb = img + (int64_t)tc * FB_IMG_BYTES + lane * 16;
+        const uint32_t lb = ring_lb + (uint32_t)slot * FB_IMG_BYTES;
+        dma16(gb + wave * 1024, lb + (uint32_t)wave * 1024u);
+        dma16(gb + (wave + 4) * 1024, lb + (uint32_t)(wave + 4) * 1024u);
+        if (wave == 0) dma16(gb + 8 * 1024, lb + 8u * 1024u);
+    };
+    if constexpr (SH) { ring_dma(0, 0); ring_dma(1, 1); ring_dma(2, 2); }      // land under fc1
 
     // ---------------------------------------------------------------- response rows of the wave's 64 persons
+    // SH: quarter q (items 128 q .. + 127) of the 32 persons -> slot: [32 rows][8 chunks of 16 bytes], chunk c of row r at
+    // position c ^ ((r ^ (r >> 3)) & 7); by DMA where every byte of the quarter rows lies inside y, word by word otherwise
+    const bool qdma = SH && !rows && i0 + FB2_WP <= dm.nb && (i0 + FB2_WP - 1) * (int64_t)J + 512 <= dm.nb * (int64_t)J;
+    auto stage_q = [&](int q, int slot) __attribute__((always_inline)) {
+        if (qdma) {
+            const uint32_t lb = lds_addr_uniform(R1) + (uint32_t)slot * 4096u;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int row = 8 * d + (lane >> 3), pos = lane & 7, c = pos ^ ((row ^ (row >> 3)) & 7);
+                dma16(y + (i0 + row) * J + 128 * q + 16 * c, lb + (uint32_t)d * 1024u);
+            }
+        } else {
+            uint32_t* Yw = (uint32_t*)R1 + slot * 1024;
+            for (int e = lane; e < 32 * 32; e += 64) {
+                const int row = e >> 5, w = e & 31, byte = 128 * q + 4 * w;
+                const int64_t ii = i0 + row;
+                uint32_t v = 0u;
+                if (byte < J && ii < dm.nb) {
+                    const int64_t rr = rows ? rows[ii] : ii;
+                    v = *(const uint32_t*)(y + rr * J + byte);
+                }
+                Yw[row * 32 + 4 * ((w >> 2) ^ ((row ^ (row >> 3)) & 7)) + (w & 3)] = v;
+            }
+        }
+    };
     const int n_ydma = (FB2_WP * J + 1023) / 1024;
     const bool ydense = !rows && ((J >> 2) & 1) && i0 + FB2_WP <= dm.nb && (i0 * J + (int64_t)n_ydma * 1024 <= dm.nb * (int64_t)J) &&
                         (size_t)n_ydma * 1024 <= fb2_wave_floats(D, J, NS) * sizeof(float);
     const int ysr = ydense ? J : YS;
-    if (ydense) {
+    if constexpr (SH) {
+        stage_q(0, 0); stage_q(1, 1); stage_q(2, 2);
+        if (qdma) vx_wait_vmem();
+    } else if (ydense) {
         const uint8_t* src = y + i0 * J + 16 * lane;
         const uint32_t lb = lds_addr_uniform(R1);
         for (int d = 0; d < n_ydma; ++d) dma16(src + d * 1024, lb + (uint32_t)d * 1024u);
@@ -117,7 +191,9 @@ __global__ __launch_bounds__(FB2_THREADS, (NS == 1 ? 2 : 1)) void k_mvn_enc_fwd_
         auto compute = [&](const f16x8 (&Af)[4], int ks) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < NS; ++u) {
-                const f16x8 yb = fb_y_frag((const uint32_t*)(Yi + (32 * u + p) * ysr + 16 * ks + 8 * half));
+                const int8_t* yp = SH ? Yi + ((ks >> 3) == 3 ? 0 : (ks >> 3)) * 4096 + p * 128 + 16 * ((ks & 7) ^ ((p ^ (p >> 3)) & 7)) + 8 * half
+                                      : Yi + (32 * u + p) * ysr + 16 * ks + 8 * half;
+                const f16x8 yb = fb_y_frag((const uint32_t*)yp);
                 acc[u][0] = mfma_f16(Af[1], yb, acc[u][0]); acc[u][1] = mfma_f16(Af[3], yb, acc[u][1]);
                 acc[u][0] = mfma_f16(Af[0], yb, acc[u][0]); acc[u][1] = mfma_f16(Af[2], yb, acc[u][1]);
             }
@@ -129,6 +205,17 @@ __global__ __launch_bounds__(FB2_THREADS, (NS == 1 ? 2 : 1)) void k_mvn_enc_fwd_
 #pragma unroll
             for (int u = 0; u < RG - 1; ++u) loadA(A[u], u);
             for (int c = 0; c < n_ks; c += RG) {
+                if constexpr (SH) {
+                    if (c == 8) {                              // quarter 0 has been read: its slot takes quarter 3
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
+                        stage_q(3, 0);
+                    }
+                    if (c == 24) {                             // quarter 3 has landed (the W1 loads in flight with it)
+                        if (qdma) vx_wait_vmem();
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < RG; ++u) {
                     loadA(A[(u + RG - 1) % RG], c + u + RG - 1);
@@ -145,7 +232,7 @@ __global__ __launch_bounds__(FB2_THREADS, (NS == 1 ? 2 : 1)) void k_mvn_enc_fwd_
         constexpr bool SEQ = NS == 1;
         const bool coal = i0 + FB2_WP <= dm.nb && (dm.nb & 7) == 0 && hT_out && hs_out &&
                           (((uintptr_t)hT_out | (uintptr_t)hs_out) & 15) == 0 &&
-                          fb2_wave_floats(D, J, NS) * sizeof(float) >= (SEQ ? 128 * ST_S * 2 : 64 * ST_T * 4 + 128 * ST_S * 2);   // wave-uniform
+                          WF * sizeof(float) >= (SEQ ? 128 * ST_S * 2 : 64 * ST_T * 4 + 128 * ST_S * 2);   // wave-uniform
         float* stT = R1;
         uint16_t* stS = SEQ ? (uint16_t*)R1 : (uint16_t*)(R1 + 64 * ST_T);
 #pragma unroll
@@ -239,7 +326,7 @@ __global__ __launch_bounds__(FB2_THREADS, (NS == 1 ? 2 : 1)) void k_mvn_enc_fwd_
     __builtin_amdgcn_wave_barrier();                          // response bytes no longer needed
     // ---------------------------------------------------------------- eps of the 64 persons (zero padded to DS) -> LDS, global
     const int nblk = D >> 2;                                  // D % 4 == 0 on this path
-    for (int e = lane; e < FB2_WP * DS / 4; e += 64) *(f32x4*)(R1 + 4 * e) = f32x4{0.f, 0.f, 0.f, 0.f};   // DS % 4 == 0
+    for (int e = lane; e < FB2_WP * DS / 4 + (SH ? 2 : 0); e += 64) *(f32x4*)(R1 + 4 * e) = f32x4{0.f, 0.f, 0.f, 0.f};   // DS % 4 == 0 (SH: + the 8 floats behind the last row)
     __builtin_amdgcn_wave_barrier();
     // (unrolled: one Philox call is a dependent chain of ~60 instructions, and this wave is alone on its SIMD)
 #pragma unroll 5
@@ -341,7 +428,14 @@ __global__ __launch_bounds__(FB2_THREADS, (NS == 1 ? 2 : 1)) void k_mvn_enc_fwd_
 #pragma unroll
             for (int u = 0; u < NS; ++u) {
                 const float ev = j == 0 ? E.e4[u][g].x : j == 1 ? E.e4[u][g].y : j == 2 ? E.e4[u][g].z : E.e4[u][g].w;
-                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(cur_part[u]) : "v"(a[u][4 * g + j]), "v"(ev));
+                float av = a[u][4 * g + j];
+                // The hazard recognizer does not look into asm statements, and the wait states between an MFMA and a vector
+                // read of its result are software's to insert: the FIRST read of a finished chain goes through an instruction
+                // the compiler sees (an identity DPP move of one register -- all sixteen are written by the chain's last
+                // MFMA, and volatile keeps the other reads behind this one).  Found with the three-workgroup form, whose
+                // prologue had the first FMA four instructions behind the MFMA and read the accumulator of the tile before.
+                if (g == 0 && j == 0) av = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, av), 0xE4, 0xF, 0xF, true));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(cur_part[u]) : "v"(av), "v"(ev));
             }
         if (__builtin_expect((int)code < 0, 0)) {                                 // wave-uniform, rare: the k ends here
 #pragma unroll
@@ -353,10 +447,19 @@ __global__ __launch_bounds__(FB2_THREADS, (NS == 1 ? 2 : 1)) void k_mvn_enc_fwd_
         }
     };
 
-    __syncthreads();                                           // the group table in LDS is complete
-    // (two tiles ahead with a third register set: no change, tools/fwd2_bench.hip -- the loop does not wait for the L2)
+    if constexpr (SH) vx_wait_vmem();                          // this wave's transfers of tiles 0 .. 2
+    __syncthreads();                                           // the group table in LDS is complete (SH: and the first three tiles)
+    // (two tiles ahead with a third register set: no change, tools/fwd2_bench.hip)
     TileRegs RA, RB;
-    pull(RA, 0);
+    int s_rd = 1;                                              // SH: the slot of tile t + 1
+    auto ring_read = [&](TileRegs& R, int slot) __attribute__((always_inline)) {
+        const uint8_t* lb = ring + slot * FB_IMG_BYTES + lane * 16;
+        R.bias = *(const f16x8*)(lb + FB_A_BYTES);
+#pragma unroll
+        for (int sp = 1; sp >= 0; --sp)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) R.a[sp][s] = *(const f16x8*)(lb + (sp * 4 + s) * 1024);
+    };
     f32x16 accP[NS];
 #pragma unroll
     for (int u = 0; u < NS; ++u) accP[u] = zero16();
@@ -365,7 +468,7 @@ __global__ __launch_bounds__(FB2_THREADS, (NS == 1 ? 2 : 1)) void k_mvn_enc_fwd_
         constexpr bool first = decltype(firstc)::value;
         EpiOps E;
         if constexpr (!first) epi_read(E, codeP);
-        pull(Rn, t + 1);
+        if constexpr (SH) ring_read(Rn, s_rd); else pull(Rn, t + 1);
         // two chains per tile (one per person set) on the same fragments; the epilogue of the previous tile between the
         // product groups
         f32x16 a[NS];
@@ -402,7 +505,22 @@ __global__ __launch_bounds__(FB2_THREADS, (NS == 1 ? 2 : 1)) void k_mvn_enc_fwd_
         const uint4 cv = *(const uint4*)(gt_lds + 4 * t);
         codeP.x = __builtin_amdgcn_readfirstlane(cv.x); codeP.y = __builtin_amdgcn_readfirstlane(cv.y);
         codeP.z = __builtin_amdgcn_readfirstlane(cv.z); codeP.w = __builtin_amdgcn_readfirstlane(cv.w);
+        if constexpr (SH) {                                    // the turn of the ring (see the head of the kernel)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (wave == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | 3); else __builtin_amdgcn_s_waitcnt(0x0F70 | 2);
+            __builtin_amdgcn_s_barrier();
+            ring_dma(t + 4, s_rd);
+            s_rd = s_rd == FB2_RING_SLOTS - 1 ? 0 : s_rd + 1;
+        }
     };
+    if constexpr (SH) {                                        // (tiles 0 .. 2 have landed: the wait in front of the barrier above)
+        ring_read(RA, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        ring_dma(3, 0);
+    } else {
+        pull(RA, 0);
+    }
     off_iter(RA, RB, 0, std::true_type{});
     off_iter(RB, RA, 1, std::false_type{});
     for (int t = 2; t < n_off; t += 2) {
