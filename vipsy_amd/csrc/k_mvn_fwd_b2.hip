@@ -98,6 +98,7 @@ __global__ __launch_bounds__(FB2_THREADS, (NS == 1 ? 2 : 1)) void k_mvn_enc_fwd_
     // build no stamp executes
 #ifdef FB2_STAMPS
     uint64_t st_[10]; int sn_ = 0;
+    uint64_t w_lds_ = 0, w_vm_ = 0, w_bar_ = 0;                // SH: cycles of the turn's three waits, summed over the tiles
 #define STAMP() do { __builtin_amdgcn_s_waitcnt(0); st_[sn_++] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP() do {} while (0)
@@ -506,9 +507,21 @@ __global__ __launch_bounds__(FB2_THREADS, (NS == 1 ? 2 : 1)) void k_mvn_enc_fwd_
         codeP.x = __builtin_amdgcn_readfirstlane(cv.x); codeP.y = __builtin_amdgcn_readfirstlane(cv.y);
         codeP.z = __builtin_amdgcn_readfirstlane(cv.z); codeP.w = __builtin_amdgcn_readfirstlane(cv.w);
         if constexpr (SH) {                                    // the turn of the ring (see the head of the kernel)
+#ifdef FB2_STAMPS
+            const uint64_t tw0_ = __builtin_amdgcn_s_memtime();
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef FB2_STAMPS
+            const uint64_t tw1_ = __builtin_amdgcn_s_memtime();
+#endif
             if (wave == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | 3); else __builtin_amdgcn_s_waitcnt(0x0F70 | 2);
+#ifdef FB2_STAMPS
+            const uint64_t tw2_ = __builtin_amdgcn_s_memtime();
+#endif
             __builtin_amdgcn_s_barrier();
+#ifdef FB2_STAMPS
+            { const uint64_t tw3_ = __builtin_amdgcn_s_memtime(); w_lds_ += tw1_ - tw0_; w_vm_ += tw2_ - tw1_; w_bar_ += tw3_ - tw2_; }
+#endif
             ring_dma(t + 4, s_rd);
             s_rd = s_rd == FB2_RING_SLOTS - 1 ? 0 : s_rd + 1;
         }
@@ -660,9 +673,9 @@ __global__ __launch_bounds__(FB2_THREADS, (NS == 1 ? 2 : 1)) void k_mvn_enc_fwd_
     }
 #ifdef FB2_STAMPS
     STAMP();                                                  // 6: x image
-    if ((blockIdx.x == 100 || blockIdx.x == 2000) && lane == 0 && (wave == 0 || wave == 3))
-        printf("STAMPS blk %d wave %d: y %llu fc1 %llu hout %llu eps %llu off %llu sec %llu ximg %llu total %llu\n", (int)blockIdx.x, wave,
-               st_[1] - st_[0], st_[2] - st_[1], st_[3] - st_[2], st_[4] - st_[3], st_[5] - st_[4], st_[6] - st_[5], st_[7] - st_[6],
-               st_[7] - st_[0]);
+    if ((blockIdx.x == 100 || blockIdx.x == 2000 || blockIdx.x == 5000) && lane == 0 && (wave == 0 || wave == 3))
+        printf("STAMPS blk %d wave %d: y %llu fc1 %llu hout %llu eps %llu off %llu sec %llu ximg %llu total %llu | turn waits: lds %llu dma %llu barrier %llu\n",
+               (int)blockIdx.x, wave, st_[1] - st_[0], st_[2] - st_[1], st_[3] - st_[2], st_[4] - st_[3], st_[5] - st_[4], st_[6] - st_[5],
+               st_[7] - st_[6], st_[7] - st_[0], w_lds_, w_vm_, w_bar_);
 #endif
 }

@@ -115,6 +115,16 @@ int mfma16_mode() {
     }
     return v;
 }
+// VX_FWD_RING = 0: the large-batch guide forward pulls its head tiles per wave (the form before the shared LDS ring of
+// k_mvn_fwd_b2.hip; a test seam: tests/test_gpu_parity.py::test_forward_ring_and_plain_forms_agree)
+bool fwd_ring_on() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("VX_FWD_RING");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v != 0;
+}
 bool fwb_shape(const vx_irt_cfg* cfg) {
     return (mfma16_mode() & 1) && packed_ok(cfg) && cfg->D <= 128 && fb_lds_bytes(cfg->D, cfg->J) <= 160 * 1024;
 }
@@ -481,15 +491,20 @@ static int mvn_enc_forward_kernels(const vx_irt_cfg* cfg, const uint8_t* y, cons
                 if (rc) return rc;                                  // (the scope joins)
             }
             if (n_done > 0) {
-                const size_t lds2 = fb2_lds_bytes(dm.D, dm.J, FNS);
-                rc = set_lds(k_mvn_enc_fwd_b2<FNS>, lds2);
+                // the head tiles through the workgroup's LDS ring where the shape allows it: a quarter of the L2 -> CU bytes
+                const bool ring = fwd_ring_on() && fb2s_shape_ok((int)dm.D, (int)dm.J);
+                const size_t lds2 = ring ? fb2s_lds_bytes((int)dm.D) : fb2_lds_bytes(dm.D, dm.J, FNS);
+                rc = ring ? set_lds(k_mvn_enc_fwd_b2<FNS, true>, lds2) : set_lds(k_mvn_enc_fwd_b2<FNS, false>, lds2);
                 if (rc) return rc;
                 ProfScope ps("k_mvn_enc_fwd_b2", (hipStream_t)hs, n_done);
                 const int wg = FB2_WAVES * 32 * FNS;
-                hipLaunchKernelGGL(k_mvn_enc_fwd_b2<FNS>, dim3((unsigned)((n_done + wg - 1) / wg)),
-                                   dim3(FB2_THREADS), lds2, (hipStream_t)hs, dm, y, rows, gid0, (const uint8_t*)w1img, b1,
-                                   (const uint8_t*)img, (const uint32_t*)gt2, (const float*)sc, eps_in, cfg->seed, cfg->step,
-                                   cfg->step_dev, cfg->stream, h, x, eps, ldT, ent, hT, epsT, ximg, hs_out);      // the grid stops at n_done
+                const dim3 grid2((unsigned)((n_done + wg - 1) / wg));                                             // the grid stops at n_done
+#define LAUNCH_FWD_B2(SH)                                                                                                          \
+    hipLaunchKernelGGL((k_mvn_enc_fwd_b2<FNS, SH>), grid2, dim3(FB2_THREADS), lds2, (hipStream_t)hs, dm, y, rows, gid0,          \
+                       (const uint8_t*)w1img, b1, (const uint8_t*)img, (const uint32_t*)gt2, (const float*)sc, eps_in, cfg->seed, \
+                       cfg->step, cfg->step_dev, cfg->stream, h, x, eps, ldT, ent, hT, epsT, ximg, hs_out)
+                if (ring) { LAUNCH_FWD_B2(true); } else { LAUNCH_FWD_B2(false); }
+#undef LAUNCH_FWD_B2
                 VX_CHECK_LAUNCH();
                 if (n_done == nb) return VX_OK;
             }
