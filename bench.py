@@ -31,7 +31,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: dense bf16 / fp16 matrix peak (t
 # an fp32 product computed from two fp16 terms per operand costs three fp16 MFMA products:
 PEAK_F16X2_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBS = 8000.0
-PROFILE_TAG = "r04_headline"
+PROFILE_TAG = "r04b_headline"
 
 WORKLOADS = {
     # name: (model, N, J, D, H, amortized, missing)

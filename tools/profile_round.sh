@@ -13,11 +13,12 @@ python3 $R/tools/rocpd_stats.py /tmp/prof_$TAG/r_results.db $OUT/kernel_stats.cs
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" \
-         "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
+         "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
+         "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
     i=$((i+1))
     rocprofv3 --pmc $C -d /tmp/pmc_${TAG}_$i -o r -- python3 $R/bench.py --no-cpu-baseline --steps 1 --warmup 1 "$@" > $OUT/pmc_$i.log 2>&1
 done
-python3 $R/tools/rocpd_pmc.py /tmp/pmc_${TAG}_1/r_results.db /tmp/pmc_${TAG}_2/r_results.db /tmp/pmc_${TAG}_3/r_results.db /tmp/pmc_${TAG}_4/r_results.db --match k_ --json $OUT/pmc_counters.json > /dev/null
+python3 $R/tools/rocpd_pmc.py /tmp/pmc_${TAG}_1/r_results.db /tmp/pmc_${TAG}_2/r_results.db /tmp/pmc_${TAG}_3/r_results.db /tmp/pmc_${TAG}_4/r_results.db /tmp/pmc_${TAG}_5/r_results.db --match k_ --json $OUT/pmc_counters.json > /dev/null
 # HBM bytes per launch (MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE count KB; on gfx950 FETCH_SIZE reports
 # half of the bytes of wide streaming reads, so it is doubled)
 python3 - "$OUT/pmc_counters.json" "$OUT/hbm_traffic.json" <<'PY'
