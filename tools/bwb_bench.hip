@@ -19,6 +19,13 @@ __global__ void k_fill(float* p, int64_t n, float amp, uint32_t seed) {
     }
 }
 
+__global__ void k_csum(const uint32_t* p, int64_t n, unsigned long long* out) {
+    unsigned long long a = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        a += (unsigned long long)p[i] * (unsigned long long)(((uint32_t)i * 2654435761u) | 1u);
+    atomicAdd(out, a);
+}
+
 int main(int argc, char** argv) {
     const int D = 100, H = 64;
     const int64_t nb = argc > 1 ? atoll(argv[1]) : 1000000;
@@ -56,5 +63,9 @@ int main(int argc, char** argv) {
     std::vector<float> out(8);
     CK(hipMemcpy(out.data(), slabs + 640, 32, hipMemcpyDeviceToHost));
     printf("check %g %g %g %g\n", out[0], out[1], out[2], out[3]);
+    unsigned long long* cs; CK(hipMalloc(&cs, 8)); CK(hipMemset(cs, 0, 8));
+    hipLaunchKernelGGL(k_csum, dim3(1024), dim3(256), 0, 0, (const uint32_t*)slabs, (int64_t)n_prw * Rp * 65, cs);
+    unsigned long long cv = 0; CK(hipMemcpy(&cv, cs, 8, hipMemcpyDeviceToHost));
+    printf("csum slabs %llx\n", cv);
     return 0;
 }

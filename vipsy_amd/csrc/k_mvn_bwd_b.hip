@@ -65,6 +65,9 @@ __global__ void k_clear_words(uint32_t* __restrict__ w, int n) { if ((int)thread
                                                                        // product -- 8 vector instructions a group less, and no faster
                                                                        // (2.88-2.91 against 2.83-2.84 ms on one box, tools/bwb_bench.hip)
 #endif
+#ifndef BWB_MIX
+#define BWB_MIX 1                                                       // 1: the two fp16 terms of a product straight from v_fma_mix*_f16 (below)
+#endif
 #define BWB_RT (16 / BWB_WAVES)
 #define BWB_THREADS (64 * BWB_WAVES)
 __global__ __launch_bounds__(BWB_THREADS, 1) void k_mvn_enc_bwd_w_b(
@@ -93,6 +96,9 @@ __global__ __launch_bounds__(BWB_THREADS, 1) void k_mvn_enc_bwd_w_b(
         out_inv = ldexpf(1.0f, -sv) / sc[3];                              // takes 2^(sv + sh) off the accumulators
     }
 
+    __shared__ uint32_t row_used[16];                                  // bit r: row unit r of the tile map is read by some row of the slab
+    if (tid < 16) row_used[tid] = 0u;
+    __syncthreads();
     // ---- per-lane LDS addresses: fp32 rows, persons 16 c + 8 half + 0..7 = chunks 4c + 2 half and + 1
     uint32_t aG[BWB_RT][2], aE[BWB_RT][2], aHf[2][2][2];                 // [..][chunk c]; H: [term][hidden tile][chunk]
 #pragma unroll
@@ -108,6 +114,8 @@ __global__ __launch_bounds__(BWB_THREADS, 1) void k_mvn_enc_bwd_w_b(
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) { aG[t][c] = bt_addr(g, 4 * c + 2 * half); aE[t][c] = bt_addr(e, 4 * c + 2 * half); }
+        // which row units of the tile this workgroup's 512 rows read at all (see "only what the slab reads" below)
+        if (half == 0) { atomicOr(&row_used[g >> 5], 1u << (g & 31)); atomicOr(&row_used[e >> 5], 1u << (e & 31)); }
     }
     // second 16-byte piece of a row's pair: chunk index + 1 = slot XOR 1 (4c + 2 half is even)
 #pragma unroll
@@ -138,6 +146,25 @@ __global__ __launch_bounds__(BWB_THREADS, 1) void k_mvn_enc_bwd_w_b(
     const char* vbase[BB_MAXD];
     uint32_t vsh[BB_MAXD];
     uint32_t voff[BB_MAXD];
+    // Only what the slab reads is staged.  A slab of 512 packed rows reads the G rows of its own k (a dozen of the D), the E
+    // rows below its largest k, h, and GD only in the slab with the diagonal rows: 14-23 KB a tile of 32 persons instead of the
+    // whole map's 34 KB for every slab (17.7 GB a launch through the L2 -> LDS path before).  A transfer (8 row units: 4 and
+    // the 4 eight further on) is issued if one of its units is in row_used.  The kernel's time did not change (it does not
+    // wait for these bytes, docs/NOTEBOOK.md); the L2 it shares with the kernel that runs beside it carries 40 % less.
+    __syncthreads();                                                   // row_used is complete
+    uint32_t need_u = 0u;                                              // bit u: transfer wave + BWB_WAVES u is issued
+#pragma unroll
+    for (int u = 0; u < BB_MAXD; ++u) {
+        const int d = wave + BWB_WAVES * u;
+        if (d >= dH0 && d < dGD0) {
+            need_u |= 1u << u;
+        } else if (d < n_dma) {
+            const int r0 = 16 * (d >> 1) + 4 * (d & 1);                // units r0 .. r0 + 3 and r0 + 8 .. r0 + 11
+            const uint64_t w2 = ((uint64_t)row_used[(r0 >> 5) + 1] << 32) | row_used[r0 >> 5];
+            if ((w2 >> (r0 & 31)) & 0x0F0Full) need_u |= 1u << u;
+        }
+    }
+    need_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)need_u);
 #pragma unroll
     for (int u = 0; u < BB_MAXD; ++u) {
         const int d = wave + BWB_WAVES * u;
@@ -173,7 +200,7 @@ __global__ __launch_bounds__(BWB_THREADS, 1) void k_mvn_enc_bwd_w_b(
 #pragma unroll
         for (int u = 0; u < BB_MAXD; ++u) {
             const int d = wave + BWB_WAVES * u;
-            if (d < n_dma) {
+            if (d < n_dma && ((need_u >> u) & 1u)) {
                 const bool isH = d >= dH0 && d < dGD0;
                 const char* src = vbase[u] + ((uint64_t)i0 << vsh[u]);
                 if (pv == BT_P) {
@@ -236,12 +263,12 @@ __global__ __launch_bounds__(BWB_THREADS, 1) void k_mvn_enc_bwd_w_b(
     };
     auto products0 = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { pv_[j] = amul(rg0[j], re0[j]); ps_[j] = BWB_PRESCALE ? pv_[j] : amul(pv_[j], v_scale); }
+        for (int j = 0; j < 4; ++j) { pv_[j] = amul(rg0[j], re0[j]); if (!BWB_MIX) ps_[j] = BWB_PRESCALE ? pv_[j] : amul(pv_[j], v_scale); }
         s0 = aadd(pv_[0], pv_[1]); s1 = aadd(pv_[2], pv_[3]);
     };
     auto products1 = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { pv_[4 + j] = amul(rg1[j], re1[j]); ps_[4 + j] = BWB_PRESCALE ? pv_[4 + j] : amul(pv_[4 + j], v_scale); }
+        for (int j = 0; j < 4; ++j) { pv_[4 + j] = amul(rg1[j], re1[j]); if (!BWB_MIX) ps_[4 + j] = BWB_PRESCALE ? pv_[4 + j] : amul(pv_[4 + j], v_scale); }
         s2 = aadd(pv_[4], pv_[5]); s3 = aadd(pv_[6], pv_[7]);
     };
     auto asub = [](float x, float y) -> float { float d; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; };
@@ -268,6 +295,38 @@ __global__ __launch_bounds__(BWB_THREADS, 1) void k_mvn_enc_bwd_w_b(
     auto C4 = [&](auto pc, auto nc) __attribute__((always_inline)) {
         constexpr int p = decltype(pc)::value, nx = decltype(nc)::value;
         fq[nx][1][p] = acvt(pr_[2 * p], pr_[2 * p + 1]);
+    };
+    // BWB_MIX: the split of an element pair in FOUR instructions instead of eight (two scalings, head conversion, two
+    // conversions back, two subtractions, remainder conversion).  v_fma_mixlo_f16 / v_fma_mixhi_f16 compute an fp32 fma of
+    // operands that are fp32 or one half of a register read as fp16, and write the result, rounded to fp16, into one half
+    // of the destination: head = rn16(v * 2^sv + 0), remainder = rn16(v * 2^sv - head).  Both fmas are exact in fp32 (a
+    // power-of-two scaling; the difference of a value and its own fp16 rounding), so each result is rounded once, to fp16,
+    // exactly as in the longer sequence: the same bits, except that a product of -0 splits into (+0, -0) instead of (-0, +0)
+    // (tools/bwb_bench.hip: the checksum of every slab word is the same).  16 vector instructions a group less -- and the
+    // same 2.65-2.70 ms: this kernel does not wait for its vector instructions (docs/NOTEBOOK.md, round 4).
+    // (the asm statements sit in plain lambdas: operands that are captures of a GENERIC lambda do not compile)
+    const float vs_s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v_scale)));
+    auto mix_h_lo = [](uint32_t& d, float v, float sc_) { asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(d) : "v"(v), "s"(sc_)); };
+    auto mix_h_hi = [](uint32_t& d, float v, float sc_) { asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(d) : "v"(v), "s"(sc_)); };
+    auto mix_l_lo = [](uint32_t& d, float v, float sc_, uint32_t h) {
+        asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(d) : "v"(v), "s"(sc_), "v"(h)); };
+    auto mix_l_hi = [](uint32_t& d, float v, float sc_, uint32_t h) {
+        asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(d) : "v"(v), "s"(sc_), "v"(h)); };
+    auto H1 = [&](auto pc, auto nc) __attribute__((always_inline)) {     // head of element 2 p -> low half
+        constexpr int p = decltype(pc)::value, nx = decltype(nc)::value;
+        mix_h_lo(fq[nx][0][p], pv_[2 * p], vs_s);
+    };
+    auto H2 = [&](auto pc, auto nc) __attribute__((always_inline)) {     // head of element 2 p + 1 -> high half
+        constexpr int p = decltype(pc)::value, nx = decltype(nc)::value;
+        mix_h_hi(fq[nx][0][p], pv_[2 * p + 1], vs_s);
+    };
+    auto L1 = [&](auto pc, auto nc) __attribute__((always_inline)) {     // remainder of element 2 p
+        constexpr int p = decltype(pc)::value, nx = decltype(nc)::value;
+        mix_l_lo(fq[nx][1][p], pv_[2 * p], vs_s, fq[nx][0][p]);
+    };
+    auto L2 = [&](auto pc, auto nc) __attribute__((always_inline)) {     // remainder of element 2 p + 1
+        constexpr int p = decltype(pc)::value, nx = decltype(nc)::value;
+        mix_l_hi(fq[nx][1][p], pv_[2 * p + 1], vs_s, fq[nx][0][p]);
     };
     auto frag = [&](auto cc, auto kc) -> f16x8 {
         constexpr int cu = decltype(cc)::value, k = decltype(kc)::value;
@@ -314,6 +373,21 @@ __global__ __launch_bounds__(BWB_THREADS, 1) void k_mvn_enc_bwd_w_b(
             __builtin_amdgcn_sched_barrier(0);
             acc[t][1] = mfma_f16(vh, hf[c][1][1], acc[t][1]);
             __builtin_amdgcn_sched_barrier(0);
+#if BWB_MIX
+            H1(I0, nxtc); H1(I1, nxtc); s0 = aadd(s0, s1); H2(I0, nxtc); H2(I1, nxtc); H1(I2, nxtc); H1(I3, nxtc);
+            s2 = aadd(s2, s3); H2(I2, nxtc); H2(I3, nxtc); s0 = aadd(s0, s2);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[t][0] = mfma_f16(vh, hf[c][0][0], acc[t][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            L1(I0, nxtc); L1(I1, nxtc); L2(I0, nxtc); L2(I1, nxtc);
+            if constexpr (last) bsum[tn] = aadd(bsum[tn], has_next ? s0 : 0.f); else bsum[tn] = aadd(bsum[tn], s0);
+            L1(I2, nxtc); L1(I3, nxtc);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[t][1] = mfma_f16(vh, hf[c][0][1], acc[t][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            L2(I2, nxtc); L2(I3, nxtc);
+            __builtin_amdgcn_sched_barrier(0);
+#else
             C1(I0, nxtc); C1(I1, nxtc); s0 = aadd(s0, s1); C2(I0, nxtc); C2(I1, nxtc); C3(I0); C1(I2, nxtc);
             C3(I1); C4(I0, nxtc); s2 = aadd(s2, s3); C1(I3, nxtc); s0 = aadd(s0, s2);
             __builtin_amdgcn_sched_barrier(0);
@@ -327,6 +401,7 @@ __global__ __launch_bounds__(BWB_THREADS, 1) void k_mvn_enc_bwd_w_b(
             __builtin_amdgcn_sched_barrier(0);
             C4(I2, nxtc); C4(I3, nxtc);
             __builtin_amdgcn_sched_barrier(0);
+#endif
         });
     };
 
@@ -350,10 +425,17 @@ __global__ __launch_bounds__(BWB_THREADS, 1) void k_mvn_enc_bwd_w_b(
             constexpr std::integral_constant<int, 1> o1{};
             constexpr std::integral_constant<int, 2> o2{};
             constexpr std::integral_constant<int, 3> o3{};
+#if BWB_MIX
+            H1(z, z); H2(z, z); L1(z, z); L2(z, z);
+            H1(o1, z); H2(o1, z); L1(o1, z); L2(o1, z);
+            H1(o2, z); H2(o2, z); L1(o2, z); L2(o2, z);
+            H1(o3, z); H2(o3, z); L1(o3, z); L2(o3, z);
+#else
             C1(z, z); C2(z, z); C3(z); C4(z, z);
             C1(o1, z); C2(o1, z); C3(o1); C4(o1, z);
             C1(o2, z); C2(o2, z); C3(o2); C4(o2, z);
             C1(o3, z); C2(o3, z); C3(o3); C4(o3, z);
+#endif
         }
         bsum[0] += (s0 + s1) + (s2 + s3);
         int64_t tile = t0;

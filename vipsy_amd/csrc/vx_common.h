@@ -324,7 +324,7 @@ __device__ __forceinline__ uint32_t lds_addr_uniform(const void* lds) {
     return __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) const void*)lds);
 }
 __device__ __forceinline__ void dma16(const void* gptr, uint32_t lds_byte_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_byte_addr) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_byte_addr) : "memory", "m0");
 }
 // scalar base + 32-bit per-lane byte offset (no 64-bit VALU address arithmetic per transfer)
 __device__ __forceinline__ void dma16s(const void* sbase_uniform, uint32_t voff, uint32_t lds_byte_addr) {
@@ -332,10 +332,10 @@ __device__ __forceinline__ void dma16s(const void* sbase_uniform, uint32_t voff,
     const uint64_t sa = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sa),
-                 "s"(__builtin_amdgcn_readfirstlane((int)lds_byte_addr)) : "memory");
+                 "s"(__builtin_amdgcn_readfirstlane((int)lds_byte_addr)) : "memory", "m0");
 }
 __device__ __forceinline__ void dma4(const void* gptr, uint32_t lds_byte_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gptr), "s"(lds_byte_addr) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gptr), "s"(lds_byte_addr) : "memory", "m0");
 }
 __device__ __forceinline__ void vx_wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0) only
 
