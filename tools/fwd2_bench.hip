@@ -104,6 +104,24 @@ int main(int argc, char** argv) {
                csum(ximg, (size_t)((nb + 63) / 64) * LB_XT_BYTES));
         return 0;
     };
+    if (argc > 2) {                                            // small batch: the SPLIT kernel of k_mvn_fwd_b.hip, gathered rows
+        int64_t* rows; CK(hipMalloc(&rows, nb * 8));
+        std::vector<int64_t> hr(nb); for (int64_t i = 0; i < nb; ++i) hr[i] = (i * 7919 + 13) % nb;
+        CK(hipMemcpy(rows, hr.data(), nb * 8, hipMemcpyHostToDevice));
+        const size_t ldsb = fb_lds_bytes(D, J);
+        CK(hipFuncSetAttribute((const void*)k_mvn_enc_fwd_b<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+        const unsigned gs = (unsigned)(((nb + 63) / 64) * 2);
+        for (int rep = 0; rep < 4; ++rep) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(k_mvn_enc_fwd_b<true>, dim3(gs), dim3(FB_THREADS), ldsb, 0, dm, (const uint8_t*)y, (const int64_t*)(argv[2][0] == 'd' ? nullptr : rows), (int64_t)0,
+                               (const uint8_t*)w1img, (const float*)b1, (const uint8_t*)img, (const uint32_t*)gt2, (const float*)sc, (const float*)nullptr,
+                               (uint64_t)1234, 0u, (const uint32_t*)nullptr, 0u, h, x, eps, ldT, ent, hT, epsT, ximg, hs, (int64_t)0);
+            hipEventRecord(e1); CK(hipEventSynchronize(e1));
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("k_mvn_enc_fwd_b<true> nb=%lld grid %u: %.1f us\n", (long long)nb, gs, 1000.f * ms);
+        }
+        return 0;
+    }
     if (run(std::integral_constant<int, 1>{}, std::false_type{})) return 1;
     if (run(std::integral_constant<int, 1>{}, std::true_type{})) return 1;
     return 0;

@@ -232,13 +232,20 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     float* x_lds = S1 + FB_WP * DS;                           //          [32][DX]
     uint32_t* gt_lds = (uint32_t*)(smem + FB_WAVES * enc_p_wave_floats(D, J));
     float* ent_s = (float*)(gt_lds + ((pk_off_total(D) / 8 + 4) / 4 * 4));   // SPLIT: [4][32] partial entropy sums
-    const bool writer = !SPLIT || wave == 0;
     const int64_t i0 = i_base + (SPLIT ? (int64_t)blockIdx.x * FB_WP : ((int64_t)blockIdx.x * FB_WAVES + wave) * FB_WP);
     const int p = l31;
     const int64_t i = i0 + p;
     // NOTE: no early exit -- every wave takes part in the workgroup barrier that publishes the group table; waves (and
     // lanes) past the last person compute on clamped inputs and store nothing.
     const bool wave_live = i0 < dm.nb;
+    // diagnostic build (tools/fwd2_bench.hip -DFB_STAMPS): cycles per phase of one workgroup, printed at the end
+#ifdef FB_STAMPS
+    uint64_t fst_[10]; int fsn_ = 0;
+#define FSTAMP() do { __builtin_amdgcn_s_waitcnt(0); fst_[fsn_++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FSTAMP() do {} while (0)
+#endif
+    FSTAMP();
 
     const int n_off = pk_off_total(D) / 32;                   // multiple of 6
     const int n_sec = pk_sec(D) / 32;
@@ -256,12 +263,14 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     constexpr int FB_EQ = 16;                                 // 32 * (D / 4) / 64 <= 16 for D <= 128
     f32x4 zq[FB_EQ];
     const int nblk = D >> 2;                                  // D % 4 == 0 on this path
+    // (SPLIT: the four waves have the same 32 persons and each draws a quarter of the slots, q = wave mod 4: drawn by every
+    // wave in full the normals were 45 k of the kernel's 141 k cycles at B = 100, tools/fwd2_bench.hip -DFB_STAMPS)
     auto draw_eps = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < FB_EQ; ++q) {
             const int e = lane + 64 * q;
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            if (e < FB_WP * nblk) {
+            if ((!SPLIT || (q & (FB_WAVES - 1)) == wave) && e < FB_WP * nblk) {
                 const int pp = e / nblk, blk = e - pp * nblk;
                 int64_t ii = i0 + pp;
                 if (ii >= dm.nb) ii = dm.nb - 1;              // absent persons: any finite values, never stored
@@ -282,32 +291,48 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         draw_eps();
         vx_wait_vmem();
     } else {
-        draw_eps();
+        // gathered rows, person by person: the row's byte offset is wave-uniform (read once per lane = person, handed out by
+        // v_readlane), so a load is a scalar base plus 4 * lane -- no per-element (person, word) arithmetic, which with its two
+        // integer divisions was 33 k of this phase's 50 k cycles at B = 100 (tools/fwd2_bench.hip -DFB_STAMPS; the loads
+        // themselves were not: all of a batch in flight made no difference).  16 persons a batch, the normals drawn under
+        // the first batch's latency.
+        constexpr int PB = 16, MAXLD = 4;                       // J <= 1024: at most four 64-word pieces a row
         const int YW = YS / 4, JW = J / 4;
+        const int nld = (JW + 63) >> 6, nch = (YW + 63) >> 6;   // pieces with response words | pieces of the LDS row (padding)
         uint32_t* Yw = (uint32_t*)R1;
-        for (int base = 0; base < FB_WP * YW; base += 64 * 8) {
-            uint32_t v[8];
+        int64_t rowb = 0;
+        {
+            const int64_t ii = i0 + l31;
+            if (ii < dm.nb) rowb = (rows ? rows[ii] : ii) * J;
+        }
+        const int rowb_lo = (int)(uint32_t)rowb, rowb_hi = (int)(uint32_t)((uint64_t)rowb >> 32);
+        for (int p0 = 0; p0 < FB_WP; p0 += PB) {
+            uint32_t v[PB][MAXLD];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int idx = base + q * 64 + lane;
-                v[q] = 0u;
-                if (idx < FB_WP * YW) {
-                    const int pp = idx / YW, wq = idx - pp * YW;
-                    const int64_t ii = i0 + pp;
-                    if (wq < JW && ii < dm.nb) {
-                        const int64_t row = rows ? rows[ii] : ii;
-                        v[q] = *(const uint32_t*)(y + row * J + 4 * wq);    // bytes 0/1/255 == int8 0/1/-1 (vi.py:689-691)
-                    }
+            for (int u = 0; u < PB; ++u) {
+                const int pp = p0 + u;
+                const uint64_t rb = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(rowb_hi, pp) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readlane(rowb_lo, pp);
+                const uint32_t* src = (const uint32_t*)(y + (int64_t)rb) + lane;
+                const bool live = i0 + pp < dm.nb;              // wave-uniform
+#pragma unroll
+                for (int c = 0; c < MAXLD; ++c) {
+                    v[u][c] = 0u;
+                    if (c < nld && live && lane + 64 * c < JW) v[u][c] = src[64 * c];   // bytes 0/1/255 == int8 0/1/-1 (vi.py:689-691)
                 }
             }
+            if (p0 == 0) draw_eps();
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int idx = base + q * 64 + lane;
-                if (idx < FB_WP * YW) Yw[idx] = v[q];
+            for (int u = 0; u < PB; ++u) {
+                uint32_t* dst = Yw + (p0 + u) * YW + lane;
+#pragma unroll
+                for (int c = 0; c < MAXLD + 1; ++c)
+                    if (c < nch && lane + 64 * c < YW) dst[64 * c] = c < MAXLD ? v[u][c < MAXLD ? c : 0] : 0u;
             }
         }
     }
     __builtin_amdgcn_wave_barrier();
+    FSTAMP();                                                 // 1: responses staged, normals drawn
     // ---------------------------------------------------------------- phase A: fc1 (+ softplus), both hidden tiles
     f16x8 hb[2][4];                                           // [term][k-step]: B fragments of every head tile
     {
@@ -352,24 +377,27 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
                 hv.w = softplusf_(fmaf((ht ? acc1 : acc0)[4 * g + 3], w1_inv, bb.w));
                 hreg[ht][4 * g + 0] = hv.x; hreg[ht][4 * g + 1] = hv.y;
                 hreg[ht][4 * g + 2] = hv.z; hreg[ht][4 * g + 3] = hv.w;
-                if (writer && i < dm.nb) *(float4*)(h_out + i * H + hh0) = hv;
+                if ((SPLIT ? wave == ht : true) && i < dm.nb) *(float4*)(h_out + i * H + hh0) = hv;   // SPLIT: wave ht writes tile ht
             }
         }
-        if (writer && hT_out && i < dm.nb) {                  // dimension-major copy for the weight-gradient kernel
+        // (SPLIT: every wave has h of the same persons: waves 2 and 3 write the two tiles of hT, waves 0 and 1 those of hs)
+        if (hT_out && i < dm.nb) {                            // dimension-major copy for the weight-gradient kernel
 #pragma unroll
             for (int ht = 0; ht < 2; ++ht)
+                if (SPLIT ? wave == 2 + ht : true)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hT_out[(int64_t)(32 * ht + crow32(r, half)) * dm.nb + i] = hreg[ht][r];
+                    for (int r = 0; r < 16; ++r) hT_out[(int64_t)(32 * ht + crow32(r, half)) * dm.nb + i] = hreg[ht][r];
         }
-        if (writer && hs_out && i < dm.nb) {                  // ... and the two fp16 terms of h 2^sh (as k_split2_f16)
+        if (hs_out && i < dm.nb) {                            // ... and the two fp16 terms of h 2^sh (as k_split2_f16)
             const int64_t plane = (int64_t)64 * dm.nb;
 #pragma unroll
             for (int ht = 0; ht < 2; ++ht)
+                if (SPLIT ? wave == ht : true)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t o = (int64_t)(32 * ht + crow32(r, half)) * dm.nb + i;
-                    split2h_bits(hreg[ht][r] * h_scale, hs_out[o], hs_out[plane + o]);
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t o = (int64_t)(32 * ht + crow32(r, half)) * dm.nb + i;
+                        split2h_bits(hreg[ht][r] * h_scale, hs_out[o], hs_out[plane + o]);
+                    }
         }
         // k-step s of the head GEMM takes accumulator registers 8 (s & 1) .. + 7 of hidden tile s >> 1
 #pragma unroll
@@ -381,9 +409,27 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         }
     }
     __builtin_amdgcn_wave_barrier();                          // response bytes no longer needed
+    FSTAMP();                                                 // 2: fc1, h outputs
     // ---------------------------------------------------------------- eps (zero padded to DS), x := 0
-    if (writer) {
-        for (int e = lane; e < FB_WP * (DS + DX); e += 64) S1[e] = 0.f;
+    if constexpr (SPLIT) {
+        __syncthreads();                                       // wave 0 has read its response bytes: its region takes the tile
+        // x := 0 and the padding columns of eps (disjoint from the values written below: no barrier between them)
+        for (int e = tid; e < FB_WP * DX / 4; e += FB_THREADS) *(f32x4*)(x_lds + 4 * e) = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int e = tid; e < FB_WP * (DS - D) / 4; e += FB_THREADS) {
+            const int pp = e / ((DS - D) / 4), c = e - pp * ((DS - D) / 4);
+            *(f32x4*)(eps_lds + pp * DS + D + 4 * c) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < FB_EQ; ++q) {
+            const int e = lane + 64 * q;
+            if ((q & (FB_WAVES - 1)) == wave && e < FB_WP * nblk) {       // the slots this wave drew
+                const int pp = e / nblk, blk = e - pp * nblk;
+                *(f32x4*)(eps_lds + pp * DS + 4 * blk) = zq[q];
+                if (i0 + pp < dm.nb) *(f32x4*)(eps_out + (i0 + pp) * D + 4 * blk) = zq[q];
+            }
+        }
+    } else {
+        for (int e = lane; e < FB_WP * (DS + DX) / 4; e += 64) *(f32x4*)(S1 + 4 * e) = f32x4{0.f, 0.f, 0.f, 0.f};   // DS, DX % 4 == 0
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < FB_EQ; ++q) {
@@ -394,11 +440,11 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
                 if (i0 + pp < dm.nb) *(f32x4*)(eps_out + (i0 + pp) * D + 4 * blk) = zq[q];
             }
         }
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (writer && epsT_out && i < dm.nb) {                    // dimension-major copy: 128-byte rows per half-wave
+        __builtin_amdgcn_wave_barrier();
+        if (epsT_out && i < dm.nb) {                          // dimension-major copy: 128-byte rows per half-wave
 #pragma unroll 4
-        for (int k = half; k < D; k += 2) epsT_out[(int64_t)k * dm.nb + i] = eps_lds[p * DS + k];
+            for (int k = half; k < D; k += 2) epsT_out[(int64_t)k * dm.nb + i] = eps_lds[p * DS + k];
+        }
     }
     // ---------------------------------------------------------------- phase B: packed head rows, 32 per tile
     float ent_acc = 0.f;
@@ -463,7 +509,15 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
         }
     };
 
+    FSTAMP();                                                 // 3: eps tile, epsT
     __syncthreads();                                           // the group table in LDS is complete
+    FSTAMP();                                                 // 4: barrier
+    if constexpr (SPLIT) {                                     // dimension-major copy of eps, the rows shared out over the waves
+        if (epsT_out && i < dm.nb) {
+#pragma unroll 4
+            for (int k = 2 * wave + half; k < D; k += 2 * FB_WAVES) epsT_out[(int64_t)k * dm.nb + i] = eps_lds[p * DS + k];
+        }
+    }
     // OFF tiles of this wave: all of them, or (SPLIT) a quarter -- even counts, the last range takes the remainder
     int t_lo = 0, t_hi = n_off;
     if (SPLIT) {
@@ -531,7 +585,9 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
             cur_part = 0.f;
         }
     }
+    FSTAMP();                                                 // 5: OFF tiles
     if (SPLIT) __syncthreads();                                // every OFF row is in x: the sections update it in place
+    FSTAMP();                                                 // 6: barrier
     // ---- DIAG section (exp(M_kk) eps_k, entropy, ldT) and LOC section (the loc head): 2 * n_sec tiles; RA holds the
     // first of them.  The 16 x entries a lane updates are read together, updated and written together.
     auto tile_sec = [&](const f32x16& a, int t2) __attribute__((always_inline)) {
@@ -588,14 +644,17 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     }
     vx_wait_vmem();
     __builtin_amdgcn_wave_barrier();
+    FSTAMP();                                                 // 7: sections
     // ---------------------------------------------------------------- write x, entropy part
-    if (writer && ximg_out && i0 < (dm.nb + 63) / 64 * 64) {
+    // (SPLIT: the tile is the workgroup's and complete: all four waves write the outputs)
+    const int e_lo = SPLIT ? tid : lane, e_st = SPLIT ? FB_THREADS : 64;
+    if (ximg_out && i0 < (dm.nb + 63) / 64 * 64) {
         // the likelihood kernel's operand: x_aug = [x, 1, 0..] 2^LH_XEXP as two fp16 terms (k_irt_lik_h.hip), in its LDS tile order (lb_xoff): this
         // wave's 32 persons are one half of a 64-person tile (absent persons: all-zero rows); 14 chunks of 8 columns each
         const int pvi = (int)((dm.nb - i0) < FB_WP ? (dm.nb - i0) : FB_WP);       // may be <= 0
         uint8_t* out = ximg_out + (i0 >> 6) * LH_XT_BYTES;
         const int pbase = (int)(i0 & 63);
-        for (int e = lane; e < FB_WP * 2 * LB_NKS; e += 64) {
+        for (int e = e_lo; e < FB_WP * 2 * LB_NKS; e += e_st) {
             // order of the image bytes: 32 consecutive lanes fill one 512-byte subtile (8 persons x 4 chunks), then the
             // 256-byte half subtiles (8 persons x 2 chunks): whole contiguous runs per store instruction
             int pp, ch;
@@ -621,20 +680,30 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
             *(f16x8*)(out + LB_PLANE + o) = fl;
         }
     }
-    if (writer && wave_live) {
+    if (wave_live) {
         const int pv = (int)((dm.nb - i0) < FB_WP ? (dm.nb - i0) : FB_WP);
         const int c4 = D >> 2;
-        for (int e = lane; e < pv * c4; e += 64) {
+        for (int e = e_lo; e < pv * c4; e += e_st) {
             const int pp = e / c4, c = e - pp * c4;
             *(f32x4*)(x_out + (i0 + pp) * D + 4 * c) = *(const f32x4*)(x_lds + pp * DX + 4 * c);
         }
         if (!SPLIT) ent_acc += __shfl_xor(ent_acc, 32, 64);
-        if (half == 0 && i < dm.nb) {
+        if ((SPLIT ? wave == FB_WAVES - 1 : true) && half == 0 && i < dm.nb) {
             float s = 0.f;
-            for (int k = 0; k < D; ++k) { const float e = eps_lds[p * DS + k]; s += e * e; }
+            for (int k = 0; k < D; k += 4) {                   // (D % 4 == 0; the additions in the order k = 0, 1, 2, ..)
+                const f32x4 e = *(const f32x4*)(eps_lds + p * DS + k);
+                s += e[0] * e[0]; s += e[1] * e[1]; s += e[2] * e[2]; s += e[3] * e[3];
+            }
             ent_out[i] = 0.5f * s + ent_acc;                  // -log q + const = 0.5|eps|^2 + sum_k M_kk
         }
     }
+#ifdef FB_STAMPS
+    FSTAMP();                                                 // 8: x image, x, entropy
+    if (blockIdx.x == 1 && lane == 0)
+        printf("FSTAMPS blk %d wave %d: y+draw %llu fc1 %llu eps %llu bar %llu off %llu bar %llu sec %llu out %llu total %llu\n", (int)blockIdx.x, wave,
+               fst_[1] - fst_[0], fst_[2] - fst_[1], fst_[3] - fst_[2], fst_[4] - fst_[3], fst_[5] - fst_[4], fst_[6] - fst_[5], fst_[7] - fst_[6],
+               fst_[8] - fst_[7], fst_[8] - fst_[0]);
+#endif
 }
 
 
