@@ -56,6 +56,25 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(sc, hsc, 64, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_pack_heads_hb, dim3(hb_units(D)), dim3(64), 0, 0, D, W21, W22, (const float*)sc, img, maxw);
     EncDims dm; dm.D = D; dm.J = 500; dm.H = 64; dm.Hp = 64; dm.DS = enc_ds(D); dm.T = T; dm.nb = nb;
+    if (argc > 3) {                                              // small batch: the SPLIT form of k_mvn_bwd_hb.hip
+        const size_t ldsh = hb_lds_bytes(D);
+        CK(hipFuncSetAttribute((const void*)k_mvn_enc_bwd_h_b<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh));
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int rep = 0; rep < 4; ++rep) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(k_mvn_enc_bwd_h_b<true>, dim3((unsigned)((nb + 31) / 32)), dim3(HB_THREADS), ldsh, 0, dm, (const uint8_t*)img,
+                               (const float*)sc, (const float*)h, (const float*)eps, (const float*)gxT, (const float*)gdT, (float*)nullptr,
+                               (const float*)hT, out, maxw, (int64_t)0);
+            hipEventRecord(e1); CK(hipEventSynchronize(e1));
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("k_mvn_enc_bwd_h_b<true> nb=%lld: %.1f us\n", (long long)nb, 1000.f * ms);
+        }
+        std::vector<float> o(64 * nb);
+        CK(hipMemcpy(o.data(), out, 64 * nb * 4, hipMemcpyDeviceToHost));
+        double cs = 0; for (size_t i = 0; i < o.size(); ++i) cs += (double)o[i] * (double)((i * 2654435761u) % 1000 + 1);
+        printf("checksum %.17g\n", cs);
+        return 0;
+    }
     std::vector<float> a, b;
     if (run<2>(dm, img, sc, h, eps, gxT, gdT, hT, out, maxw, nb, a)) return 1;
     CK(hipMemset(out, 0, nb * 64 * 4));

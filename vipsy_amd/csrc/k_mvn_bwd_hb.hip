@@ -124,6 +124,14 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
     (void)voff;
     if (!SPLIT) { stage_pair(0); stage_pair(1); stage_pair(2); }
 
+    // diagnostic build (tools/hb2_bench.hip -DHB_STAMPS): cycles per phase of one workgroup of the SPLIT form
+#ifdef HB_STAMPS
+    uint64_t hst_[8]; int hsn_ = 0;
+#define HSTAMP() do { __builtin_amdgcn_s_waitcnt(0); hst_[hsn_++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HSTAMP() do {} while (0)
+#endif
+    HSTAMP();
     // ---- B fragments: contraction index c = 16 s + 8 half + j of person ic as two fp16 terms of v 2^e; e from the largest
     // magnitude among the wave's persons (two passes over the values: the maximum, then the split)
     const float w_inv = 1.0f / sc[2];                                  // 2^-sw (a power of two: exact)
@@ -140,55 +148,60 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
                 v[4 * q + 0] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
             }
         };
+        // (one pass: the values stay in registers between the maximum and the split -- read twice they were two chains of
+        // loads; tools/hb2_bench.hip -DHB_STAMPS)
+        float vv[HB_NS][8];
         float m = 0.f;
 #pragma unroll
-        for (int s = 0; s < HB_NS; ++s) {
-            float v[8];
-            load8(s, v);
+        for (int s = 0; s < HB_NS; ++s) load8(s, vv[s]);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
-        }
+        for (int s = 0; s < HB_NS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(vv[s][j]));
         e_max = wave_max_dpp(m);
         const float e_scale = ldexpf(1.0f, f16_scale_exp(e_max));
 #pragma unroll
-        for (int s = 0; s < HB_NS; ++s) {
-            float v[8];
-            load8(s, v);
-            split2h_frag(v, e_scale, bf[0][s], bf[1][s]);
-        }
+        for (int s = 0; s < HB_NS; ++s) split2h_frag(vv[s], e_scale, bf[0][s], bf[1][s]);
     }
     const float u_inv = w_inv * ldexpf(1.0f, -f16_scale_exp(e_max));   // takes 2^(sw + se) off U_k, folded into gx[p][k]
+    HSTAMP();                                                          // 1: eps fragments
     // ---- this wave's gx tile [D][32] (lanes = persons: 128-byte rows of gxT), times u_inv
     float g_max = 0.f;
-    for (int k = half; k < D; k += 2) {
-        const float g = gxT[(int64_t)k * nb + ic];
-        g_max = fmaxf(g_max, fabsf(g));
-        gx_lds[k * 32 + l31] = g * u_inv;
+    for (int k0 = 0; k0 < D; k0 += 64) {                               // 32 rows per lane half in flight together (one at a
+        float t[32];                                                   // time this loop was a chain of 50 misses)
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const int k = k0 + half + 2 * q;
+            t[q] = k < D ? gxT[(int64_t)k * nb + ic] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const int k = k0 + half + 2 * q;
+            g_max = fmaxf(g_max, fabsf(t[q]));
+            if (k < D) gx_lds[k * 32 + l31] = t[q] * u_inv;
+        }
     }
     g_max = wave_max_dpp(g_max);
     // fragments of a dimension-major operand; returns the power of two that takes its scale (and the weights') off
     auto frags_from_T = [&](const float* __restrict__ srcT, float& vmax) __attribute__((always_inline)) -> float {
+        float vv[HB_NS][8];                                            // (one pass, every load in flight: as the eps fragments above)
         float m = 0.f;
 #pragma unroll
         for (int s = 0; s < HB_NS; ++s)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int c = 16 * s + 8 * half + j;
-                if (c < D) m = fmaxf(m, fabsf(srcT[(int64_t)c * nb + ic]));
+                vv[s][j] = (c < D) ? srcT[(int64_t)c * nb + ic] : 0.f;
             }
+#pragma unroll
+        for (int s = 0; s < HB_NS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(vv[s][j]));
         vmax = wave_max_dpp(m);
         const int se = f16_scale_exp(vmax);
         const float scl = ldexpf(1.0f, se);
 #pragma unroll
-        for (int s = 0; s < HB_NS; ++s) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int c = 16 * s + 8 * half + j;
-                v[j] = (c < D) ? srcT[(int64_t)c * nb + ic] : 0.f;
-            }
-            split2h_frag(v, scl, bf[0][s], bf[1][s]);
-        }
+        for (int s = 0; s < HB_NS; ++s) split2h_frag(vv[s], scl, bf[0][s], bf[1][s]);
         return w_inv * ldexpf(1.0f, -se);
     };
 
@@ -225,6 +238,7 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
     float d_max = 0.f, x_max = 0.f;                                    // wave maxima of |gd| and (again) |gx|
 
     if constexpr (SPLIT) {
+        HSTAMP();                                                      // 2: gx tile
         // ---- this wave's share of the units, fragments global -> registers one unit ahead
         auto uoff = [&](int k) -> int {                                // index of unit (k, 0): blocks of 16 k have kb + 1 units per k
             const int kb2 = (k - 1) >> 4;
@@ -266,6 +280,7 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
                 for (int r = 0; r < 16; ++r) { gh0[r] = fmaf(gk, U0[r], gh0[r]); gh1[r] = fmaf(gk, U1[r], gh1[r]); }
             }
         });
+        HSTAMP();                                                      // 3: OFF units
         // ---- DIAG (operand gd) and LOC (operand gx) units: s = wave, wave + 8, ..
         const int u_sec = hb_units_off(D);
         {
@@ -288,8 +303,10 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
 #pragma unroll
             for (int r = 0; r < 16; ++r) { gh0[r] = fmaf(cinv, S0[r], gh0[r]); gh1[r] = fmaf(cinv, S1[r], gh1[r]); }
         }
+        HSTAMP();                                                      // 4: section units
         // ---- sum of the eight partial tiles, fixed order; wave 0 keeps the result
         __syncthreads();                                               // every wave is done with its gx tile
+        HSTAMP();                                                      // 5: barrier
         float* red = (float*)smem_hb;                                  // [8 waves][32 registers][64 lanes]
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -302,6 +319,11 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
             atomic_max_raise(maxw + 1, d_max);
             atomic_max_raise(maxw + 2, e_max);
         }
+#ifdef HB_STAMPS
+        if (blockIdx.x == 1 && lane == 0 && wave != 0)
+            printf("HSTAMPS blk 1 wave %d: epsfrag %llu gx %llu off %llu sec %llu bar %llu\n", wave, hst_[1] - hst_[0], hst_[2] - hst_[1],
+                   hst_[3] - hst_[2], hst_[4] - hst_[3], hst_[5] - hst_[4]);
+#endif
         if (wave != 0) return;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -392,4 +414,11 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
                 *(float4*)(ghpre_out + i * H + hh0) = o;
             }
     }
+#ifdef HB_STAMPS
+    if (SPLIT && blockIdx.x == 1 && lane == 0) {
+        HSTAMP();
+        printf("HSTAMPS blk 1 wave 0: epsfrag %llu gx %llu off %llu sec %llu bar %llu reduce+out %llu total %llu\n", hst_[1] - hst_[0], hst_[2] - hst_[1],
+               hst_[3] - hst_[2], hst_[4] - hst_[3], hst_[5] - hst_[4], hst_[6] - hst_[5], hst_[6] - hst_[0]);
+    }
+#endif
 }
