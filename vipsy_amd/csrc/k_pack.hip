@@ -35,8 +35,15 @@ __device__ __forceinline__ void pk_decode(int pr, int D, int T, int& src, uint32
     gcode = PK_NONE << 28;
     if (pr < offT) {
         if (pr < pk_off_rows(D)) {
-            int k = 1;
-            while (k + 1 <= D - 1 && pk_off_rows(k + 1) <= pr) ++k;   // D <= 127: a short search
+            // the largest k <= D - 1 with pk_off_rows(k) <= pr.  Blocks of eight k: 32 q (q + 1) rows before k = 8 q + 1, then
+            // 8 (q + 1) rows a k -- the block from a square root (and a step either way for its rounding), the k inside it by
+            // a division.  (A linear search over k was up to 99 trips a wave: most of the 17-20 us of the two launches that
+            // decode every packed row, at any batch size.)
+            int q = (int)((sqrtf(1.0f + 0.125f * (float)pr) - 1.0f) * 0.5f);
+            while (32 * (q + 1) * (q + 2) <= pr) ++q;
+            while (q > 0 && 32 * q * (q + 1) > pr) --q;
+            int k = 8 * q + 1 + (pr - 32 * q * (q + 1)) / (8 * (q + 1));
+            if (k > D - 1) k = D - 1;
             const int l = pr - pk_off_rows(k);
             if (l < k) src = k * (k + 1) / 2 + l;
             gcode = (PK_OFF << 28) | ((uint32_t)k << 12) | (uint32_t)(l & ~7);
