@@ -492,13 +492,14 @@ np.savez(sys.argv[2], loss=float(eng.G[eng.n_params].item()), g=eng.G[:eng.n_par
         assert np.abs(g0 - g1).max() <= 2e-5 * max(1.0, np.abs(g1).max())
 
 
-@pytest.mark.parametrize("N", [33024, 70016])
-def test_forward_ring_and_plain_forms_agree(N, tmp_path):
+@pytest.mark.parametrize("N,D", [(33024, 100), (70016, 100), (33024, 92), (33024, 84)])
+def test_forward_ring_and_plain_forms_agree(N, D, tmp_path):
     """The large-batch guide forward takes its head tiles through an LDS ring shared by a workgroup's four waves
     (k_mvn_fwd_b2.hip, SH); VX_FWD_RING=0 in a child process selects the form in which every wave pulls them itself.
     The arithmetic and its order are the same: every output of the forward -- and with it the loss and every gradient of
     the step -- has to agree BIT FOR BIT (33 024: whole workgroups only; 70 016: a ragged last tile beside the whole
-    rounds).  Both are checked against the oracle by test_headline_large_batch_kernels_vs_oracle."""
+    rounds; D = 92 and 84: the other latent widths whose tiles fit the ring's LDS budget, eps rows of a different bank
+    phase).  Both are checked against the oracle by test_headline_large_batch_kernels_vs_oracle."""
     import os
     import subprocess
     import sys
@@ -507,7 +508,7 @@ import os, sys, numpy as np, torch
 sys.path.insert(0, %r)
 from vipsy_amd.engine import IrtEngine
 rng = np.random.RandomState(9)
-N, J, D, H = int(sys.argv[1]), 500, 100, 64
+N, J, D, H = int(sys.argv[1]), 500, int(sys.argv[3]), 64
 y = rng.randint(0, 2, size=(N, J)).astype(np.uint8); y[rng.rand(N, J) < 0.2] = 255
 eng = IrtEngine(torch.from_numpy(y).cuda(), model="irt_2pl", D=D, amortized=True, H=H, seed=23)
 eng.unconstrained("b").copy_(torch.from_numpy(0.5 * rng.randn(1, J)).float())
@@ -522,7 +523,7 @@ np.savez(sys.argv[2], loss=eng.G[eng.n_params:eng.n_params + 1].cpu().numpy(), g
     for mode in ("1", "0"):
         env = dict(os.environ, VX_FWD_RING=mode, VX_FORCE_GENERIC="0")
         out = str(tmp_path / ("ring_%s.npz" % mode))
-        p = subprocess.run([sys.executable, "-c", code, str(N), out], env=env, capture_output=True, text=True, timeout=900)
+        p = subprocess.run([sys.executable, "-c", code, str(N), out, str(D)], env=env, capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, p.stderr[-2000:]
         res[mode] = dict(np.load(out))
     assert set(res["1"]) == set(res["0"]) and {"x", "eps", "h", "hT", "loss", "g"} <= set(res["1"])
