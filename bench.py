@@ -399,6 +399,9 @@ def main():
         out["config"]["launch"] = ("whole step replayed from HIP graphs (one; two around the eager all-reduce when sharded); "
                                    "phase_ms / kernel_ms / roofline.avg_launch_ms from an eager pass with HIP events AFTER the "
                                    "timed region") if graphed else "kernel by kernel, HIP events around the large kernels inside the timed region"
+        if getattr(eng, "graph_fallback", None):             # capture beside the live communicator failed: said in the line
+            out["config"]["launch"] = ("kernel by kernel -- HIP graph capture of the sharded step failed on this rank (%s); same "
+                                       "kernels, launched one by one" % eng.graph_fallback[:160])
         if graph_ms is not None:
             out["graph_replay_ms_per_step"] = graph_ms         # same step, same engine, replayed from its HIP graph afterwards
         if os.environ.get("VX_MFMA16"):                     # non-default kernel selection: say so in the line itself

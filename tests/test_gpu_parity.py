@@ -780,6 +780,45 @@ def test_captured_amortized_step_equals_eager_step(N, B):
         assert np.array_equal(u, v)
 
 
+def test_failed_capture_of_a_sharded_step_degrades_to_the_eager_step(monkeypatch):
+    """A sharded step is captured WITHOUT its collective (two replays around an eager all-reduce).  If that capture fails
+    beside a live communicator, the rank must warn and carry on kernel by kernel with the same results -- not end the job
+    (VX_GRAPH_STRICT=1 keeps it an error).  The failure is injected: the process group is a one-rank gloo group, the graph
+    object raises when the capture begins."""
+    import torch.distributed as dist
+    from vipsy_amd.engine import IrtEngine, LrSpec
+    if not dist.is_initialized():
+        dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:29731", rank=0, world_size=1)
+    N, J, D, H = 2048, 500, 100, 64
+    y, _, _ = _random_problem(N, J, D, H, "irt_2pl", 0.1, seed=77)
+    lrs = LrSpec(lambda m, p: {"lr": 1e-2 if p in ("a", "b") else 1e-3})
+    ref = IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_2pl", D=D, amortized=True, H=H, seed=11)
+    ref.use_graph = False
+    want = [float(ref.step(lrs)) for _ in range(4)]
+
+    class Broken(torch.cuda.CUDAGraph):
+        def capture_begin(self, *a, **k):
+            raise RuntimeError("injected: capture refused")
+    eng = IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_2pl", D=D, amortized=True, H=H, seed=11, group=dist.group.WORLD)
+    monkeypatch.setattr(torch.cuda, "CUDAGraph", Broken)
+    with pytest.warns(UserWarning, match="graph capture of the sharded step failed"):
+        got = [float(eng.step(lrs)) for _ in range(4)]
+    monkeypatch.undo()
+    torch.cuda.synchronize()
+    assert eng.graph_fallback and eng.use_graph is False
+    assert got == want
+    np.testing.assert_array_equal(eng.P.cpu().numpy(), ref.P.cpu().numpy())
+    # strict mode: the same failure is an error
+    eng2 = IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_2pl", D=D, amortized=True, H=H, seed=11, group=dist.group.WORLD)
+    monkeypatch.setattr(torch.cuda, "CUDAGraph", Broken)
+    monkeypatch.setenv("VX_GRAPH_STRICT", "1")
+    eng2.step(lrs)                                             # the first step of a form is eager
+    with pytest.raises(RuntimeError, match="injected"):
+        eng2.step(lrs)
+    monkeypatch.undo()
+    dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("H", [96, 128])
 def test_irt1d_amortized_wide_hidden_layer(H):
     """NormEncoder with hidden_dim > 64 (vi.py:417-435 takes any width)."""

@@ -667,6 +667,11 @@ class _EngineBase(object):
                     raise RuntimeError("capturing the step with its RCCL all-reduce failed; the communicator may be unusable "
                                        "after a half-recorded collective, so this process must not carry on -- run again "
                                        "without VX_GRAPH_COLLECTIVE=1 (two replays around an eager all-reduce)") from e
+                if self.group is not None and os.environ.get("VX_GRAPH_STRICT", "0") != "1":
+                    # no collective was being recorded: the communicator is untouched and the same kernels can be launched one
+                    # by one.  Sharded steps have never been captured next to a live RCCL communicator on the builder's boxes
+                    # (one GPU each), so a failure here degrades -- loudly -- to the eager step instead of ending the job.
+                    raise _GraphCaptureFailed(repr(e)) from e
                 raise
             finally:
                 self._step_dev = None
@@ -702,9 +707,19 @@ class _EngineBase(object):
             if not hasattr(self, "_graphs"):
                 self._graphs = {}
             if mode in self._graphs:
-                return self._step_graph(lrs, mode, rows)
-            self._graphs[mode] = {"graph": None}             # the first step of a form runs eagerly: workspaces and lists get built
-            self._graph = self._graphs[mode]
+                try:
+                    return self._step_graph(lrs, mode, rows)
+                except _GraphCaptureFailed as e:
+                    import warnings
+                    warnings.warn("HIP graph capture of the sharded step failed (%s): this rank steps kernel by kernel from "
+                                  "here on (VX_GRAPH_STRICT=1 makes this an error)" % e)
+                    self.use_graph = False                   # (same kernels, same results: launched one by one)
+                    self.graph_fallback = str(e)
+                    del self._graphs[mode]
+                    mode = None
+            if mode is not None:
+                self._graphs[mode] = {"graph": None}         # the first step of a form runs eagerly: workspaces and lists get built
+                self._graph = self._graphs[mode]
         rows = self._rows_on_device(rows)
         if S == 1:
             self.loss_and_grads(rows[0] if isinstance(rows, (list, tuple)) else rows, b_global,
@@ -727,6 +742,10 @@ class _EngineBase(object):
         with self._phase("optimizer"):
             self.apply_optim(lrs)
         return self.step_loss()
+
+
+class _GraphCaptureFailed(RuntimeError):
+    """Capture of a sharded step (no collective inside) failed; _EngineBase.step() falls back to the eager step."""
 
 
 class IrtEngine(_EngineBase):
