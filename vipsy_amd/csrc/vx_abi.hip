@@ -26,6 +26,7 @@
 #include "k_mvn_bwd_hb2.hip"
 #include "k_pack_fused.hip"
 #include "k_fc1_bwd_b.hip"
+#include "k_fc1_bwd_c.hip"
 #include "k_cdm_sf.hip"
 #include "k_synth.hip"
 #include "k_vaeccdm.hip"
@@ -121,6 +122,16 @@ bool fwd_ring_on() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("VX_FWD_RING");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v != 0;
+}
+// VX_FC1_LDS = 0: the fc1 weight gradient of the full-batch MVN step with operands global -> registers (k_fc1_bwd_b.hip, the
+// form before k_fc1_bwd_c.hip's LDS staging)
+bool fc1_lds_on() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("VX_FC1_LDS");
         v = (e && e[0] == '0') ? 0 : 1;
     }
     return v != 0;
@@ -1166,7 +1177,12 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
             const hipStream_t fs = f1_fork.side();
             {
                 ProfScope ps("k_fc1_bwd_b", fs);
-                if (maxw_ready)
+                if (maxw_ready && fc1_lds_on()) {                       // operands through LDS (k_fc1_bwd_c.hip)
+                    rc = set_lds(k_fc1_bwd_c<true>, f1c_lds_bytes());
+                    if (rc) return rc;
+                    hipLaunchKernelGGL(k_fc1_bwd_c<true>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(256),
+                                       f1c_lds_bytes(), fs, dm, yT, yT_stride, ghpre, slabs_f, lenf, (const uint32_t*)maxw);
+                } else if (maxw_ready)
                     hipLaunchKernelGGL(k_fc1_bwd_b<true>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0,
                                        fs, dm, yT, yT_stride, ghpre, slabs_f, lenf, (const uint32_t*)maxw);
                 else
@@ -1269,7 +1285,12 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
         // (joined below)
     } else if (nb > 0 && f1t && (mfma16_mode() & 8)) {
         ProfScope ps("k_fc1_bwd_b", st);
-        if (maxw_ready)
+        if (maxw_ready && fc1_lds_on()) {
+            rc = set_lds(k_fc1_bwd_c<true>, f1c_lds_bytes());
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_fc1_bwd_c<true>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(256), f1c_lds_bytes(),
+                               st, dm, yT, yT_stride, ghpre, slabs_f, lenf, (const uint32_t*)maxw);
+        } else if (maxw_ready)
             hipLaunchKernelGGL(k_fc1_bwd_b<true>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0, st, dm,
                                yT, yT_stride, ghpre, slabs_f, lenf, (const uint32_t*)maxw);
         else
