@@ -4,12 +4,16 @@
 // k_fc1_bwd_b reads its operands global -> registers with every lane on a row of its own: 8 load instructions a k-step
 // and wave, each touching 64 different cache lines.  That is what it waits for (0.36 ms for 0.9 GB: 17 % of the matrix pipe,
 // 2.5 TB/s; the same with two waves a SIMD) -- the texture path takes a line a cycle.  Here a workgroup moves the operands
-// of 64 persons as whole 1 KB transfers (LDS-DMA, rows of 256 / 64 contiguous bytes: 16 KB of ghpreT, 32 KB of yT), double
-// buffered, and the four waves read their fragments from LDS: the per-k-step arithmetic (split of ghpre, response bytes
+// of 64 persons as whole 1 KB transfers (LDS-DMA, rows of 256 / 64 contiguous bytes: 16 KB of ghpreT, 32 KB of yT), three
+// chunks deep (a wave's transfers a chunk are always the same number: the wait for a chunk is counted and leaves the next one's in
+// flight), and the four waves read their fragments from LDS: the per-k-step arithmetic (split of ghpre, response bytes
 // to fp16 / bf16, MFMAs, their order) is k_fc1_bwd_b's.
 //   G tile [64 rows][16 chunks of 16 B] (64 persons fp32): chunk c of row r at position c ^ (r & 15)
 //   Y tile [512 rows][4 chunks of 16 B] (64 persons, bytes): chunk c of row r at position c ^ ((r >> 2) & 3)
 // (the swizzles are applied to the per-lane SOURCE address of a transfer: the LDS side of a transfer is lane-linear)
+// Measured (the 1M x 500 step, same box): 0.354-0.361 ms for k_fc1_bwd_b, 0.232-0.244 here -- and the same for four waves of
+// four item tiles or eight of two, two chunks deep or three, the eight-instruction split of ghpre or the four-instruction one:
+// what is left is the 0.9 GB themselves, read as 64-byte pieces of 500 rows a megabyte apart (3.8 TB/s).
 // A workgroup's persons are a whole number of 64-person chunks (the last workgroup takes the ragged end): the slabs are
 // cut at other places than k_fc1_bwd_b's, so the two kernels' results differ in the last bits (summation order).
 // (included by vx_abi.hip after k_fc1_bwd_b.hip)
@@ -17,16 +21,24 @@
 #define F1C_GBYTES (64 * F1C_PC * 4)                                    // 16 384
 #define F1C_YBYTES (512 * F1C_PC)                                       // 32 768
 #define F1C_BUF (F1C_GBYTES + F1C_YBYTES)
-__host__ __device__ inline size_t f1c_lds_bytes() { return 2 * (size_t)F1C_BUF; }
+#define F1C_NBUF 3                                                      // chunks in LDS: one in the MFMAs, two in flight
+__host__ __device__ inline size_t f1c_lds_bytes() { return F1C_NBUF * (size_t)F1C_BUF; }
 
+#ifndef F1C_NT
+#define F1C_NT 2                                                        // item tiles a wave; 16 / F1C_NT waves a workgroup (512 items)
+#endif
+#define F1C_WAVES (16 / F1C_NT)
+#define F1C_THREADS (64 * F1C_WAVES)
 template <bool F16>
-__global__ __launch_bounds__(256, 1) void k_fc1_bwd_c(
+__global__ __launch_bounds__(F1C_THREADS, 1) void k_fc1_bwd_c(
     EncDims dm, const uint8_t* __restrict__ yT, int64_t ystride, const float* __restrict__ ghpreT,
     float* __restrict__ slabs, int64_t slab_len, const uint32_t* __restrict__ maxw = nullptr /*F16: float bits, [3] = max |ghpre|*/) {
     extern __shared__ __attribute__((aligned(16))) char smem_f1[];
     typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2w __attribute__((ext_vector_type(2)));
-    constexpr int NT = 4;                                               // item tiles a wave: 4 waves x 4 x 32 = 512 items a workgroup
+    constexpr int NT = F1C_NT, NW = F1C_WAVES;                          // item tiles a wave, waves: NW x NT x 32 = 512 items a workgroup
+    constexpr int NG = 16 / NW, NY = 32 / NW, NOWN = NG + NY;          // transfers a wave and chunk: G tile, Y tile, both
+    static_assert(NOWN <= 15, "counted wait: vmcnt's low four bits");
     const int J = dm.J;
     const int64_t nb = dm.nb;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -56,19 +68,21 @@ __global__ __launch_bounds__(256, 1) void k_fc1_bwd_c(
     const int64_t n_ch = (nb + F1C_PC - 1) / F1C_PC, per = (n_ch + gridDim.y - 1) / gridDim.y;
     const int64_t ch0 = (int64_t)blockIdx.y * per, ch1 = (ch0 + per < n_ch) ? ch0 + per : n_ch;
 
-    // ---- transfers of a chunk: 16 of the G tile (4 rows each), 32 of the Y tile (16 rows each); wave w moves d = w + 4 u
-    const char* gsrc[4];                                                // per-lane source at person 0 of the chunk
-    const char* ysrc[8];
-    bool ylive[8];
+    // ---- transfers of a chunk: 16 of the G tile (4 rows each), 32 of the Y tile (16 rows each); wave w moves d = w + NW u
+    const char* gsrc[NG];                                               // per-lane source at person 0 of the chunk
+    const char* ysrc[NY];
+    bool ylive[NY];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int d = wave + 4 * u, row = 4 * d + (lane >> 4), c = (lane & 15) ^ (row & 15);
+    for (int u = 0; u < NG; ++u) {
+        const int d = wave + NW * u, row = 4 * d + (lane >> 4), c = (lane & 15) ^ (row & 15);
         gsrc[u] = (const char*)(ghpreT + (int64_t)row * nb + 4 * c);
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int d = wave + 4 * u, row = 16 * d + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
-        ylive[u] = jb0 + row < J;                                       // rows of the bias column and past it are never read as data
+    for (int u = 0; u < NY; ++u) {
+        const int d = wave + NW * u, row = 16 * d + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+        // (rows of the bias column and past it are never read as data: their transfers re-read row 0, so that every wave
+        // issues the same number of transfers a chunk)
+        ylive[u] = true;
         ysrc[u] = (const char*)(yT + (int64_t)(jb0 + row < J ? jb0 + row : 0) * ystride + 16 * c);
     }
     auto stage = [&](int64_t ch, int b) __attribute__((always_inline)) {
@@ -76,18 +90,18 @@ __global__ __launch_bounds__(256, 1) void k_fc1_bwd_c(
         const uint32_t lb = lds_addr_uniform(smem_f1 + b * F1C_BUF) + (uint32_t)wave * 1024u;
         const bool whole = p0 + F1C_PC <= nb;                           // block-uniform
         if (!whole) {                                                   // the ragged last chunk: absent persons are zeros of ghpre
-            for (int e = tid; e < F1C_GBYTES / 16; e += 256) *(f32x4*)(smem_f1 + b * F1C_BUF + 16 * e) = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int e = tid; e < F1C_GBYTES / 16; e += F1C_THREADS) *(f32x4*)(smem_f1 + b * F1C_BUF + 16 * e) = f32x4{0.f, 0.f, 0.f, 0.f};
             __syncthreads();
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = 4 * (wave + 4 * u) + (lane >> 4), c = (lane & 15) ^ (row & 15);
-            if (whole || p0 + 4 * c + 4 <= nb) dma16(gsrc[u] + p0 * 4, lb + (uint32_t)u * 4096u);      // nb % 4 == 0
+        for (int u = 0; u < NG; ++u) {
+            const int row = 4 * (wave + NW * u) + (lane >> 4), c = (lane & 15) ^ (row & 15);
+            if (whole || p0 + 4 * c + 4 <= nb) dma16(gsrc[u] + p0 * 4, lb + (uint32_t)u * (1024u * NW));      // nb % 4 == 0
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {                                   // (a yT row is ystride bytes long: nothing is read past it)
-            const int row = 16 * (wave + 4 * u) + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
-            if (ylive[u] && (whole || p0 + 16 * c + 16 <= ystride)) dma16(ysrc[u] + p0, lb + (uint32_t)F1C_GBYTES + (uint32_t)u * 4096u);
+        for (int u = 0; u < NY; ++u) {                                  // (a yT row is ystride bytes long: nothing is read past it)
+            const int row = 16 * (wave + NW * u) + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+            if (ylive[u] && (whole || p0 + 16 * c + 16 <= ystride)) dma16(ysrc[u] + p0, lb + (uint32_t)F1C_GBYTES + (uint32_t)u * (1024u * NW));
         }
     };
 
@@ -115,7 +129,7 @@ __global__ __launch_bounds__(256, 1) void k_fc1_bwd_c(
         for (int ht = 0; ht < 2; ++ht) {
             const float v[8] = {o.g[ht][0][0], o.g[ht][0][1], o.g[ht][0][2], o.g[ht][0][3],
                                 o.g[ht][1][0], o.g[ht][1][1], o.g[ht][1][2], o.g[ht][1][3]};
-            if constexpr (F16) split2h_frag(v, g_scale, ah[ht][0], ah[ht][1]);
+            if constexpr (F16) split2h_frag_mix(v, g_scale, ah[ht][0], ah[ht][1]);
             else fb_split8(v, a[ht][0], a[ht][1], a[ht][2]);
         }
 #pragma unroll
@@ -147,12 +161,16 @@ __global__ __launch_bounds__(256, 1) void k_fc1_bwd_c(
     };
 
     if (ch0 < ch1) {
+        // whole(ch): the chunk's transfers are the full NOWN a wave (the ragged last chunk skips some)
+        auto whole = [&](int64_t ch) -> bool { return (ch + 1) * F1C_PC <= nb; };
         stage(ch0, 0);
-        vx_wait_vmem();
+        if (ch0 + 1 < ch1) stage(ch0 + 1, 1);
+        if (ch0 + 1 < ch1 && whole(ch0 + 1)) __builtin_amdgcn_s_waitcnt(0x0F70 | NOWN); else vx_wait_vmem();
         __syncthreads();
         int b = 0;
         for (int64_t ch = ch0; ch < ch1; ++ch) {
-            if (ch + 1 < ch1) stage(ch + 1, b ^ 1);                    // (its buffer was released by the barrier below)
+            const int b2 = b + 2 >= F1C_NBUF ? b + 2 - F1C_NBUF : b + 2;
+            if (ch + 2 < ch1) stage(ch + 2, b2);                       // (its buffer was released by the barrier of the chunk before)
             Ops o0, o1;
             read_ops(o0, b, 0);
             read_ops(o1, b, 1);
@@ -162,9 +180,10 @@ __global__ __launch_bounds__(256, 1) void k_fc1_bwd_c(
             read_ops(o1, b, 3);
             compute(o0);
             compute(o1);
-            vx_wait_vmem();                                            // this wave's transfers of the next chunk
+            // this wave's transfers of the next chunk (those of the one after it may stay in flight: loads complete in order)
+            if (ch + 2 < ch1 && whole(ch + 2)) __builtin_amdgcn_s_waitcnt(0x0F70 | NOWN); else vx_wait_vmem();
             __syncthreads();                                           // ... everybody's; and this chunk's buffer is free
-            b ^= 1;
+            b = b + 1 >= F1C_NBUF ? 0 : b + 1;
         }
     }
     // slab: [W1-grad: 64 * J | b1-grad: 64]

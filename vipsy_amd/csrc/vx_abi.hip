@@ -1180,7 +1180,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                 if (maxw_ready && fc1_lds_on()) {                       // operands through LDS (k_fc1_bwd_c.hip)
                     rc = set_lds(k_fc1_bwd_c<true>, f1c_lds_bytes());
                     if (rc) return rc;
-                    hipLaunchKernelGGL(k_fc1_bwd_c<true>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(256),
+                    hipLaunchKernelGGL(k_fc1_bwd_c<true>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1C_THREADS),
                                        f1c_lds_bytes(), fs, dm, yT, yT_stride, ghpre, slabs_f, lenf, (const uint32_t*)maxw);
                 } else if (maxw_ready)
                     hipLaunchKernelGGL(k_fc1_bwd_b<true>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0,
@@ -1288,7 +1288,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
         if (maxw_ready && fc1_lds_on()) {
             rc = set_lds(k_fc1_bwd_c<true>, f1c_lds_bytes());
             if (rc) return rc;
-            hipLaunchKernelGGL(k_fc1_bwd_c<true>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(256), f1c_lds_bytes(),
+            hipLaunchKernelGGL(k_fc1_bwd_c<true>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1C_THREADS), f1c_lds_bytes(),
                                st, dm, yT, yT_stride, ghpre, slabs_f, lenf, (const uint32_t*)maxw);
         } else if (maxw_ready)
             hipLaunchKernelGGL(k_fc1_bwd_b<true>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0, st, dm,

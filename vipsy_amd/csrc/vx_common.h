@@ -87,6 +87,28 @@ __device__ __forceinline__ void split2h_frag(const float (&v)[8], float scale, f
     fh = __builtin_bit_cast(f16x8, ph);
     fl = __builtin_bit_cast(f16x8, pl);
 }
+// The same two fragments in FOUR instructions an element pair instead of eight: v_fma_mixlo_f16 / v_fma_mixhi_f16 compute an
+// fp32 fma of operands that are fp32 or one half of a register read as fp16 and write the result, rounded to fp16, into one
+// half of the destination -- head = rn16(v * scale + 0), remainder = rn16(v * scale - head).  Both fmas are exact in fp32 (a
+// power-of-two scaling; the difference of a value and its own fp16 rounding), so every result is rounded once, to fp16, as in
+// split2h_frag: the same bits, except that a value of -0 splits into (+0, -0) instead of (-0, +0).  `scale` must be
+// wave-uniform (it is read from a scalar register).
+__device__ __forceinline__ void split2h_frag_mix(const float (&v)[8], float scale, f16x8& fh, f16x8& fl) {
+    typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+    const float sc_ = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scale)));
+    u32x4s ph, pl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t h, l;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(v[2 * q]), "s"(sc_));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(v[2 * q + 1]), "s"(sc_));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(v[2 * q]), "s"(sc_), "v"(h));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(v[2 * q + 1]), "s"(sc_), "v"(h));
+        ph[q] = h; pl[q] = l;
+    }
+    fh = __builtin_bit_cast(f16x8, ph);
+    fl = __builtin_bit_cast(f16x8, pl);
+}
 // one value for the image builders (host-rate code): bit patterns of the two terms
 __device__ __forceinline__ void split2h_bits(float v, uint16_t& bh, uint16_t& bl) {
     const _Float16 h = (_Float16)v;
