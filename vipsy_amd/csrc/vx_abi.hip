@@ -1646,8 +1646,15 @@ int vx_norm_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t*
             VX_CHECK_LAUNCH();
             if (mfma16_mode() & 8) {
                 ProfScope ps("k_fc1_bwd_b", st);
-                hipLaunchKernelGGL(k_fc1_bwd_b<false>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0,
-                                   st, dm, yT, yT_stride, ghpreT, slabs_f, lenf, (const uint32_t*)nullptr);
+                if (fc1_lds_on() && nb % 4 == 0 && aligned16(ghpreT)) {     // operands through LDS (k_fc1_bwd_c.hip), three bf16 terms
+                    rc = set_lds(k_fc1_bwd_c<false>, f1c_lds_bytes());
+                    if (rc) return rc;
+                    hipLaunchKernelGGL(k_fc1_bwd_c<false>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1C_THREADS),
+                                       f1c_lds_bytes(), st, dm, yT, yT_stride, ghpreT, slabs_f, lenf, (const uint32_t*)nullptr);
+                } else {
+                    hipLaunchKernelGGL(k_fc1_bwd_b<false>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0,
+                                       st, dm, yT, yT_stride, ghpreT, slabs_f, lenf, (const uint32_t*)nullptr);
+                }
             } else {
                 const size_t ldst = f1_lds_bytes(cfg->J);
                 rc = set_lds(k_fc1_bwd_t, ldst);
