@@ -32,6 +32,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: dense bf16 / fp16 matrix peak (t
 PEAK_F16X2_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBS = 8000.0
 PROFILE_TAG = "r04b_headline"
+PAIR = "k_mvn_enc_bwd_h_b2 | k_mvn_enc_bwd_w_b side by side"      # the bracket name vx_mvn_enc_backward files the pair under
 
 WORKLOADS = {
     # name: (model, N, J, D, H, amortized, missing)
@@ -69,6 +70,11 @@ def kernel_model(name, J, D, H):
         "k_irt_lik_b": (2.0 * 3 * (D + 1) * J, PEAK_BF16_MFMA_TFLOPS * 3.0 / 16.0,
                         "f32 via bf16 terms on the bf16 MFMA (Z: six products, gx and GA: five)"),
         "k_irt_lik_h": (2.0 * 3 * (D + 1) * J, PEAK_F16X2_TFLOPS, f16x2),               # Z, gx, GA
+        # the hidden gradient and the head weight gradient run SIDE BY SIDE on two streams: one bracket on the launch stream
+        # from in front of the fork to behind the join, priced with the flops of both
+        PAIR: (2.0 * heads, PEAK_F16X2_TFLOPS, f16x2),
+        "k_fc1_bwd_c": (2.0 * J * H, PEAK_BF16_MFMA_TFLOPS / 2.0,
+                        "response bytes exact in fp16 x two fp16 terms of ghpre: two products on the fp16 MFMA, fp32 accumulate"),
     }
     if D == 1:
         # the 1-D amortized guide (BASELINE config 4, amortized variant; SURVEY.md section 8d: "MFMA/FMA (encoder)"): fc1 and
@@ -76,7 +82,7 @@ def kernel_model(name, J, D, H):
         # three bf16 terms = three products per f32 product
         bf16x3 = "response bytes exact in bf16 x three bf16 terms of the f32 operand: three products on the bf16 MFMA, fp32 accumulate"
         table = {"k_norm_enc_fwd_b": (2.0 * J * H, PEAK_BF16_MFMA_TFLOPS / 3.0, bf16x3),
-                 "k_fc1_bwd_b": (2.0 * J * H, PEAK_BF16_MFMA_TFLOPS / 3.0, bf16x3)}
+                 "k_fc1_bwd_c": (2.0 * J * H, PEAK_BF16_MFMA_TFLOPS / 3.0, bf16x3)}
     return table.get(name)
 
 
@@ -90,10 +96,13 @@ def measured_traffic(kernel_prefix):
             kernels = json.load(f)["kernels"]
     except (OSError, ValueError, KeyError):
         return None
+    want = [w.strip().split(" ")[0] for w in kernel_prefix.split("|")]      # a side-by-side bracket: the sum of its kernels
+    tot, found = 0.0, 0
     for name, v in kernels.items():
-        if name.split("<")[0].split("(")[0] == kernel_prefix:          # template arguments are part of the traced name
-            return float(v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"])
-    return None
+        if name.split("<")[0].split("(")[0] in want:                   # template arguments are part of the traced name
+            tot += float(v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"])
+            found += 1
+    return tot if found == len(want) else None
 
 
 def physical_bytes(workload):
@@ -231,8 +240,8 @@ def self_launch(args, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="default: 5 for the headline, 200 for the secondary workloads")
-    ap.add_argument("--warmup", type=int, default=None, help="default: 2 for the headline, 50 for the secondary workloads")
+    ap.add_argument("--steps", type=int, default=None, help="default: 50 for the headline, 200 for the secondary workloads")
+    ap.add_argument("--warmup", type=int, default=None, help="default: 5 for the headline, 50 for the secondary workloads")
     ap.add_argument("--workload", default="irt2pl_100d_amortized_1Mx500", choices=sorted(WORKLOADS))
     ap.add_argument("--persons", type=int, default=None, help="override N (debug only; makes the line non-headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -247,9 +256,9 @@ def main():
     # HO-DINA 2 830 steps/s over 5 steps, 3 310 over 200)
     headline = args.workload == "irt2pl_100d_amortized_1Mx500"
     if args.steps is None:
-        args.steps = 5 if headline else 200
+        args.steps = 50 if headline else 200
     if args.warmup is None:
-        args.warmup = 2 if headline else 50
+        args.warmup = 5 if headline else 50
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args, sys.argv[1:]))
@@ -429,7 +438,9 @@ def main():
                                              "dense bf16 MFMA peak 2500 / (16 / 3) products per f32 product"
                                              if peak == PEAK_BF16_MFMA_TFLOPS * 3.0 / 16.0 else
                                              "dense bf16 MFMA peak 2500 / 3 products per f32 product"
-                                             if peak == PEAK_BF16_MFMA_TFLOPS / 3.0 else "dense f32 MFMA peak",
+                                             if peak == PEAK_BF16_MFMA_TFLOPS / 3.0 else
+                                             "dense fp16 MFMA peak 2500 / 2 products per f32 x {-1,0,1} product"
+                                             if peak == PEAK_BF16_MFMA_TFLOPS / 2.0 else "dense f32 MFMA peak",
                                "algorithmic_flops_per_launch": fl, "avg_launch_ms": priced[name],
                                "persons_per_launch": kernel_units.get(name, n_local)}
             if graphed:

@@ -21,6 +21,10 @@ def main():
     rng = np.random.RandomState(123)
     if case == "irt1d":
         N, J, D, model, amort = 240, 17, 1, "irt_4pl", False
+    elif case == "irt1d8":                                  # eight ranks: shards of 30 and a ragged last one of 27
+        N, J, D, model, amort = 237, 17, 1, "irt_4pl", False
+    elif case == "mvn8":                                    # eight ranks: shards of 12 and a last one of 7
+        N, J, D, model, amort = 91, 21, 3, "irt_2pl", True
     else:
         N, J, D, model, amort = 96, 21, 3, "irt_2pl", True
     y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
@@ -44,7 +48,8 @@ def main():
         if t == 1:
             rows, bg = None, N                                    # one full-batch step
         else:
-            idx = np.sort(g.permutation(N)[:N // 2])
+            # (t == 2 of the eight-rank cases: a subsample so small that some ranks hold none of it)
+            idx = np.sort(g.permutation(N)[:(5 if (t == 2 and case.endswith("8")) else N // 2)])
             mine = idx[(idx >= lo) & (idx < hi)] - lo
             rows, bg = torch.from_numpy(mine.astype(np.int64)), len(idx)
         losses.append(float(eng.step(lrs, rows=rows, b_global=bg)))

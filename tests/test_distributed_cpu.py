@@ -1,5 +1,6 @@
-"""world_size-2 gloo runs of the engine's host logic (oracle-backed compute, CPU): the sharded run must
-reproduce the single-process run -- same losses, same replicated parameters, same per-person rows."""
+"""world_size-2 and world_size-8 gloo runs of the engine's host logic (oracle-backed compute, CPU): the sharded run must
+reproduce the single-process run -- same losses, same replicated parameters, same per-person rows.  World 8 is the
+driver's multi-GPU shape: eight contiguous person ranges, the last one shorter when N % 8 != 0."""
 import json
 import os
 import subprocess
@@ -39,6 +40,42 @@ def test_two_ranks_match_one_rank(case, port, tmp_path):
         raw = np.concatenate([np.array(r["PP"])[len(r["PP"]) // 2:] for r in two])
         np.testing.assert_allclose(loc, np.array(one["PP"])[:n], rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(raw, np.array(one["PP"])[n:], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("case,port", [("irt1d8", 29641), ("mvn8", 29643)])
+def test_eight_ranks_match_one_rank(case, port, tmp_path):
+    """The 8-way partition the driver's scaling run uses: contiguous person ranges with a ragged
+    last shard (N % 8 != 0), ranks whose share of a global subsample is small or EMPTY, epsilon keyed by the global person id,
+    one all-reduce a step, replicated Adam -- world 8 against world 1, every rank bit-identical to rank 0."""
+    one = _run(case, 1, tmp_path, port)[0]
+    eight = _run(case, 8, tmp_path, port + 1)
+    assert len(eight) == 8
+    for r in eight:
+        np.testing.assert_allclose(r["loss"], one["loss"], rtol=1e-5)
+        np.testing.assert_allclose(r["P"], one["P"], rtol=1e-4, atol=1e-6)
+        assert r["P"] == eight[0]["P"]                                            # replicated state: bit-identical across ranks
+    if "PP" in one:
+        n = len(one["PP"]) // 2
+        assert [r["lo"] for r in eight] == sorted(r["lo"] for r in eight) and eight[-1]["hi"] == n
+        assert eight[-1]["hi"] - eight[-1]["lo"] < eight[0]["hi"] - eight[0]["lo"]     # the ragged last shard
+        loc = np.concatenate([np.array(r["PP"])[:len(r["PP"]) // 2] for r in eight])
+        raw = np.concatenate([np.array(r["PP"])[len(r["PP"]) // 2:] for r in eight])
+        np.testing.assert_allclose(loc, np.array(one["PP"])[:n], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(raw, np.array(one["PP"])[n:], rtol=1e-4, atol=1e-6)
+
+
+def test_fit_loop_draws_a_stratified_subsample_on_eight_ranks():
+    """vipsy_amd/vi.py::_subsample with world = 8: every rank draws B / 8 distinct rows of ITS shard and reports the global
+    batch 8 * (B / 8) (the plate scale N / B the engine applies uses the global figures)."""
+    import torch
+    from tests.oracle_backend import OracleBackend
+    from vipsy_amd import vi
+    y = torch.from_numpy(np.random.RandomState(4).randint(0, 2, size=(125, 6)).astype(np.uint8))
+    m = vi.VIRT(data=y, model="irt_2pl", subsample_size=100, backend=OracleBackend(), seed=5)
+    m.world, m.sample_size = 8, 1000                          # (what BasePsy derives from a process group of eight)
+    idx, bg = m._subsample()
+    a = idx.cpu().numpy()
+    assert bg == 96 and a.shape == (12,) and len(set(a.tolist())) == 12 and a.min() >= 0 and a.max() < 125
 
 
 def test_harness_replications_over_two_ranks(tmp_path):

@@ -1,5 +1,6 @@
-"""The sharded step on the real HIP path: world 2 against world 1 (tests/test_distributed_cpu.py covers the same host
-logic with the oracle backend on CPU).  With two devices visible the ranks use RCCL (backend nccl); on a one-GPU box
+"""The sharded step on the real HIP path: world 2 and world 4 against world 1 (tests/test_distributed_cpu.py covers the same
+host logic with the oracle backend on CPU, up to world 8; a GPU box admits at most six processes on its card, so four ranks is
+the widest rehearsal that may touch it).  With two devices visible the ranks use RCCL (backend nccl); on a one-GPU box
 both ranks share cuda:0 and exchange through gloo -- everything but the RCCL transport is what the 8-GPU run executes."""
 import json
 import os
@@ -52,6 +53,40 @@ def test_hip_two_ranks_match_one_rank(case, port, tmp_path):
         raw = np.concatenate([np.array(r["PP"])[len(r["PP"]) // 2:] for r in two])
         np.testing.assert_allclose(loc, np.array(one["PP"])[:n_one], rtol=2e-4, atol=2e-6)
         np.testing.assert_allclose(raw, np.array(one["PP"])[n_one:], rtol=2e-4, atol=2e-6)
+
+
+def test_hip_four_ranks_match_one_rank(tmp_path):
+    """Four shards of the amortized multivariate step (264 persons each; rank 3's share of the subsampled step is its own
+    count): losses and parameters against the single-rank run, every rank bit-identical, every rank replaying its graphs."""
+    import torch
+    one = _run("mvn", 1, tmp_path, 29731)[0]
+    four = _run("mvn", 4, tmp_path, 29732)
+    if torch.cuda.device_count() >= 4:
+        assert all(r["backend"] == "nccl" for r in four), [r["backend"] for r in four]
+    assert one["graphed"] and all(r["graphed"] for r in four)
+    for r in four:
+        np.testing.assert_allclose(r["loss"], one["loss"], rtol=2e-5)
+        np.testing.assert_allclose(r["P"], one["P"], rtol=2e-4, atol=2e-6)
+        assert r["P"] == four[0]["P"]
+
+
+def test_bench_self_launch_four_ranks_of_125k():
+    """`python bench.py --gpus 4` on shards of 125 000 persons -- the shard one of EIGHT GPUs holds in the driver's scaling run
+    (four ranks is what a one-GPU box admits): the ranks start, shard, replay their two graphs
+    around the all-reduce and print one line."""
+    import torch
+    backend = "nccl" if torch.cuda.device_count() >= 4 else "gloo"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "3",
+                        "--persons", "500000", "--no-cpu-baseline", "--dist-backend", backend],
+                       capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 4 and d["value"] > 0 and d["config"]["persons_per_rank"] == 125000
+    assert d["config"]["launch"].startswith("whole step replayed from HIP graphs"), d["config"]["launch"]
+    assert np.isfinite(d["loss_first"]) and np.isfinite(d["loss_last"]) and d["loss_last"] < d["loss_first"]
 
 
 def test_bench_self_launch_two_ranks():

@@ -70,3 +70,36 @@ def test_small_subsamples_are_distinct_rows_drawn_on_the_host():
     assert np.array_equal(m2._subsample()[0].cpu().numpy(), draws[0][0].cpu().numpy())   # reproducible from the seed
     hits = np.bincount(np.concatenate([d[0].cpu().numpy() for d in draws]), minlength=4000)
     assert hits.max() <= 8                                     # 5000 draws over 4000 rows: no row is favoured
+
+
+def test_captured_row_forms_are_bounded():
+    """Every distinct (nb, b_global) subsample form would keep a captured graph for ever: beyond
+    graph_max_row_forms the least recently used forms are dropped, the most recently used stay."""
+    y = torch.from_numpy(np.random.RandomState(2).randint(0, 2, size=(64, 6)).astype(np.uint8))
+    eng = IrtEngine(y, model="irt_2pl", D=1, backend=OracleBackend())
+    eng._graphs, eng._graph = {}, None
+    full = ("full", 64, 64)
+    eng._graphs[full] = {"graph": object()}
+    for nb in range(1, 21):
+        eng._graphs[("rows", nb, 100)] = {"graph": object(), "rows": object()}
+        eng._evict_graph_forms()
+        if nb == 5:                                            # a form that is used again moves to the recent end
+            eng._graphs[("rows", 1, 100)] = eng._graphs.pop(("rows", 1, 100))
+    rows_forms = [m for m in eng._graphs if m[0] == "rows"]
+    assert len(rows_forms) == eng.graph_max_row_forms == 8
+    assert rows_forms == [("rows", nb, 100) for nb in range(13, 21)]
+    assert full in eng._graphs                                 # the full-batch form is not a candidate
+
+
+def test_loss_reaches_the_ring_without_an_optimiser_launch():
+    """A step whose optimiser has nothing to launch still files its loss (the ring slot used to be written only
+    as a side effect of the first Adam launch)."""
+    from vipsy_amd.engine import LrSpec, LOSS_RING
+    y = torch.from_numpy(np.random.RandomState(3).randint(0, 2, size=(32, 5)).astype(np.uint8))
+    eng = IrtEngine(y, model="irt_2pl", D=1, backend=OracleBackend())
+    eng.loss_and_grads(None, None, None, 0)
+    want = float(eng.G[eng.n_params])
+    eng.names = lambda: []                                     # no trainable replicated segment ...
+    eng.per_person = False                                     # ... and no per-person one: apply_optim launches nothing
+    eng.apply_optim(LrSpec(1e-2))
+    assert float(eng.step_loss()) == want and float(eng.loss_ring[eng.t % LOSS_RING]) == want

@@ -1,22 +1,31 @@
-// fc1 weight gradient, operands staged through LDS (round 4): the same mathematics, arguments and slab format as
-// k_fc1_bwd_b (k_fc1_bwd_b.hip),
+// fc1 weight gradient on the 16-bit MFMA, from dimension-major operands (full batch, no row gather): the same result and
+// slab format as k_fc1_bwd_t (k_mvn_bwd_t.hip; autograd of vi.py:417-455's fc1),
 //     GW1[hh][j] = sum_p ghpreT[hh][p] yin[p][j],   Gb1[hh] = sum_p ghpreT[hh][p]         (yin = int8 -1 / 0 / 1)
-// k_fc1_bwd_b reads its operands global -> registers with every lane on a row of its own: 8 load instructions a k-step
-// and wave, each touching 64 different cache lines.  That is what it waits for (0.36 ms for 0.9 GB: 17 % of the matrix pipe,
-// 2.5 TB/s; the same with two waves a SIMD) -- the texture path takes a line a cycle.  Here a workgroup moves the operands
-// of 64 persons as whole 1 KB transfers (LDS-DMA, rows of 256 / 64 contiguous bytes: 16 KB of ghpreT, 32 KB of yT), three
-// chunks deep (a wave's transfers a chunk are always the same number: the wait for a chunk is counted and leaves the next one's in
-// flight), and the four waves read their fragments from LDS: the per-k-step arithmetic (split of ghpre, response bytes
-// to fp16 / bf16, MFMAs, their order) is k_fc1_bwd_b's.
+// MFMA 32x32x16: C rows = hidden units, columns = items, contraction index = persons (16 per k-step).
+//   B = the response bytes of 8 consecutive persons of an item row of yT: exact in bf16 and in fp16, converted in registers;
+//   A = 8 consecutive persons of a ghpreT row, split in registers:
+//       F16 (the step's largest |ghpre| is known: the hidden-gradient kernel collected it, maxw[3]): two fp16 terms of
+//       ghpre 2^s -> 2 products per k-step, the power of two taken off the accumulators at the end;
+//       otherwise (the 1-D encoder's caller has no such maximum): three bf16 terms -> 3 products.
+//   The bias gradient is the column of a virtual item J whose responses are all 1.
+// Operands are staged through LDS (round 4).  The form before it (k_fc1_bwd_b, retired in round 5) read them global ->
+// registers with every lane on a row of its own: 8 load instructions a k-step and wave, each touching 64 different cache
+// lines.  That is what it waited for (0.36 ms for 0.9 GB: 17 % of the matrix pipe, 2.5 TB/s; the same with two waves a SIMD)
+// -- the texture path takes a line a cycle (docs/HARDWARE.md, rule 33).  Here a workgroup moves the operands of 64 persons as
+// whole 1 KB transfers (LDS-DMA, rows of 256 / 64 contiguous bytes: 16 KB of ghpreT, 32 KB of yT), three chunks deep (a
+// wave's transfers a chunk are always the same number: the wait for a chunk is counted and leaves the next one's in flight),
+// and the waves read their fragments from LDS.
 //   G tile [64 rows][16 chunks of 16 B] (64 persons fp32): chunk c of row r at position c ^ (r & 15)
 //   Y tile [512 rows][4 chunks of 16 B] (64 persons, bytes): chunk c of row r at position c ^ ((r >> 2) & 3)
 // (the swizzles are applied to the per-lane SOURCE address of a transfer: the LDS side of a transfer is lane-linear)
-// Measured (the 1M x 500 step, same box): 0.354-0.361 ms for k_fc1_bwd_b, 0.232-0.244 here -- and the same for four waves of
-// four item tiles or eight of two, two chunks deep or three, the eight-instruction split of ghpre or the four-instruction one:
-// what is left is the 0.9 GB themselves, read as 64-byte pieces of 500 rows a megabyte apart (3.8 TB/s).
-// A workgroup's persons are a whole number of 64-person chunks (the last workgroup takes the ragged end): the slabs are
-// cut at other places than k_fc1_bwd_b's, so the two kernels' results differ in the last bits (summation order).
-// (included by vx_abi.hip after k_fc1_bwd_b.hip)
+// Measured (the 1M x 500 step, same box): 0.354-0.361 ms for the register form, 0.232-0.244 here -- and the same for four
+// waves of four item tiles or eight of two, two chunks deep or three, the eight-instruction split of ghpre or the
+// four-instruction one: what is left is the 0.9 GB themselves, read as 64-byte pieces of 500 rows a megabyte apart (3.8 TB/s).
+// A workgroup's persons are a whole number of 64-person chunks (the last workgroup takes the ragged end).
+// The ragged last chunk (nb % 64 != 0; nb % 4 == 0 and ystride % 16 == 0 are the caller's contract): BOTH tiles are cleared
+// before the transfers that are still inside the batch are issued, so an absent person is ghpre = 0 AND response byte 0 -- no
+// product of the chunk depends on bytes that were not written this chunk.
+// (included by vx_abi.hip after k_mvn_fwd_b.hip)
 #define F1C_PC 64                                                       // persons a chunk (four k-steps)
 #define F1C_GBYTES (64 * F1C_PC * 4)                                    // 16 384
 #define F1C_YBYTES (512 * F1C_PC)                                       // 32 768
@@ -71,7 +80,6 @@ __global__ __launch_bounds__(F1C_THREADS, 1) void k_fc1_bwd_c(
     // ---- transfers of a chunk: 16 of the G tile (4 rows each), 32 of the Y tile (16 rows each); wave w moves d = w + NW u
     const char* gsrc[NG];                                               // per-lane source at person 0 of the chunk
     const char* ysrc[NY];
-    bool ylive[NY];
 #pragma unroll
     for (int u = 0; u < NG; ++u) {
         const int d = wave + NW * u, row = 4 * d + (lane >> 4), c = (lane & 15) ^ (row & 15);
@@ -82,15 +90,14 @@ __global__ __launch_bounds__(F1C_THREADS, 1) void k_fc1_bwd_c(
         const int d = wave + NW * u, row = 16 * d + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
         // (rows of the bias column and past it are never read as data: their transfers re-read row 0, so that every wave
         // issues the same number of transfers a chunk)
-        ylive[u] = true;
         ysrc[u] = (const char*)(yT + (int64_t)(jb0 + row < J ? jb0 + row : 0) * ystride + 16 * c);
     }
     auto stage = [&](int64_t ch, int b) __attribute__((always_inline)) {
         const int64_t p0 = ch * F1C_PC;
         const uint32_t lb = lds_addr_uniform(smem_f1 + b * F1C_BUF) + (uint32_t)wave * 1024u;
         const bool whole = p0 + F1C_PC <= nb;                           // block-uniform
-        if (!whole) {                                                   // the ragged last chunk: absent persons are zeros of ghpre
-            for (int e = tid; e < F1C_GBYTES / 16; e += F1C_THREADS) *(f32x4*)(smem_f1 + b * F1C_BUF + 16 * e) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!whole) {                                                   // the ragged last chunk: absent persons are zeros of both tiles
+            for (int e = tid; e < F1C_BUF / 16; e += F1C_THREADS) *(f32x4*)(smem_f1 + b * F1C_BUF + 16 * e) = f32x4{0.f, 0.f, 0.f, 0.f};
             __syncthreads();
         }
 #pragma unroll
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(F1C_THREADS, 1) void k_fc1_bwd_c(
 #pragma unroll
         for (int u = 0; u < NY; ++u) {                                  // (a yT row is ystride bytes long: nothing is read past it)
             const int row = 16 * (wave + NW * u) + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
-            if (ylive[u] && (whole || p0 + 16 * c + 16 <= ystride)) dma16(ysrc[u] + p0, lb + (uint32_t)F1C_GBYTES + (uint32_t)u * (1024u * NW));
+            if (whole || p0 + 16 * c + 16 <= ystride) dma16(ysrc[u] + p0, lb + (uint32_t)F1C_GBYTES + (uint32_t)u * (1024u * NW));
         }
     };
 

@@ -25,7 +25,6 @@
 #include "k_mvn_bwd_hb.hip"
 #include "k_mvn_bwd_hb2.hip"
 #include "k_pack_fused.hip"
-#include "k_fc1_bwd_b.hip"
 #include "k_fc1_bwd_c.hip"
 #include "k_cdm_sf.hip"
 #include "k_synth.hip"
@@ -37,6 +36,7 @@
 #include <cstring>
 #include <vector>
 #include <utility>
+#include <optional>
 #include <cstdio>
 
 namespace {
@@ -126,16 +126,6 @@ bool fwd_ring_on() {
     }
     return v != 0;
 }
-// VX_FC1_LDS = 0: the fc1 weight gradient of the full-batch MVN step with operands global -> registers (k_fc1_bwd_b.hip, the
-// form before k_fc1_bwd_c.hip's LDS staging)
-bool fc1_lds_on() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("VX_FC1_LDS");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v != 0;
-}
 bool fwb_shape(const vx_irt_cfg* cfg) {
     return (mfma16_mode() & 1) && packed_ok(cfg) && cfg->D <= 128 && fb_lds_bytes(cfg->D, cfg->J) <= 160 * 1024;
 }
@@ -150,7 +140,7 @@ bool enc_cfg_ok(const vx_irt_cfg* cfg) {
 // entry points then record nothing.
 struct ProfSlot { const char* name; int64_t units; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
 bool g_prof = false;
-ProfSlot g_prof_slots[8];
+ProfSlot g_prof_slots[12];
 int g_prof_n = 0;
 struct ProfScope {
     hipEvent_t a = nullptr, b = nullptr;
@@ -162,16 +152,20 @@ struct ProfScope {
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = nullptr; return; }
         (void)hipEventRecord(a, st);
     }
+    void cancel() {                                                   // the bracket turned out not to apply: nothing is filed
+        if (a) { (void)hipEventDestroy(a); a = nullptr; }
+        if (b) { (void)hipEventDestroy(b); b = nullptr; }
+    }
     ~ProfScope() {
         if (!a) return;
         (void)hipEventRecord(b, st);
         for (int i = 0; i < g_prof_n; ++i)
             if (!strcmp(g_prof_slots[i].name, name)) { g_prof_slots[i].units = units; g_prof_slots[i].ev.emplace_back(a, b); return; }
-        if (g_prof_n < 8) {
+        if (g_prof_n < 12) {
             g_prof_slots[g_prof_n].name = name; g_prof_slots[g_prof_n].units = units;
             g_prof_slots[g_prof_n].ev.emplace_back(a, b); ++g_prof_n; return;
         }
-        (void)hipEventDestroy(a); (void)hipEventDestroy(b);           // more than eight kernel names: not recorded, not leaked
+        (void)hipEventDestroy(a); (void)hipEventDestroy(b);           // more than twelve kernel names: not recorded, not leaked
     }
 };
 
@@ -185,19 +179,47 @@ struct SideStream {
 };
 SideStream& side_stream(int which, hipStream_t main_st) {
     // keyed by (host thread, device, launch stream): two call sequences that run side by side on two launch streams (the two
-    // person slices of a large batch, engine.py) must not share a side stream -- they would queue behind each other there
+    // person slices of a large batch, engine.py) must not share a side stream -- they would queue behind each other there.
+    // MAXMAIN launch streams a device keep a pair of side streams each; one more evicts the least recently used pair (its
+    // streams and events are destroyed -- work already queued on them still completes -- so a launch stream whose handle is
+    // re-used after hipStreamDestroy cannot inherit a live slot for long, and nothing aliases another live stream's pair);
+    // everything is destroyed when the host thread ends.
     constexpr int MAXDEV = 16, MAXMAIN = 4;
-    struct Slot { hipStream_t main_st; SideStream ss[2]; bool used; };
-    static thread_local Slot slots[MAXDEV][MAXMAIN];
+    struct Slot { hipStream_t main_st = nullptr; SideStream ss[2]; bool used = false; uint64_t last = 0; };
+    struct Slots {
+        Slot s[MAXDEV][MAXMAIN];
+        uint64_t clock = 0;
+        static void release(Slot& sl) {
+            for (SideStream& x : sl.ss) {
+                if (x.s) (void)hipStreamDestroy(x.s);
+                if (x.fork) (void)hipEventDestroy(x.fork);
+                if (x.join) (void)hipEventDestroy(x.join);
+                x = SideStream();
+            }
+            sl.used = false;
+        }
+        ~Slots() {
+            for (auto& d : s) for (Slot& sl : d) if (sl.used) release(sl);
+        }
+    };
+    static thread_local Slots slots;
     static thread_local SideStream none;                   // ok == false: the single-stream paths
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return none;
     Slot* sl = nullptr;
     for (int i = 0; i < MAXMAIN && !sl; ++i)
-        if (slots[dev][i].used && slots[dev][i].main_st == main_st) sl = &slots[dev][i];
+        if (slots.s[dev][i].used && slots.s[dev][i].main_st == main_st) sl = &slots.s[dev][i];
     for (int i = 0; i < MAXMAIN && !sl; ++i)
-        if (!slots[dev][i].used) { sl = &slots[dev][i]; sl->used = true; sl->main_st = main_st; }
-    if (!sl) sl = &slots[dev][0];                          // more launch streams than slots: share the first (still correct)
+        if (!slots.s[dev][i].used) { sl = &slots.s[dev][i]; sl->used = true; sl->main_st = main_st; }
+    if (!sl) {                                             // more launch streams than slots: the least recently used pair goes
+        sl = &slots.s[dev][0];
+        for (int i = 1; i < MAXMAIN; ++i)
+            if (slots.s[dev][i].last < sl->last) sl = &slots.s[dev][i];
+        Slots::release(*sl);
+        sl->used = true;
+        sl->main_st = main_st;
+    }
+    sl->last = ++slots.clock;
     SideStream& ss = sl->ss[which & 1];
     if (!ss.init) {
         ss.init = true;
@@ -1048,6 +1070,26 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     ForkScope f1_fork;                                     // ... joined below, or by the scope on an error return
     ForkScope bwb_fork;
     bool bwb_done = false;
+    std::optional<ProfScope> pair_ps;
+    // the fc1 weight gradient from dimension-major operands (k_fc1_bwd_c.hip; ghpre holds ghpreT): two fp16 terms of ghpre when
+    // the hidden-gradient kernel collected the step's largest |ghpre| (maxw[3]), three bf16 terms otherwise
+    auto launch_fc1_c = [&](hipStream_t fs) -> int {
+        ProfScope ps("k_fc1_bwd_c", fs);
+        const dim3 grid((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf);
+        if (maxw_ready) {
+            int r = set_lds(k_fc1_bwd_c<true>, f1c_lds_bytes());
+            if (r) return r;
+            hipLaunchKernelGGL(k_fc1_bwd_c<true>, grid, dim3(F1C_THREADS), f1c_lds_bytes(), fs, dm, yT, yT_stride, ghpre, slabs_f, lenf,
+                               (const uint32_t*)maxw);
+        } else {
+            int r = set_lds(k_fc1_bwd_c<false>, f1c_lds_bytes());
+            if (r) return r;
+            hipLaunchKernelGGL(k_fc1_bwd_c<false>, grid, dim3(F1C_THREADS), f1c_lds_bytes(), fs, dm, yT, yT_stride, ghpre, slabs_f, lenf,
+                               (const uint32_t*)nullptr);
+        }
+        VX_CHECK_LAUNCH();
+        return VX_OK;
+    };
     if (packed) {
         const float* Wp = packws;
         const uint32_t* gtab = (const uint32_t*)(packws + Rp * 64 + Rp);
@@ -1063,11 +1105,17 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
             const size_t lds = bb_lds_bytes(dm.D);
             int r = set_lds(k_mvn_enc_bwd_w_b, lds);
             if (r) return r;
+            // (its own bracket on ITS stream: the kernel's span while it shares the chip with the hidden gradient)
+            ProfScope ps("k_mvn_enc_bwd_w_b beside k_mvn_enc_bwd_h_b2", bwb_fork.side());
             hipLaunchKernelGGL(k_mvn_enc_bwd_w_b, dim3((unsigned)n_rowslabs, (unsigned)n_prw), dim3(BWB_THREADS), lds, bwb_fork.side(),
                                dm, hs3, epsT, gdT, gxT, gtab, sc, (const uint32_t*)maxw, slabs_w, Rp * (H + 1));
             VX_CHECK_LAUNCH();
             return VX_OK;
         };
+        // the bracket of the PAIR on the launch stream: from in front of the fork to behind the join of the head weight gradient's
+        // stream = the span of {hidden gradient | head weight gradient} side by side (what bench.py prices with the sum of the two
+        // kernels' flops); dropped at once when the two do not run side by side
+        pair_ps.emplace("k_mvn_enc_bwd_h_b2 | k_mvn_enc_bwd_w_b side by side", st);
         if ((gd_ready & 4) && (gd_ready & 2) && (gd_ready & 1) && hb_fw && use_t && bwb_shape(cfg, nb) && nb >= 4 &&
             bh_lds_bytes(dm.D) <= 160 * 1024 && (mfma16_mode() & 8) && bwb_fork.fork(side_stream(1, st), st)) {
             // The head weight gradient needs nothing the hidden gradient makes once the step's operand maxima are there (bit 2:
@@ -1080,6 +1128,8 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
             bwb_done = true;
             rc = launch_bwb();
             if (rc) return rc;
+        } else {
+            pair_ps->cancel();                                 // one kernel after the other: each has a bracket of its own
         }
         if (use_t && nb >= 4 && bh_lds_bytes(dm.D) <= 160 * 1024) {
             const float* WpT = (const float*)(gtab + Rp / 8 + 8);
@@ -1100,7 +1150,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                 maxw_ready = true;
                 const size_t ldsh = hb_lds_bytes(dm.D);
                 // (beside the head weight gradient the bracket spans both kernels: filed under a name of its own, not priced)
-                ProfScope ps(bwb_done ? "k_mvn_enc_bwd_h_b2 | k_mvn_enc_bwd_w_b side by side" : "k_mvn_enc_bwd_h_b", st);
+                ProfScope ps(bwb_done ? "k_mvn_enc_bwd_h_b2 beside k_mvn_enc_bwd_w_b" : "k_mvn_enc_bwd_h_b", st);
                 if (nb <= HB_SPLIT_MAX) {                               // small batch: the eight waves of a workgroup share the units
                     rc = set_lds(k_mvn_enc_bwd_h_b<true>, ldsh);
                     if (rc) return rc;
@@ -1176,19 +1226,8 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
             // (0.33 ms of a 1M step that used to follow it) and is joined before this call returns (also on an error return)
             const hipStream_t fs = f1_fork.side();
             {
-                ProfScope ps("k_fc1_bwd_b", fs);
-                if (maxw_ready && fc1_lds_on()) {                       // operands through LDS (k_fc1_bwd_c.hip)
-                    rc = set_lds(k_fc1_bwd_c<true>, f1c_lds_bytes());
-                    if (rc) return rc;
-                    hipLaunchKernelGGL(k_fc1_bwd_c<true>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1C_THREADS),
-                                       f1c_lds_bytes(), fs, dm, yT, yT_stride, ghpre, slabs_f, lenf, (const uint32_t*)maxw);
-                } else if (maxw_ready)
-                    hipLaunchKernelGGL(k_fc1_bwd_b<true>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0,
-                                       fs, dm, yT, yT_stride, ghpre, slabs_f, lenf, (const uint32_t*)maxw);
-                else
-                    hipLaunchKernelGGL(k_fc1_bwd_b<false>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0,
-                                       fs, dm, yT, yT_stride, ghpre, slabs_f, lenf, (const uint32_t*)nullptr);
-                VX_CHECK_LAUNCH();
+                rc = launch_fc1_c(fs);                                  // operands through LDS (k_fc1_bwd_c.hip)
+                if (rc) return rc;
             }
             rc = vx_reduce_slabs(slabs_f, n_prf, lenf, -1.0f, genc, (void*)fs);
             if (rc) return rc;
@@ -1197,6 +1236,7 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
         if (bwb_done) {
             rc = bwb_fork.join();
             if (rc) return rc;
+            pair_ps.reset();                                   // the launch stream is behind both kernels here
         } else if (use_t && bwb_shape(cfg, nb)) {
             float* gdT = slabs_f + (int64_t)n_prf * lenf;
             uint16_t* hs3 = (uint16_t*)(gdT + nb * D + 4);
@@ -1284,19 +1324,8 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     if (f1_done) {
         // (joined below)
     } else if (nb > 0 && f1t && (mfma16_mode() & 8)) {
-        ProfScope ps("k_fc1_bwd_b", st);
-        if (maxw_ready && fc1_lds_on()) {
-            rc = set_lds(k_fc1_bwd_c<true>, f1c_lds_bytes());
-            if (rc) return rc;
-            hipLaunchKernelGGL(k_fc1_bwd_c<true>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1C_THREADS), f1c_lds_bytes(),
-                               st, dm, yT, yT_stride, ghpre, slabs_f, lenf, (const uint32_t*)maxw);
-        } else if (maxw_ready)
-            hipLaunchKernelGGL(k_fc1_bwd_b<true>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0, st, dm,
-                               yT, yT_stride, ghpre, slabs_f, lenf, (const uint32_t*)maxw);
-        else
-            hipLaunchKernelGGL(k_fc1_bwd_b<false>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0, st, dm,
-                               yT, yT_stride, ghpre, slabs_f, lenf, (const uint32_t*)nullptr);
-        VX_CHECK_LAUNCH();
+        rc = launch_fc1_c(st);
+        if (rc) return rc;
     } else if (nb > 0 && f1t) {
         const size_t lds = f1_lds_bytes(cfg->J);
         rc = set_lds(k_fc1_bwd_t, lds);
@@ -1645,16 +1674,11 @@ int vx_norm_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t*
             hipLaunchKernelGGL(k_norm_enc_bwd_t64, dim3(nblk), dim3(256), 0, st, nb, W21, W22, h, gloc, graw, ghpreT, slabs_h);
             VX_CHECK_LAUNCH();
             if (mfma16_mode() & 8) {
-                ProfScope ps("k_fc1_bwd_b", st);
-                if (fc1_lds_on() && nb % 4 == 0 && aligned16(ghpreT)) {     // operands through LDS (k_fc1_bwd_c.hip), three bf16 terms
-                    rc = set_lds(k_fc1_bwd_c<false>, f1c_lds_bytes());
-                    if (rc) return rc;
-                    hipLaunchKernelGGL(k_fc1_bwd_c<false>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1C_THREADS),
-                                       f1c_lds_bytes(), st, dm, yT, yT_stride, ghpreT, slabs_f, lenf, (const uint32_t*)nullptr);
-                } else {
-                    hipLaunchKernelGGL(k_fc1_bwd_b<false>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1B_THREADS), 0,
-                                       st, dm, yT, yT_stride, ghpreT, slabs_f, lenf, (const uint32_t*)nullptr);
-                }
+                ProfScope ps("k_fc1_bwd_c", st);                          // operands through LDS (k_fc1_bwd_c.hip), three bf16 terms
+                rc = set_lds(k_fc1_bwd_c<false>, f1c_lds_bytes());             // (tmajor: nb % 4 == 0, ghpreT 16-byte aligned)
+                if (rc) return rc;
+                hipLaunchKernelGGL(k_fc1_bwd_c<false>, dim3((unsigned)((cfg->J + 1 + 511) / 512), (unsigned)n_prf), dim3(F1C_THREADS),
+                                   f1c_lds_bytes(), st, dm, yT, yT_stride, ghpreT, slabs_f, lenf, (const uint32_t*)nullptr);
             } else {
                 const size_t ldst = f1_lds_bytes(cfg->J);
                 rc = set_lds(k_fc1_bwd_t, ldst);

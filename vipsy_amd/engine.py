@@ -536,6 +536,7 @@ class _EngineBase(object):
             self.be.adam2((self.P, self.G, self.M, self.V), self.free, self.n_params, _merge_segments(segs),
                           (self.PP, self.GP, self.MP, self.VP), self.pp_len, _merge_segments(pp_hyper[(betas, eps)]),
                           self.t, betas, eps, **kw)
+            kw.pop("loss", None)
         else:
             for (betas, eps), segs in by_hyper.items():     # one launch per distinct (betas, eps): normally one
                 self.be.adam(self.P, self.G, self.M, self.V, self.free, self.n_params, _merge_segments(segs), self.t, betas, eps, **kw)
@@ -543,7 +544,9 @@ class _EngineBase(object):
             for (betas, eps), segs in pp_hyper.items():
                 self.be.adam(self.PP, self.GP, self.MP, self.VP, None, self.pp_len, _merge_segments(segs), self.t, betas, eps, **kw)
                 kw.pop("loss", None)
-        if not hip:                                          # (the CPU rehearsal backends of tests/)
+        if not hip or "loss" in kw:
+            # the CPU rehearsal backends of tests/ -- or a HIP step that launched no optimiser kernel at all (no trainable
+            # segment): nothing filed the loss, so it is copied into its slot here
             self.loss_ring[self.t % LOSS_RING] = self.G[self.n_params]
 
     def step_loss(self):
@@ -689,6 +692,19 @@ class _EngineBase(object):
         self._ctr_t = self.t
         return self.step_loss()
 
+    graph_max_row_forms = 8
+
+    def _evict_graph_forms(self):
+        """Every distinct (nb, b_global) subsample form holds a captured graph, its private pool and a rows buffer.  A fit loop
+        has one form per rank; a caller whose local row count varies from step to step would otherwise keep one per count for
+        ever: beyond graph_max_row_forms the least recently used 'rows' forms are dropped, graph and buffer."""
+        forms = [m for m in self._graphs if m[0] == "rows"]
+        for m in forms[:max(0, len(forms) - self.graph_max_row_forms)]:
+            st = self._graphs.pop(m)
+            if self._graph is st:
+                self._graph = None
+            st.clear()                                       # releases the CUDAGraph objects (and their pool) and the rows buffer
+
     def _rows_on_device(self, rows):
         """Host row indices (the fit loop's draw) for an eager step."""
         if rows is None or isinstance(rows, (list, tuple)):
@@ -707,6 +723,7 @@ class _EngineBase(object):
             if not hasattr(self, "_graphs"):
                 self._graphs = {}
             if mode in self._graphs:
+                self._graphs[mode] = self._graphs.pop(mode)  # most recently used last (dicts keep insertion order)
                 try:
                     return self._step_graph(lrs, mode, rows)
                 except _GraphCaptureFailed as e:
@@ -720,6 +737,7 @@ class _EngineBase(object):
             if mode is not None:
                 self._graphs[mode] = {"graph": None}         # the first step of a form runs eagerly: workspaces and lists get built
                 self._graph = self._graphs[mode]
+                self._evict_graph_forms()
         rows = self._rows_on_device(rows)
         if S == 1:
             self.loss_and_grads(rows[0] if isinstance(rows, (list, tuple)) else rows, b_global,
