@@ -541,6 +541,8 @@ np.savez(sys.argv[2], loss=eng.G[eng.n_params:eng.n_params + 1].cpu().numpy(), g
     (333, 32, 5, 0.2, 77, False),                    # 5 <= K <= 8, J <= 32: the MFMA kernel (k_hodina_m.hip), one pattern tile
     (260, 17, 6, 0.3, None, True),                   # ... two tiles, amortized guide
     (131, 25, 7, 0.1, None, False),                  # ... four tiles; large lambda: clamped prior probabilities
+    (900, 30, 6, 0.15, None, False),                 # ... 29 waves, most on the no-clamp form, a few with a clamped prior
+    (2048, 30, 8, 0.0, None, False),                 # ... eight tiles, every wave full
 ])
 def test_hodina_step_vs_oracle(N, J, K, miss, B, amort):
     from vipsy_amd.engine import HoDinaEngine, ENC_KEYS

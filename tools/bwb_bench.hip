@@ -5,7 +5,11 @@
 #include "../vipsy_amd/csrc/k_mvn_enc.hip"
 #include "../vipsy_amd/csrc/k_pack.hip"
 #include "../vipsy_amd/csrc/k_mvn_bwd_t.hip"
+#ifdef BWB_KERNEL_FILE                                  // another generation of the kernel (e.g. a saved copy of round 4's file)
+#include BWB_KERNEL_FILE
+#else
 #include "../vipsy_amd/csrc/k_mvn_bwd_b.hip"
+#endif
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -49,12 +53,21 @@ int main(int argc, char** argv) {
     const int n_rowslabs = (Rp + BT_ROWS - 1) / BT_ROWS;
     int n_prw = 256 / n_rowslabs;
     CK(hipMalloc(&slabs, (size_t)n_prw * Rp * 65 * 4));
+#ifdef BWB_KERNEL_FILE
     const size_t lds = bb_lds_bytes(D);
-    CK(hipFuncSetAttribute((const void*)k_mvn_enc_bwd_w_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    auto kern = k_mvn_enc_bwd_w_b;
+#else
+#ifndef BWB_NBUF
+#define BWB_NBUF 3
+#endif
+    const size_t lds = BWB_NBUF == 3 ? bb_lds_bytes_n(D) : bb_lds_bytes(D);
+    auto kern = k_mvn_enc_bwd_w_b<BWB_NBUF>;
+#endif
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k_mvn_enc_bwd_w_b, dim3(n_rowslabs, n_prw), dim3(BWB_THREADS), lds, 0, dm, hs, epsT, gdT, gxT, gtab,
+        hipLaunchKernelGGL(kern, dim3(n_rowslabs, n_prw), dim3(BWB_THREADS), lds, 0, dm, hs, epsT, gdT, gxT, gtab,
                            (const float*)sc, (const uint32_t*)maxw, slabs, (int64_t)Rp * 65);
         hipEventRecord(e1); CK(hipEventSynchronize(e1));
         float ms; hipEventElapsedTime(&ms, e0, e1);

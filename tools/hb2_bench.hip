@@ -40,6 +40,11 @@ static int run(const EncDims& dm, const uint8_t* img, const float* sc, const flo
     return 0;
 }
 
+__global__ void k_tr64(const float* h, float* hT, int64_t nb) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb * 64; i += (int64_t)gridDim.x * blockDim.x)
+        hT[(i & 63) * nb + (i >> 6)] = h[i];
+}
+
 int main(int argc, char** argv) {
     const int D = argc > 2 ? atoi(argv[2]) : 100;
     const int64_t nb = argc > 1 ? atoll(argv[1]) : 1000000;
@@ -51,7 +56,8 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&eps, nb * D * 4)); CK(hipMalloc(&gxT, nb * D * 4)); CK(hipMalloc(&gdT, nb * D * 4));
     k_fill<<<1024, 256>>>(W22, (int64_t)T * 64, 0.1f, 1); k_fill<<<64, 256>>>(W21, D * 64, 0.1f, 2);
     k_fill<<<4096, 256>>>(eps, nb * D, 3.0f, 3); k_fill<<<4096, 256>>>(gdT, nb * D, 2.0f, 4); k_fill<<<4096, 256>>>(gxT, nb * D, 2.0f, 5);
-    k_fill<<<4096, 256>>>(h, nb * 64, 1.5f, 6); k_fill<<<4096, 256>>>(hT, nb * 64, 1.5f, 6);
+    k_fill<<<4096, 256>>>(h, nb * 64, 1.5f, 6);
+    k_tr64<<<4096, 256>>>(h, hT, nb);                              // hT[hh][p] = h[p][hh]: the two layouts of the same values
     float hsc[16] = {0}; hsc[2] = 65536.f; hsc[3] = 1024.f;
     CK(hipMemcpy(sc, hsc, 64, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_pack_heads_hb, dim3(hb_units(D)), dim3(64), 0, 0, D, W21, W22, (const float*)sc, img, maxw);

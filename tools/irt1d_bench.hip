@@ -1,0 +1,145 @@
+// Stand-alone check + timing of k_irt1d (the D = 1 step kernel, person-per-lane form) against a double-precision CPU reference.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I vipsy_amd/csrc -o tools/irt1d_bench tools/irt1d_bench.hip
+//   tools/irt1d_bench            checks at small sizes (all four links, ragged J, subsample), then times BASELINE config 2
+#include "k_irt1d.hip"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+static uint32_t rs = 777;
+static float rnd() { rs = rs * 1664525u + 1013904223u; return (rs >> 8) * (1.0f / 16777216.0f); }
+
+// ITEMS: 0 = the person-per-lane kernel (k_irt1d), else the item-per-lane kernel (k_irt1d_items) with ITEMS words a lane
+template <int MODEL, int ITEMS = 0>
+static float run(int J, int64_t nb, int64_t n_rows_src, bool use_rows, bool check, int reps, float miss, int blocks_cap) {
+    Irt1dDims dm; dm.J = J; dm.model = MODEL; dm.Dc = 1.702f; dm.scale = 2.5f; dm.nb = nb;
+    const int64_t NS = use_rows ? n_rows_src : nb;                     // rows of y
+    std::vector<uint8_t> hy((size_t)NS * J);
+    std::vector<float> hl(nb), hr(nb), he(nb), ha(J), hb(J), hc(J), hd(J);
+    std::vector<int64_t> hrows(nb);
+    for (auto& v : hy) { float u = rnd(); v = u < miss ? 255 : (rnd() < 0.5f ? 1 : 0); }
+    for (auto& v : hl) v = 2.f * (rnd() - 0.5f);
+    for (auto& v : hr) v = 0.5f * (rnd() - 0.5f);
+    for (auto& v : he) v = 3.f * (rnd() - 0.5f);
+    for (auto& v : ha) v = 0.5f + 2.f * rnd();
+    for (auto& v : hb) v = 2.f * (rnd() - 0.5f);
+    for (auto& v : hc) v = -2.f + rnd();
+    for (auto& v : hd) v = 2.f + rnd();
+    for (int64_t i = 0; i < nb; ++i) hrows[i] = use_rows ? (int64_t)(rnd() * NS) % NS : i;
+    uint8_t* y; float *l, *r, *e, *a, *b, *c, *d, *gl, *gr, *el, *slabs; int64_t* rows;
+    int64_t blocks = (nb + 63) / 64;
+    if (ITEMS) { blocks = (blocks + 3) / 4; if (blocks_cap > 1024) blocks_cap = 1024; }
+    if (blocks > blocks_cap) blocks = blocks_cap;
+    if (blocks < 1) blocks = 1;
+    CK(hipMalloc(&y, hy.size())); CK(hipMalloc(&l, nb * 4)); CK(hipMalloc(&r, nb * 4)); CK(hipMalloc(&e, nb * 4));
+    CK(hipMalloc(&a, J * 4)); CK(hipMalloc(&b, J * 4)); CK(hipMalloc(&c, J * 4)); CK(hipMalloc(&d, J * 4));
+    CK(hipMalloc(&gl, nb * 4)); CK(hipMalloc(&gr, nb * 4)); CK(hipMalloc(&el, nb * 4)); CK(hipMalloc(&rows, nb * 8));
+    CK(hipMalloc(&slabs, (size_t)blocks * (4 * J + 1) * 4));
+    CK(hipMemcpy(y, hy.data(), hy.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(l, hl.data(), nb * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(r, hr.data(), nb * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(e, he.data(), nb * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(a, ha.data(), J * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(b, hb.data(), J * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(c, hc.data(), J * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d, hd.data(), J * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(rows, hrows.data(), nb * 8, hipMemcpyHostToDevice));
+    const size_t lds = ITEMS ? sizeof(float) * 4 * (size_t)J * (I1_THREADS / 64) : i1_lds_bytes(J, MODEL);
+    const bool words = J % 4 == 0;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+#define LAUNCH(K) do { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(K, dim3((unsigned)blocks), dim3(I1_THREADS), lds, 0, dm, y, use_rows ? rows : nullptr, (int64_t)0, l, r,     \
+                           check ? e : nullptr, 1234ull, 3u, (const uint32_t*)nullptr, 0u, a, b, c, d, gl, gr, el, slabs); } while (0)
+    for (int rep = 0; rep < reps + 1; ++rep) {
+        if (rep == 1) hipEventRecord(e0);
+        // eps handed in when checking (the reference uses the same draws); drawn inside the kernel when timing
+        if constexpr (ITEMS == 0) { if (words) LAUNCH((k_irt1d<MODEL, true>)); else LAUNCH((k_irt1d<MODEL, false>)); }
+        else { if (words) LAUNCH((k_irt1d_items<MODEL, ITEMS, true>)); else LAUNCH((k_irt1d_items<MODEL, ITEMS, false>)); }
+    }
+    hipEventRecord(e1); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+    if (reps > 0) { hipEventElapsedTime(&ms, e0, e1); ms /= reps; }
+    if (check) {
+        std::vector<float> ggl(nb), ggr(nb), gel(nb), gs((size_t)blocks * (4 * J + 1));
+        CK(hipMemcpy(ggl.data(), gl, nb * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(ggr.data(), gr, nb * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(gel.data(), el, nb * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(gs.data(), slabs, gs.size() * 4, hipMemcpyDeviceToHost));
+        const double eps32 = 1.1920928955078125e-07;
+        std::vector<double> ritem(4 * J, 0.0);
+        double rel = 0, e_l = 0, e_r = 0, e_e = 0, m_l = 0, m_r = 0, m_e = 0;
+        for (int64_t i = 0; i < nb; ++i) {
+            const double sig = exp((double)hr[i]), x = hl[i] + sig * he[i];
+            double ll = 0, gx = 0;
+            for (int j = 0; j < J; ++j) {
+                const uint8_t yy = hy[(size_t)hrows[i] * J + j];
+                if (yy == 255) { ll += -1.1920928244535389e-07; continue; }
+                const double z = dm.Dc * (x * (MODEL >= 2 ? ha[j] : 1.0) + hb[j]);
+                const double sg = 1.0 / (1.0 + exp(-z));
+                double cc = 0, dd = 1;
+                if (MODEL >= 3) cc = fmin(1.0 / (1.0 + exp(-(double)hc[j])), 1 - eps32);
+                if (MODEL >= 4) dd = fmin(1.0 / (1.0 + exp(-(double)hd[j])), 1 - eps32);
+                const double P = cc + (dd - cc) * sg;
+                const bool inside = P >= eps32 && P <= 1 - eps32;
+                const double Pc = P < eps32 ? eps32 : (P > 1 - eps32 ? 1 - eps32 : P);
+                ll += yy ? log(Pc) : log(1 - Pc);
+                const double dP = inside ? ((double)yy - Pc) / (Pc * (1 - Pc)) : 0.0;
+                const double dz = dP * (dd - cc) * sg * (1 - sg), t = dm.Dc * dz;
+                gx += t * (MODEL >= 2 ? ha[j] : 1.0);
+                if (MODEL >= 2) ritem[j] += dm.scale * t * x;
+                ritem[J + j] += dm.scale * t;
+                if (MODEL >= 3) ritem[2 * J + j] += dm.scale * dP * (1 - sg) * cc * (1 - cc);
+                if (MODEL >= 4) ritem[3 * J + j] += dm.scale * dP * sg * dd * (1 - dd);
+            }
+            const double gxt = dm.scale * (gx - x);
+            const double rl = -gxt, rr = -(gxt * sig * he[i] + dm.scale), re = ll - 0.5 * x * x + 0.5 * (double)he[i] * he[i] + hr[i];
+            e_l = fmax(e_l, fabs(ggl[i] - rl)); m_l = fmax(m_l, fabs(rl));
+            e_r = fmax(e_r, fabs(ggr[i] - rr)); m_r = fmax(m_r, fabs(rr));
+            e_e = fmax(e_e, fabs(gel[i] - re)); m_e = fmax(m_e, fabs(re));
+            rel += dm.scale * re;
+        }
+        double e_i = 0, m_i = 0, gsum_el = 0;
+        for (int q = 0; q < 4 * J; ++q) {
+            double v = 0;
+            for (int64_t bb = 0; bb < blocks; ++bb) v += gs[(size_t)bb * (4 * J + 1) + q];
+            e_i = fmax(e_i, fabs(v - ritem[q])); m_i = fmax(m_i, fabs(ritem[q]));
+        }
+        for (int64_t bb = 0; bb < blocks; ++bb) gsum_el += gs[(size_t)bb * (4 * J + 1) + 4 * J];
+        printf("model %d J=%d nb=%lld rows=%d miss=%.2f blocks=%lld: gloc %.2e/%.2e graw %.2e/%.2e elbo %.2e/%.2e item %.2e/%.2e  sum-elbo rel %.2e %s\n",
+               MODEL, J, (long long)nb, (int)use_rows, miss, (long long)blocks, e_l, m_l, e_r, m_r, e_e, m_e, e_i, m_i, fabs(gsum_el - rel) / fabs(rel),
+               (e_l < 3e-5 * m_l && e_r < 3e-5 * m_r && e_e < 3e-5 * m_e && e_i < 3e-5 * m_i) ? "ok" : "FAIL");
+    }
+    hipFree(y); hipFree(l); hipFree(r); hipFree(e); hipFree(a); hipFree(b); hipFree(c); hipFree(d); hipFree(gl); hipFree(gr); hipFree(el);
+    hipFree(rows); hipFree(slabs);
+    return ms;
+}
+
+int main(int argc, char** argv) {
+    run<2>(5, 1000, 0, false, true, 0, 0.0f, 2048);            // LSAT-6's shape
+    run<1>(37, 777, 0, false, true, 0, 0.2f, 2048);            // ragged J: byte loads
+    run<2>(100, 4096, 0, false, true, 0, 0.1f, 2048);
+    run<3>(24, 300, 0, false, true, 0, 0.3f, 2048);
+    run<4>(100, 5000, 0, false, true, 0, 0.0f, 2048);
+    run<4>(100, 5000, 0, false, true, 0, 0.0f, 7);             // strided chunks: 12 chunks a block
+    run<4>(101, 333, 4000, true, true, 0, 0.5f, 2048);         // subsample, ragged everything
+    run<2>(500, 700, 0, false, true, 0, 0.9f, 2048);
+    run<4>(1024, 200, 0, false, true, 0, 0.1f, 2048);          // the largest J
+    run<2>(1024, 200, 0, false, true, 0, 0.1f, 2048);
+    run<2, 2>(500, 700, 0, false, true, 0, 0.9f, 2048);        // the item-per-lane kernel
+    run<4, 1>(160, 1000, 0, false, true, 0, 0.1f, 2048);
+    run<3, 4>(1000, 300, 4000, true, true, 0, 0.1f, 2048);
+    if (argc > 1 && argv[1][0] == 't') {
+        for (int rep = 0; rep < 2; ++rep) {
+            printf("cfg2  4PL 100k x 100:  person-lanes %.4f ms   item-lanes %.4f ms\n", run<4>(100, 100000, 0, false, false, 20, 0.0f, 2048),
+                   run<4, 1>(100, 100000, 0, false, false, 20, 0.0f, 2048));
+            printf("      4PL 100k x 160:  person-lanes %.4f ms   item-lanes %.4f ms\n", run<4>(160, 100000, 0, false, false, 20, 0.0f, 2048),
+                   run<4, 1>(160, 100000, 0, false, false, 20, 0.0f, 2048));
+            printf("      4PL 100k x 256:  person-lanes %.4f ms   item-lanes %.4f ms\n", run<4>(256, 100000, 0, false, false, 20, 0.0f, 2048),
+                   run<4, 1>(256, 100000, 0, false, false, 20, 0.0f, 2048));
+            printf("      2PL 1M x 128:    person-lanes %.4f ms   item-lanes %.4f ms\n", run<2>(128, 1000000, 0, false, false, 5, 0.0f, 2048),
+                   run<2, 1>(128, 1000000, 0, false, false, 5, 0.0f, 2048));
+            printf("      2PL 1M x 256:    person-lanes %.4f ms   item-lanes %.4f ms\n", run<2>(256, 1000000, 0, false, false, 5, 0.0f, 2048),
+                   run<2, 1>(256, 1000000, 0, false, false, 5, 0.0f, 2048));
+            printf("dense 2PL 1M x 500:    person-lanes %.4f ms   item-lanes %.4f ms\n", run<2>(500, 1000000, 0, false, false, 5, 0.0f, 2048),
+                   run<2, 2>(500, 1000000, 0, false, false, 5, 0.0f, 2048));
+        }
+    }
+    return 0;
+}

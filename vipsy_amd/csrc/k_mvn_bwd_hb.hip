@@ -99,7 +99,8 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
     const int64_t nb = dm.nb;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    float* gx_lds = (float*)smem_hb + (size_t)wave * D * 32;           // [D][32] of this wave
+    // [D][32] of this wave; SPLIT: the eight waves work on the SAME 32 persons and share one tile (each loads an eighth of it)
+    float* gx_lds = (float*)smem_hb + (SPLIT ? (size_t)0 : (size_t)wave * D * 32);
     const char* ring = smem_hb + (size_t)HB_WAVES * D * 32 * sizeof(float);
     const uint32_t ring_lds = lds_addr_uniform(ring);
     const int64_t i0 = i_base + (SPLIT ? (int64_t)blockIdx.x * 32 : ((int64_t)blockIdx.x * HB_WAVES + wave) * 32);
@@ -167,6 +168,22 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
     HSTAMP();                                                          // 1: eps fragments
     // ---- this wave's gx tile [D][32] (lanes = persons: 128-byte rows of gxT), times u_inv
     float g_max = 0.f;
+    if constexpr (SPLIT) {
+        // rows k = 16 j + 2 wave + half of the shared tile: at most eight loads a lane, all in flight together; published by the
+        // barrier below (round 5: every wave used to load the whole tile for itself -- 8 k cycles of a 128 k-cycle workgroup)
+        float t[HB_NS];
+#pragma unroll
+        for (int q = 0; q < HB_NS; ++q) {
+            const int k = 16 * q + 2 * wave + half;
+            t[q] = k < D ? gxT[(int64_t)k * nb + ic] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < HB_NS; ++q) {
+            const int k = 16 * q + 2 * wave + half;
+            g_max = fmaxf(g_max, fabsf(t[q]));
+            if (k < D) gx_lds[k * 32 + l31] = t[q] * u_inv;          // (u_inv: the waves share the persons, hence e_max and u_inv)
+        }
+    } else {
     for (int k0 = 0; k0 < D; k0 += 64) {                               // 32 rows per lane half in flight together (one at a
         float t[32];                                                   // time this loop was a chain of 50 misses)
 #pragma unroll
@@ -180,6 +197,7 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
             g_max = fmaxf(g_max, fabsf(t[q]));
             if (k < D) gx_lds[k * 32 + l31] = t[q] * u_inv;
         }
+    }
     }
     g_max = wave_max_dpp(g_max);
     // fragments of a dimension-major operand; returns the power of two that takes its scale (and the weights') off
@@ -238,6 +256,7 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
     float d_max = 0.f, x_max = 0.f;                                    // wave maxima of |gd| and (again) |gx|
 
     if constexpr (SPLIT) {
+        __syncthreads();                                               // the shared gx tile is complete
         HSTAMP();                                                      // 2: gx tile
         // ---- this wave's share of the units, fragments global -> registers one unit ahead
         auto uoff = [&](int k) -> int {                                // index of unit (k, 0): blocks of 16 k have kb + 1 units per k
@@ -259,21 +278,29 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
             U1 = mfma_f16(Au[2], bf[1][s], U1);
             U1 = mfma_f16(Au[2], bf[0][s], U1);
         };
-        f16x8 Ac[4], An[4];
-        load_unit(Ac, uoff(1 + wave));
+        // (round 5: THREE units ahead -- one ahead, a unit cost an L2 round trip, ~530 cycles for 192 of MFMA; the wave's units
+        // are a fixed sequence -- k = 1 + wave, 9 + wave, .., the k-steps s = 0 .. (k - 1) / 16 of each -- walked by a cursor)
+        f16x8 Ac[4], An[4], An2[4], An3[4];
+        int nk = 1 + wave, nsx = 0;                                    // the unit to request next
+        auto next_unit = [&]() __attribute__((always_inline)) -> int {
+            const int uu = uoff(nk) + nsx;
+            if (++nsx > ((nk - 1) >> 4)) { nsx = 0; nk += HB_WAVES; }
+            return uu;
+        };
+        load_unit(Ac, next_unit());
+        load_unit(An, next_unit());
+        load_unit(An2, next_unit());
         static_for<HB_NS>([&](auto kbc) {
             constexpr int kb = decltype(kbc)::value;
             const int k_lo = 16 * kb + 1, k_hi = (16 * kb + 16 < D - 1) ? 16 * kb + 16 : D - 1;
             // the k of this wave in the block: k = 1 + wave (mod 8)
             for (int k = k_lo + ((wave - (k_lo - 1)) & (HB_WAVES - 1)); k <= k_hi; k += HB_WAVES) {
                 f32x16 U0 = zero16(), U1 = zero16();
-                const int u0 = uoff(k);
                 static_for<kb + 1>([&](auto sc) {
-                    constexpr int s = decltype(sc)::value;
-                    load_unit(An, s < kb ? u0 + s + 1 : uoff(k + HB_WAVES));
+                    load_unit(An3, next_unit());
                     mma_unit(Ac, sc, U0, U1);
 #pragma unroll
-                    for (int f = 0; f < 4; ++f) Ac[f] = An[f];
+                    for (int f = 0; f < 4; ++f) { Ac[f] = An[f]; An[f] = An2[f]; An2[f] = An3[f]; }
                 });
                 const float gk = gx_lds[k * 32 + l31];
 #pragma unroll
@@ -282,26 +309,40 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
         });
         HSTAMP();                                                      // 3: OFF units
         // ---- DIAG (operand gd) and LOC (operand gx) units: s = wave, wave + 8, ..
+        // Wave w runs the ONE unit s = w of each section (ns <= 8 = the waves), so it needs the eight operand values of its own
+        // k-step only -- sixteen loads a lane for both sections, not the 2 x 56 of a whole tile each (round 5: 20 k cycles of a
+        // 128 k-cycle workgroup) -- and scales them by its own power of two: its partial sum carries its own cinv.
         const int u_sec = hb_units_off(D);
-        {
-            const float cinv = frags_from_T(gxT, x_max);
-            f32x16 S0 = zero16(), S1 = zero16();
-            static_for<HB_NS>([&](auto sc) {
-                constexpr int s = decltype(sc)::value;
-                if (s < ns && (s & (HB_WAVES - 1)) == wave) { load_unit(Ac, u_sec + s); mma_unit(Ac, sc, S0, S1); }
-            });
+        if (wave < ns) {
+            float vx_[8], vd_[8], mxv = 0.f, mdv = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { gh0[r] = fmaf(cinv, S0[r], gh0[r]); gh1[r] = fmaf(cinv, S1[r], gh1[r]); }
-        }
-        {
-            const float cinv = frags_from_T(gdT, d_max);
-            f32x16 S0 = zero16(), S1 = zero16();
-            static_for<HB_NS>([&](auto sc) {
-                constexpr int s = decltype(sc)::value;
-                if (s < ns && (s & (HB_WAVES - 1)) == wave) { load_unit(Ac, u_sec + ns + s); mma_unit(Ac, sc, S0, S1); }
-            });
+            for (int j = 0; j < 8; ++j) {
+                const int c = 16 * wave + 8 * half + j;
+                vx_[j] = (c < D) ? gxT[(int64_t)c * nb + ic] : 0.f;
+                vd_[j] = (c < D) ? gdT[(int64_t)c * nb + ic] : 0.f;
+            }
+            f16x8 Ad[4];
+            load_unit(Ac, u_sec + wave);
+            load_unit(Ad, u_sec + ns + wave);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { gh0[r] = fmaf(cinv, S0[r], gh0[r]); gh1[r] = fmaf(cinv, S1[r], gh1[r]); }
+            for (int j = 0; j < 8; ++j) { mxv = fmaxf(mxv, fabsf(vx_[j])); mdv = fmaxf(mdv, fabsf(vd_[j])); }
+            x_max = wave_max_dpp(mxv);
+            d_max = wave_max_dpp(mdv);
+            const int sx = f16_scale_exp(x_max), sd = f16_scale_exp(d_max);
+            f16x8 fxh, fxl, fdh, fdl;
+            split2h_frag(vx_, ldexpf(1.0f, sx), fxh, fxl);
+            split2h_frag(vd_, ldexpf(1.0f, sd), fdh, fdl);
+            const float cx = w_inv * ldexpf(1.0f, -sx), cd = w_inv * ldexpf(1.0f, -sd);
+            f32x16 S0 = zero16(), S1 = zero16(), T0 = zero16(), T1 = zero16();
+            S0 = mfma_f16(Ac[1], fxh, S0); S0 = mfma_f16(Ac[0], fxl, S0); S0 = mfma_f16(Ac[0], fxh, S0);
+            S1 = mfma_f16(Ac[3], fxh, S1); S1 = mfma_f16(Ac[2], fxl, S1); S1 = mfma_f16(Ac[2], fxh, S1);
+            T0 = mfma_f16(Ad[1], fdh, T0); T0 = mfma_f16(Ad[0], fdl, T0); T0 = mfma_f16(Ad[0], fdh, T0);
+            T1 = mfma_f16(Ad[3], fdh, T1); T1 = mfma_f16(Ad[2], fdl, T1); T1 = mfma_f16(Ad[2], fdh, T1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                gh0[r] = fmaf(cx, S0[r], gh0[r]); gh1[r] = fmaf(cx, S1[r], gh1[r]);
+                gh0[r] = fmaf(cd, T0[r], gh0[r]); gh1[r] = fmaf(cd, T1[r], gh1[r]);
+            }
         }
         HSTAMP();                                                      // 4: section units
         // ---- sum of the eight partial tiles, fixed order; wave 0 keeps the result
@@ -324,17 +365,43 @@ __global__ __launch_bounds__(HB_THREADS, 1) void k_mvn_enc_bwd_h_b(
             printf("HSTAMPS blk 1 wave %d: epsfrag %llu gx %llu off %llu sec %llu bar %llu\n", wave, hst_[1] - hst_[0], hst_[2] - hst_[1],
                    hst_[3] - hst_[2], hst_[4] - hst_[3], hst_[5] - hst_[4]);
 #endif
-        if (wave != 0) return;
+        // Round 5: the sum and the output are divided between the eight waves -- wave w takes the four accumulator registers
+        // 4 g .. 4 g + 3 of hidden tile ht (w = 4 ht + g: the hidden units 32 ht + 8 g + 4 half + 0..3 of its lanes' persons),
+        // 32 LDS reads a lane instead of wave 0's 224 with seven waves gone (63 k of a 128 k-cycle workgroup), in the same
+        // fixed order w' = 0..7.
+        {
+            const int ht = wave >> 2, g = wave & 3;
+            float a4[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float a0 = red[(size_t)r * 64 + lane], a1 = red[(size_t)(16 + r) * 64 + lane];
+            for (int c = 0; c < 4; ++c) {
+                float a = red[((size_t)(16 * ht + 4 * g + c)) * 64 + lane];
 #pragma unroll
-            for (int w = 1; w < HB_WAVES; ++w) {
-                a0 += red[((size_t)w * 32 + r) * 64 + lane];
-                a1 += red[((size_t)w * 32 + 16 + r) * 64 + lane];
+                for (int w = 1; w < HB_WAVES; ++w) a += red[((size_t)w * 32 + 16 * ht + 4 * g + c) * 64 + lane];
+                a4[c] = a;
             }
-            gh0[r] = a0; gh1[r] = a1;
+            const int hh0 = 32 * ht + 8 * g + 4 * half;
+            float p_max = 0.f;
+            if (i < nb) {
+                const float4 hv = *(const float4*)(h_in + i * H + hh0);
+                float4 o;
+                o.x = a4[0] * (1.0f - __expf(-hv.x));
+                o.y = a4[1] * (1.0f - __expf(-hv.y));
+                o.z = a4[2] * (1.0f - __expf(-hv.z));
+                o.w = a4[3] * (1.0f - __expf(-hv.w));
+                p_max = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
+                if (ghpreT_out) {                                      // dimension-major rows hh0 .. hh0 + 3
+                    ghpreT_out[(int64_t)(hh0 + 0) * nb + i] = o.x; ghpreT_out[(int64_t)(hh0 + 1) * nb + i] = o.y;
+                    ghpreT_out[(int64_t)(hh0 + 2) * nb + i] = o.z; ghpreT_out[(int64_t)(hh0 + 3) * nb + i] = o.w;
+                } else {
+                    *(float4*)(ghpre_out + i * H + hh0) = o;
+                }
+            }
+            if (ghpreT_out) {
+                p_max = wave_max_dpp(p_max);
+                if (lane == 0 && maxw) atomic_max_raise(maxw + 3, p_max);
+            }
         }
+        return;
     } else {
     vx_wait_vmem();                                                    // pairs 0..2 of the ring (and nothing else)
     __syncthreads();

@@ -49,30 +49,96 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ 
     }
 }
 
-// Many slabs, few columns, and the tail of a D = 1 step folded in: block = 32 columns x 32 slab groups (group g sums
-// slabs g, g + 32, ... in ascending order; the 32 group sums are added in ascending order) -> deterministic.  The last
-// column may go to its own address (the loss slot), and the step counter of a captured step advances here.
-__global__ __launch_bounds__(1024) void k_reduce_wide(const float* __restrict__ slabs, int64_t n_slabs, int64_t stride,
-                                                      int64_t len, float alpha, float* __restrict__ out,
-                                                      float* __restrict__ last_out, uint32_t* __restrict__ tick) {
-    __shared__ float part[32][33];
-    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    if (tick && blockIdx.x == 0 && threadIdx.x == 0) *tick += 1u;
-    for (int64_t c0 = (int64_t)blockIdx.x * 32; c0 < len; c0 += (int64_t)gridDim.x * 32) {
+// One launch behind an item-stationary likelihood kernel whose item chunks went to `groups` workgroups (k_irt_lik_r; on the
+// reference's own B = 100 step three reductions, a clearing pass and the DIAG-row operand were five launches of ~5 us each):
+//   blocks [0, nblk_gx)              gx = the chunk partials added in ascending chunk order; with gdT: gd = gx eps ld + scale
+//   blocks [nblk_gx, + nblk_ll)      ll = the log-lik partials added the same way
+//   the rest                         gitem = -(sum of the person ranges' item slabs), 64 columns a block as k_reduce_slabs;
+//                                    columns from len_w on (the c / d leaves of a model that has none) are not written by the
+//                                    likelihood kernel and come out as zeros: the slabs need no clearing
+// Every sum has a fixed order: bit-reproducible.
+__global__ __launch_bounds__(256) void k_lik_finish(const float* __restrict__ gx_part, int groups, int64_t n_gx, float* __restrict__ gx_sum,
+                                                   const float* __restrict__ epsT, const float* __restrict__ ldT, float* __restrict__ gdT,
+                                                   float scale, const float* __restrict__ ll_part, int64_t nb, float* __restrict__ ll,
+                                                   const float* __restrict__ slabs, int64_t n_slabs, int64_t slab_len, int64_t len_w,
+                                                   float* __restrict__ gitem, int nblk_gx, int nblk_ll) {
+    const int bid = blockIdx.x;
+    if (bid < nblk_gx) {
+        for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < n_gx; i += (int64_t)nblk_gx * 256) {
+            float acc = gx_part[i];
+            for (int g = 1; g < groups; ++g) acc += gx_part[(int64_t)g * n_gx + i];
+            gx_sum[i] = acc;
+            if (gdT) gdT[i] = fmaf(acc * epsT[i], ldT[i], scale);
+        }
+        return;
+    }
+    if (bid < nblk_gx + nblk_ll) {
+        for (int64_t i = (int64_t)(bid - nblk_gx) * 256 + threadIdx.x; i < nb; i += (int64_t)nblk_ll * 256) {
+            float acc = ll_part[i];
+            for (int g = 1; g < groups; ++g) acc += ll_part[(int64_t)g * nb + i];
+            ll[i] = acc;
+        }
+        return;
+    }
+    __shared__ float part[4][64];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int nblk_s = (int)gridDim.x - nblk_gx - nblk_ll;
+    for (int64_t c0 = (int64_t)(bid - nblk_gx - nblk_ll) * 64; c0 < slab_len; c0 += (int64_t)nblk_s * 64) {
         const int64_t i = c0 + col;
         float acc = 0.f;
-        if (i < len) {
-#pragma unroll 4
-            for (int64_t s = grp; s < n_slabs; s += 32) acc += slabs[s * stride + i];
+        if (i < len_w) {
+#pragma unroll 8
+            for (int64_t s2 = grp; s2 < n_slabs; s2 += 4) acc += slabs[s2 * slab_len + i];
         }
         part[grp][col] = acc;
         __syncthreads();
-        if (grp == 0 && i < len) {
-            float t = part[0][col];
+        if (grp == 0 && i < slab_len) gitem[i] = -((part[0][col] + part[1][col]) + (part[2][col] + part[3][col]));
+        __syncthreads();
+    }
+}
+
+// Many slabs, few columns, and the tail of a D = 1 step folded in: block = COLS columns x (1024 / COLS) slab groups (group g
+// sums slabs g, g + GRPS, ... in ascending order; the group sums are added in a fixed order: ascending for COLS = 32, a
+// fixed pairwise tree for COLS = 8) -> deterministic.  The last column may go to its own address (the loss slot), and the
+// step counter of a captured step advances here.  COLS = 8 is for MANY slabs (the person-per-lane D = 1 kernel writes one
+// per 64 persons while they fit the chip: 1 563 at 100 k persons): four times the workgroups and a quarter of the
+// dependent loads a thread -- the kernel is a chain of load latencies, not bytes.
+template <int COLS>
+__global__ __launch_bounds__(1024) void k_reduce_wide(const float* __restrict__ slabs, int64_t n_slabs, int64_t stride,
+                                                      int64_t len, float alpha, float* __restrict__ out,
+                                                      float* __restrict__ last_out, uint32_t* __restrict__ tick) {
+    constexpr int GRPS = 1024 / COLS;
+    __shared__ float part[GRPS][COLS + 1];
+    const int col = threadIdx.x % COLS, grp = threadIdx.x / COLS;
+    if (tick && blockIdx.x == 0 && threadIdx.x == 0) *tick += 1u;
+    for (int64_t c0 = (int64_t)blockIdx.x * COLS; c0 < len; c0 += (int64_t)gridDim.x * COLS) {
+        const int64_t i = c0 + col;
+        float acc = 0.f;
+        if (i < len) {
+#pragma unroll 8
+            for (int64_t s = grp; s < n_slabs; s += GRPS) acc += slabs[s * stride + i];
+        }
+        part[grp][col] = acc;
+        __syncthreads();
+        if constexpr (COLS == 32) {
+            if (grp == 0 && i < len) {
+                float t = part[0][col];
 #pragma unroll
-            for (int g = 1; g < 32; ++g) t += part[g][col];
-            if (last_out && i == len - 1) last_out[0] = alpha * t;
-            else out[i] = alpha * t;
+                for (int g = 1; g < GRPS; ++g) t += part[g][col];
+                if (last_out && i == len - 1) last_out[0] = alpha * t;
+                else out[i] = alpha * t;
+            }
+        } else {
+#pragma unroll
+            for (int s = GRPS / 2; s > 0; s >>= 1) {
+                if (grp < s) part[grp][col] += part[grp + s][col];
+                __syncthreads();
+            }
+            if (grp == 0 && i < len) {
+                const float t = part[0][col];
+                if (last_out && i == len - 1) last_out[0] = alpha * t;
+                else out[i] = alpha * t;
+            }
         }
         __syncthreads();
     }
@@ -94,7 +160,10 @@ __global__ __launch_bounds__(256) void k_reduce_few(const float4* __restrict__ s
 
 // two-stage fixed-order sum: stage 1 -> partial[blockIdx], stage 2 (1 block) -> out[0]
 __global__ void k_sum_stage1(const float* __restrict__ v, int64_t n, float* __restrict__ partial,
-                             const float* __restrict__ v2 = nullptr /*optional second vector of the same length*/) {
+                             const float* __restrict__ v2 = nullptr /*optional second vector of the same length*/,
+                             float alpha = 0.f, float* __restrict__ out = nullptr /*ONE block: the launch is the whole sum, out[0]
+                             = alpha * total -- what stage 2 would make of one partial, bit for bit, without its launch*/,
+                             uint32_t* __restrict__ tick = nullptr) {
     __shared__ float red[256 / VX_WAVE];
     float acc = 0.f;
     const int64_t per = (n + gridDim.x - 1) / gridDim.x;
@@ -109,6 +178,10 @@ __global__ void k_sum_stage1(const float* __restrict__ v, int64_t n, float* __re
         float t = 0.f;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
         partial[blockIdx.x] = t;
+        if (out) {                                             // (gridDim.x == 1)
+            out[0] = alpha * t;
+            if (tick) *tick += 1u;                             // (every kernel that reads it as the Philox step ran before this one)
+        }
     }
 }
 __global__ void k_sum_stage2(const float* __restrict__ partial, int n, float alpha, float* __restrict__ out,

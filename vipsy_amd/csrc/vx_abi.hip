@@ -336,8 +336,12 @@ int vx_reduce_slabs(const float* slabs, int64_t n_slabs, int64_t len, float alph
 static int reduce_step_slabs(const float* slabs, int64_t n_slabs, int J, float* gitem, float* loss, uint32_t* tick,
                              void* hs) {
     const int64_t len = 4 * (int64_t)J + (loss ? 1 : 0);
-    hipLaunchKernelGGL(k_reduce_wide, dim3(grid_1d(len, 32)), dim3(1024), 0, (hipStream_t)hs, slabs, n_slabs,
-                       4 * (int64_t)J + 1, len, -1.0f, gitem, loss, tick);
+    if (n_slabs > 512)
+        hipLaunchKernelGGL(k_reduce_wide<8>, dim3(grid_1d(len, 8)), dim3(1024), 0, (hipStream_t)hs, slabs, n_slabs,
+                           4 * (int64_t)J + 1, len, -1.0f, gitem, loss, tick);
+    else
+        hipLaunchKernelGGL(k_reduce_wide<32>, dim3(grid_1d(len, 32)), dim3(1024), 0, (hipStream_t)hs, slabs, n_slabs,
+                           4 * (int64_t)J + 1, len, -1.0f, gitem, loss, tick);
     VX_CHECK_LAUNCH();
     return VX_OK;
 }
@@ -349,6 +353,12 @@ int vx_sum(const float* v, int64_t n, float alpha, float* out, float* workspace,
     int nblk = (int)((n + 4095) / 4096);
     if (nblk < 1) nblk = 1;
     if (nblk > 1024) nblk = 1024;
+    if (nblk == 1) {                                       // a small batch: one launch (k_sum_stage1's final form)
+        hipLaunchKernelGGL(k_sum_stage1, dim3(1), dim3(256), 0, (hipStream_t)hs, v, n, workspace, (const float*)nullptr, alpha, out,
+                           (uint32_t*)nullptr);
+        VX_CHECK_LAUNCH();
+        return VX_OK;
+    }
     hipLaunchKernelGGL(k_sum_stage1, dim3(nblk), dim3(256), 0, (hipStream_t)hs, v, n, workspace, (const float*)nullptr);
     VX_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_sum_stage2, dim3(1), dim3(256), 0, (hipStream_t)hs, workspace, nblk, alpha, out);
@@ -361,6 +371,11 @@ int vx_sum2(const float* v1, const float* v2, int64_t n, float alpha, float* out
     int nblk = (int)((n + 4095) / 4096);
     if (nblk < 1) nblk = 1;
     if (nblk > 1024) nblk = 1024;
+    if (nblk == 1) {
+        hipLaunchKernelGGL(k_sum_stage1, dim3(1), dim3(256), 0, (hipStream_t)hs, v1, n, workspace, v2, alpha, out, step_dev);
+        VX_CHECK_LAUNCH();
+        return VX_OK;
+    }
     hipLaunchKernelGGL(k_sum_stage1, dim3(nblk), dim3(256), 0, (hipStream_t)hs, v1, n, workspace, v2);
     VX_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_sum_stage2, dim3(1), dim3(256), 0, (hipStream_t)hs, workspace, nblk, alpha, out, step_dev);
@@ -789,8 +804,13 @@ static int irt_lik_grad_kernels(const vx_irt_cfg* cfg, const uint8_t* y, const i
         float* gx_part = groups > 1 ? workspace + (int64_t)n_pr * dm.slab_len : gx_sum;
         float* ll_part = groups > 1 ? gx_part + (int64_t)groups * nb * cfg->D : ll;
         hipStream_t st = (hipStream_t)hs;
-        hipError_t he = hipMemsetAsync(slabs, 0, sizeof(float) * (size_t)n_pr * dm.slab_len, st);
-        if (he != hipSuccess) return (int)he;
+        // several item chunks and dimension-major partials: ONE finishing launch sums the partials, makes the DIAG-row operand
+        // and reduces the item slabs (k_lik_finish); otherwise the slabs are cleared and reduced as before
+        const bool finish1 = nb > 0 && groups > 1 && !(gxT && gx);
+        if (!finish1) {
+            hipError_t he = hipMemsetAsync(slabs, 0, sizeof(float) * (size_t)n_pr * dm.slab_len, st);
+            if (he != hipSuccess) return (int)he;
+        }
         if (nb > 0) {
             const size_t lds = likr_lds_bytes(dm.XS);
             const dim3 grid((unsigned)(groups * n_pr));
@@ -814,6 +834,20 @@ static int irt_lik_grad_kernels(const vx_irt_cfg* cfg, const uint8_t* y, const i
 #undef DISPATCH_LIKR
 #undef LAUNCH_LIKR
             VX_CHECK_LAUNCH();
+            if (finish1) {
+                const int64_t n_gx = nb * cfg->D;
+                const bool with_gd = gdT && gxT && !opmax;       // (the maxima, when asked for, come from k_absmax3 behind k_mvn_gd)
+                const int nblk_gx = grid_1d(n_gx, 256), nblk_ll = grid_1d(nb, 256), nblk_s = grid_1d(dm.slab_len, 64);
+                // (the kernel writes the a and b columns of every item, and the c / d columns only for the 3PL / 4PL links)
+                const int64_t len_w = cfg->model >= VX_IRT_3PL ? dm.slab_len : (int64_t)(cfg->D + 1) * cfg->J;
+                hipLaunchKernelGGL(k_lik_finish, dim3((unsigned)(nblk_gx + nblk_ll + nblk_s)), dim3(256), 0, st, (const float*)gx_part,
+                                   groups, n_gx, gx_sum, with_gd ? epsT : (const float*)nullptr, ldT, with_gd ? gdT : (float*)nullptr,
+                                   cfg->scale, (const float*)ll_part, nb, ll, (const float*)slabs, (int64_t)n_pr, dm.slab_len, len_w,
+                                   gitem, nblk_gx, nblk_ll);
+                VX_CHECK_LAUNCH();
+                if (with_gd) gd_done = true;
+                return VX_OK;
+            }
             if (groups > 1) {
                 int r2 = vx_reduce_slabs(gx_part, groups, nb * cfg->D, 1.0f, gx_sum, hs);
                 if (r2) return r2;
@@ -1099,18 +1133,22 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                                (const float4*)ldT, cfg->scale, nb * D / 4, (float4*)gdT0);
             VX_CHECK_LAUNCH();
         }
+        // (two full-size tile buffers: the three-buffer form of k_mvn_bwd_b.hip measured no faster -- docs/NOTEBOOK.md, round 5)
+        auto launch_bwb_on = [&](hipStream_t ws, const float* gdT, const uint16_t* hs3) -> int {
+            const size_t lds = bb_lds_bytes(dm.D);
+            int r = set_lds(k_mvn_enc_bwd_w_b<2>, lds);
+            if (r) return r;
+            hipLaunchKernelGGL(k_mvn_enc_bwd_w_b<2>, dim3((unsigned)n_rowslabs, (unsigned)n_prw), dim3(BWB_THREADS), lds, ws, dm, hs3, epsT,
+                               gdT, gxT, gtab, sc, (const uint32_t*)maxw, slabs_w, Rp * (H + 1));
+            VX_CHECK_LAUNCH();
+            return VX_OK;
+        };
         auto launch_bwb = [&]() -> int {
             float* gdT = slabs_f + (int64_t)n_prf * lenf;
             uint16_t* hs3 = (uint16_t*)(gdT + nb * D + 4);
-            const size_t lds = bb_lds_bytes(dm.D);
-            int r = set_lds(k_mvn_enc_bwd_w_b, lds);
-            if (r) return r;
             // (its own bracket on ITS stream: the kernel's span while it shares the chip with the hidden gradient)
             ProfScope ps("k_mvn_enc_bwd_w_b beside k_mvn_enc_bwd_h_b2", bwb_fork.side());
-            hipLaunchKernelGGL(k_mvn_enc_bwd_w_b, dim3((unsigned)n_rowslabs, (unsigned)n_prw), dim3(BWB_THREADS), lds, bwb_fork.side(),
-                               dm, hs3, epsT, gdT, gxT, gtab, sc, (const uint32_t*)maxw, slabs_w, Rp * (H + 1));
-            VX_CHECK_LAUNCH();
-            return VX_OK;
+            return launch_bwb_on(bwb_fork.side(), gdT, hs3);
         };
         // the bracket of the PAIR on the launch stream: from in front of the fork to behind the join of the head weight gradient's
         // stream = the span of {hidden gradient | head weight gradient} side by side (what bench.py prices with the sum of the two
@@ -1249,13 +1287,9 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                 hipLaunchKernelGGL(k_absmax3, dim3(grid_1d(nb * cfg->D, 1024)), dim3(256), 0, st, gxT, (const float*)gdT, epsT, nb * D, maxw);
                 VX_CHECK_LAUNCH();
             }
-            const size_t lds = bb_lds_bytes(dm.D);
-            rc = set_lds(k_mvn_enc_bwd_w_b, lds);
-            if (rc) return rc;
             ProfScope ps("k_mvn_enc_bwd_w_b", st);
-            hipLaunchKernelGGL(k_mvn_enc_bwd_w_b, dim3((unsigned)n_rowslabs, (unsigned)n_prw), dim3(BWB_THREADS), lds, st,
-                               dm, hs3, epsT, gdT, gxT, gtab, sc, (const uint32_t*)maxw, slabs_w, Rp * (H + 1));
-            VX_CHECK_LAUNCH();
+            rc = launch_bwb_on(st, gdT, hs3);
+            if (rc) return rc;
         } else if (use_t) {
             const size_t lds = bt_lds_bytes(dm.D);
             rc = set_lds(k_mvn_enc_bwd_w_t, lds);
@@ -1368,10 +1402,21 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
 }
 
 // ------------------------------------------------------------------------------------------------
-static int irt1d_blocks(int64_t nb) {
-    const int64_t n_groups = (nb + 63) / 64;
-    int64_t blocks = (n_groups + 3) / 4;
-    const int64_t cap = (int64_t)num_cu() * 4;
+// J <= I1_PERSON_LANES_MAX_J: the person-per-lane kernel (k_irt1d); above it the item-per-lane kernel (k_irt1d_items) -- see
+// the measurements at the head of k_irt1d_items
+#define I1_PERSON_LANES_MAX_J 256
+static int irt1d_blocks(int64_t nb, int J) {
+    int64_t blocks, cap;
+    if (J <= I1_PERSON_LANES_MAX_J) {
+        // a workgroup takes chunks of 64 persons: one chunk each while they all fit the chip together (eight workgroups a
+        // CU), strided chunks beyond that -- the slabs a block writes are summed by one small kernel either way
+        blocks = (nb + 63) / 64;
+        cap = (int64_t)num_cu() * 8;
+    } else {
+        const int64_t n_groups = (nb + 63) / 64;                       // a wave walks groups of 64 persons
+        blocks = (n_groups + 3) / 4;
+        cap = (int64_t)num_cu() * 4;
+    }
     if (blocks > cap) blocks = cap;
     return (int)(blocks < 1 ? 1 : blocks);
 }
@@ -1383,7 +1428,7 @@ static bool irt1d_cfg_ok(const vx_irt_cfg* cfg) {
 
 int64_t vx_irt1d_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
     if (!irt1d_cfg_ok(cfg) || nb < 0) return VX_EINVAL;
-    return (int64_t)irt1d_blocks(nb) * (4 * cfg->J + 1);
+    return (int64_t)irt1d_blocks(nb, cfg->J) * (4 * cfg->J + 1);
 }
 
 int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, int64_t gid0,
@@ -1395,38 +1440,37 @@ int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, 
     if (cfg->model >= VX_IRT_2PL && !a) return VX_EINVAL;
     if (cfg->model >= VX_IRT_3PL && !c_un) return VX_EINVAL;
     if (cfg->model == VX_IRT_4PL && !d_un) return VX_EINVAL;
-    const int blocks = irt1d_blocks(nb);
+    const int blocks = irt1d_blocks(nb, cfg->J);
     Irt1dDims dm;
     dm.J = cfg->J; dm.model = cfg->model; dm.Dc = cfg->Dc; dm.scale = cfg->scale; dm.nb = nb;
-    const size_t lds = sizeof(float) * 4 * (size_t)cfg->J * (I1_THREADS / 64);       // one partial slot per wave
+    const bool by_person = cfg->J <= I1_PERSON_LANES_MAX_J;
+    // person-per-lane: item table, item sums, parked terms; item-per-lane: one partial slot per wave
+    const size_t lds = by_person ? i1_lds_bytes(cfg->J, cfg->model) : sizeof(float) * 4 * (size_t)cfg->J * (I1_THREADS / 64);
     hipStream_t st = (hipStream_t)hs;
-    const int wpl_need = (cfg->J + 255) / 256;
     const int words_ok = (cfg->J % 4 == 0 && aligned16(y)) ? 1 : 0;     // 4-byte response loads need aligned rows
-#define LAUNCH_1DW(MODEL, WPL, WORDS)                                                                         \
-    hipLaunchKernelGGL((k_irt1d<MODEL, WPL, WORDS>), dim3(blocks), dim3(I1_THREADS), lds, st, dm, y, rows, gid0, loc, \
-                       raw, eps_in, cfg->seed, cfg->step, step_dev, cfg->stream, a, b, c_un, d_un, gloc, graw, elbo, workspace)
-#define LAUNCH_1D(MODEL, WPL)                                      \
-    if (words_ok) { LAUNCH_1DW(MODEL, WPL, true); } else { LAUNCH_1DW(MODEL, WPL, false); }
-#define LAUNCH_1DH(MODEL)                                          \
-    if (words_ok) { hipLaunchKernelGGL((k_irt1d<MODEL, 1, true, true>), dim3(blocks), dim3(I1_THREADS), lds, st, dm, y, rows, gid0, loc, \
-                       raw, eps_in, cfg->seed, cfg->step, step_dev, cfg->stream, a, b, c_un, d_un, gloc, graw, elbo, workspace); }    \
-    else { hipLaunchKernelGGL((k_irt1d<MODEL, 1, false, true>), dim3(blocks), dim3(I1_THREADS), lds, st, dm, y, rows, gid0, loc,     \
-                       raw, eps_in, cfg->seed, cfg->step, step_dev, cfg->stream, a, b, c_un, d_un, gloc, graw, elbo, workspace); }
-#define DISPATCH_IPL(MODEL)                                        \
-    if (cfg->J <= 128) { LAUNCH_1DH(MODEL); }                      \
-    else if (wpl_need <= 1) { LAUNCH_1D(MODEL, 1); }               \
-    else if (wpl_need <= 2) { LAUNCH_1D(MODEL, 2); }               \
-    else { LAUNCH_1D(MODEL, 4); }
+    const int wpl_need = (cfg->J + 255) / 256;
+    int rc = VX_EINVAL;
+#define LAUNCH_1DK(KERNEL)                                                                                    \
+    rc = set_lds(KERNEL, lds);                                                                                \
+    if (rc) return rc;                                                                                        \
+    hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(I1_THREADS), lds, st, dm, y, rows, gid0, loc, raw, eps_in, cfg->seed, \
+                       cfg->step, step_dev, cfg->stream, a, b, c_un, d_un, gloc, graw, elbo, workspace)
+#define LAUNCH_1DW(MODEL, WORDS)                                                                              \
+    if (by_person) { LAUNCH_1DK((k_irt1d<MODEL, WORDS>)); }                                                   \
+    else if (wpl_need <= 1) { LAUNCH_1DK((k_irt1d_items<MODEL, 1, WORDS>)); }                                 \
+    else if (wpl_need <= 2) { LAUNCH_1DK((k_irt1d_items<MODEL, 2, WORDS>)); }                                 \
+    else { LAUNCH_1DK((k_irt1d_items<MODEL, 4, WORDS>)); }
+#define LAUNCH_1D(MODEL)                                           \
+    if (words_ok) { LAUNCH_1DW(MODEL, true) } else { LAUNCH_1DW(MODEL, false) }
     switch (cfg->model) {
-        case VX_IRT_1PL: DISPATCH_IPL(1) break;
-        case VX_IRT_2PL: DISPATCH_IPL(2) break;
-        case VX_IRT_3PL: DISPATCH_IPL(3) break;
-        default: DISPATCH_IPL(4) break;
+        case VX_IRT_1PL: LAUNCH_1D(1) break;
+        case VX_IRT_2PL: LAUNCH_1D(2) break;
+        case VX_IRT_3PL: LAUNCH_1D(3) break;
+        default: LAUNCH_1D(4) break;
     }
-#undef DISPATCH_IPL
-#undef LAUNCH_1DH
 #undef LAUNCH_1D
 #undef LAUNCH_1DW
+#undef LAUNCH_1DK
     VX_CHECK_LAUNCH();
     return reduce_step_slabs(workspace, blocks, cfg->J, gitem, loss, step_dev, hs);
 }

@@ -96,16 +96,26 @@ __device__ __forceinline__ void split2h_frag(const float (&v)[8], float scale, f
 __device__ __forceinline__ void split2h_frag_mix(const float (&v)[8], float scale, f16x8& fh, f16x8& fl) {
     typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
     const float sc_ = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scale)));
+    // The hazard recogniser does not look into asm statements (docs/HARDWARE.md rule 31): a value that a TRANSCENDENTAL
+    // instruction has just written (v_exp_f32 in k_hodina_m: the posterior weights) needs a wait state before a vector
+    // instruction reads it, and nothing inserts it in front of the v_fma_mix below -- one build of k_hodina_m returned garbage
+    // for ~3 % of the persons, the next one, with another schedule, did not.  The eight values pass through one s_nop that the
+    // asm statements below depend on.
+    float w[8] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+    asm volatile("s_nop 0" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]));
     u32x4s ph, pl;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         uint32_t h, l;
-        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(v[2 * q]), "s"(sc_));
-        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(v[2 * q + 1]), "s"(sc_));
-        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(v[2 * q]), "s"(sc_), "v"(h));
-        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(v[2 * q + 1]), "s"(sc_), "v"(h));
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(w[2 * q]), "s"(sc_));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(w[2 * q + 1]), "s"(sc_));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(w[2 * q]), "s"(sc_), "v"(h));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(w[2 * q + 1]), "s"(sc_), "v"(h));
         ph[q] = h; pl[q] = l;
     }
+    // ... and out: a register that a vector instruction INSIDE an asm statement has just written needs two wait states before an
+    // MFMA reads it as an operand (cdna_hip_programming.md section 5.7, item 2: "wrong values on some waves of some launches")
+    asm volatile("s_nop 1" : "+v"(ph[0]), "+v"(ph[1]), "+v"(ph[2]), "+v"(ph[3]), "+v"(pl[0]), "+v"(pl[1]), "+v"(pl[2]), "+v"(pl[3]));
     fh = __builtin_bit_cast(f16x8, ph);
     fl = __builtin_bit_cast(f16x8, pl);
 }
@@ -182,6 +192,10 @@ __device__ __forceinline__ float softplusf_(float x) {
 // (omd = 1-d = sigmoid(-d_un) comes from the leaf), so (y-P)/(P(1-P)) = y ? 1/P : -1/Q keeps full
 // float32 accuracy where the reference's own float32 chain (sigmoid -> clamp -> log / log1p) loses it.
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// ln of a NORMAL positive float on the hardware log2 (one transcendental + one multiply; the library's __logf expands to ten
+// instructions of denormal handling and an extended-precision multiply by ln 2 -- the clamped probabilities of the 3PL / 4PL
+// cell lie in [eps32, 1 - eps32])
+__device__ __forceinline__ float fast_log(float x) { return 0.6931471805599453f * __builtin_amdgcn_logf(x); }
 
 template <int MODEL>
 __device__ __forceinline__ void irt_cell(float z, unsigned y, float c, float d, float omd, float& lp, float& dz,
@@ -218,7 +232,7 @@ __device__ __forceinline__ void irt_cell(float z, unsigned y, float c, float d, 
         const float Pc = fminf(fmaxf(P, VX_EPS32), 1.0f - VX_EPS32);
         const float Qc = fminf(fmaxf(Q, VX_EPS32), 1.0f - VX_EPS32);
         const float sel = (y == 1u) ? Pc : Qc;
-        lp = obs ? __logf(sel) : (y == 255u ? VX_LOGP_MISSING : 0.f);
+        lp = obs ? fast_log(sel) : (y == 255u ? VX_LOGP_MISSING : 0.f);
         const float inv = fast_rcp(sel);
         const float dP = inside ? ((y == 1u) ? inv : -inv) : 0.f;
         dz = dP * dmc * sg * sn;
@@ -260,7 +274,7 @@ __device__ __forceinline__ void irt_cell_f(float z, float yf, float c, float d, 
         const float Pc = fminf(fmaxf(P, VX_EPS32), 1.0f - VX_EPS32);
         const float Qc = fminf(fmaxf(Q, VX_EPS32), 1.0f - VX_EPS32);
         const float sel = one ? Pc : Qc;
-        lp = obs ? __logf(sel) : (yf > 254.5f ? VX_LOGP_MISSING : 0.f);
+        lp = obs ? fast_log(sel) : (yf > 254.5f ? VX_LOGP_MISSING : 0.f);
         const float inv = fast_rcp(sel);
         const float dP = inside ? (one ? inv : -inv) : 0.f;
         dz = dP * dmc * sg * sn;
