@@ -31,7 +31,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: dense bf16 / fp16 matrix peak (t
 # an fp32 product computed from two fp16 terms per operand costs three fp16 MFMA products:
 PEAK_F16X2_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBS = 8000.0
-PROFILE_TAG = "r04b_headline"
+PROFILE_TAG = "r05_headline"
 PAIR = "k_mvn_enc_bwd_h_b2 | k_mvn_enc_bwd_w_b side by side"      # the bracket name vx_mvn_enc_backward files the pair under
 
 WORKLOADS = {
@@ -108,7 +108,7 @@ def measured_traffic(kernel_prefix):
 def physical_bytes(workload):
     """HBM bytes one launch of the D = 1 step kernel physically moves (PMC, the committed summaries of this round:
     profiles/r04_cfg2_hbm_traffic.json, profiles/r04_cfg4_hbm_traffic.json), or None."""
-    tag = {"irt2pl_1d_bbvi_missing90_1Mx500": "r04_cfg4", "irt4pl_1d_bbvi_100kx100": "r04_cfg2"}.get(workload)
+    tag = {"irt2pl_1d_bbvi_missing90_1Mx500": "r04_cfg4", "irt4pl_1d_bbvi_100kx100": "r05_cfg2"}.get(workload)
     if tag is None:
         return None
     try:

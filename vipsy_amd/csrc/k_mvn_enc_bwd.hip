@@ -238,7 +238,9 @@ __host__ __device__ inline size_t fc1_bwd_lds_floats(int Hp) {
 // slab layout: [W1: H*J | b1: H]
 // fast != 0 (H == 64, J % 4 == 0, aligned ghpre / y): tiles are fetched as batches of independent 16-byte /
 // 4-byte loads one person tile ahead (issue before the MFMA phase, write to LDS after it).
-template <int HT>
+// IT: item tiles of 32 a wave -- 128 IT items a workgroup.  IT = 4 is the form for large batches; IT = 1 (round 5) gives a small
+// batch four times the workgroups: at B = 100 the kernel was two workgroups, each with 8 fp32 MFMAs a step and a 128 KB slab.
+template <int HT, int IT = 4>
 __global__ __launch_bounds__(ENC_THREADS) void k_fc1_bwd(
     EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows,
     const float* __restrict__ ghpre, float* __restrict__ slabs, int64_t slab_len, int fast) {
@@ -246,20 +248,21 @@ __global__ __launch_bounds__(ENC_THREADS) void k_fc1_bwd(
     const int J = dm.J, H = dm.H, Hp = dm.Hp;
     const int HS = fast ? 64 : Hp + 1;
     float* g_lds = smem;                                   // [P][HS]
-    int8_t* Yi = (int8_t*)(g_lds + ENC_P * (Hp + 1));      // [P][FC1_YS] encoder input as int8 (-1,0,1)
+    int8_t* Yi = (int8_t*)(g_lds + ENC_P * (Hp + 1));      // [P][YSI] encoder input as int8 (-1,0,1)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int jg0 = blockIdx.x * FC1_JG;
-    f32x16 acc[FC1_IT][HT];
+    constexpr int JG = 4 * IT * 32, YSI = JG + 4, WPP = JG / 4;          // items, LDS row stride, response words a person
+    const int jg0 = blockIdx.x * JG;
+    f32x16 acc[IT][HT];
     float bsum[HT];
 #pragma unroll
     for (int ht = 0; ht < HT; ++ht) bsum[ht] = 0.f;
 #pragma unroll
-    for (int t = 0; t < FC1_IT; ++t)
+    for (int t = 0; t < IT; ++t)
 #pragma unroll
         for (int ht = 0; ht < HT; ++ht) acc[t][ht] = zero16();
     const int64_t n_ptiles = (dm.nb + ENC_P - 1) / ENC_P;
     float4 pg[4];
-    uint32_t pw[32];
+    uint32_t pw[8 * IT];
     auto prefetch = [&](int64_t tile) {
         const int64_t i0 = tile * ENC_P;
         const int pv = (int)((dm.nb - i0) < ENC_P ? (dm.nb - i0) : ENC_P);
@@ -270,9 +273,9 @@ __global__ __launch_bounds__(ENC_THREADS) void k_fc1_bwd(
             pg[q] = (idx < pv * 16) ? g4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const int idx = tid + ENC_THREADS * q;                  // P x 128 words
-            const int p = idx >> 7, jw = jg0 + 4 * (idx & 127);
+        for (int q = 0; q < 8 * IT; ++q) {
+            const int idx = tid + ENC_THREADS * q;                  // P x WPP words
+            const int p = idx / WPP, jw = jg0 + 4 * (idx % WPP);
             pw[q] = 0u;
             if (p < pv && jw < J) {
                 const int64_t row = rows ? rows[i0 + p] : i0 + p;
@@ -289,9 +292,9 @@ __global__ __launch_bounds__(ENC_THREADS) void k_fc1_bwd(
 #pragma unroll
             for (int q = 0; q < 4; ++q) ((float4*)g_lds)[tid + ENC_THREADS * q] = pg[q];
 #pragma unroll
-            for (int q = 0; q < 32; ++q) {
+            for (int q = 0; q < 8 * IT; ++q) {
                 const int idx = tid + ENC_THREADS * q;
-                ((uint32_t*)Yi)[(idx >> 7) * (FC1_YS / 4) + (idx & 127)] = pw[q];
+                ((uint32_t*)Yi)[(idx / WPP) * (YSI / 4) + (idx % WPP)] = pw[q];
             }
         } else {
             for (int e = tid; e < ENC_P * Hp; e += ENC_THREADS) {
@@ -299,8 +302,8 @@ __global__ __launch_bounds__(ENC_THREADS) void k_fc1_bwd(
                 const int64_t i = i0 + p;
                 g_lds[p * HS + hh] = (i < dm.nb && hh < H) ? ghpre[i * H + hh] : 0.f;
             }
-            for (int e = tid; e < ENC_P * FC1_JG; e += ENC_THREADS) {
-                const int p = e / FC1_JG, jj = e - p * FC1_JG;
+            for (int e = tid; e < ENC_P * JG; e += ENC_THREADS) {
+                const int p = e / JG, jj = e - p * JG;
                 const int64_t i = i0 + p;
                 int8_t v = 0;
                 if (i < dm.nb && jg0 + jj < J) {
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_fc1_bwd(
                     const unsigned yy = y[row * J + jg0 + jj];
                     v = (yy == 255u) ? (int8_t)-1 : (int8_t)yy;
                 }
-                Yi[p * FC1_YS + jj] = v;
+                Yi[p * YSI + jj] = v;
             }
         }
         __syncthreads();
@@ -320,8 +323,8 @@ __global__ __launch_bounds__(ENC_THREADS) void k_fc1_bwd(
 #pragma unroll
             for (int ht = 0; ht < HT; ++ht) { av[ht] = g_lds[p * HS + 32 * ht + l31]; bsum[ht] += av[ht]; }
 #pragma unroll
-            for (int t = 0; t < FC1_IT; ++t) {
-                const float bv = (float)Yi[p * FC1_YS + 32 * (wave * FC1_IT + t) + l31];
+            for (int t = 0; t < IT; ++t) {
+                const float bv = (float)Yi[p * YSI + 32 * (wave * IT + t) + l31];
 #pragma unroll
                 for (int ht = 0; ht < HT; ++ht) acc[t][ht] = mfma32(av[ht], bv, acc[t][ht]);
             }
@@ -329,8 +332,8 @@ __global__ __launch_bounds__(ENC_THREADS) void k_fc1_bwd(
     }
     float* slab = slabs + (int64_t)blockIdx.y * slab_len;
 #pragma unroll
-    for (int t = 0; t < FC1_IT; ++t) {
-        const int j = jg0 + 32 * (wave * FC1_IT + t) + l31;
+    for (int t = 0; t < IT; ++t) {
+        const int j = jg0 + 32 * (wave * IT + t) + l31;
 #pragma unroll
         for (int ht = 0; ht < HT; ++ht)
 #pragma unroll

@@ -1376,7 +1376,14 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     rc = set_lds(k_fc1_bwd<HT>, lds);                                                                        \
     if (rc) return rc;                                                                                       \
     hipLaunchKernelGGL(k_fc1_bwd<HT>, grid, dim3(ENC_THREADS), lds, st, dm, y, rows, ghpre, slabs_f, lenf, f1fast)
-            if (dm.Hp == 32) { LAUNCH_F1(1); } else if (dm.Hp == 64) { LAUNCH_F1(2); } else if (dm.Hp == 96) { LAUNCH_F1(3); } else { LAUNCH_F1(4); }
+            if (dm.Hp == 64 && (int64_t)n_jg * n_prf * 16 <= num_cu()) {
+                // a small batch (the reference's B = 100: two person tiles): 128 items a workgroup instead of 512 -- four times the
+                // workgroups, a quarter of the MFMA chain, the response words and the slab piece each
+                rc = set_lds((k_fc1_bwd<2, 1>), lds);
+                if (rc) return rc;
+                hipLaunchKernelGGL((k_fc1_bwd<2, 1>), dim3((unsigned)((cfg->J + 127) / 128), (unsigned)n_prf), dim3(ENC_THREADS), lds, st, dm, y,
+                                   rows, ghpre, slabs_f, lenf, f1fast);
+            } else if (dm.Hp == 32) { LAUNCH_F1(1); } else if (dm.Hp == 64) { LAUNCH_F1(2); } else if (dm.Hp == 96) { LAUNCH_F1(3); } else { LAUNCH_F1(4); }
 #undef LAUNCH_F1
             VX_CHECK_LAUNCH();
         }
