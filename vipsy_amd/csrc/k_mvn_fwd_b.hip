@@ -28,8 +28,14 @@ __host__ __device__ inline int fb_tiles(int D) { return (pk_off_total(D) + 2 * p
 __host__ __device__ inline int64_t fb_img_floats(int D) {               // tile images + the OFF group table
     return (int64_t)fb_tiles(D) * (FB_IMG_BYTES / 4) + (pk_off_total(D) / 8 + 8 + 3) / 4 * 4;
 }
+// A wave's region: the packed encoder's, and never less than the 32 x 64 floats of the SPLIT form's fc1 exchange
+// (each wave hands its partial pre-activations, 32 registers of 64 lanes, to the other three).
+__host__ __device__ inline size_t fb_wave_floats(int D, int J) {
+    const size_t w = enc_p_wave_floats(D, J);
+    return w < 2048 ? 2048 : w;
+}
 __host__ __device__ inline size_t fb_lds_bytes(int D, int J) {
-    return FB_WAVES * enc_p_wave_floats(D, J) * sizeof(float) +
+    return FB_WAVES * fb_wave_floats(D, J) * sizeof(float) +
            (size_t)(pk_off_total(D) / 8 + 4) / 4 * 16 + 512;            // wave regions | OFF group table | SPLIT: entropy parts
 }
 
@@ -225,12 +231,12 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     const int YS = ef_ys(J);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    float* R1 = smem + wave * enc_p_wave_floats(D, J);
+    float* R1 = smem + wave * fb_wave_floats(D, J);
     int8_t* Yi = (int8_t*)R1;                                 // phase A
     float* S1 = SPLIT ? smem : R1;                            // SPLIT: the tile of wave 0 serves the workgroup
     float* eps_lds = S1;                                      // phase B  [32][DS]
     float* x_lds = S1 + FB_WP * DS;                           //          [32][DX]
-    uint32_t* gt_lds = (uint32_t*)(smem + FB_WAVES * enc_p_wave_floats(D, J));
+    uint32_t* gt_lds = (uint32_t*)(smem + FB_WAVES * fb_wave_floats(D, J));
     float* ent_s = (float*)(gt_lds + ((pk_off_total(D) / 8 + 4) / 4 * 4));   // SPLIT: [4][32] partial entropy sums
     const int64_t i0 = i_base + (SPLIT ? (int64_t)blockIdx.x * FB_WP : ((int64_t)blockIdx.x * FB_WAVES + wave) * FB_WP);
     const int p = l31;
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     // ---------------------------------------------------------------- stage this wave's response rows (bytes)
     const int n_ydma = (32 * J + 1023) / 1024;
     const bool ydense = !rows && ((J >> 2) & 1) && i0 + FB_WP <= dm.nb && (i0 * J + (int64_t)n_ydma * 1024 <= dm.nb * (int64_t)J) &&
-                        (size_t)n_ydma * 1024 <= enc_p_wave_floats(D, J) * sizeof(float);
+                        (size_t)n_ydma * 1024 <= fb_wave_floats(D, J) * sizeof(float);
     const int ysr = ydense ? J : YS;                          // LDS row stride of the response bytes
     // the normals of this wave's 32 persons (D / 4 Philox blocks each) are drawn into registers while the response
     // rows are in flight: the draw needs no memory, the DMA latency at the head of the workgroup is otherwise exposed
@@ -306,6 +312,34 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
             if (ii < dm.nb) rowb = (rows ? rows[ii] : ii) * J;
         }
         const int rowb_lo = (int)(uint32_t)rowb, rowb_hi = (int)(uint32_t)((uint64_t)rowb >> 32);
+        if constexpr (SPLIT) {
+            // Round 5: the four waves DIVIDE fc1 (k-steps [ks_lo, ks_hi) each, partial sums joined below), so a wave stages the
+            // response words of ITS items only -- 4 (ks_hi - ks_lo) words a person, two persons a load instruction -- instead of all
+            // four staging all 32 rows whole (22 k of the workgroup's 92 k cycles at B = 100, tools/fwd2_bench.hip -DFB_STAMPS).
+            const int n_ks_all = (J + 15) / 16, ks_per = (n_ks_all + FB_WAVES - 1) / FB_WAVES;
+            const int w_lo = 4 * ks_per * wave;                    // first word of this wave's items; 4 ks_per words a person
+            const int wpp = 4 * ks_per;                            // <= 64 (J <= 1024)
+            const int ppl = 64 / wpp > 0 ? 64 / wpp : 1;           // persons a load instruction
+            const int pl = lane / wpp, wl = lane - pl * wpp;       // this lane's person within the instruction, word within the range
+            draw_eps();                                            // (no memory: under the latency of the row offsets)
+            for (int p0 = 0; p0 < FB_WP; p0 += ppl * 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int pp = p0 + ppl * u + pl;
+                    const int ppc = pp < FB_WP ? pp : FB_WP - 1;
+                    const uint64_t rb = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(4 * ppc, rowb_hi) << 32) |
+                                        (uint32_t)__builtin_amdgcn_ds_bpermute(4 * ppc, rowb_lo);
+                    v[u] = 0u;
+                    if (pl < ppl && pp < FB_WP && i0 + pp < dm.nb && w_lo + wl < JW) v[u] = ((const uint32_t*)(y + (int64_t)rb))[w_lo + wl];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int pp = p0 + ppl * u + pl;
+                    if (pl < ppl && pp < FB_WP && w_lo + wl < YW) Yw[pp * YW + w_lo + wl] = v[u];
+                }
+            }
+        } else
         for (int p0 = 0; p0 < FB_WP; p0 += PB) {
             uint32_t v[PB][MAXLD];
 #pragma unroll
@@ -353,7 +387,36 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
             acc0 = mfma_f16(Af[1], yb, acc0); acc1 = mfma_f16(Af[3], yb, acc1);
             acc0 = mfma_f16(Af[0], yb, acc0); acc1 = mfma_f16(Af[2], yb, acc1);
         };
-        {
+        if constexpr (SPLIT) {
+            // this wave's quarter of the k-steps (its items: what it staged above; the dense staging has every row whole)
+            const int ks_per = (n_ks + FB_WAVES - 1) / FB_WAVES;
+            const int ks_lo = ks_per * wave, ks_hi = (ks_lo + ks_per < n_ks) ? ks_lo + ks_per : n_ks;
+            f16x8 A[4][4];
+            loadA(A[0], ks_lo); loadA(A[1], ks_lo + 1); loadA(A[2], ks_lo + 2);
+            for (int c = ks_lo; c < ks_hi; c += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    loadA(A[(u + 3) & 3], c + u + 3);
+                    if (c + u < ks_hi) compute(A[u], c + u);
+                }
+            }
+            // the four partial pre-activations meet in LDS -- every wave needs all of h in registers -- and are added in the
+            // fixed order of the waves: [wave][32 registers][64 lanes] floats, each wave's slab in its own region (the response
+            // bytes there have been consumed)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { R1[r * 64 + lane] = acc0[r]; R1[(16 + r) * 64 + lane] = acc1[r]; }
+            __syncthreads();
+            const size_t wstride = fb_wave_floats(D, J);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float a0 = smem[r * 64 + lane], a1 = smem[(16 + r) * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < FB_WAVES; ++w) { a0 += smem[w * wstride + r * 64 + lane]; a1 += smem[w * wstride + (16 + r) * 64 + lane]; }
+                acc0[r] = a0; acc1[r] = a1;
+            }
+            __syncthreads();                                       // (the regions are written again below: eps / x tile of the workgroup)
+        } else {
             f16x8 A[4][4];
             loadA(A[0], 0); loadA(A[1], 1); loadA(A[2], 2);
             for (int c = 0; c < n_ks; c += 4) {
