@@ -36,7 +36,7 @@ extern "C" {
 #define VX_OK 0
 #define VX_EINVAL (-1)       /* bad argument / unsupported shape */
 #define VX_EUNIMPL (-2)
-#define VX_ABI_VERSION 3
+#define VX_ABI_VERSION 4
 
 enum vx_model { VX_IRT_1PL = 1, VX_IRT_2PL = 2, VX_IRT_3PL = 3, VX_IRT_4PL = 4 }; /* vi.py:538-543 */
 
@@ -54,6 +54,16 @@ typedef struct vx_irt_cfg {
     const uint32_t* step_dev; /* or NULL: the step counter in DEVICE memory -- vx_mvn_enc_forward reads the Philox step from it
                             instead of `step`, so that a whole step can be captured once in a HIP graph and replayed
                             (vx_sum2 advances it, vx_adam_step reads it; the D = 1 entry points take it as an argument) */
+    const int64_t* rows_ring; /* or NULL.  A captured subsampled step (test.py:338-343: a new draw of B rows every step) needs its
+                            row indices on the device without a copy of its own in front of every replay: the host writes
+                            the draw of step t into slot t % rows_ring_slots of this PINNED HOST buffer
+                            ([rows_ring_slots][rows_ring_stride] int64), and vx_mvn_enc_forward -- with step_dev, and `rows`
+                            then being the DEVICE buffer the kernels of the step read -- first copies slot
+                            *step_dev % rows_ring_slots into `rows` (nb indices), inside its first launch where it can.  The
+                            host must not rewrite a slot before the step that read it has finished. */
+    int64_t rows_ring_stride;
+    int32_t rows_ring_slots;
+    int32_t _pad;
 } vx_irt_cfg;
 
 int vx_abi_version(void);
@@ -164,6 +174,18 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
                         int32_t gd_ready /*bit 0: vx_irt_lik_grad already wrote gdT into the workspace; bit 1:
                                            vx_mvn_enc_forward already wrote hs there; bit 2: the operand maxima are in packws
                                            (vx_irt_lik_grad's opmax)*/, void* hip_stream);
+/* The same call, and the loss of the step with it: loss[0] = loss_alpha * (sum ll + sum ent) over the nb persons of the
+ * batch -- what vx_sum2 computes, bit for bit (vi.py:516, the value svi.step returns) -- from the call's LAST launch, and the
+ * device step counter of a captured step (cfg->step_dev) advanced there as vx_sum2 would.  A B = 100 step (test.py:338) is
+ * a dozen launches of which this saves one; batches above 4 096 persons run vx_sum2's two launches behind the gradients.
+ * sum_workspace: vx_sum_workspace_floats() floats. */
+int vx_mvn_enc_backward_loss(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
+                             const float* W21, const float* W22,
+                             const float* h, const float* eps, const float* ldT, const float* gx,
+                             const float* hT /*or NULL*/, const float* epsT /*or NULL*/, const float* gxT /*or NULL*/,
+                             const uint8_t* yT /*or NULL*/, int64_t yT_stride, float* genc, float* workspace,
+                             const float* packws, int32_t gd_ready, const float* ll /*[nb]*/, const float* ent /*[nb]*/,
+                             float loss_alpha, float* loss /*[1]*/, float* sum_workspace, void* hip_stream);
 /* float offset of gdT[D][nb] inside the backward workspace, or -1 when this (cfg, nb) has no such operand */
 int64_t vx_mvn_enc_bwd_gd_offset(const vx_irt_cfg* cfg, int64_t nb);
 /* float offset of hs[2][64][nb] (fp16) inside the backward workspace, or -1 when this (cfg, nb) does not use it */

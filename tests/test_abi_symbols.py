@@ -26,13 +26,14 @@ def test_library_exports_every_declared_symbol():
     # the ctypes binding covers exactly the declared surface
     assert sorted(_hip.SIGNATURES) == declared
     lib = _hip.lib()
-    assert lib.vx_abi_version() == 3
+    assert lib.vx_abi_version() == 4
     assert b"gfx950" in lib.vx_build_info()
 
 
 def test_struct_layout_matches_header():
     from vipsy_amd import _hip
-    assert ctypes.sizeof(_hip.IrtCfg) == 48          # 4*int32 + 2*float + uint64 + 2*uint32 + the device step pointer
+    assert ctypes.sizeof(_hip.IrtCfg) == 72          # 4*int32 + 2*float + uint64 + 2*uint32 + the device step pointer + the rows ring
+    assert _hip.IrtCfg.rows_ring.offset == 48 and _hip.IrtCfg.rows_ring_slots.offset == 64
     assert ctypes.sizeof(_hip.AdamSeg) == 24
 
 

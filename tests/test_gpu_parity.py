@@ -839,22 +839,26 @@ def test_captured_amortized_step_equals_eager_step(N, B):
     J, D, H = 500, 100, 64
     y, _, _ = _random_problem(N, J, D, H, "irt_2pl", 0.1, seed=N + 1)
     draws = np.random.RandomState(5)
-    rows_all = [None if B is None else torch.from_numpy(draws.choice(N, size=B, replace=False).astype(np.int64)) for _ in range(7)]
+    n_steps = 7 if B is None else 19                           # (a subsample: more steps than the pinned row ring has slots)
+    rows_all = [None if B is None else torch.from_numpy(draws.choice(N, size=B, replace=False).astype(np.int64)) for _ in range(n_steps)]
     out = []
     for graph in (True, False):
         eng = IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_2pl", D=D, amortized=True, H=H, seed=11)
         eng.use_graph = graph
         lrs = LrSpec(lambda m, p: {"lr": 1e-2 if p in ("a", "b") else 1e-3}, milestones=(4,), gamma=0.5)
         losses = []
-        for t in range(7):
+        for t in range(n_steps):
             losses.append(eng.step(lrs, rows=rows_all[t], b_global=B))       # host indices, as the fit loop hands them over
             lrs.scheduler_step()
         torch.cuda.synchronize()
-        assert eng.t == 7
+        assert eng.t == n_steps
         st = getattr(eng, "_graph", None) or {}
         assert (st.get("graph") is not None) == graph
+        if graph and B is not None:
+            # the replay fetches its draw from the pinned host ring (vx_irt_cfg.rows_ring): no copy in front of it
+            assert st.get("ring") is not None and st["ring"].is_pinned() and eng.rows_ring_slots < n_steps
         out.append((torch.stack(losses).cpu().numpy(), eng.P.cpu().numpy().copy()))
-    assert np.isfinite(out[0][0]).all() and len(set(out[0][0].tolist())) == 7
+    assert np.isfinite(out[0][0]).all() and len(set(out[0][0].tolist())) == n_steps
     for u, v in zip(out[0], out[1]):
         assert np.array_equal(u, v)
 

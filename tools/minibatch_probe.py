@@ -3,6 +3,7 @@
 host-side cost of a step (rows drawn and staged, launches) separated from the device-side cost.
     python tools/minibatch_probe.py [--persons N] [--B 100] [--steps 300]"""
 import argparse
+import gc
 import os
 import sys
 import time
@@ -21,6 +22,7 @@ def main():
     ap.add_argument("--B", type=int, default=100)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--modes", default="eager,graph")
+    ap.add_argument("--time-sync", action="store_true", help="time the host's waits for the GPU (Event.synchronize)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     J, D, H = 500, 100, 64
@@ -37,10 +39,22 @@ def main():
         for _ in range(10):
             eng.step(lrs, rows=draw(), b_global=args.B)
         torch.cuda.synchronize()
+        gc.collect()
+        gc.freeze()                                            # (a full collection of the interpreter's heap is a 40 ms stall of the
+        blocked = [0.0]                                        #  host, once, somewhere in the first few hundred steps: not the step's cost)
+        ev_sync = torch.cuda.Event.synchronize
+
+        def timed_sync(ev):                                    # time the host spends waiting for the GPU (ring slots / pinned buffers)
+            tb = time.perf_counter()
+            ev_sync(ev)
+            blocked[0] += time.perf_counter() - tb
+        if args.time_sync:
+            torch.cuda.Event.synchronize = timed_sync
         t0 = time.perf_counter()
         for _ in range(args.steps):
             eng.step(lrs, rows=draw(), b_global=args.B)
         t_host = time.perf_counter() - t0                      # the host has enqueued everything
+        torch.cuda.Event.synchronize = ev_sync
         torch.cuda.synchronize()
         t_all = time.perf_counter() - t0
         # the same replays without a new draw (device-side cost of the step alone)
@@ -55,9 +69,10 @@ def main():
         for _ in range(args.steps):
             draw()
         t_draw = time.perf_counter() - t2
-        print("%-6s B=%d: %.1f us/step (%.0f steps/s); host enqueue %.1f us/step; same rows re-used %.1f us/step; draw alone %.1f us"
+        print("%-6s B=%d: %.1f us/step (%.0f steps/s); host enqueue %.1f us/step of which %.1f waiting for the GPU; same rows "
+              "re-used %.1f us/step; draw alone %.1f us"
               % (mode, args.B, 1e6 * t_all / args.steps, args.steps / t_all, 1e6 * t_host / args.steps,
-                 1e6 * t_fixed / args.steps, 1e6 * t_draw / args.steps))
+                 1e6 * blocked[0] / args.steps, 1e6 * t_fixed / args.steps, 1e6 * t_draw / args.steps))
 
 
 if __name__ == "__main__":

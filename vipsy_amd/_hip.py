@@ -20,7 +20,9 @@ class IrtCfg(ctypes.Structure):
     """struct vx_irt_cfg (include/vipsy_amd.h)."""
     _fields_ = [("model", ctypes.c_int32), ("D", ctypes.c_int32), ("J", ctypes.c_int32), ("H", ctypes.c_int32),
                 ("Dc", ctypes.c_float), ("scale", ctypes.c_float), ("seed", ctypes.c_uint64),
-                ("step", ctypes.c_uint32), ("stream", ctypes.c_uint32), ("step_dev", ctypes.c_void_p)]
+                ("step", ctypes.c_uint32), ("stream", ctypes.c_uint32), ("step_dev", ctypes.c_void_p),
+                ("rows_ring", ctypes.c_void_p), ("rows_ring_stride", ctypes.c_int64), ("rows_ring_slots", ctypes.c_int32),
+                ("_pad", ctypes.c_int32)]
 
 
 class AdamSeg(ctypes.Structure):
@@ -63,6 +65,8 @@ SIGNATURES = {
     "vx_mvn_enc_bwd_workspace_floats": (_I64, [_CFG, _I64]),
     "vx_mvn_enc_bwd_layout": (ctypes.c_int, [_CFG, _I64]),
     "vx_mvn_enc_backward": (ctypes.c_int, [_CFG, _P, _P, _I64] + [_P] * 6 + [_P] * 3 + [_P, _I64] + [_P, _P, _P, _I32, _P]),
+    "vx_mvn_enc_backward_loss": (ctypes.c_int, [_CFG, _P, _P, _I64] + [_P] * 6 + [_P] * 3 + [_P, _I64] + [_P, _P, _P, _I32] +
+                                 [_P, _P, _F, _P, _P, _P]),
     "vx_mvn_enc_bwd_gd_offset": (_I64, [_CFG, _I64]),
     "vx_mvn_enc_bwd_hs_offset": (_I64, [_CFG, _I64]),
     "vx_irt1d_workspace_floats": (_I64, [_CFG, _I64]),

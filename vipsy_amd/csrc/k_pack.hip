@@ -85,12 +85,12 @@ __global__ void k_pack_heads(int D, int H, const float* __restrict__ W21, const 
 
 // out = alpha * sum_s slabs[s] gathered from packed rows back to the reference layout
 //   slab: [Wp-grad: Rp*H | bp-grad: Rp];  out: [W21: D*H | b21: D | W22: T*H | b22: T]
-__global__ __launch_bounds__(256) void k_unpack_head_grads(int D, int H, const float* __restrict__ slabs, int n_slabs,
-                                                           int64_t slab_len, float alpha, float* __restrict__ out) {
+__device__ __forceinline__ void unpack_head_rows(int blk, int D, int H, const float* __restrict__ slabs, int n_slabs,
+                                                 int64_t slab_len, float alpha, float* __restrict__ out) {
     // one wave per packed row (four rows a block): lane = hidden unit, the slabs summed in ascending order, eight loads
     // in flight per lane
     const int T = D * (D + 1) / 2, Rp = pk_rows(D);
-    const int pr = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int pr = blk * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (pr >= Rp) return;
     int src;
     uint32_t gcode;
@@ -105,4 +105,8 @@ __global__ __launch_bounds__(256) void k_unpack_head_grads(int D, int H, const f
         for (int s = 0; s < n_slabs; ++s) acc += sp[(int64_t)s * slab_len];
         if (hh < H) oW[hh] = alpha * acc; else *ob = alpha * acc;
     }
+}
+__global__ __launch_bounds__(256) void k_unpack_head_grads(int D, int H, const float* __restrict__ slabs, int n_slabs,
+                                                           int64_t slab_len, float alpha, float* __restrict__ out) {
+    unpack_head_rows((int)blockIdx.x, D, H, slabs, n_slabs, slab_len, alpha, out);
 }

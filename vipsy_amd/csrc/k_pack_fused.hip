@@ -13,14 +13,35 @@
 // (included by vx_abi.hip after k_mvn_bwd_hb.hip)
 #pragma once
 
+__device__ __forceinline__ void rows_from_ring(const int64_t* __restrict__ ring, int64_t ring_stride, int ring_slots,
+                                               const uint32_t* __restrict__ step_dev, int64_t* __restrict__ rows_out, int64_t nb) {
+    const int64_t* src = ring + (int64_t)(*step_dev % (uint32_t)ring_slots) * ring_stride;
+    for (int64_t i = threadIdx.x; i < nb; i += blockDim.x) rows_out[i] = __builtin_nontemporal_load(src + i);
+}
+// (the same as a launch of its own: a forward path without the fused pack)
+__global__ __launch_bounds__(256) void k_rows_from_ring(const int64_t* __restrict__ ring, int64_t ring_stride, int ring_slots,
+                                                        const uint32_t* __restrict__ step_dev, int64_t* __restrict__ rows_out,
+                                                        int64_t nb) {
+    rows_from_ring(ring, ring_stride, ring_slots, step_dev, rows_out, nb);
+}
+
 __global__ __launch_bounds__(256) void k_pack_stage1(int D, int J, const float* __restrict__ W1, const float* __restrict__ b1,
                                                      const float* __restrict__ W21, const float* __restrict__ b21,
                                                      const float* __restrict__ W22, const float* __restrict__ b22,
                                                      float* __restrict__ Wp, float* __restrict__ bp, uint32_t* __restrict__ gtab,
                                                      float* __restrict__ WpT /*or null: no kernel of this step reads it*/,
-                                                     float* __restrict__ sc) {
+                                                     float* __restrict__ sc, const int64_t* __restrict__ ring = nullptr,
+                                                     int64_t ring_stride = 0, int ring_slots = 1,
+                                                     const uint32_t* __restrict__ step_dev = nullptr,
+                                                     int64_t* __restrict__ rows_out = nullptr, int64_t nb = 0) {
     const int Rp = pk_rows(D), n_row_blocks = (Rp + 3) / 4;
     const int blk = blockIdx.x, tid = threadIdx.x;
+    if (blk == n_row_blocks + FB_SC_BLOCKS) {
+        // one more block, with a ring: the step's row indices from the pinned host ring (vx_irt_cfg.rows_ring) into the
+        // device buffer the kernels behind this launch read -- no copy and no gap in front of the replay
+        rows_from_ring(ring, ring_stride, ring_slots, step_dev, rows_out, nb);
+        return;
+    }
     if (blk < n_row_blocks) {
         const int T = D * (D + 1) / 2;
         const int pr = 4 * blk + (tid >> 6), hh = tid & 63;
@@ -68,4 +89,25 @@ __global__ __launch_bounds__(256) void k_pack_stage2(int D, int J, int n_tiles, 
     if (blk < n_w1) { pack_w1_b_kstep(blk, J, W1, scl[0], w1img); return; }
     if (blk < n_w1 + n_tiles) { pack_heads_b_tile(blk - n_w1, n_off_groups, Wp, bp, gtab, scl[2], scl[5], img, gt2); return; }
     if (himg) pack_heads_hb_unit(blk - n_w1 - n_tiles, D, W21, W22, scl[2], himg);
+}
+
+// The last launch of vx_mvn_enc_backward on the packed row space, three kernels of ~5 us in one:
+//   blocks [0, n_unpack)            the head gradients summed over their slabs, back in the reference layout (k_unpack_head_grads)
+//   blocks [n_unpack, + n_f1)       the fc1 slabs summed (k_reduce_slabs) -- none when the side stream's kernel did it
+//   one more block, with ll         the loss of a small batch, out[0] = alpha (sum ll + sum ent) in k_sum_stage1's one-block
+//                                   order; the device step counter of a captured step advances here (no block of this launch
+//                                   reads it)
+// Same bodies, same sums, bit for bit.
+__global__ __launch_bounds__(256) void k_enc_bwd_tail(int D, int H, const float* __restrict__ slabs_w, int n_prw, int64_t lenw,
+                                                      float alpha, float* __restrict__ out_w, int n_unpack,
+                                                      const float* __restrict__ slabs_f, int64_t n_prf, int64_t lenf,
+                                                      float* __restrict__ out_f, int n_f1, const float* __restrict__ ll,
+                                                      const float* __restrict__ ent, int64_t nb, float loss_alpha,
+                                                      float* __restrict__ loss, float* __restrict__ sum_ws,
+                                                      uint32_t* __restrict__ tick) {
+    __shared__ float part[4][64];
+    const int blk = blockIdx.x;
+    if (blk < n_unpack) { unpack_head_rows(blk, D, H, slabs_w, n_prw, lenw, alpha, out_w); return; }
+    if (blk < n_unpack + n_f1) { reduce_slabs_cols(blk - n_unpack, n_f1, part, slabs_f, n_prf, lenf, lenf, alpha, out_f); return; }
+    if (ll) sum_block(0, 1, &part[0][0], ll, nb, sum_ws, ent, loss_alpha, loss, tick);
 }

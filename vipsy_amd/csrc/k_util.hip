@@ -31,11 +31,11 @@ __global__ void k_philox_raw(uint32_t* __restrict__ out, int64_t gid0, int64_t n
 // out[i] = alpha * sum_s slabs[s * stride + i].  Block = 64 columns x 4 slab groups (slab s goes to group s % 4,
 // summed in ascending s; the four group sums are added in fixed order) -> deterministic, and parallel enough
 // when there are many slabs but few columns (the D = 1 kernels: ~1000 slabs x 2000 columns).
-__global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ slabs, int64_t n_slabs, int64_t stride,
-                                                      int64_t len, float alpha, float* __restrict__ out) {
-    __shared__ float part[4][64];
+__device__ __forceinline__ void reduce_slabs_cols(int blk, int nblk, float (*part)[64], const float* __restrict__ slabs,
+                                                  int64_t n_slabs, int64_t stride, int64_t len, float alpha,
+                                                  float* __restrict__ out) {
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    for (int64_t c0 = (int64_t)blockIdx.x * 64; c0 < len; c0 += (int64_t)gridDim.x * 64) {
+    for (int64_t c0 = (int64_t)blk * 64; c0 < len; c0 += (int64_t)nblk * 64) {
         const int64_t i = c0 + col;
         float acc = 0.f;
         if (i < len) {
@@ -47,6 +47,11 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ 
         if (grp == 0 && i < len) out[i] = alpha * ((part[0][col] + part[1][col]) + (part[2][col] + part[3][col]));
         __syncthreads();
     }
+}
+__global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ slabs, int64_t n_slabs, int64_t stride,
+                                                      int64_t len, float alpha, float* __restrict__ out) {
+    __shared__ float part[4][64];
+    reduce_slabs_cols((int)blockIdx.x, (int)gridDim.x, part, slabs, n_slabs, stride, len, alpha, out);
 }
 
 // One launch behind an item-stationary likelihood kernel whose item chunks went to `groups` workgroups (k_irt_lik_r; on the
@@ -159,15 +164,12 @@ __global__ __launch_bounds__(256) void k_reduce_few(const float4* __restrict__ s
 }
 
 // two-stage fixed-order sum: stage 1 -> partial[blockIdx], stage 2 (1 block) -> out[0]
-__global__ void k_sum_stage1(const float* __restrict__ v, int64_t n, float* __restrict__ partial,
-                             const float* __restrict__ v2 = nullptr /*optional second vector of the same length*/,
-                             float alpha = 0.f, float* __restrict__ out = nullptr /*ONE block: the launch is the whole sum, out[0]
-                             = alpha * total -- what stage 2 would make of one partial, bit for bit, without its launch*/,
-                             uint32_t* __restrict__ tick = nullptr) {
-    __shared__ float red[256 / VX_WAVE];
+__device__ __forceinline__ void sum_block(int blk, int nblk, float* red, const float* __restrict__ v, int64_t n,
+                                          float* __restrict__ partial, const float* __restrict__ v2, float alpha,
+                                          float* __restrict__ out, uint32_t* __restrict__ tick) {
     float acc = 0.f;
-    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
-    const int64_t lo = (int64_t)blockIdx.x * per;
+    const int64_t per = (n + nblk - 1) / nblk;
+    const int64_t lo = (int64_t)blk * per;
     const int64_t hi = lo + per < n ? lo + per : n;
     if (v2) { for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) acc += v[i] + v2[i]; }
     else { for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) acc += v[i]; }
@@ -177,12 +179,20 @@ __global__ void k_sum_stage1(const float* __restrict__ v, int64_t n, float* __re
     if (threadIdx.x == 0) {
         float t = 0.f;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
-        partial[blockIdx.x] = t;
-        if (out) {                                             // (gridDim.x == 1)
+        partial[blk] = t;
+        if (out) {                                             // (nblk == 1)
             out[0] = alpha * t;
             if (tick) *tick += 1u;                             // (every kernel that reads it as the Philox step ran before this one)
         }
     }
+}
+__global__ void k_sum_stage1(const float* __restrict__ v, int64_t n, float* __restrict__ partial,
+                             const float* __restrict__ v2 = nullptr /*optional second vector of the same length*/,
+                             float alpha = 0.f, float* __restrict__ out = nullptr /*ONE block: the launch is the whole sum, out[0]
+                             = alpha * total -- what stage 2 would make of one partial, bit for bit, without its launch*/,
+                             uint32_t* __restrict__ tick = nullptr) {
+    __shared__ float red[256 / VX_WAVE];
+    sum_block((int)blockIdx.x, (int)gridDim.x, red, v, n, partial, v2, alpha, out, tick);
 }
 __global__ void k_sum_stage2(const float* __restrict__ partial, int n, float alpha, float* __restrict__ out,
                              uint32_t* __restrict__ tick = nullptr /*the device step counter: advanced by one*/) {

@@ -448,7 +448,7 @@ static int mvn_enc_forward_kernels(const vx_irt_cfg* cfg, const uint8_t* y, cons
                                    const float* W1, const float* b1, const float* W21, const float* b21, const float* W22,
                                    const float* b22, const float* eps_in, float* h, float* x, float* eps, float* ldT,
                                    float* ent, float* hT, float* epsT, float* packws, uint8_t* ximg, uint16_t* hs_out, void* hs,
-                                   bool& ximg_done, bool& hs_done, const float*& hscale) {
+                                   bool& ximg_done, bool& hs_done, const float*& hscale, const int64_t*& ring) {
     EncDims dm = make_enc_dims(cfg, nb);
     const dim3 grid((unsigned)((nb + ENC_P - 1) / ENC_P));
     int rc;
@@ -483,8 +483,11 @@ static int mvn_enc_forward_kernels(const vx_irt_cfg* cfg, const uint8_t* y, cons
             const bool hb = hb_from_forward(cfg, nb);
             uint8_t* himg = hb ? (uint8_t*)((float*)sc - hb_img_floats(dm.D)) : nullptr;
             const int n_row_blocks = (Rp + 3) / 4, n_w1 = (dm.J + 15) / 16;
-            hipLaunchKernelGGL(k_pack_stage1, dim3(n_row_blocks + FB_SC_BLOCKS), dim3(256), 0, (hipStream_t)hs, (int)dm.D, (int)dm.J,
-                               W1, b1, W21, b21, W22, b22, Wp, bp, gtab, hb ? (float*)nullptr : WpT, sc);
+            hipLaunchKernelGGL(k_pack_stage1, dim3(n_row_blocks + FB_SC_BLOCKS + (ring ? 1 : 0)), dim3(256), 0, (hipStream_t)hs,
+                               (int)dm.D, (int)dm.J, W1, b1, W21, b21, W22, b22, Wp, bp, gtab, hb ? (float*)nullptr : WpT, sc, ring,
+                               (int64_t)cfg->rows_ring_stride, (int)cfg->rows_ring_slots, cfg->step_dev, const_cast<int64_t*>(rows),
+                               nb);
+            ring = nullptr;                                // (done)
             VX_CHECK_LAUNCH();
             hipLaunchKernelGGL(k_pack_stage2, dim3(n_w1 + n_tiles + (hb ? hb_units(dm.D) : 0)), dim3(256), 0, (hipStream_t)hs,
                                (int)dm.D, (int)dm.J, n_tiles, pk_off_total(dm.D) / 8, W1, W21, W22, (const float*)Wp, (const float*)bp,
@@ -612,8 +615,25 @@ int vx_mvn_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* r
     const float* hscale = nullptr;
     uint32_t* ovf = ximg ? (uint32_t*)(ximg + (nb + LB_P - 1) / LB_P * (int64_t)LH_XT_BYTES) : nullptr;   // k_irt_lik_h.hip
     if (ovf && hipMemsetAsync(ovf, 0, sizeof(uint32_t), (hipStream_t)hs) != hipSuccess) return VX_EINVAL;
+    // the step's row indices from the pinned host ring (vx_irt_cfg.rows_ring): inside the first launch of the fused pack, or
+    // as a launch of its own in front of every other forward path
+    const int64_t* ring = nullptr;
+    if (cfg->rows_ring) {
+        if (!rows || !cfg->step_dev || cfg->rows_ring_slots < 1 || cfg->rows_ring_stride < nb) return VX_EINVAL;
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, const_cast<int64_t*>(cfg->rows_ring), 0) != hipSuccess || !dp) return VX_EINVAL;
+        ring = (const int64_t*)dp;
+        if (!fwb_shape(cfg) || !(packed_ok(cfg) && packws && aligned16(packws) && aligned16(y) && aligned16(W1) && aligned16(b1) &&
+                                 aligned16(W21) && aligned16(W22) && aligned16(h))) {
+            hipLaunchKernelGGL(k_rows_from_ring, dim3(1), dim3(256), 0, (hipStream_t)hs, ring, (int64_t)cfg->rows_ring_stride,
+                               (int)cfg->rows_ring_slots, cfg->step_dev, const_cast<int64_t*>(rows), nb);
+            VX_CHECK_LAUNCH();
+            ring = nullptr;
+        }
+    }
     const int rc = mvn_enc_forward_kernels(cfg, y, rows, nb, gid0, W1, b1, W21, b21, W22, b22, eps_in, h, x, eps, ldT, ent, hT,
-                                           epsT, packws, ximg, hs_out, hs, ximg_done, hs_done, hscale);
+                                           epsT, packws, ximg, hs_out, hs, ximg_done, hs_done, hscale, ring);
+    if (!rc && ring) return VX_EINVAL;                                // (a ring nobody read: cannot happen -- the test above mirrors the path)
     if (rc) return rc;                                               // nothing is launched on buffers an error left unwritten
     if (ximg && !ximg_done) {
         hipLaunchKernelGGL(k_lik_ximg_h, dim3((unsigned)((nb + LB_P - 1) / LB_P)), dim3(256), 0, (hipStream_t)hs, (int)cfg->D, nb,
@@ -1060,10 +1080,14 @@ int64_t vx_mvn_enc_bwd_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
            8;                                              // the step's operand maxima (k_pack_heads_hb)
 }
 
-int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
+// the loss of the step, summed by the call's last launch (vx_mvn_enc_backward_loss)
+struct LossTail { const float* ll; const float* ent; float alpha; float* loss; float* sum_ws; };
+
+static int mvn_enc_backward_impl(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
                         const float* W21, const float* W22, const float* h, const float* eps, const float* ldT,
                         const float* gx, const float* hT, const float* epsT, const float* gxT, const uint8_t* yT,
-                        int64_t yT_stride, float* genc, float* workspace, const float* packws, int32_t gd_ready, void* hs) {
+                        int64_t yT_stride, float* genc, float* workspace, const float* packws, int32_t gd_ready, void* hs,
+                        const LossTail* tail) {
     if (!enc_cfg_ok(cfg) || !y || !W21 || !W22 || !h || !eps || !ldT || (!gx && !gxT) || !genc || !workspace || nb < 0)
         return VX_EINVAL;
     int n_rowslabs, n_prw, n_jg, n_prf;
@@ -1395,17 +1419,49 @@ int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* 
     if (f1_done) {
         rc = f1_fork.join();                               // the fc1 gradient is in genc
         if (rc) return rc;
-    } else {
+    }
+    if (packed) {
+        // ONE launch ends the call (k_enc_bwd_tail): the head gradients back in the reference layout, the fc1 slabs summed
+        // (unless the side stream did), the loss of a small batch -- three launches of ~5 us until round 5
+        const int n_unpack = (int)((Rp + 3) / 4);
+        const int n_f1 = f1_done ? 0 : grid_1d(lenf, 64);
+        const bool loss_here = tail && nb <= 4096;
+        hipLaunchKernelGGL(k_enc_bwd_tail, dim3((unsigned)(n_unpack + n_f1 + (loss_here ? 1 : 0))), dim3(256), 0, st, (int)D, (int)H,
+                           slabs_w, n_prw, Rp * (H + 1), -1.0f, genc + lenf, n_unpack, (const float*)slabs_f, (int64_t)n_prf, lenf,
+                           genc, n_f1, loss_here ? tail->ll : nullptr, loss_here ? tail->ent : nullptr, nb,
+                           loss_here ? tail->alpha : 0.f, loss_here ? tail->loss : nullptr, loss_here ? tail->sum_ws : nullptr,
+                           loss_here ? const_cast<uint32_t*>(cfg->step_dev) : nullptr);
+        VX_CHECK_LAUNCH();
+        if (tail && !loss_here) return vx_sum2(tail->ll, tail->ent, nb, tail->alpha, tail->loss, tail->sum_ws, const_cast<uint32_t*>(cfg->step_dev), hs);
+        return VX_OK;
+    }
+    if (!f1_done) {
         rc = vx_reduce_slabs(slabs_f, n_prf, lenf, -1.0f, genc, hs);
         if (rc) return rc;
     }
-    if (packed) {
-        hipLaunchKernelGGL(k_unpack_head_grads, dim3((unsigned)((Rp + 3) / 4)), dim3(256), 0, st, (int)D, (int)H, slabs_w, n_prw,
-                           Rp * (H + 1), -1.0f, genc + lenf);
-        VX_CHECK_LAUNCH();
-        return VX_OK;
-    }
-    return vx_reduce_slabs(slabs_w, n_prw, lenw_ref, -1.0f, genc + lenf, hs);
+    rc = vx_reduce_slabs(slabs_w, n_prw, lenw_ref, -1.0f, genc + lenf, hs);
+    if (rc) return rc;
+    if (tail) return vx_sum2(tail->ll, tail->ent, nb, tail->alpha, tail->loss, tail->sum_ws, const_cast<uint32_t*>(cfg->step_dev), hs);
+    return VX_OK;
+}
+
+int vx_mvn_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
+                        const float* W21, const float* W22, const float* h, const float* eps, const float* ldT,
+                        const float* gx, const float* hT, const float* epsT, const float* gxT, const uint8_t* yT,
+                        int64_t yT_stride, float* genc, float* workspace, const float* packws, int32_t gd_ready, void* hs) {
+    return mvn_enc_backward_impl(cfg, y, rows, nb, W21, W22, h, eps, ldT, gx, hT, epsT, gxT, yT, yT_stride, genc, workspace,
+                                 packws, gd_ready, hs, nullptr);
+}
+
+int vx_mvn_enc_backward_loss(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
+                             const float* W21, const float* W22, const float* h, const float* eps, const float* ldT,
+                             const float* gx, const float* hT, const float* epsT, const float* gxT, const uint8_t* yT,
+                             int64_t yT_stride, float* genc, float* workspace, const float* packws, int32_t gd_ready,
+                             const float* ll, const float* ent, float loss_alpha, float* loss, float* sum_workspace, void* hs) {
+    if (!ll || !ent || !loss || !sum_workspace) return VX_EINVAL;
+    const LossTail tail{ll, ent, loss_alpha, loss, sum_workspace};
+    return mvn_enc_backward_impl(cfg, y, rows, nb, W21, W22, h, eps, ldT, gx, hT, epsT, gxT, yT, yT_stride, genc, workspace,
+                                 packws, gd_ready, hs, &tail);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -36,10 +36,14 @@ class HipBackend(object):
 
     # -- helpers -----------------------------------------------------------------------------
     @staticmethod
-    def cfg(model, D, J, H, Dc, scale, seed, step, stream, step_dev=None):
-        """step_dev: the device step counter of a captured step (vx_irt_cfg.step_dev) or None."""
-        return _hip.IrtCfg(MODEL_CODE[model], D, J, H, Dc, scale, seed, step, stream,
-                           None if step_dev is None else step_dev.data_ptr())
+    def cfg(model, D, J, H, Dc, scale, seed, step, stream, step_dev=None, rows_ring=None):
+        """step_dev: the device step counter of a captured step (vx_irt_cfg.step_dev) or None; rows_ring: the pinned
+        [slots][stride] int64 host tensor a captured subsampled step takes its row indices from (vx_irt_cfg.rows_ring)."""
+        c = _hip.IrtCfg(MODEL_CODE[model], D, J, H, Dc, scale, seed, step, stream,
+                        None if step_dev is None else step_dev.data_ptr())
+        if rows_ring is not None:
+            c.rows_ring, c.rows_ring_stride, c.rows_ring_slots = rows_ring.data_ptr(), rows_ring.shape[1], rows_ring.shape[0]
+        return c
 
     def mvn_enc_forward(self, cfg, y, rows, nb, gid0, enc, eps_in, out):
         rc = self.L.vx_mvn_enc_forward(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb, gid0,
@@ -98,16 +102,23 @@ class HipBackend(object):
     def mvn_enc_bwd_hs_offset(self, cfg, nb):
         return int(self.L.vx_mvn_enc_bwd_hs_offset(ctypes.byref(cfg), nb))
 
-    def mvn_enc_backward(self, cfg, y, rows, nb, enc, fw, gx, genc, ws, gxT=None, gd_ready=False, opmax_ready=False):
-        rc = self.L.vx_mvn_enc_backward(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb,
-                                        _hip.ptr(enc["fc21.weight"]), _hip.ptr(enc["fc22.weight"]),
-                                        _hip.ptr(fw["h"]), _hip.ptr(fw["eps"]), _hip.ptr(fw["ldT"]), _hip.ptr(gx),
-                                        _hip.ptr(fw.get("hT")), _hip.ptr(fw.get("epsT")), _hip.ptr(gxT),
-                                        _hip.ptr(fw.get("yT")), int(fw["yT"].shape[1]) if fw.get("yT") is not None else 0,
-                                        _hip.ptr(genc), _hip.ptr(ws), _hip.ptr(fw.get("packws")),
-                                        int(bool(gd_ready)) | (2 if fw.get("hs") is not None else 0) | (4 if opmax_ready else 0),
-                                        _hip.stream_ptr())
-        _hip.check(rc, "vx_mvn_enc_backward")
+    def mvn_enc_backward(self, cfg, y, rows, nb, enc, fw, gx, genc, ws, gxT=None, gd_ready=False, opmax_ready=False, loss=None):
+        """loss = (ll, ent, alpha, slot, sum_ws): the step's loss from the call's last launch (vx_mvn_enc_backward_loss)."""
+        args = [ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb,
+                _hip.ptr(enc["fc21.weight"]), _hip.ptr(enc["fc22.weight"]),
+                _hip.ptr(fw["h"]), _hip.ptr(fw["eps"]), _hip.ptr(fw["ldT"]), _hip.ptr(gx),
+                _hip.ptr(fw.get("hT")), _hip.ptr(fw.get("epsT")), _hip.ptr(gxT),
+                _hip.ptr(fw.get("yT")), int(fw["yT"].shape[1]) if fw.get("yT") is not None else 0,
+                _hip.ptr(genc), _hip.ptr(ws), _hip.ptr(fw.get("packws")),
+                int(bool(gd_ready)) | (2 if fw.get("hs") is not None else 0) | (4 if opmax_ready else 0)]
+        if loss is None:
+            rc = self.L.vx_mvn_enc_backward(*args, _hip.stream_ptr())
+            _hip.check(rc, "vx_mvn_enc_backward")
+            return
+        ll, ent, alpha, slot, sum_ws = loss
+        rc = self.L.vx_mvn_enc_backward_loss(*args, _hip.ptr(ll), _hip.ptr(ent), alpha, _hip.ptr(slot), _hip.ptr(sum_ws),
+                                             _hip.stream_ptr())
+        _hip.check(rc, "vx_mvn_enc_backward_loss")
 
     def irt1d_workspace(self, cfg, nb):
         n = self.L.vx_irt1d_workspace_floats(ctypes.byref(cfg), nb)
@@ -613,11 +624,35 @@ class _EngineBase(object):
         ptrs = tuple(sorted((k, t.data_ptr()) for k, t in self._ws.items()))
         return hyp, ptrs, self._one_graph()
 
-    def _stage_rows(self, rows, buf):
+    # the pinned host ring a captured subsampled step fetches its draw from: 16 slots, an event behind every 4th replay (a
+    # record between two replays costs the GPU ~4 us of gap; tools/ring_sweep.sh: 8 / 1: 173.7 us a B = 100 step, 16 / 4: 168.9)
+    rows_ring_slots = 16
+    rows_ring_event_every = 4
+
+    def _stage_rows(self, rows, buf, st=None):
         """The step's row indices into the fixed device buffer the captured kernels read.  Host indices (what the fit loop
         draws) go through a small ring of pinned buffers: one asynchronous copy, no staging allocation, no sync unless the
-        GPU is a whole ring behind."""
+        GPU is a whole ring behind.  A form whose capture reads the ring itself (st["ring"]: vx_irt_cfg.rows_ring) only has
+        the draw written into slot t % slots -- the replay fetches it."""
         nb = buf.numel()
+        if st is not None and st.get("ring") is not None:
+            if rows.is_cuda:
+                rows = rows.cpu()
+            # the replay that last read this slot (step t - slots, if this form ran it) has finished once the OLDEST event
+            # recorded at or behind that step has: events follow every `every`-th replay, so the host still runs
+            # slots - every steps ahead of the GPU
+            slot = self.t % self.rows_ring_slots
+            lo, evs = st["ring_read"][slot], st["ring_ev"]
+            if lo is not None:                               # the step that last read this slot
+                for k in [k for k in evs if k < lo]:
+                    del evs[k]
+                if evs:
+                    evs[min(evs)].synchronize()
+                else:
+                    torch.cuda.current_stream().synchronize()
+                st["ring_read"][slot] = None
+            st["ring"][slot, :nb].copy_(rows.reshape(-1))
+            return
         if rows.is_cuda:
             buf.copy_(rows)
             return
@@ -643,16 +678,21 @@ class _EngineBase(object):
             if getattr(self, "_ctr", None) is None:
                 self._ctr, self._ctr_t = torch.zeros(1, dtype=torch.int32, device=self.dev), None
             rows_buf = None
+            ring = None
             if mode[0] == "rows":
                 rows_buf = st.get("rows")
                 if rows_buf is None:
                     rows_buf = torch.zeros(mode[1], dtype=torch.int64, device=self.dev)
                 self._stage_rows(rows, rows_buf)             # valid indices while the capture records
+                ring = st.get("ring")
+                if ring is None and not rows.is_cuda:
+                    ring = torch.zeros(self.rows_ring_slots, max(int(mode[1]), 1), dtype=torch.int64).pin_memory()
             one = self._one_graph()
             torch.cuda.synchronize()
             gA, gB = torch.cuda.CUDAGraph(), None
             t0 = self.t
             self._step_dev = self._ctr
+            self._capture_ring, self._capture_ring_used = ring, False
             try:
                 # (thread-local capture mode: a process group's watchdog thread may query its events while this thread records)
                 with torch.cuda.graph(gA, capture_error_mode="thread_local"):
@@ -678,16 +718,27 @@ class _EngineBase(object):
                 raise
             finally:
                 self._step_dev = None
+                self._capture_ring = None
                 self.t = t0                                  # capture records, it does not run
-            st.update(graph=gA, tail=gB, key=key, rows=rows_buf)
+            if not self._capture_ring_used:
+                ring = None                                  # (this engine's forward does not read a ring: the copy stays)
+            if st.get("ring_ev"):
+                torch.cuda.current_stream().synchronize()
+            st.update(graph=gA, tail=gB, key=key, rows=rows_buf, ring=ring, ring_ev={} if ring is not None else None,
+                      ring_read=[None] * self.rows_ring_slots)
         if mode[0] == "rows":
-            self._stage_rows(rows, st["rows"])
+            self._stage_rows(rows, st["rows"], st)
         if self._ctr_t != self.t:                            # (re)seed the device counter
             self._ctr.fill_(self.t)
         st["graph"].replay()
         if st["tail"] is not None:
             self.allreduce()
             st["tail"].replay()
+        if st.get("ring") is not None:
+            st["ring_read"][self.t % self.rows_ring_slots] = self.t
+            if (self.t + 1) % self.rows_ring_event_every == 0:
+                ev = st["ring_ev"][self.t] = torch.cuda.Event()
+                ev.record()
         self.t += 1
         self._ctr_t = self.t
         return self.step_loss()
@@ -964,7 +1015,15 @@ class IrtEngine(_EngineBase):
             if hs_off >= 0:
                 fw["hs"] = encb_ws[hs_off:hs_off + nb * 64]
             with self._phase("guide_forward"):
-                be.mvn_enc_forward(cfg, self.y, rows, nb, self.gid0, enc, eps, fw)
+                cfg_f = cfg
+                ring = getattr(self, "_capture_ring", None)
+                if ring is not None and rows is not None and sd is not None and isinstance(be, HipBackend):
+                    # a captured subsampled step: the forward call's first launch fetches the step's draw from the pinned
+                    # host ring (vx_irt_cfg.rows_ring) -- no copy in front of every replay
+                    cfg_f = be.cfg(self.model, self.D, self.J, self.H, self.Dc, scale, self.seed, self.t, stream_id,
+                                   step_dev=sd, rows_ring=ring)
+                    self._capture_ring_used = True
+                be.mvn_enc_forward(cfg_f, self.y, rows, nb, self.gid0, enc, eps, fw)
             gd_off = be.mvn_enc_bwd_gd_offset(cfg, nb)     # the backward's DIAG-row operand, made in the likelihood's last pass
             gdT = encb_ws[gd_off:gd_off + nb * D] if gd_off >= 0 else None
             # the step's largest |gx|, |gd|, |eps| (the head weight gradient's power of two), collected by the likelihood's last
@@ -991,11 +1050,15 @@ class IrtEngine(_EngineBase):
                                           fw["ent"], base, beta, by_row, log_r, None, None, gxT, gdT)
                     self.last_log_r = log_r
             with self._phase("guide_backward"):
+                # loss = -scale * sum_i (ll_i + ent_i), from the backward call's last launch; a captured step's counter
+                # advances there, behind every kernel that read it
+                fused_loss = isinstance(be, HipBackend)
                 be.mvn_enc_backward(cfg, self.y, rows, nb, enc, fw, gx,
                                     self.G[self.enc_off0:self.enc_off0 + self.n_enc], encb_ws, gxT=gxT,
-                                    gd_ready=gdT is not None, **({"opmax_ready": True} if opmax is not None else {}))
-            # loss = -scale * sum_i (ll_i + ent_i); a captured step's counter advances here, behind every kernel that read it
-            be.sum2_into(ll, fw["ent"], nb, -scale, lossslot, self.sum_ws, **sdc)
+                                    gd_ready=gdT is not None, **({"opmax_ready": True} if opmax is not None else {}),
+                                    **({"loss": (ll, fw["ent"], -scale, lossslot, self.sum_ws)} if fused_loss else {}))
+            if not fused_loss:
+                be.sum2_into(ll, fw["ent"], nb, -scale, lossslot, self.sum_ws, **sdc)
             self.last = {"fw": fw, "gx": gx, "gxT": gxT, "ll": ll, "nb": nb}
         else:
             # D = 1: the flat item layout [a: J | b: J | c: J | d: J] IS the kernels' gradient layout -> written in place
