@@ -25,10 +25,22 @@
 #define HB_NSLOT 8
 #define HB_NS 8                                                        // k-steps of 16 covering D <= 128
 
+// OFF units: row k = 1 .. D - 1 has ceil(k / 16) of them.  Closed forms, not loops over k: rows 16 q + 1 .. 16 q + 16 have
+// q + 1 units each, so 8 q (q + 1) units lie before row 16 q + 1 (tools/pack_bench.hip: the two 99-trip loops of the pack
+// body -- this count, then the search for the unit's row -- were 5 of the 9 us of k_pack_heads_hb).
 __host__ __device__ inline int hb_units_off(int D) {
-    int n = 0;
-    for (int k = 1; k < D; ++k) n += (k + 15) / 16;
-    return n;
+    if (D < 2) return 0;
+    const int m = D - 1, q = m >> 4, r = m & 15;
+    return 8 * q * (q + 1) + r * (q + 1);
+}
+// OFF unit u -> its row k and k-step s
+__host__ __device__ inline void hb_unit_row(int u, int& k, int& s) {
+    int q = (int)((sqrtf(1.0f + 0.5f * (float)u) - 1.0f) * 0.5f);
+    while (8 * (q + 1) * (q + 2) <= u) ++q;
+    while (q > 0 && 8 * q * (q + 1) > u) --q;
+    const int rem = u - 8 * q * (q + 1), r = rem / (q + 1);
+    s = rem - r * (q + 1);
+    k = 16 * q + 1 + r;
 }
 __host__ __device__ inline int hb_units(int D) { return hb_units_off(D) + 2 * ((D + 15) / 16); }
 __host__ __device__ inline int64_t hb_img_floats(int D) { return (int64_t)hb_units(D) * (HB_UNIT_BYTES / 4); }
@@ -50,28 +62,44 @@ __device__ __forceinline__ void pack_heads_hb_unit(int u, int D, const float* __
     if (u >= n_off + 2 * ns) return;
     int type = 0, k = 0, s = 0;                                        // 0 OFF, 1 DIAG, 2 LOC
     if (u < n_off) {
-        int rem = u;
-        for (k = 1; k < D; ++k) {
-            const int n = (k + 15) / 16;
-            if (rem < n) break;
-            rem -= n;
-        }
-        s = rem;
+        hb_unit_row(u, k, s);
     } else {
         type = (u - n_off) < ns ? 2 : 1;                               // the LOC units first, the DIAG units last
         s = (u - n_off) % ns;
     }
     uint8_t* out = img + (int64_t)u * HB_UNIT_BYTES;
-    for (int e = threadIdx.x; e < 2 * 64 * 8; e += blockDim.x) {       // (ht, lane, j)
+    if (blockDim.x != 256) {                                           // (any other block size: element by element)
+        for (int e = threadIdx.x; e < 2 * 64 * 8; e += blockDim.x) {
+            const int j = e & 7, lane = (e >> 3) & 63, ht = e >> 9;
+            const int half = lane >> 5, hh = 32 * ht + (lane & 31);
+            const int c = 16 * s + 8 * half + j;
+            float w = 0.f;
+            if (type == 0) { if (c < k) w = W22[((int64_t)k * (k + 1) / 2 + c) * 64 + hh]; }
+            else if (type == 1) { if (c < D) w = W22[((int64_t)c * (c + 1) / 2 + c) * 64 + hh]; }
+            else { if (c < D) w = W21[(int64_t)c * 64 + hh]; }
+            uint16_t* o = (uint16_t*)(out + (ht * 2) * 1024 + lane * 16) + j;
+            split2h_bits(w_scale * w, o[0], o[512]);
+        }
+        return;
+    }
+    float v[4];                                                        // (256 threads: the loads of all four trips first)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                      // (ht, lane, j)
+        const int e = threadIdx.x + 256 * i;
         const int j = e & 7, lane = (e >> 3) & 63, ht = e >> 9;
         const int half = lane >> 5, hh = 32 * ht + (lane & 31);
         const int c = 16 * s + 8 * half + j;
-        float v = 0.f;
-        if (type == 0) { if (c < k) v = W22[((int64_t)k * (k + 1) / 2 + c) * 64 + hh]; }
-        else if (type == 1) { if (c < D) v = W22[((int64_t)c * (c + 1) / 2 + c) * 64 + hh]; }
-        else { if (c < D) v = W21[(int64_t)c * 64 + hh]; }
+        v[i] = 0.f;
+        if (type == 0) { if (c < k) v[i] = W22[((int64_t)k * (k + 1) / 2 + c) * 64 + hh]; }
+        else if (type == 1) { if (c < D) v[i] = W22[((int64_t)c * (c + 1) / 2 + c) * 64 + hh]; }
+        else { if (c < D) v[i] = W21[(int64_t)c * 64 + hh]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        const int j = e & 7, lane = (e >> 3) & 63, ht = e >> 9;
         uint16_t* o = (uint16_t*)(out + (ht * 2) * 1024 + lane * 16) + j;
-        split2h_bits(w_scale * v, o[0], o[512]);
+        split2h_bits(w_scale * v[i], o[0], o[512]);
     }
 }
 __global__ void k_pack_heads_hb(int D, const float* __restrict__ W21, const float* __restrict__ W22,

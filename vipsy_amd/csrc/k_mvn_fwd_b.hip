@@ -61,13 +61,39 @@ __device__ __forceinline__ void enc_scales_block_max(int blk, int D, int J, cons
     const int T = D * (D + 1) / 2;
     const int gt = blk * 256 + tid, gn = FB_SC_BLOCKS * 256;
     mw = 0.f; mb = 0.f; m1 = 0.f; l1 = 0.f;
-    for (int e = gt; e < D * 64; e += gn) mw = fmaxf(mw, fabsf(W21[e]));
-    for (int e = gt; e < T * 64; e += gn) mw = fmaxf(mw, fabsf(W22[e]));
+    // (maxima: any order.  16-byte loads, four of them in flight: the loop over single floats was 20 dependent trips of an
+    // L2 latency each, most of the 9 us of this launch)
+    auto max4 = [&](const float* __restrict__ w, int n) __attribute__((always_inline)) {
+        if (((uintptr_t)w & 15) == 0 && (n & 3) == 0) {
+            const f32x4* w4 = (const f32x4*)w;
+            const int n4 = n >> 2;
+            for (int e = gt; e < n4; e += 4 * gn) {
+                f32x4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = (e + q * gn < n4) ? w4[e + q * gn] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    mw = fmaxf(fmaxf(mw, fmaxf(fabsf(v[q][0]), fabsf(v[q][1]))), fmaxf(fabsf(v[q][2]), fabsf(v[q][3])));
+            }
+        } else {
+            for (int e = gt; e < n; e += gn) mw = fmaxf(mw, fabsf(w[e]));
+        }
+    };
+    max4(W21, D * 64);
+    max4(W22, T * 64);
     for (int e = gt; e < D; e += gn) mb = fmaxf(mb, fabsf(b21[e]));
     for (int e = gt; e < T; e += gn) mb = fmaxf(mb, fabsf(b22[e]));
     for (int u = blk * 4 + wave; u < 64; u += FB_SC_BLOCKS * 4) {          // hidden unit u: |W1[u, :]|_1 + |b1[u]|
         float sacc = 0.f;
-        for (int j = lane; j < J; j += 64) { const float w = fabsf(W1[(int64_t)u * J + j]); sacc += w; m1 = fmaxf(m1, w); }
+        const float* wu = W1 + (int64_t)u * J;
+        for (int j0 = 0; j0 < J; j0 += 512) {                              // eight loads in flight; the sum in the order of j
+            float w[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) w[q] = (j0 + 64 * q + lane < J) ? fabsf(wu[j0 + 64 * q + lane]) : 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (j0 + 64 * q + lane < J) { sacc += w[q]; m1 = fmaxf(m1, w[q]); }
+        }
         sacc = wave_sum(sacc) + fabsf(b1[u]);
         l1 = fmaxf(l1, sacc);
     }
@@ -107,37 +133,89 @@ __global__ void k_enc_scales(float* __restrict__ sc) {
 // remainders of Wp 2^sw; element j of it = Wp[32 T + row][16 s + 8 (j >> 2) + 4 half + (j & 3)];  a 9th fragment at
 // FB_A_BYTES carries the bias
 // gt2[group] (OFF groups only): byte offset of eps[l0] | byte offset of x[k] << 12 | (last group of its k) << 31
+// DIRECT: the rows come straight from W21 / W22 / b21 / b22 through pk_decode (what k_pack_heads would have put into Wp / bp)
+// and the block also writes its four words of gtab -- the fused pack then has no packed copy to wait for.
+template <bool DIRECT = false>
 __device__ __forceinline__ void pack_heads_b_tile(int T, int n_off_groups, const float* __restrict__ Wp, const float* __restrict__ bp,
                                                   const uint32_t* __restrict__ gtab, float w_scale, float b_scale,
-                                                  uint8_t* __restrict__ img, uint32_t* __restrict__ gt2) {
+                                                  uint8_t* __restrict__ img, uint32_t* __restrict__ gt2, int D = 0,
+                                                  const float* __restrict__ W21 = nullptr, const float* __restrict__ b21 = nullptr,
+                                                  const float* __restrict__ W22 = nullptr, const float* __restrict__ b22 = nullptr,
+                                                  uint32_t* __restrict__ gtab_out = nullptr) {
     uint8_t* out = img + (int64_t)T * FB_IMG_BYTES;
-    if (threadIdx.x < 4 && 4 * T + (int)threadIdx.x < n_off_groups) {
-        const int G = 4 * T + threadIdx.x;
+    const int tid = threadIdx.x;
+    const int Tt = D * (D + 1) / 2;
+    if constexpr (DIRECT) {
+        if (tid < 4) {
+            const int G = 4 * T + tid;
+            int src;
+            uint32_t c, cn = 0u;
+            pk_decode(8 * G, D, Tt, src, c);
+            gtab_out[G] = c;
+            if (G < n_off_groups) {
+                if (G + 1 < n_off_groups) pk_decode(8 * (G + 1), D, Tt, src, cn);
+                const uint32_t k = (c >> 12) & 0xFFFFu, l0 = c & 0xFFFu;
+                const bool last = (G + 1 == n_off_groups) || (((cn >> 12) & 0xFFFFu) != k);
+                gt2[G] = (4u * l0) | ((4u * k) << 12) | (last ? 0x80000000u : 0u);
+            }
+        }
+    } else if (tid < 4 && 4 * T + tid < n_off_groups) {
+        const int G = 4 * T + tid;
         const uint32_t c = gtab[G], k = (c >> 12) & 0xFFFFu, l0 = c & 0xFFFu;
         const bool last = (G + 1 == n_off_groups) || (((gtab[G + 1] >> 12) & 0xFFFFu) != k);
         gt2[G] = (4u * l0) | ((4u * k) << 12) | (last ? 0x80000000u : 0u);
     }
-    for (int e = threadIdx.x; e < 4 * 64 * 8; e += blockDim.x) {          // (s, lane, j)
-        const int j = e & 7, lane = (e >> 3) & 63, s = e >> 9;
-        const int half = lane >> 5, row = lane & 31;
-        const float v = w_scale * Wp[((int64_t)T * 32 + row) * 64 + 16 * s + 8 * (j >> 2) + 4 * half + (j & 3)];
-        uint16_t* o = (uint16_t*)(out + s * 1024 + lane * 16) + j;
-        split2h_bits(v, o[0], o[2048]);                                   // + 4 fragments = 4096 bytes
+    // (s, lane, j) = e = tid + 256 i: row = lane & 31 is the thread's own for every i; all eight loads first (one L2 latency,
+    // not eight)
+    const int row = (tid >> 3) & 31;
+    const float* wrow;
+    int bsrc = -1;
+    if constexpr (DIRECT) {
+        uint32_t gc;
+        pk_decode(T * 32 + row, D, Tt, bsrc, gc);
+        wrow = bsrc < 0 ? nullptr : (bsrc < Tt ? W22 + (int64_t)bsrc * 64 : W21 + (int64_t)(bsrc - Tt) * 64);
+    } else {
+        wrow = Wp + ((int64_t)T * 32 + row) * 64;
+    }
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = tid + 256 * i;
+        const int j = e & 7, lane = (e >> 3) & 63, sx = e >> 9;
+        const int half = lane >> 5;
+        v[i] = wrow ? wrow[16 * sx + 8 * (j >> 2) + 4 * half + (j & 3)] : 0.f;
+    }
+    float bv = 0.f;                                                       // bias fragment: lane = row (half 0), thread 8 lane + j, j < 2
+    const bool bias_thread = tid < 256 && (tid & 7) < 2;
+    if (bias_thread) {
+        if constexpr (DIRECT) {
+            // (thread 8 r + j holds row r = (tid >> 3) & 31 already)
+            bv = bsrc < 0 ? 0.f : (bsrc < Tt ? b22[bsrc] : b21[bsrc - Tt]);
+        } else {
+            bv = bp[T * 32 + (tid >> 3)];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = tid + 256 * i;
+        const int j = e & 7, lane = (e >> 3) & 63, sx = e >> 9;
+        uint16_t* o = (uint16_t*)(out + sx * 1024 + lane * 16) + j;
+        split2h_bits(w_scale * v[i], o[0], o[2048]);                      // + 4 fragments = 4096 bytes
     }
     // bias fragment (9th): lane = row (half 0), elements 0, 1 = the two fp16 terms of the row's bias 2^sb, the rest zero; one
     // MFMA against a fragment of the constant 2^(sw + sh - sb) starts the accumulator chain from the (scaled) bias
-    for (int e = threadIdx.x; e < FB_AUX_BYTES / 2; e += blockDim.x) {
-        const int j = e & 7, lane = e >> 3;
+    for (int e = tid; e < FB_AUX_BYTES / 2; e += 256) {
+        const int j = e & 7;
         uint16_t w = 0;
-        if (lane < 32 && j < 2) {
+        if (e < 256 && j < 2) {
             uint16_t bh, bl;
-            split2h_bits(b_scale * bp[T * 32 + lane], bh, bl);
+            split2h_bits(b_scale * bv, bh, bl);
             w = j == 0 ? bh : bl;
         }
         ((uint16_t*)(out + FB_A_BYTES))[e] = w;
     }
 }
-__global__ void k_pack_heads_b(int n_tiles, int n_off_groups, const float* __restrict__ Wp, const float* __restrict__ bp,
+__global__ __launch_bounds__(256) void k_pack_heads_b(int n_tiles, int n_off_groups, const float* __restrict__ Wp, const float* __restrict__ bp,
                                const uint32_t* __restrict__ gtab, const float* __restrict__ sc, uint8_t* __restrict__ img,
                                uint32_t* __restrict__ gt2) {
     if ((int)blockIdx.x >= n_tiles) return;
@@ -151,13 +229,32 @@ __global__ void k_pack_heads_b(int n_tiles, int n_off_groups, const float* __res
 __host__ __device__ inline int64_t fb_w1img_floats(int J) { return (int64_t)((J + 15) / 16) * (FB_W1_KS / 4); }
 __device__ __forceinline__ void pack_w1_b_kstep(int ks, int J, const float* __restrict__ W1, float w1_scale, uint8_t* __restrict__ w1img) {
     uint8_t* out = w1img + (int64_t)ks * FB_W1_KS;
-    for (int e = threadIdx.x; e < 2 * 64 * 8; e += blockDim.x) {       // (ht, lane, j)
+    if (blockDim.x != 256) {                                           // (any other block size: element by element)
+        for (int e = threadIdx.x; e < 2 * 64 * 8; e += blockDim.x) {
+            const int j = e & 7, lane = (e >> 3) & 63, ht = e >> 9;
+            const int half = lane >> 5, hh = 32 * ht + (lane & 31);
+            const int it = 16 * ks + 8 * half + j;
+            const float w = it < J ? w1_scale * W1[(int64_t)hh * J + it] : 0.f;
+            uint16_t* o = (uint16_t*)(out + (ht * 2) * 1024 + lane * 16) + j;
+            split2h_bits(w, o[0], o[512]);
+        }
+        return;
+    }
+    float v[4];                                                        // (256 threads: the loads of all four trips first)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                      // (ht, lane, j)
+        const int e = threadIdx.x + 256 * i;
         const int j = e & 7, lane = (e >> 3) & 63, ht = e >> 9;
         const int half = lane >> 5, hh = 32 * ht + (lane & 31);
         const int it = 16 * ks + 8 * half + j;
-        const float v = it < J ? w1_scale * W1[(int64_t)hh * J + it] : 0.f;
+        v[i] = it < J ? w1_scale * W1[(int64_t)hh * J + it] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        const int j = e & 7, lane = (e >> 3) & 63, ht = e >> 9;
         uint16_t* o = (uint16_t*)(out + (ht * 2) * 1024 + lane * 16) + j;
-        split2h_bits(v, o[0], o[512]);
+        split2h_bits(v[i], o[0], o[512]);
     }
 }
 __global__ void k_pack_w1_b(int J, const float* __restrict__ W1, const float* __restrict__ sc, uint8_t* __restrict__ w1img) {

@@ -78,7 +78,7 @@ __global__ void k_pack_heads(int D, int H, const float* __restrict__ W21, const 
         if (WpT) WpT[(int64_t)hh * Rp + pr] = v;
     }
     if (threadIdx.x == 0) {
-        bp[pr] = (src < 0) ? 0.f : (src < T ? b22[src] : b21[src - T]);
+        if (bp) bp[pr] = (src < 0) ? 0.f : (src < T ? b22[src] : b21[src - T]);   // (null: a caller that needs Wp and gtab only)
         if ((pr & 7) == 0) gtab[pr >> 3] = gcode;
     }
 }

@@ -33,8 +33,11 @@ __global__ __launch_bounds__(256) void k_pack_stage1(int D, int J, const float* 
                                                      float* __restrict__ sc, const int64_t* __restrict__ ring = nullptr,
                                                      int64_t ring_stride = 0, int ring_slots = 1,
                                                      const uint32_t* __restrict__ step_dev = nullptr,
-                                                     int64_t* __restrict__ rows_out = nullptr, int64_t nb = 0) {
-    const int Rp = pk_rows(D), n_row_blocks = (Rp + 3) / 4;
+                                                     int64_t* __restrict__ rows_out = nullptr, int64_t nb = 0,
+                                                     int n_row_blocks = -1 /*(Rp + 3) / 4, or 0: stage 2 reads the parameters
+                                                     themselves (direct) and nothing of this step needs Wp / bp / WpT*/) {
+    if (n_row_blocks < 0) n_row_blocks = (pk_rows(D) + 3) / 4;
+    const int Rp = pk_rows(D);
     const int blk = blockIdx.x, tid = threadIdx.x;
     if (blk == n_row_blocks + FB_SC_BLOCKS) {
         // one more block, with a ring: the step's row indices from the pinned host ring (vx_irt_cfg.rows_ring) into the
@@ -72,7 +75,10 @@ __global__ __launch_bounds__(256) void k_pack_stage2(int D, int J, int n_tiles, 
                                                      const float* __restrict__ Wp, const float* __restrict__ bp,
                                                      const uint32_t* __restrict__ gtab, float* __restrict__ sc,
                                                      uint8_t* __restrict__ w1img, uint8_t* __restrict__ img, uint32_t* __restrict__ gt2,
-                                                     uint8_t* __restrict__ himg /*or null*/) {
+                                                     uint8_t* __restrict__ himg /*or null*/,
+                                                     const float* __restrict__ b21 = nullptr /*direct: the tile images from the
+                                                     parameters themselves, gtab written here (stage 1 made no packed copy)*/,
+                                                     const float* __restrict__ b22 = nullptr, uint32_t* __restrict__ gtab_out = nullptr) {
     __shared__ float scl[16];
     const int tid = threadIdx.x, blk = blockIdx.x;
     if (tid < 64) {
@@ -87,7 +93,11 @@ __global__ __launch_bounds__(256) void k_pack_stage2(int D, int J, int n_tiles, 
     }
     const int n_w1 = (J + 15) / 16;
     if (blk < n_w1) { pack_w1_b_kstep(blk, J, W1, scl[0], w1img); return; }
-    if (blk < n_w1 + n_tiles) { pack_heads_b_tile(blk - n_w1, n_off_groups, Wp, bp, gtab, scl[2], scl[5], img, gt2); return; }
+    if (blk < n_w1 + n_tiles) {
+        if (gtab_out) pack_heads_b_tile<true>(blk - n_w1, n_off_groups, Wp, bp, gtab, scl[2], scl[5], img, gt2, D, W21, b21, W22, b22, gtab_out);
+        else pack_heads_b_tile<false>(blk - n_w1, n_off_groups, Wp, bp, gtab, scl[2], scl[5], img, gt2);
+        return;
+    }
     if (himg) pack_heads_hb_unit(blk - n_w1 - n_tiles, D, W21, W22, scl[2], himg);
 }
 

@@ -482,16 +482,21 @@ static int mvn_enc_forward_kernels(const vx_irt_cfg* cfg, const uint8_t* y, cons
             // WpT only when a kernel of this step reads it (the fp32 hidden-gradient kernel)
             const bool hb = hb_from_forward(cfg, nb);
             uint8_t* himg = hb ? (uint8_t*)((float*)sc - hb_img_floats(dm.D)) : nullptr;
-            const int n_row_blocks = (Rp + 3) / 4, n_w1 = (dm.J + 15) / 16;
+            // with the f16x2 hidden gradient (hb) no kernel of the step reads the packed copy Wp / bp / WpT: stage 1 is the maxima
+            // alone and stage 2 takes the tile images from the parameters themselves (and writes gtab, which the head weight
+            // gradient reads)
+            const bool direct = hb;
+            const int n_row_blocks = direct ? 0 : (Rp + 3) / 4, n_w1 = (dm.J + 15) / 16;
             hipLaunchKernelGGL(k_pack_stage1, dim3(n_row_blocks + FB_SC_BLOCKS + (ring ? 1 : 0)), dim3(256), 0, (hipStream_t)hs,
                                (int)dm.D, (int)dm.J, W1, b1, W21, b21, W22, b22, Wp, bp, gtab, hb ? (float*)nullptr : WpT, sc, ring,
                                (int64_t)cfg->rows_ring_stride, (int)cfg->rows_ring_slots, cfg->step_dev, const_cast<int64_t*>(rows),
-                               nb);
+                               nb, n_row_blocks);
             ring = nullptr;                                // (done)
             VX_CHECK_LAUNCH();
             hipLaunchKernelGGL(k_pack_stage2, dim3(n_w1 + n_tiles + (hb ? hb_units(dm.D) : 0)), dim3(256), 0, (hipStream_t)hs,
                                (int)dm.D, (int)dm.J, n_tiles, pk_off_total(dm.D) / 8, W1, W21, W22, (const float*)Wp, (const float*)bp,
-                               (const uint32_t*)gtab, sc, w1img, img, gt2, himg);
+                               (const uint32_t*)gtab, sc, w1img, img, gt2, himg, direct ? b21 : (const float*)nullptr,
+                               direct ? b22 : (const float*)nullptr, direct ? gtab : (uint32_t*)nullptr);
             VX_CHECK_LAUNCH();
             const size_t ldsb = fb_lds_bytes(dm.D, dm.J);
             ximg_done = true;
@@ -1276,6 +1281,14 @@ static int mvn_enc_backward_impl(const vx_irt_cfg* cfg, const uint8_t* y, const 
             }
         } else {
             if (!gx) return VX_EINVAL;                     // the person-major kernel needs gx[nb][D]
+            if (hb_fw) {
+                // the forward call packed for the f16x2 hidden gradient and made no packed copy of the heads (k_pack_fused.hip,
+                // direct): this kernel reads one
+                hipLaunchKernelGGL(k_pack_heads, dim3((unsigned)Rp), dim3(64), 0, st, (int)cfg->D, 64, W21, (const float*)nullptr,
+                                   W22, (const float*)nullptr, const_cast<float*>(packws), (float*)nullptr,
+                                   const_cast<uint32_t*>(gtab), (float*)nullptr);
+                VX_CHECK_LAUNCH();
+            }
             const size_t lds = enc_bwdh_p_lds_floats(dm.D) * sizeof(float);
             rc = set_lds(k_mvn_enc_bwd_h_p, lds);
             if (rc) return rc;
