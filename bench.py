@@ -333,14 +333,27 @@ def main():
     if not graphed:
         eng.events = ev
         _hip.lib().vx_prof_enable(1)                        # HIP events on the launch stream around the large kernels
+    else:
+        eng.capture_steps(lrs)                              # (records the four-step graph; runs nothing)
     sync()
     t0 = time.perf_counter()
     loss_first = None
-    for i in range(args.steps):
-        loss = eng.step(lrs)
-        if i == 0:                                          # a slot of the engine's loss ring: kept as it is while the timed
-            loss_first = loss if args.steps < 60 else loss.clone()    # region is shorter than the ring, copied otherwise
-        lrs.scheduler_step()
+    if graphed:
+        # as a fit loop runs them (vipsy_amd/vi.py::_loop -> IrtEngine.steps): graph_steps steps a replay where the form allows
+        i = 0
+        while i < args.steps:
+            n = min(32, args.steps - i)
+            losses = eng.steps(lrs, [None] * n, scheduler=True)
+            if i == 0:                                      # a slot of the engine's loss ring: kept as it is while the timed
+                loss_first = losses[0] if args.steps < 60 else losses[0].clone()    # region is shorter than the ring, copied otherwise
+            loss = losses[-1]
+            i += n
+    else:
+        for i in range(args.steps):
+            loss = eng.step(lrs)
+            if i == 0:
+                loss_first = loss if args.steps < 60 else loss.clone()
+            lrs.scheduler_step()
     sync()
     dt = time.perf_counter() - t0
     loss_v = float(loss.item())
@@ -369,12 +382,10 @@ def main():
         # the line above was timed kernel by kernel (HIP events inside the timed region); for comparison the same step replayed
         # from its HIP graph, after the timed region (the first call of the form runs eagerly, the second captures)
         ng = min(args.steps, 20)
-        for _ in range(3):
-            eng.step(lrs)
+        eng.steps(lrs, [None] * 8)                          # (eager, the captures, a replay)
         sync()
         tg = time.perf_counter()
-        for _ in range(ng):
-            eng.step(lrs)
+        eng.steps(lrs, [None] * ng)
         sync()
         graph_ms = 1e3 * (time.perf_counter() - tg) / ng
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
@@ -479,14 +490,16 @@ def main():
             rg = np.random.Generator(np.random.PCG64(7))
             def draw():                                     # host indices, as the fit loop draws them (vipsy_amd/vi.py::_subsample)
                 return torch.from_numpy(rg.choice(n_local, size=100, replace=False).astype(np.int64))
-            for _ in range(5):
-                eng.step(lrs, rows=draw(), b_global=100)
+            import gc
+            eng.steps(lrs, [draw() for _ in range(12)], b_global=100)      # (eager, the captures, a replay)
             torch.cuda.synchronize()
+            gc.collect()                                    # (a full collection is a 40 ms stall of the host, once: not the step's cost)
             tb = time.perf_counter()
-            for _ in range(100):
-                eng.step(lrs, rows=draw(), b_global=100)
+            n_b100 = 400
+            for _ in range(n_b100 // 4):                    # as the fit loop does: four draws, one replay (IrtEngine.steps)
+                eng.steps(lrs, [draw() for _ in range(4)], b_global=100)
             torch.cuda.synchronize()
-            gpu_b100 = 100.0 / (time.perf_counter() - tb)
+            gpu_b100 = n_b100 / (time.perf_counter() - tb)
             n_s = 4000
             cb = cpu_baseline(J, D, H, n_s)
             best_one = cb["sec_one"] is not None and cb["sec_one"] < cb["sec_all"]     # BLAS oversubscription happens

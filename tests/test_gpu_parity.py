@@ -863,6 +863,48 @@ def test_captured_amortized_step_equals_eager_step(N, B):
         assert np.array_equal(u, v)
 
 
+@pytest.mark.parametrize("kind", ["irt1d_full", "amortized_rows", "amortized_full"])
+def test_steps_replayed_four_at_a_time_equal_single_steps(kind):
+    """IrtEngine.steps (what the fit loop calls): graph_steps consecutive steps replayed from ONE graph -- the Philox step and
+    Adam's t from the device counter, a subsample's rows from the pinned ring -- against step() called in a loop: same bits in
+    every loss and every parameter, across a scheduler milestone (the steps around it fall back to single replays) and with a
+    remainder that is not a multiple of graph_steps."""
+    from vipsy_amd.engine import IrtEngine, LrSpec
+    rng = np.random.RandomState(11)
+    n_steps = 27
+    if kind == "irt1d_full":
+        N, J = 3000, 40
+        y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+        y[rng.rand(N, J) < 0.1] = 255
+        mk = lambda: IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_4pl", D=1, seed=11)
+        rows_all, B = [None] * n_steps, None
+    else:
+        N, J, D, H = 5000 if kind == "amortized_rows" else 2048, 500, 100, 64
+        y, _, _ = _random_problem(N, J, D, H, "irt_2pl", 0.1, seed=N + 3)
+        mk = lambda: IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_2pl", D=D, amortized=True, H=H, seed=11)
+        B = 100 if kind == "amortized_rows" else None
+        rows_all = [None if B is None else torch.from_numpy(rng.choice(N, size=B, replace=False).astype(np.int64)) for _ in range(n_steps)]
+    out = []
+    for multi in (True, False):
+        eng = mk()
+        lrs = LrSpec(lambda m, p: {"lr": 1e-2 if p in ("a", "b") else 1e-3}, milestones=(13,), gamma=0.5)
+        if multi:
+            assert eng.graph_steps == 4
+            losses = eng.steps(lrs, rows_all, b_global=B, scheduler=True)
+            assert (eng._graph or {}).get("multi") is not None          # the K-step graph was captured and replayed
+        else:
+            losses = []
+            for t in range(n_steps):
+                losses.append(eng.step(lrs, rows=rows_all[t], b_global=B))
+                lrs.scheduler_step()
+        torch.cuda.synchronize()
+        assert eng.t == n_steps and lrs.epoch == n_steps
+        out.append((torch.stack(losses).cpu().numpy(), eng.P.cpu().numpy().copy(), eng.PP.cpu().numpy().copy() if eng.per_person else None))
+    assert np.isfinite(out[0][0]).all() and len(set(out[0][0].tolist())) == n_steps
+    for u, v in zip(out[0], out[1]):
+        assert (u is None and v is None) or np.array_equal(u, v)
+
+
 def test_failed_capture_of_a_sharded_step_degrades_to_the_eager_step(monkeypatch):
     """A sharded step is captured WITHOUT its collective (two replays around an eager all-reduce).  If that capture fails
     beside a live communicator, the rank must warn and carry on kernel by kernel with the same results -- not end the job

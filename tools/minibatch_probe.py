@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--persons", type=int, default=200000)
     ap.add_argument("--B", type=int, default=100)
     ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--modes", default="eager,graph")
+    ap.add_argument("--modes", default="eager,graph,graph4")
     ap.add_argument("--time-sync", action="store_true", help="time the host's waits for the GPU (Event.synchronize)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -35,9 +35,19 @@ def main():
         return torch.from_numpy(rg.choice(args.persons, size=args.B, replace=False).astype(np.int64))
     for mode in args.modes.split(","):
         eng = IrtEngine(y, model="irt_2pl", D=D, amortized=True, H=H, seed=1234)
-        eng.use_graph = mode == "graph"
-        for _ in range(10):
-            eng.step(lrs, rows=draw(), b_global=args.B)
+        eng.use_graph = mode in ("graph", "graph4")
+        if mode == "graph4":                                   # what the fit loop does: four steps a replay (IrtEngine.steps)
+            def run(n, fixed=None):
+                i = 0
+                while i < n:
+                    k = min(eng.graph_steps, n - i)
+                    eng.steps(lrs, [fixed if fixed is not None else draw() for _ in range(k)], b_global=args.B)
+                    i += k
+        else:
+            def run(n, fixed=None):
+                for _ in range(n):
+                    eng.step(lrs, rows=(fixed.to(dev) if mode == "eager" else fixed) if fixed is not None else draw(), b_global=args.B)
+        run(12)                                                # (eager step, the captures, a few replays)
         torch.cuda.synchronize()
         gc.collect()
         gc.freeze()                                            # (a full collection of the interpreter's heap is a 40 ms stall of the
@@ -51,8 +61,7 @@ def main():
         if args.time_sync:
             torch.cuda.Event.synchronize = timed_sync
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            eng.step(lrs, rows=draw(), b_global=args.B)
+        run(args.steps)
         t_host = time.perf_counter() - t0                      # the host has enqueued everything
         torch.cuda.Event.synchronize = ev_sync
         torch.cuda.synchronize()
@@ -61,8 +70,7 @@ def main():
         r = draw()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
-            eng.step(lrs, rows=r.to(dev) if mode == "eager" else r, b_global=args.B)
+        run(args.steps, fixed=r)
         torch.cuda.synchronize()
         t_fixed = time.perf_counter() - t1
         t2 = time.perf_counter()

@@ -629,7 +629,7 @@ class _EngineBase(object):
     rows_ring_slots = 16
     rows_ring_event_every = 4
 
-    def _stage_rows(self, rows, buf, st=None):
+    def _stage_rows(self, rows, buf, st=None, t=None):
         """The step's row indices into the fixed device buffer the captured kernels read.  Host indices (what the fit loop
         draws) go through a small ring of pinned buffers: one asynchronous copy, no staging allocation, no sync unless the
         GPU is a whole ring behind.  A form whose capture reads the ring itself (st["ring"]: vx_irt_cfg.rows_ring) only has
@@ -641,7 +641,7 @@ class _EngineBase(object):
             # the replay that last read this slot (step t - slots, if this form ran it) has finished once the OLDEST event
             # recorded at or behind that step has: events follow every `every`-th replay, so the host still runs
             # slots - every steps ahead of the GPU
-            slot = self.t % self.rows_ring_slots
+            slot = (self.t if t is None else t) % self.rows_ring_slots
             lo, evs = st["ring_read"][slot], st["ring_ev"]
             if lo is not None:                               # the step that last read this slot
                 for k in [k for k in evs if k < lo]:
@@ -742,6 +742,106 @@ class _EngineBase(object):
         self.t += 1
         self._ctr_t = self.t
         return self.step_loss()
+
+    # -- several steps of a fit loop from ONE replay ----------------------------------------------
+    # Between two replays the GPU idles 6-9 us (the end of a graph releases to the system scope, the next one starts behind
+    # it): a fifth of BASELINE config 2's 42 us step, 5 % of the reference's own B = 100 step.  Nothing a step needs from the
+    # host is made by the step before it -- the Philox step and Adam's t come from the device counter, a subsample's rows from
+    # the pinned ring (slot = counter % slots), the loss goes into the ring -- so graph_steps consecutive steps are captured
+    # as one graph and a fit loop replays that (steps(): same kernels, same order, same bits as step() called in a loop).
+    graph_steps = 4
+
+    def _steps_form(self, lrs, rows_seq, b_global, scheduler):
+        """The single-step form whose K-step graph can take the next K = graph_steps steps of a fit loop, or None."""
+        K = self.graph_steps
+        if K < 2 or len(rows_seq) < K or not hasattr(self, "_graphs") or not self._one_graph():
+            return None
+        mode = self._graph_mode(rows_seq[0], b_global, None, 1)
+        if mode is None or any(self._graph_mode(r, b_global, None, 1) != mode for r in rows_seq[1:K]):
+            return None
+        st = self._graphs.get(mode)
+        if st is None or st.get("graph") is None or st.get("key") != self._graph_key(lrs):
+            return None                                      # (the form's first steps run one by one: eager, then its own capture)
+        if mode[0] == "rows" and (st.get("ring") is None or any(r.is_cuda for r in rows_seq[:K])):
+            return None
+        if scheduler and any(lrs.epoch < m <= lrs.epoch + K - 1 for m in lrs.milestones):
+            return None                                      # a milestone inside the K steps: their learning rates differ
+        return mode
+
+    def capture_steps(self, lrs, rows=None, b_global=None):
+        """Captures the graph_steps-step graph of this form now (nothing runs), so that the first steps() call of a timed loop
+        does not pay for it; True when the form has one afterwards (its single-step graph must exist: two steps taken)."""
+        mode = self._steps_form(lrs, [rows] * self.graph_steps, b_global, False)
+        if mode is None:
+            return False
+        self._steps_capture(lrs, mode)
+        return True
+
+    def _steps_capture(self, lrs, mode):
+        st, K = self._graphs[mode], self.graph_steps
+        mk = st.get("multi")
+        key = (self._graph_key(lrs), K)
+        if mk is None or mk["key"] != key:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            t0 = self.t
+            self._step_dev = self._ctr
+            self._capture_ring, self._capture_ring_used = st.get("ring"), False
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    for _ in range(K):
+                        self.loss_and_grads(st.get("rows"), mode[2] if mode[0] == "rows" else None, None, 0)
+                        self.allreduce()                      # (a no-op without a group; with one: the captured collective)
+                        self.apply_optim(lrs)
+            finally:
+                self._step_dev = None
+                self._capture_ring = None
+                self.t = t0
+            mk = st["multi"] = {"graph": g, "key": key}
+        return mk
+
+    def _steps_graph(self, lrs, mode, rows_seq, scheduler):
+        st, K = self._graphs[mode], self.graph_steps
+        self._graphs[mode] = self._graphs.pop(mode)          # most recently used last
+        self._graph = st
+        mk = self._steps_capture(lrs, mode)
+        t0 = self.t
+        if mode[0] == "rows":
+            for j in range(K):
+                self._stage_rows(rows_seq[j], st["rows"], st, t=t0 + j)
+        if self._ctr_t != self.t:
+            self._ctr.fill_(self.t)
+        mk["graph"].replay()
+        if st.get("ring") is not None:
+            for j in range(K):
+                st["ring_read"][(t0 + j) % self.rows_ring_slots] = t0 + j
+            ev = st["ring_ev"][t0 + K - 1] = torch.cuda.Event()      # (behind all K steps)
+            ev.record()
+        self.t += K
+        self._ctr_t = self.t
+        if scheduler:
+            for _ in range(K):
+                lrs.scheduler_step()
+        return [self.loss_ring[(t0 + j + 1) % LOSS_RING] for j in range(K)]
+
+    def steps(self, lrs, rows_seq, b_global=None, scheduler=False):
+        """len(rows_seq) consecutive steps of a fit loop -- what step(lrs, rows=r, b_global=b_global) for r in rows_seq does,
+        each followed by lrs.scheduler_step() when `scheduler` (vi.py:639-640) -- with the same results bit for bit, replayed
+        graph_steps at a time from one graph where the form allows.  rows_seq: one entry per step (None = the full batch, or
+        host / device int64 LOCAL row indices).  Returns the losses, one 0-d device tensor per step (slots of the loss ring:
+        the last LOSS_RING - 1 of them stay valid)."""
+        out, i, n = [], 0, len(rows_seq)
+        while i < n:
+            mode = self._steps_form(lrs, rows_seq[i:], b_global, scheduler)
+            if mode is not None:
+                out += self._steps_graph(lrs, mode, rows_seq[i:i + self.graph_steps], scheduler)
+                i += self.graph_steps
+                continue
+            out.append(self.step(lrs, rows=rows_seq[i], b_global=b_global))
+            if scheduler:
+                lrs.scheduler_step()
+            i += 1
+        return out
 
     graph_max_row_forms = 8
 

@@ -158,6 +158,24 @@ class BasePsy(object):
             except Exception:  # pragma: no cover
                 bar = None
         last = None
+        sched = isinstance(optim, PyroLRScheduler)
+        K = getattr(self.engine, "graph_steps", 1) if S == 1 and hasattr(self.engine, "steps") else 1
+        if K > 1:
+            # one particle: the iterations go to the engine K at a time (IrtEngine.steps: several steps of the loop replayed from
+            # one graph where the step's form allows; the draws are made in the same order, the results are the same bits)
+            i = 0
+            while i < max_iter:
+                n = min(K, max_iter - i)
+                draws = [self._subsample() for _ in range(n)]
+                last = self.engine.steps(lrs, [d[0] for d in draws], b_global=draws[0][1], scheduler=sched)[-1]
+                i += n
+                if bar is not None:
+                    bar.update(n)
+                    if (i - n) // 50 != i // 50 or i >= max_iter:
+                        bar.set_postfix(loss="{0:1.2f}".format(float(last.item())), **self._postfix())
+            if bar is not None:
+                bar.close()
+            return None if last is None else float(last.item())
         for i in it:
             if S == 1:
                 rows, bg = self._subsample()
@@ -165,7 +183,7 @@ class BasePsy(object):
                 draws = [self._subsample() for _ in range(S)]
                 rows, bg = [d[0] for d in draws], draws[0][1]
             last = self.engine.step(lrs, rows=rows, b_global=bg, num_particles=S)
-            if isinstance(optim, PyroLRScheduler):
+            if sched:
                 lrs.scheduler_step()                                   # vi.py:639-640
             if bar is not None and (i % 50 == 0 or i == max_iter - 1):
                 bar.set_postfix(loss="{0:1.2f}".format(float(last.item())), **self._postfix())
