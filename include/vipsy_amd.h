@@ -422,6 +422,33 @@ int vx_adam_step2(float* pA, const float* gA, float* mA, float* vA, const float*
                   const vx_adam_seg* segsB, int32_t n_segsB, int32_t t, const uint32_t* t_dev, float beta1, float beta2,
                   float eps, const float* loss_src, float* loss_ring /*[VX_LOSS_RING]*/, void* hip_stream);
 
+/* ---- a D = 1 step on ONE rank with its optimiser: vx_irt1d_grad / vx_irt1d_sparse_grad and vx_adam_step2 in one call,
+ * the slab sum and Adam in ONE launch (three graph nodes a step become two; BASELINE config 2: 38.7 -> ~33 us).  What
+ * SVI.step does between loss_and_grads and optim(params) (vi.py:505-514) needs no other rank here -- with a process group
+ * the all-reduce sits between the two and the separate calls are used.
+ *   A = the item leaves: pA / mA / vA / freeA of exactly 4 J floats, gradient = gitem (still written);
+ *   B = the per-person rows [loc | raw] (may be empty: nB = 0): gradients gB as written by the step kernel;
+ *   t: Adam's 1-based count (ignored with step_dev: the count is then the device counter + 1, which the call advances);
+ *   loss_ring (or NULL): loss[0] is also filed in loss_ring[t % VX_LOSS_RING].
+ * Same sums in the same order, same Adam arithmetic: the results are those of the separate calls, bit for bit.
+ * workspace as for the separate calls (vx_irt1d_workspace_floats / vx_irt1d_sparse_workspace_floats). */
+typedef struct vx_adam_tail {
+    float* pA; float* mA; float* vA; const float* freeA /*or NULL*/; int64_t nA; const vx_adam_seg* segsA /*host*/;
+    float* pB; const float* gB; float* mB; float* vB; int64_t nB; const vx_adam_seg* segsB /*host*/;
+    int32_t n_segsA, n_segsB, t;
+    float beta1, beta2, eps;
+    float* loss_ring /*[VX_LOSS_RING] or NULL*/;
+} vx_adam_tail;
+int vx_irt1d_grad_adam(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, int64_t gid0,
+                       const float* loc, const float* raw, const float* eps_in, const float* a, const float* b,
+                       const float* c_un, const float* d_un, float* gloc, float* graw, float* elbo, float* gitem,
+                       float* loss, uint32_t* step_dev /*or NULL*/, float* workspace, const vx_adam_tail* opt,
+                       void* hip_stream);
+int vx_irt1d_sparse_grad_adam(const vx_irt_cfg* cfg, const uint16_t* pent, const int32_t* glen, int32_t Lq,
+                              const int32_t* pidx, int64_t n_groups, int64_t gid0, const float* loc, const float* raw,
+                              const float* eps_in, const float* a, const float* b, const float* c_un, const float* d_un,
+                              float* gloc, float* graw, float* elbo, float* gitem, float* loss,
+                              uint32_t* step_dev /*or NULL*/, float* workspace, const vx_adam_tail* opt, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -863,6 +863,34 @@ def test_captured_amortized_step_equals_eager_step(N, B):
         assert np.array_equal(u, v)
 
 
+@pytest.mark.parametrize("miss,model,graph", [(0.0, "irt_4pl", True), (0.0, "irt_2pl", False), (0.9, "irt_2pl", True), (0.9, "irt_3pl", False)])
+def test_optimiser_in_the_steps_last_launch_equals_separate_launches(miss, model, graph):
+    """One rank, D = 1 per-person guide: the slab sum and Adam in ONE launch (vx_irt1d_grad_adam / vx_irt1d_sparse_grad_adam,
+    k_reduce_adam) against k_reduce_wide + k_adam2 (IrtEngine.fuse_tail = False): same losses, same replicated and
+    per-person parameters and Adam moments, bit for bit -- eager and replayed, dense and on the observed-cell lists, across a
+    scheduler milestone."""
+    from vipsy_amd.engine import IrtEngine, LrSpec
+    rng = np.random.RandomState(5)
+    N, J = 70000 if miss == 0.0 and graph else 3000, 40       # (70 000 persons: more than 512 slabs -> the eight-column form)
+    y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+    y[rng.rand(N, J) < miss] = 255
+    out = []
+    for fuse in (True, False):
+        eng = IrtEngine(torch.from_numpy(y).to(_dev()), model=model, D=1, seed=11)
+        eng.use_graph, eng.fuse_tail = graph, fuse
+        lrs = LrSpec(lambda m, p: {"lr": 1e-2 if p in ("a", "b") else 1e-3}, milestones=(3,), gamma=0.5)
+        losses = []
+        for _ in range(7):
+            losses.append(eng.step(lrs))
+            lrs.scheduler_step()
+        torch.cuda.synchronize()
+        assert eng.t == 7
+        out.append([torch.stack(losses).cpu().numpy()] + [t.cpu().numpy().copy() for t in (eng.P, eng.PP, eng.M, eng.V, eng.MP, eng.VP, eng.G[:eng.n_params])])
+    assert np.isfinite(out[0][0]).all() and len(set(out[0][0].tolist())) == 7
+    for u, v in zip(out[0], out[1]):
+        assert np.array_equal(u, v)
+
+
 @pytest.mark.parametrize("kind", ["irt1d_full", "amortized_rows", "amortized_full"])
 def test_steps_replayed_four_at_a_time_equal_single_steps(kind):
     """IrtEngine.steps (what the fit loop calls): graph_steps consecutive steps replayed from ONE graph -- the Philox step and

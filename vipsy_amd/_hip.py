@@ -29,6 +29,17 @@ class AdamSeg(ctypes.Structure):
     _fields_ = [("begin", ctypes.c_int64), ("end", ctypes.c_int64), ("lr", ctypes.c_float), ("_pad", ctypes.c_float)]
 
 
+class AdamTail(ctypes.Structure):
+    """struct vx_adam_tail (include/vipsy_amd.h)."""
+    _fields_ = [("pA", ctypes.c_void_p), ("mA", ctypes.c_void_p), ("vA", ctypes.c_void_p), ("freeA", ctypes.c_void_p),
+                ("nA", ctypes.c_int64), ("segsA", ctypes.POINTER(AdamSeg)),
+                ("pB", ctypes.c_void_p), ("gB", ctypes.c_void_p), ("mB", ctypes.c_void_p), ("vB", ctypes.c_void_p),
+                ("nB", ctypes.c_int64), ("segsB", ctypes.POINTER(AdamSeg)),
+                ("n_segsA", ctypes.c_int32), ("n_segsB", ctypes.c_int32), ("t", ctypes.c_int32),
+                ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
+                ("loss_ring", ctypes.c_void_p)]
+
+
 class HoDinaCfg(ctypes.Structure):
     """struct vx_hodina_cfg (include/vipsy_amd.h)."""
     _fields_ = [("K", ctypes.c_int32), ("J", ctypes.c_int32), ("H", ctypes.c_int32), ("_pad", ctypes.c_int32),
@@ -73,6 +84,9 @@ SIGNATURES = {
     "vx_irt1d_grad": (ctypes.c_int, [_CFG, _P, _P, _I64, _I64] + [_P] * 3 + [_P] * 4 + [_P] * 4 + [_P, _P, _P, _P]),
     "vx_irt1d_sparse_workspace_floats": (_I64, [_CFG, _I64]),
     "vx_irt1d_sparse_grad": (ctypes.c_int, [_CFG, _P, _P, _I32, _P, _I64, _I64] + [_P] * 3 + [_P] * 4 + [_P] * 4 + [_P, _P, _P, _P]),
+    "vx_irt1d_grad_adam": (ctypes.c_int, [_CFG, _P, _P, _I64, _I64] + [_P] * 3 + [_P] * 4 + [_P] * 4 + [_P, _P, _P, ctypes.POINTER(AdamTail), _P]),
+    "vx_irt1d_sparse_grad_adam": (ctypes.c_int, [_CFG, _P, _P, _I32, _P, _I64, _I64] + [_P] * 3 + [_P] * 4 + [_P] * 4 +
+                                  [_P, _P, _P, ctypes.POINTER(AdamTail), _P]),
     "vx_mvn_bbvi_forward": (ctypes.c_int, [_CFG, _I64, _P, _I64, _P, _P, _I32, _P, _P, _P, _P, _P]),
     "vx_mvn_bbvi_bwd_workspace_floats": (_I64, [_CFG, _I64, _I32]),
     "vx_mvn_bbvi_backward": (ctypes.c_int, [_CFG, _I64, _P, _P, _I32, _P, _P, _P, _P, _P, _P]),

@@ -61,6 +61,8 @@ __global__ __launch_bounds__(I1_THREADS) void k_irt1d(
     uint32_t* const rws = (uint32_t*)(xs + 64);                        // [2][64]: the persons' response rows
     static_assert(I1_RB * SCR >= 128, "the (ll, gx) hand-over of a wave fits its parked-terms region");
     if (step_dev) step = *step_dev;                                    // replayed from a HIP graph: the counter lives on the device
+    // Adam's count of this step for a fused optimiser tail (k_reduce_adam reads it; nobody in its launch reads step_dev)
+    if (blockIdx.x == 0 && threadIdx.x == 0) ((uint32_t*)slabs)[(size_t)gridDim.x * (4 * (size_t)dm.J + 1)] = step + 1u;
     for (int j = tid; j < J; j += I1_THREADS) {
         ptab[j * NPF + 0] = dm.Dc * ((MODEL >= 2) ? a[j] : 1.0f);
         ptab[j * NPF + 1] = dm.Dc * b[j];
@@ -223,6 +225,8 @@ __global__ __launch_bounds__(I1_THREADS) void k_irt1d_items(
     __shared__ float el_w[I1_THREADS / 64];
     float el_acc = 0.f;
     if (step_dev) step = *step_dev;                                // replayed from a HIP graph: the counter lives on the device
+    // Adam's count of this step for a fused optimiser tail (k_reduce_adam reads it; nobody in its launch reads step_dev)
+    if (blockIdx.x == 0 && threadIdx.x == 0) ((uint32_t*)slabs)[(size_t)gridDim.x * (4 * (size_t)dm.J + 1)] = step + 1u;
     const int ilane = threadIdx.x & 63;                            // the lane's position on the item axis
     constexpr int IPL = 4 * WPL;
     const int J = dm.J;

@@ -45,6 +45,8 @@ __global__ __launch_bounds__(SP_THREADS) void k_irt1d_sp(
     const float* __restrict__ d_un, float* __restrict__ gloc, float* __restrict__ graw, float* __restrict__ elbo,
     float* __restrict__ slabs) {
     if (step_dev) step = *step_dev;                                    // replayed from a HIP graph: the counter lives on the device
+    // Adam's count of this step for a fused optimiser tail (k_reduce_adam reads it; nobody in its launch reads step_dev)
+    if (blockIdx.x == 0 && threadIdx.x == 0) ((uint32_t*)slabs)[(size_t)gridDim.x * (4 * (size_t)dm.J + 1)] = step + 1u;
     __shared__ float el_w[SP_THREADS / 64];
     float el_acc = 0.f;
     // LDS: ab [J] float2 | acc [J] packed (t x, t) | big [J] fixed point t x | (3PL+) accc, accd [J], cs, ds, os [J] floats

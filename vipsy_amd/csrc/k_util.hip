@@ -250,9 +250,96 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
     }
 }
 
+// torch.optim.Adam for element i of one buffer with gradient gi (k_adam / k_adam2 / k_reduce_adam: one arithmetic)
+struct AdamBuf { float* p; const float* g; float* m; float* v; const float* free_mask; int64_t n; };
+__device__ __forceinline__ void adam_one(const AdamBuf& buf, const AdamSegs& segs, int64_t i, float gi, float beta1, float beta2,
+                                         float eps, float bc1, float bc2_sqrt) {
+    float lr = 0.f;
+    bool found = false;
+    for (int s = 0; s < segs.n; ++s)
+        if (i >= segs.begin[s] && i < segs.end[s]) { lr = segs.lr[s]; found = true; }
+    if (!found) return;
+    if (buf.free_mask) gi *= buf.free_mask[i];
+    const float mi = beta1 * buf.m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * buf.v[i] + (1.f - beta2) * gi * gi;
+    buf.m[i] = mi; buf.v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    buf.p[i] = buf.p[i] - (lr / bc1) * (mi / denom);
+}
+
+// The tail of a D = 1 step on ONE rank in ONE launch (k_reduce_wide + k_adam2, 5 us each at BASELINE config 2, a quarter of
+// its step): blocks [0, n_red) sum the slabs column by column exactly as k_reduce_wide<COLS> does -- and hand every finished
+// column straight to Adam (buffer A = the item leaves, gA = out) or, the last column, to the loss slot and the loss ring;
+// the blocks behind them run Adam over buffer B (the per-person rows, whose gradients the step kernel wrote).  Adam's count
+// comes from the word the step kernel left behind its slabs (t_copy; a captured step) or from the host (t_host): nobody in
+// this launch reads the device step counter, so block 0 may advance it.  Same sums, same arithmetic, same bits.
+template <int COLS>
+__global__ __launch_bounds__(1024) void k_reduce_adam(const float* __restrict__ slabs, int64_t n_slabs, int64_t stride, int64_t len,
+                                                      float alpha, float* __restrict__ out, float* __restrict__ last_out,
+                                                      uint32_t* __restrict__ tick, const uint32_t* __restrict__ t_copy, uint32_t t_host,
+                                                      AdamBuf A, AdamSegs sA, AdamBuf B, AdamSegs sB, float beta1, float beta2, float eps,
+                                                      float bc1, float bc2_sqrt, float* __restrict__ loss_ring, int n_red) {
+    constexpr int GRPS = 1024 / COLS;
+    __shared__ float part[GRPS][COLS + 1];
+    __shared__ float bc[2];
+    const uint32_t tt = t_copy ? *t_copy : t_host;
+    if (tick && blockIdx.x == 0 && threadIdx.x == 0) *tick += 1u;
+    if (t_copy) {
+        if (threadIdx.x == 0) {
+            const double t = (double)tt;
+            bc[0] = (float)(1.0 - pow((double)beta1, t));
+            bc[1] = (float)sqrt(1.0 - pow((double)beta2, t));
+        }
+        __syncthreads();
+        bc1 = bc[0]; bc2_sqrt = bc[1];
+    }
+    if ((int)blockIdx.x >= n_red) {
+        const int64_t nblk = (int64_t)gridDim.x - n_red;
+        for (int64_t i = ((int64_t)blockIdx.x - n_red) * 1024 + threadIdx.x; i < B.n; i += nblk * 1024)
+            adam_one(B, sB, i, B.g[i], beta1, beta2, eps, bc1, bc2_sqrt);
+        return;
+    }
+    const int col = threadIdx.x % COLS, grp = threadIdx.x / COLS;
+    auto finish = [&](int64_t i, float t) __attribute__((always_inline)) {
+        const float g = alpha * t;
+        if (last_out && i == len - 1) {
+            last_out[0] = g;
+            if (loss_ring) loss_ring[tt & (VX_LOSS_RING - 1)] = g;
+        } else {
+            out[i] = g;
+            adam_one(A, sA, i, g, beta1, beta2, eps, bc1, bc2_sqrt);
+        }
+    };
+    for (int64_t c0 = (int64_t)blockIdx.x * COLS; c0 < len; c0 += (int64_t)n_red * COLS) {
+        const int64_t i = c0 + col;
+        float acc = 0.f;
+        if (i < len) {
+#pragma unroll 8
+            for (int64_t s = grp; s < n_slabs; s += GRPS) acc += slabs[s * stride + i];
+        }
+        part[grp][col] = acc;
+        __syncthreads();
+        if constexpr (COLS == 32) {
+            if (grp == 0 && i < len) {
+                float t = part[0][col];
+#pragma unroll
+                for (int g = 1; g < GRPS; ++g) t += part[g][col];
+                finish(i, t);
+            }
+        } else {
+#pragma unroll
+            for (int s = GRPS / 2; s > 0; s >>= 1) {
+                if (grp < s) part[grp][col] += part[grp + s][col];
+                __syncthreads();
+            }
+            if (grp == 0 && i < len) finish(i, part[0][col]);
+        }
+        __syncthreads();
+    }
+}
+
 // two parameter buffers in one launch (the replicated leaves and the per-person rows of a BBVI guide): indices
 // [0, nA) -> buffer A (with its free mask), [nA, nA + nB) -> buffer B
-struct AdamBuf { float* p; const float* g; float* m; float* v; const float* free_mask; int64_t n; };
 __global__ void k_adam2(AdamBuf A, AdamSegs sA, AdamBuf B, AdamSegs sB, float beta1, float beta2, float eps, float bc1,
                         float bc2_sqrt, const uint32_t* __restrict__ t_dev, uint32_t t_host = 0,
                         const float* __restrict__ loss_src = nullptr, float* __restrict__ loss_ring = nullptr) {

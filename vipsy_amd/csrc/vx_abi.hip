@@ -332,10 +332,48 @@ int vx_reduce_slabs(const float* slabs, int64_t n_slabs, int64_t len, float alph
     return VX_OK;
 }
 
-// the tail of a D = 1 step: slabs of [4 J item gradients | ELBO share] -> gitem, loss; the device step counter advances
+// the tail of a D = 1 step: slabs of [4 J item gradients | ELBO share] -> gitem, loss; the device step counter advances.
+// opt (vx_irt1d_grad_adam): the optimiser in the same launch (k_reduce_adam)
 static int reduce_step_slabs(const float* slabs, int64_t n_slabs, int J, float* gitem, float* loss, uint32_t* tick,
-                             void* hs) {
+                             void* hs, const vx_adam_tail* opt = nullptr) {
     const int64_t len = 4 * (int64_t)J + (loss ? 1 : 0);
+    if (opt) {
+        if (!loss || !opt->pA || !opt->mA || !opt->vA || !opt->segsA || opt->nA != 4 * (int64_t)J || opt->n_segsA < 1 ||
+            opt->n_segsA > VX_MAX_SEGS || opt->nB < 0 || opt->n_segsB < 0 || opt->n_segsB > VX_MAX_SEGS ||
+            (opt->nB > 0 && (!opt->pB || !opt->gB || !opt->mB || !opt->vB || !opt->segsB || opt->n_segsB < 1)) ||
+            (opt->t < 1 && !tick))
+            return VX_EINVAL;
+        AdamSegs sa, sb;
+        sa.n = opt->n_segsA; sb.n = opt->nB > 0 ? opt->n_segsB : 0;
+        for (int i = 0; i < sa.n; ++i) {
+            if (opt->segsA[i].begin < 0 || opt->segsA[i].end > opt->nA || opt->segsA[i].begin > opt->segsA[i].end) return VX_EINVAL;
+            sa.begin[i] = opt->segsA[i].begin; sa.end[i] = opt->segsA[i].end; sa.lr[i] = opt->segsA[i].lr;
+        }
+        for (int i = 0; i < sb.n; ++i) {
+            if (opt->segsB[i].begin < 0 || opt->segsB[i].end > opt->nB || opt->segsB[i].begin > opt->segsB[i].end) return VX_EINVAL;
+            sb.begin[i] = opt->segsB[i].begin; sb.end[i] = opt->segsB[i].end; sb.lr[i] = opt->segsB[i].lr;
+        }
+        const AdamBuf A{opt->pA, gitem, opt->mA, opt->vA, opt->freeA, opt->nA}, B{opt->pB, opt->gB, opt->mB, opt->vB, nullptr, opt->nB};
+        const double bc1 = 1.0 - pow((double)opt->beta1, (double)(tick ? 1 : opt->t));
+        const double bc2 = 1.0 - pow((double)opt->beta2, (double)(tick ? 1 : opt->t));
+        // Adam's count of a captured step: the word the step kernel left behind its slabs (one slab = 4 J + 1 floats)
+        const uint32_t* t_copy = tick ? (const uint32_t*)(slabs + n_slabs * (4 * (int64_t)J + 1)) : nullptr;
+        int64_t nb_blk = (opt->nB + 1023) / 1024;
+        if (nb_blk > (int64_t)num_cu() * 2) nb_blk = (int64_t)num_cu() * 2;
+        if (n_slabs > 512) {
+            const int n_red = grid_1d(len, 8);
+            hipLaunchKernelGGL(k_reduce_adam<8>, dim3((unsigned)(n_red + nb_blk)), dim3(1024), 0, (hipStream_t)hs, slabs, n_slabs,
+                               4 * (int64_t)J + 1, len, -1.0f, gitem, loss, tick, t_copy, (uint32_t)opt->t, A, sa, B, sb, opt->beta1,
+                               opt->beta2, opt->eps, (float)bc1, (float)sqrt(bc2), opt->loss_ring, n_red);
+        } else {
+            const int n_red = grid_1d(len, 32);
+            hipLaunchKernelGGL(k_reduce_adam<32>, dim3((unsigned)(n_red + nb_blk)), dim3(1024), 0, (hipStream_t)hs, slabs, n_slabs,
+                               4 * (int64_t)J + 1, len, -1.0f, gitem, loss, tick, t_copy, (uint32_t)opt->t, A, sa, B, sb, opt->beta1,
+                               opt->beta2, opt->eps, (float)bc1, (float)sqrt(bc2), opt->loss_ring, n_red);
+        }
+        VX_CHECK_LAUNCH();
+        return VX_OK;
+    }
     if (n_slabs > 512)
         hipLaunchKernelGGL(k_reduce_wide<8>, dim3(grid_1d(len, 8)), dim3(1024), 0, (hipStream_t)hs, slabs, n_slabs,
                            4 * (int64_t)J + 1, len, -1.0f, gitem, loss, tick);
@@ -1504,13 +1542,13 @@ static bool irt1d_cfg_ok(const vx_irt_cfg* cfg) {
 
 int64_t vx_irt1d_workspace_floats(const vx_irt_cfg* cfg, int64_t nb) {
     if (!irt1d_cfg_ok(cfg) || nb < 0) return VX_EINVAL;
-    return (int64_t)irt1d_blocks(nb, cfg->J) * (4 * cfg->J + 1);
+    return (int64_t)irt1d_blocks(nb, cfg->J) * (4 * cfg->J + 1) + 4;    // the slabs | Adam's count of the step (k_reduce_adam)
 }
 
-int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, int64_t gid0,
+static int irt1d_grad_impl(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, int64_t gid0,
                   const float* loc, const float* raw, const float* eps_in, const float* a, const float* b,
                   const float* c_un, const float* d_un, float* gloc, float* graw, float* elbo, float* gitem,
-                  float* loss, uint32_t* step_dev, float* workspace, void* hs) {
+                  float* loss, uint32_t* step_dev, float* workspace, void* hs, const vx_adam_tail* opt) {
     if (!irt1d_cfg_ok(cfg) || !y || !loc || !raw || !b || !gloc || !graw || !elbo || !gitem || !workspace || nb < 0)
         return VX_EINVAL;
     if (cfg->model >= VX_IRT_2PL && !a) return VX_EINVAL;
@@ -1548,7 +1586,24 @@ int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, 
 #undef LAUNCH_1DW
 #undef LAUNCH_1DK
     VX_CHECK_LAUNCH();
-    return reduce_step_slabs(workspace, blocks, cfg->J, gitem, loss, step_dev, hs);
+    return reduce_step_slabs(workspace, blocks, cfg->J, gitem, loss, step_dev, hs, opt);
+}
+
+int vx_irt1d_grad(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, int64_t gid0,
+                  const float* loc, const float* raw, const float* eps_in, const float* a, const float* b,
+                  const float* c_un, const float* d_un, float* gloc, float* graw, float* elbo, float* gitem,
+                  float* loss, uint32_t* step_dev, float* workspace, void* hs) {
+    return irt1d_grad_impl(cfg, y, rows, nb, gid0, loc, raw, eps_in, a, b, c_un, d_un, gloc, graw, elbo, gitem, loss, step_dev,
+                           workspace, hs, nullptr);
+}
+
+int vx_irt1d_grad_adam(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, int64_t gid0,
+                       const float* loc, const float* raw, const float* eps_in, const float* a, const float* b,
+                       const float* c_un, const float* d_un, float* gloc, float* graw, float* elbo, float* gitem,
+                       float* loss, uint32_t* step_dev, float* workspace, const vx_adam_tail* opt, void* hs) {
+    if (!opt || !loss) return VX_EINVAL;
+    return irt1d_grad_impl(cfg, y, rows, nb, gid0, loc, raw, eps_in, a, b, c_un, d_un, gloc, graw, elbo, gitem, loss, step_dev,
+                           workspace, hs, opt);
 }
 
 int vx_irt1d_score_grad(int64_t nb, float scale, const float* elbo, const float* eps, const float* raw, const int64_t* rows,
@@ -1607,14 +1662,14 @@ static int irt1d_sp_blocks(int64_t n_groups) {
 
 int64_t vx_irt1d_sparse_workspace_floats(const vx_irt_cfg* cfg, int64_t n_groups) {
     if (!irt1d_cfg_ok(cfg) || n_groups < 0) return VX_EINVAL;
-    return (int64_t)irt1d_sp_blocks(n_groups) * (4 * cfg->J + 1);                          // one slab per block
+    return (int64_t)irt1d_sp_blocks(n_groups) * (4 * cfg->J + 1) + 4;                      // one slab per block | Adam's count
 }
 
-int vx_irt1d_sparse_grad(const vx_irt_cfg* cfg, const uint16_t* pent, const int32_t* glen, int32_t Lq,
+static int irt1d_sparse_grad_impl(const vx_irt_cfg* cfg, const uint16_t* pent, const int32_t* glen, int32_t Lq,
                          const int32_t* pidx, int64_t n_groups, int64_t gid0, const float* loc, const float* raw,
                          const float* eps_in, const float* a, const float* b, const float* c_un, const float* d_un,
                          float* gloc, float* graw, float* elbo, float* gitem, float* loss, uint32_t* step_dev,
-                         float* workspace, void* hs) {
+                         float* workspace, void* hs, const vx_adam_tail* opt) {
     if (!irt1d_cfg_ok(cfg) || !pent || !glen || !pidx || Lq < 0 || !loc || !raw || !b || !gloc || !graw || !elbo ||
         !gitem || !workspace || n_groups < 0 || cfg->J > 32767)
         return VX_EINVAL;
@@ -1647,7 +1702,26 @@ int vx_irt1d_sparse_grad(const vx_irt_cfg* cfg, const uint16_t* pent, const int3
     }
 #undef LAUNCH_SP
     VX_CHECK_LAUNCH();
-    return reduce_step_slabs(workspace, blocks, cfg->J, gitem, loss, step_dev, hs);
+    return reduce_step_slabs(workspace, blocks, cfg->J, gitem, loss, step_dev, hs, opt);
+}
+
+int vx_irt1d_sparse_grad(const vx_irt_cfg* cfg, const uint16_t* pent, const int32_t* glen, int32_t Lq,
+                         const int32_t* pidx, int64_t n_groups, int64_t gid0, const float* loc, const float* raw,
+                         const float* eps_in, const float* a, const float* b, const float* c_un, const float* d_un,
+                         float* gloc, float* graw, float* elbo, float* gitem, float* loss, uint32_t* step_dev,
+                         float* workspace, void* hs) {
+    return irt1d_sparse_grad_impl(cfg, pent, glen, Lq, pidx, n_groups, gid0, loc, raw, eps_in, a, b, c_un, d_un, gloc, graw, elbo,
+                                  gitem, loss, step_dev, workspace, hs, nullptr);
+}
+
+int vx_irt1d_sparse_grad_adam(const vx_irt_cfg* cfg, const uint16_t* pent, const int32_t* glen, int32_t Lq,
+                              const int32_t* pidx, int64_t n_groups, int64_t gid0, const float* loc, const float* raw,
+                              const float* eps_in, const float* a, const float* b, const float* c_un, const float* d_un,
+                              float* gloc, float* graw, float* elbo, float* gitem, float* loss, uint32_t* step_dev,
+                              float* workspace, const vx_adam_tail* opt, void* hs) {
+    if (!opt || !loss) return VX_EINVAL;
+    return irt1d_sparse_grad_impl(cfg, pent, glen, Lq, pidx, n_groups, gid0, loc, raw, eps_in, a, b, c_un, d_un, gloc, graw, elbo,
+                                  gitem, loss, step_dev, workspace, hs, opt);
 }
 
 // ------------------------------------------------------------------------------------------------

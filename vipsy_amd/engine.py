@@ -126,12 +126,36 @@ class HipBackend(object):
             raise _hip.VxError("vx_irt1d_workspace_floats: unsupported configuration (code %d)" % n)
         return n
 
+    @staticmethod
+    def _adam_tail(adam):
+        """struct vx_adam_tail from the engine's description of its optimiser step (_EngineBase._fused_tail_args); the
+        segment arrays ride along so that they outlive the call."""
+        (pA, mA, vA, freeA, nA, segsA), B = adam["A"], adam.get("B")
+        arrA = (_hip.AdamSeg * len(segsA))(*[_hip.AdamSeg(b, e, lr, 0.0) for (b, e, lr) in segsA])
+        t = _hip.AdamTail()
+        t.pA, t.mA, t.vA, t.freeA, t.nA, t.segsA, t.n_segsA = _hip.ptr(pA), _hip.ptr(mA), _hip.ptr(vA), _hip.ptr(freeA), nA, arrA, len(segsA)
+        keep = [arrA]
+        if B is not None:
+            pB, gB, mB, vB, nB, segsB = B
+            arrB = (_hip.AdamSeg * len(segsB))(*[_hip.AdamSeg(b, e, lr, 0.0) for (b, e, lr) in segsB])
+            t.pB, t.gB, t.mB, t.vB, t.nB, t.segsB, t.n_segsB = _hip.ptr(pB), _hip.ptr(gB), _hip.ptr(mB), _hip.ptr(vB), nB, arrB, len(segsB)
+            keep.append(arrB)
+        t.t, (t.beta1, t.beta2), t.eps = adam["t"], adam["betas"], adam["eps"]
+        t.loss_ring = _hip.ptr(adam.get("loss_ring"))
+        return t, keep
+
     def irt1d_grad(self, cfg, y, rows, nb, gid0, loc, raw, eps_in, a, b, c_un, d_un, gloc, graw, elbo, gitem, ws,
-                   loss=None, step_dev=None):
-        rc = self.L.vx_irt1d_grad(ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb, gid0, _hip.ptr(loc),
-                                  _hip.ptr(raw), _hip.ptr(eps_in), _hip.ptr(a), _hip.ptr(b), _hip.ptr(c_un),
-                                  _hip.ptr(d_un), _hip.ptr(gloc), _hip.ptr(graw), _hip.ptr(elbo), _hip.ptr(gitem),
-                                  _hip.ptr(loss), _hip.ptr(step_dev), _hip.ptr(ws), _hip.stream_ptr())
+                   loss=None, step_dev=None, adam=None):
+        args = [ctypes.byref(cfg), _hip.ptr(y), _hip.ptr(rows), nb, gid0, _hip.ptr(loc),
+                _hip.ptr(raw), _hip.ptr(eps_in), _hip.ptr(a), _hip.ptr(b), _hip.ptr(c_un),
+                _hip.ptr(d_un), _hip.ptr(gloc), _hip.ptr(graw), _hip.ptr(elbo), _hip.ptr(gitem),
+                _hip.ptr(loss), _hip.ptr(step_dev), _hip.ptr(ws)]
+        if adam is not None:                                 # the optimiser in the step's last launch (vx_irt1d_grad_adam)
+            tail, _keep = self._adam_tail(adam)
+            rc = self.L.vx_irt1d_grad_adam(*args, ctypes.byref(tail), _hip.stream_ptr())
+            _hip.check(rc, "vx_irt1d_grad_adam")
+            return
+        rc = self.L.vx_irt1d_grad(*args, _hip.stream_ptr())
         _hip.check(rc, "vx_irt1d_grad")
 
     def irt1d_sparse_workspace(self, cfg, n_groups):
@@ -141,13 +165,18 @@ class HipBackend(object):
         return n
 
     def irt1d_sparse_grad(self, cfg, lists, gid0, loc, raw, eps_in, a, b, c_un, d_un, gloc, graw, elbo, gitem, ws,
-                          loss=None, step_dev=None):
-        rc = self.L.vx_irt1d_sparse_grad(ctypes.byref(cfg), _hip.ptr(lists["pent"]), _hip.ptr(lists["glen"]),
-                                         int(lists["Lq"]), _hip.ptr(lists["pidx"]), int(lists["n_groups"]), gid0,
-                                         _hip.ptr(loc), _hip.ptr(raw), _hip.ptr(eps_in), _hip.ptr(a), _hip.ptr(b),
-                                         _hip.ptr(c_un), _hip.ptr(d_un), _hip.ptr(gloc), _hip.ptr(graw), _hip.ptr(elbo),
-                                         _hip.ptr(gitem), _hip.ptr(loss), _hip.ptr(step_dev), _hip.ptr(ws),
-                                         _hip.stream_ptr())
+                          loss=None, step_dev=None, adam=None):
+        args = [ctypes.byref(cfg), _hip.ptr(lists["pent"]), _hip.ptr(lists["glen"]),
+                int(lists["Lq"]), _hip.ptr(lists["pidx"]), int(lists["n_groups"]), gid0,
+                _hip.ptr(loc), _hip.ptr(raw), _hip.ptr(eps_in), _hip.ptr(a), _hip.ptr(b),
+                _hip.ptr(c_un), _hip.ptr(d_un), _hip.ptr(gloc), _hip.ptr(graw), _hip.ptr(elbo),
+                _hip.ptr(gitem), _hip.ptr(loss), _hip.ptr(step_dev), _hip.ptr(ws)]
+        if adam is not None:
+            tail, _keep = self._adam_tail(adam)
+            rc = self.L.vx_irt1d_sparse_grad_adam(*args, ctypes.byref(tail), _hip.stream_ptr())
+            _hip.check(rc, "vx_irt1d_sparse_grad_adam")
+            return
+        rc = self.L.vx_irt1d_sparse_grad(*args, _hip.stream_ptr())
         _hip.check(rc, "vx_irt1d_sparse_grad")
 
     def mvn_bbvi_forward(self, cfg, nb, rows, gid0, loc, M, shared, eps_in, x, eps, ent):
@@ -560,6 +589,54 @@ class _EngineBase(object):
             # segment): nothing filed the loss, so it is copied into its slot here
             self.loss_ring[self.t % LOSS_RING] = self.G[self.n_params]
 
+    # -- the optimiser inside the step's last launch (one rank, D = 1 per-person guides) --------------
+    fuse_tail = True
+
+    def _fused_tail_args(self, lrs, rows, eps, S):
+        """What vx_irt1d_grad_adam needs to run Adam in the launch that sums the step's slabs -- or None when this step has
+        to keep loss_and_grads | all-reduce | optimiser apart (a process group, an amortized or multivariate guide, a
+        subsample whose gradients are scattered afterwards, the score-function estimator, more than one (betas, eps))."""
+        if not (self.fuse_tail and self.group is None and S == 1 and rows is None and isinstance(self.be, HipBackend)
+                and isinstance(self, IrtEngine) and self.D == 1 and not self.amortized and self.per_person
+                and self.estimator == "pathwise" and self.events is None and self.n_params == 4 * self.J):
+            return None
+        by_hyper, pp_hyper = {}, {}
+        for name in self.names():
+            o = self.off[name]
+            by_hyper.setdefault(lrs.hyper_of(name), []).append((o, o + int(np.prod(self.shape[name])), float(lrs.lr_of(name))))
+        for nme, o in self.pp_off.items():
+            pp_hyper.setdefault(lrs.hyper_of(nme), []).append((o, o + int(np.prod(self.pp_shape[nme])), float(lrs.lr_of(nme))))
+        if not (len(by_hyper) == 1 and len(pp_hyper) == 1 and list(by_hyper) == list(pp_hyper)):
+            return None
+        (betas, eps_), segs = next(iter(by_hyper.items()))
+        return {"A": (self.P, self.M, self.V, self.free, self.n_params, _merge_segments(segs)),
+                "B": (self.PP, self.GP, self.MP, self.VP, self.pp_len, _merge_segments(pp_hyper[(betas, eps_)])),
+                "t": self.t + 1, "betas": betas, "eps": eps_, "loss_ring": self.loss_ring}
+
+    def _take_fused_tail(self):
+        """{'adam': ...} for the step kernel's call when step() armed the fused tail (once: the call consumes it)."""
+        ft, self._fused_tail = getattr(self, "_fused_tail", None), None
+        if ft is None:
+            return {}
+        self._fused_done = True
+        return {"adam": ft}
+
+    def _grads_and_optim(self, lrs, rows, b_global, eps=None):
+        """One particle's loss_and_grads, the all-reduce and the optimiser -- or, on one rank with a D = 1 per-person
+        guide, all of it inside loss_and_grads (the optimiser rides in the step's last launch)."""
+        self._fused_tail, self._fused_done = self._fused_tail_args(lrs, rows, eps, 1), False
+        try:
+            self.loss_and_grads(rows, b_global, eps, 0)
+        finally:
+            self._fused_tail = None
+        if self._fused_done:
+            self.t += 1                                      # (what apply_optim does first; the launch filed the loss in the ring)
+            return
+        with self._phase("allreduce"):
+            self.allreduce()
+        with self._phase("optimizer"):
+            self.apply_optim(lrs)
+
     def step_loss(self):
         """The loss of the step just taken as a 0-d device tensor (no host sync): its slot of the ring, not overwritten for
         the next LOSS_RING - 1 steps -- a list of returned losses holds distinct values."""
@@ -697,10 +774,10 @@ class _EngineBase(object):
                 # (thread-local capture mode: a process group's watchdog thread may query its events while this thread records)
                 with torch.cuda.graph(gA, capture_error_mode="thread_local"):
                     # reads the counter as the Philox step, then advances it
-                    self.loss_and_grads(rows_buf, mode[2] if mode[0] == "rows" else None, None, 0)
                     if one:
-                        self.allreduce()                      # (a no-op without a group)
-                        self.apply_optim(lrs)                 # reads it as Adam's t
+                        self._grads_and_optim(lrs, rows_buf, mode[2] if mode[0] == "rows" else None)   # (Adam's t: the counter)
+                    else:
+                        self.loss_and_grads(rows_buf, mode[2] if mode[0] == "rows" else None, None, 0)
                 if not one:
                     gB = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gB, pool=gA.pool(), capture_error_mode="thread_local"):
@@ -789,10 +866,8 @@ class _EngineBase(object):
             self._capture_ring, self._capture_ring_used = st.get("ring"), False
             try:
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    for _ in range(K):
-                        self.loss_and_grads(st.get("rows"), mode[2] if mode[0] == "rows" else None, None, 0)
-                        self.allreduce()                      # (a no-op without a group; with one: the captured collective)
-                        self.apply_optim(lrs)
+                    for _ in range(K):                        # (with a group: the captured collective inside)
+                        self._grads_and_optim(lrs, st.get("rows"), mode[2] if mode[0] == "rows" else None)
             finally:
                 self._step_dev = None
                 self._capture_ring = None
@@ -891,8 +966,9 @@ class _EngineBase(object):
                 self._evict_graph_forms()
         rows = self._rows_on_device(rows)
         if S == 1:
-            self.loss_and_grads(rows[0] if isinstance(rows, (list, tuple)) else rows, b_global,
-                                eps[0] if isinstance(eps, (list, tuple)) else eps, 0)
+            self._grads_and_optim(lrs, rows[0] if isinstance(rows, (list, tuple)) else rows, b_global,
+                                  eps[0] if isinstance(eps, (list, tuple)) else eps)
+            return self.step_loss()
         else:
             accG = torch.zeros_like(self.G)
             accP = torch.zeros_like(self.GP) if self.per_person else None
@@ -1181,10 +1257,10 @@ class IrtEngine(_EngineBase):
                 if lists is not None:                      # mostly-missing responses: observed cells only
                     sp_ws = self._buf("i1d_sp_ws", be.irt1d_sparse_workspace(cfg, lists["n_groups"]))
                     be.irt1d_sparse_grad(cfg, lists, self.gid0, loc, raw, eps, a, self.view("b"), c_un, d_un,
-                                         gloc, graw, elbo, g1d, sp_ws, loss=lossslot, **sdk)
+                                         gloc, graw, elbo, g1d, sp_ws, loss=lossslot, **sdk, **self._take_fused_tail())
                 else:
                     be.irt1d_grad(cfg, self.y, rows, nb, self.gid0, loc, raw, eps, a, self.view("b"), c_un, d_un,
-                                  gloc, graw, elbo, g1d, i1d_ws, loss=lossslot, **sdk)
+                                  gloc, graw, elbo, g1d, i1d_ws, loss=lossslot, **sdk, **self._take_fused_tail())
             if self.estimator == "score":
                 # score-function gradient of the guide in place of the pathwise one (the step kernel's item gradients and
                 # loss stand); the draws are the step's own Philox normals, keyed by the global person id
