@@ -267,10 +267,14 @@ int vx_mvn_bbvi_backward(const vx_irt_cfg* cfg, int64_t nb, const int64_t* rows,
  *   backward: genc = d LOSS / d [W1: H*J | b1: H | W21: H | b21: 1 | W22: H | b22: 1] from
  *             gloc / graw = d LOSS / d loc, raw (as produced by vx_irt1d_grad / vx_hodina_grad). */
 int64_t vx_norm_enc_param_floats(const vx_irt_cfg* cfg);
+/* packws (optional): vx_norm_enc_pack_floats(cfg) floats of scratch, 16-byte aligned.  With it a large batch runs fc1 from
+ * fp16-pair images of W1 made once per call (two small launches) instead of re-splitting W1 in every workgroup: 0.37 ->
+ * 0.1x ms at 1M x 500.  NULL, or a batch below 4 096 persons: the kernels that need no scratch. */
+int64_t vx_norm_enc_pack_floats(const vx_irt_cfg* cfg);           /* 0: this shape has no such kernel */
 int vx_norm_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
                         const float* W1, const float* b1, const float* W21, const float* b21,
                         const float* W22, const float* b22, float* h, float* loc, float* raw,
-                        void* hip_stream);
+                        float* packws /*or NULL*/, void* hip_stream);
 int64_t vx_norm_enc_bwd_workspace_floats(const vx_irt_cfg* cfg, int64_t nb);
 int vx_norm_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb,
                          const float* W21, const float* W22, const float* h, const float* gloc,

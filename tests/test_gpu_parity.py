@@ -586,6 +586,9 @@ HODINA_TOL = 3e-5        # (measured: <= 5.2e-6, theta_local of the K = 8 case)
     (129, 37, "irt_1pl", 0.2, 64),
     (320, 500, "irt_2pl", 0.3, None),                # N % 16 == 0, full batch: item-major responses in the fc1 gradient
     (1040, 516, "irt_3pl", 0.1, None),               # ... two 512-item groups, ragged last person tile
+    (4500, 500, "irt_2pl", 0.9, None),               # >= 4 096 persons: fc1 from the fp16-pair images (k_norm_enc_fwd_h), rows by DMA
+    (4300, 260, "irt_4pl", 0.2, 4200),               # ... gathered rows, a ragged last tile
+    (4128, 504, "irt_1pl", 0.5, None),               # ... rows staged word by word (J / 4 even)
 ])
 def test_irt1d_amortized_step_vs_oracle(N, J, model, miss, B, H=64):
     from vipsy_amd.engine import IrtEngine

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--B", type=int, default=100)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--modes", default="eager,graph,graph4")
+    ap.add_argument("--k", type=int, default=0, help="steps a replay for mode graph4 (0: the engine's graph_steps)")
     ap.add_argument("--time-sync", action="store_true", help="time the host's waits for the GPU (Event.synchronize)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -36,6 +37,8 @@ def main():
     for mode in args.modes.split(","):
         eng = IrtEngine(y, model="irt_2pl", D=D, amortized=True, H=H, seed=1234)
         eng.use_graph = mode in ("graph", "graph4")
+        if args.k:
+            eng.graph_steps = args.k
         if mode == "graph4":                                   # what the fit loop does: four steps a replay (IrtEngine.steps)
             def run(n, fixed=None):
                 i = 0

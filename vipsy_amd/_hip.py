@@ -91,7 +91,8 @@ SIGNATURES = {
     "vx_mvn_bbvi_bwd_workspace_floats": (_I64, [_CFG, _I64, _I32]),
     "vx_mvn_bbvi_backward": (ctypes.c_int, [_CFG, _I64, _P, _P, _I32, _P, _P, _P, _P, _P, _P]),
     "vx_norm_enc_param_floats": (_I64, [_CFG]),
-    "vx_norm_enc_forward": (ctypes.c_int, [_CFG, _P, _P, _I64] + [_P] * 6 + [_P] * 3 + [_P]),
+    "vx_norm_enc_pack_floats": (_I64, [_CFG]),
+    "vx_norm_enc_forward": (ctypes.c_int, [_CFG, _P, _P, _I64] + [_P] * 6 + [_P] * 3 + [_P, _P]),
     "vx_norm_enc_bwd_workspace_floats": (_I64, [_CFG, _I64]),
     "vx_norm_enc_backward": (ctypes.c_int, [_CFG, _P, _P, _I64] + [_P] * 5 + [_P, _I64] + [_P, _P, _P]),
     "vx_hodina_workspace_floats": (_I64, [ctypes.POINTER(HoDinaCfg), _I64]),

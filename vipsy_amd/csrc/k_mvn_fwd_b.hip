@@ -1005,3 +1005,191 @@ __global__ __launch_bounds__(NB_THREADS, 2) void k_norm_enc_fwd_b(
         raw_out[i] = sr + b22[0];
     }
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// The same forward with fc1 as the multivariate guide runs it (round 5): W1 2^sw1 split ONCE a step into two fp16 terms, laid
+// down as ready k-step fragments (pack_w1_b_kstep; 4 KB a k-step, L2-resident) that every wave pulls straight into registers
+// three k-steps ahead -- FOUR products of 32 cycles per k-step instead of six, no split inside the loop, no LDS round trip
+// for the weights and no workgroup barrier per k-step (k_norm_enc_fwd_b above re-splits its W1 slice in every workgroup and
+// meets at a barrier 32 times: 0.37 ms at 1M x 500 against an MFMA floor of 0.06).  Two launches make the images; small
+// batches keep k_norm_enc_fwd_b (vx_norm_enc_forward).
+//   packws: [w1img: n_ks x FB_W1_KS bytes | 16 floats: 2^sw1, 2^-sw1 | NH_MAX_BLOCKS partial maxima]
+// ---------------------------------------------------------------------------------------------
+#define NH_MAX_BLOCKS 64
+__host__ __device__ inline int64_t nh_pack_floats(int J) { return fb_w1img_floats(J) + 16 + NH_MAX_BLOCKS; }
+
+__global__ __launch_bounds__(256) void k_norm_pack_max(int J, const float* __restrict__ W1, float* __restrict__ part) {
+    __shared__ float red[4];
+    float m = 0.f;
+    const int n4 = 64 * J / 4;                                            // (J % 4 == 0, W1 16-byte aligned)
+    const f32x4* w4 = (const f32x4*)W1;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n4; e += NH_MAX_BLOCKS * 256) {
+        const f32x4 v = w4[e];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    m = wave_max_dpp(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__global__ __launch_bounds__(256) void k_norm_pack_w1(int J, const float* __restrict__ W1, const float* __restrict__ part,
+                                                      float* __restrict__ sc, uint8_t* __restrict__ w1img) {
+    __shared__ float scl;
+    if (threadIdx.x < 64) {
+        const float m = wave_max_dpp(part[threadIdx.x]);                  // NH_MAX_BLOCKS == 64: one block's maximum per lane
+        if (threadIdx.x == 0) scl = ldexpf(1.f, f16_scale_exp(m));
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc[0] = scl; sc[1] = 1.0f / scl; }
+    pack_w1_b_kstep(blockIdx.x, J, W1, scl, w1img);
+}
+
+// NP person tiles of 32 a wave (against the same weight fragments: with NP = 2 they cross the L2 once per 64 persons), 4 / NP
+// waves a workgroup; the fragments come PF k-steps ahead of their use.  Measured at 1M x 500, 90 % missing (tools/nenc_bench.hip,
+// one box): k_norm_enc_fwd_b 407 us; this kernel NP = 1: PF = 3 / 5 / 7: 294 / 306 / 295 us; NP = 2 (one wave a SIMD): PF = 3 / 7 /
+// 11: 299 / 305 / 314 -- neither the depth of the prefetch nor half the L2 traffic moves it, and neither did four independent
+// accumulator chains with the next response fragment made under this k-step's products (fc1 15 k instead of 20 k cycles of a
+// wave's 34 k by s_memtime stamps, the launch unchanged): what bounds it is a wave's LIFE (stage 8 k | fc1 15 k | softplus and
+// outputs 10 k cycles, one after the other) times sixteen rounds at eight waves a CU, which the 16.5 KB of LDS a wave hold
+// there.  A form without LDS (the response bytes through registers: 16 bytes of its own row per lane and pair of k-steps, two
+// v_permlane32_swap to serve both lane halves) is bit-identical and SLOWER at 500 items (436 us: 32 row pieces a load
+// instruction) and the fastest at 72 items (14.5 against 15.5 us for 70 k persons); not kept.  The library ships NP = 1, PF = 3
+// for J >= 256 and batches from 4 096 persons on.
+template <int NP>
+__host__ __device__ inline size_t nh_wave_floats(int J) {
+    const size_t a = (size_t)(32 * NP) * ef_ys(J) / 4, b = (size_t)(((32 * NP * J + 1023) / 1024) * 256);
+    return ((a > b ? a : b) + 3) & ~(size_t)3;
+}
+template <int NP>
+__host__ __device__ inline size_t nh_lds_bytes(int J) { return (4 / NP) * nh_wave_floats<NP>(J) * sizeof(float); }
+
+template <int NP, int PF>
+__global__ __launch_bounds__(64 * (4 / NP)) void k_norm_enc_fwd_h(
+    EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, const uint8_t* __restrict__ w1img,
+    const float* __restrict__ sc, const float* __restrict__ b1, const float* __restrict__ W21, const float* __restrict__ b21,
+    const float* __restrict__ W22, const float* __restrict__ b22, float* __restrict__ h_out,
+    float* __restrict__ loc_out, float* __restrict__ raw_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int H = 64, WP = 32 * NP, NW = 4 / NP, RING = PF + 1;
+    const int J = dm.J, YS = ef_ys(J);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    float* R1 = smem + wave * nh_wave_floats<NP>(J);
+    const int8_t* Yi = (const int8_t*)R1;
+    const int64_t i0 = ((int64_t)blockIdx.x * NW + wave) * WP;
+    if (i0 >= dm.nb) return;                                              // (no workgroup barrier in this kernel)
+#ifdef NH_STAMPS
+    unsigned long long nst_[5]; int nsn_ = 0;
+#define NSTAMP() do { __builtin_amdgcn_s_waitcnt(0); nst_[nsn_++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NSTAMP() do {} while (0)
+#endif
+    NSTAMP();
+    // ---- this wave's response rows: WP consecutive rows by DMA, or gathered word by word
+    const int n_ydma = (WP * J + 1023) / 1024;
+    const bool ydense = !rows && ((J >> 2) & 1) && i0 + WP <= dm.nb && (i0 * J + (int64_t)n_ydma * 1024 <= dm.nb * (int64_t)J);
+    const int ysr = ydense ? J : YS;
+    const int n_ks = (J + 15) / 16;
+    auto loadA = [&](f16x8 (&Af)[4], int ks) __attribute__((always_inline)) {
+        ks = ks < n_ks ? ks : n_ks - 1;                                   // past the end: reload the last k-step (never used)
+        const uint8_t* src = w1img + (int64_t)ks * FB_W1_KS + lane * 16;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) Af[f] = *(const f16x8*)(src + f * 1024);
+    };
+    f16x8 A[RING][4];
+    if (ydense) {
+        const uint8_t* src = y + i0 * J + 16 * lane;
+        const uint32_t lb = lds_addr_uniform(R1);
+        for (int d = 0; d < n_ydma; ++d) dma16(src + d * 1024, lb + (uint32_t)d * 1024u);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) loadA(A[u], u);
+        vx_wait_vmem();                                                   // the response rows (DMA) and the first fragments
+    } else {
+        const int YW = YS / 4, JW = J / 4;
+        uint32_t* Yw = (uint32_t*)R1;
+        for (int e = lane; e < WP * YW; e += 64) {
+            const int pp = e / YW, wq = e - pp * YW;
+            const int64_t ii = i0 + pp;
+            uint32_t v = 0u;
+            if (wq < JW && ii < dm.nb) {
+                const int64_t row = rows ? rows[ii] : ii;
+                v = *(const uint32_t*)(y + row * J + 4 * wq);              // bytes 0/1/255 == int8 0/1/-1 (vi.py:680-682)
+            }
+            Yw[e] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) loadA(A[u], u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    NSTAMP();                                                             // 1: responses staged
+    const float w1_inv = sc[1];
+    // [person tile][hidden tile] for the leading terms, and as many for the remainders: 4 NP independent chains, so that no
+    // MFMA waits for the one before it (with two chains of two a k-step took 600 cycles where its MFMAs take 128:
+    // -DNH_STAMPS in tools/nenc_bench.hip); the response fragment of the NEXT k-step is made while this one's products run
+    f32x16 acc[NP][2], acl[NP][2];
+#pragma unroll
+    for (int t = 0; t < NP; ++t) { acc[t][0] = zero16(); acc[t][1] = zero16(); acl[t][0] = zero16(); acl[t][1] = zero16(); }
+    const int8_t* const yl = Yi + l31 * ysr + 8 * half;
+    f16x8 yb[NP], ybn[NP];
+#pragma unroll
+    for (int t = 0; t < NP; ++t) yb[t] = fb_y_frag((const uint32_t*)(yl + 32 * t * ysr));             // rows are 4-byte aligned
+    auto compute = [&](const f16x8 (&Af)[4], int ks) __attribute__((always_inline)) {
+        const int kn = ks + 1 < n_ks ? ks + 1 : ks;
+#pragma unroll
+        for (int t = 0; t < NP; ++t) { acl[t][0] = mfma_f16(Af[1], yb[t], acl[t][0]); acl[t][1] = mfma_f16(Af[3], yb[t], acl[t][1]); }
+#pragma unroll
+        for (int t = 0; t < NP; ++t) ybn[t] = fb_y_frag((const uint32_t*)(yl + 32 * t * ysr + 16 * kn));
+#pragma unroll
+        for (int t = 0; t < NP; ++t) { acc[t][0] = mfma_f16(Af[0], yb[t], acc[t][0]); acc[t][1] = mfma_f16(Af[2], yb[t], acc[t][1]); }
+#pragma unroll
+        for (int t = 0; t < NP; ++t) yb[t] = ybn[t];
+    };
+    for (int c = 0; c < n_ks; c += RING) {
+#pragma unroll
+        for (int u = 0; u < RING; ++u) {
+            loadA(A[(u + PF) % RING], c + u + PF);
+            if (c + u < n_ks) compute(A[u], c + u);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NP; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[t][0][r] += acl[t][0][r]; acc[t][1][r] += acl[t][1][r]; }
+    NSTAMP();                                                             // 2: fc1
+    // ---- softplus, the two 1-row heads as per-lane dot products over the 32 hidden units a lane holds
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+        const int64_t i = i0 + 32 * t + l31;
+        float sl = 0.f, sr = 0.f;
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int hh0 = 32 * ht + 8 * g + 4 * half;
+                const float4 bb = *(const float4*)(b1 + hh0);
+                const float4 w21 = make_float4(W21[hh0], W21[hh0 + 1], W21[hh0 + 2], W21[hh0 + 3]);
+                const float4 w22 = make_float4(W22[hh0], W22[hh0 + 1], W22[hh0 + 2], W22[hh0 + 3]);
+                float4 hv;
+                hv.x = softplusf_(fmaf(acc[t][ht][4 * g + 0], w1_inv, bb.x));      // vi.py:432
+                hv.y = softplusf_(fmaf(acc[t][ht][4 * g + 1], w1_inv, bb.y));
+                hv.z = softplusf_(fmaf(acc[t][ht][4 * g + 2], w1_inv, bb.z));
+                hv.w = softplusf_(fmaf(acc[t][ht][4 * g + 3], w1_inv, bb.w));
+                sl += hv.x * w21.x + hv.y * w21.y + hv.z * w21.z + hv.w * w21.w;
+                sr += hv.x * w22.x + hv.y * w22.y + hv.z * w22.z + hv.w * w22.w;
+                if (i < dm.nb) *(float4*)(h_out + i * H + hh0) = hv;
+            }
+        sl = half_sum32(sl);
+        sr = half_sum32(sr);
+        if (half == 0 && i < dm.nb) {
+            loc_out[i] = sl + b21[0];
+            raw_out[i] = sr + b22[0];
+        }
+    }
+#ifdef NH_STAMPS
+    NSTAMP();                                                             // 3: softplus, heads, outputs
+    if (blockIdx.x == 3000 && lane == 0)
+        printf("NSTAMPS NP %d PF %d wave %d: stage %llu fc1 %llu out %llu total %llu\n", NP, PF, wave, nst_[1] - nst_[0], nst_[2] - nst_[1], nst_[3] - nst_[2], nst_[3] - nst_[0]);
+#endif
+#undef NSTAMP
+}
+

@@ -1788,15 +1788,53 @@ int64_t vx_norm_enc_param_floats(const vx_irt_cfg* cfg) {
     return (int64_t)cfg->H * cfg->J + 3 * (int64_t)cfg->H + 2;
 }
 
+// the f16x2 NormEncoder forward (k_norm_enc_fwd_h): hidden_dim 64, whole response words; batches from NH_MIN_PERSONS on (two
+// more launches make the weight images: not worth it for a minibatch)
+#define NH_MIN_PERSONS 4096
+#ifndef NH_NP
+#define NH_NP 1
+#endif
+#ifndef NH_PF
+#define NH_PF 3
+#endif
+static bool nenc_h_shape(const vx_irt_cfg* cfg) {
+    return !force_generic() && (mfma16_mode() & 1) && cfg->H == 64 && cfg->J % 4 == 0 && cfg->J >= 256 &&
+           nh_lds_bytes<NH_NP>(cfg->J) <= 160 * 1024;
+}
+int64_t vx_norm_enc_pack_floats(const vx_irt_cfg* cfg) {
+    if (!nenc_cfg_ok(cfg)) return VX_EINVAL;
+    return nenc_h_shape(cfg) ? nh_pack_floats(cfg->J) : 0;
+}
+
 int vx_norm_enc_forward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, const float* W1,
                         const float* b1, const float* W21, const float* b21, const float* W22, const float* b22,
-                        float* h, float* loc, float* raw, void* hs) {
+                        float* h, float* loc, float* raw, float* packws, void* hs) {
     if (!nenc_cfg_ok(cfg) || !y || !W1 || !b1 || !W21 || !b21 || !W22 || !b22 || !h || !loc || !raw || nb < 0)
         return VX_EINVAL;
     if (nb == 0) return VX_OK;
     EncDims dm;
     dm.D = 1; dm.J = cfg->J; dm.H = cfg->H; dm.Hp = (cfg->H + 31) / 32 * 32; dm.DS = 3; dm.T = 1; dm.nb = nb;
     int rc;
+    if (packws && nb >= NH_MIN_PERSONS && nenc_h_shape(cfg) && aligned16(packws) && aligned16(y) && aligned16(W1) &&
+        aligned16(b1) && aligned16(h)) {
+        uint8_t* w1img = (uint8_t*)packws;
+        float* sc = packws + fb_w1img_floats(cfg->J);
+        float* part = sc + 16;
+        const int n_ks = (cfg->J + 15) / 16;
+        hipLaunchKernelGGL(k_norm_pack_max, dim3(NH_MAX_BLOCKS), dim3(256), 0, (hipStream_t)hs, (int)cfg->J, W1, part);
+        VX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_norm_pack_w1, dim3((unsigned)n_ks), dim3(256), 0, (hipStream_t)hs, (int)cfg->J, W1, (const float*)part, sc,
+                           w1img);
+        VX_CHECK_LAUNCH();
+        const size_t ldsh = nh_lds_bytes<NH_NP>(cfg->J);
+        rc = set_lds((k_norm_enc_fwd_h<NH_NP, NH_PF>), ldsh);
+        if (rc) return rc;
+        ProfScope ps("k_norm_enc_fwd_h", (hipStream_t)hs);
+        hipLaunchKernelGGL((k_norm_enc_fwd_h<NH_NP, NH_PF>), dim3((unsigned)((nb + 127) / 128)), dim3(64 * (4 / NH_NP)), ldsh,
+                           (hipStream_t)hs, dm, y, rows, (const uint8_t*)w1img, (const float*)sc, b1, W21, b21, W22, b22, h, loc, raw);
+        VX_CHECK_LAUNCH();
+        return VX_OK;
+    }
     if (!force_generic() && (mfma16_mode() & 1) && cfg->H == 64 && cfg->J % 4 == 0 && aligned16(y) && aligned16(W1) &&
         aligned16(b1) && aligned16(h) && nb_lds_bytes(cfg->J) <= 160 * 1024) {
         const size_t ldsb = nb_lds_bytes(cfg->J);                       // fc1 on the bf16 MFMA, W1 shared by the workgroup

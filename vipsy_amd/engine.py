@@ -199,8 +199,14 @@ class HipBackend(object):
                                         _hip.ptr(enc["fc21.weight"]), _hip.ptr(enc["fc21.bias"]),
                                         _hip.ptr(enc["fc22.weight"]), _hip.ptr(enc["fc22.bias"]),
                                         _hip.ptr(out["h"]), _hip.ptr(out["loc"]), _hip.ptr(out["raw"]),
-                                        _hip.stream_ptr())
+                                        _hip.ptr(out.get("packws")), _hip.stream_ptr())
         _hip.check(rc, "vx_norm_enc_forward")
+
+    def norm_enc_pack_floats(self, cfg):
+        n = self.L.vx_norm_enc_pack_floats(ctypes.byref(cfg))
+        if n < 0:
+            raise _hip.VxError("vx_norm_enc_pack_floats: unsupported configuration (code %d)" % n)
+        return n
 
     def norm_enc_bwd_workspace(self, cfg, nb):
         n = self.L.vx_norm_enc_bwd_workspace_floats(ctypes.byref(cfg), nb)
@@ -1244,6 +1250,9 @@ class IrtEngine(_EngineBase):
                 H = self.H
                 enc = self._enc()
                 fw = {"h": self._buf("h", nb * H), "loc": self._buf("loc", nb), "raw": self._buf("raw", nb)}
+                n_pk = be.norm_enc_pack_floats(cfg) if hasattr(be, "norm_enc_pack_floats") else 0
+                if n_pk > 0:
+                    fw["packws"] = self._buf("nenc_packws", n_pk)      # the forward's fp16-pair images of W1 (large batches)
                 gloc, graw = self._buf("gloc", nb), self._buf("graw", nb)
                 nb_ws = self._buf("nencb_ws", be.norm_enc_bwd_workspace(cfg, nb))
                 with self._phase("guide_forward"):
@@ -1401,6 +1410,9 @@ class HoDinaEngine(_EngineBase):
             icfg = be.cfg("irt_2pl", 1, self.J, self.H, 1.0, scale, self.seed, self.t, stream_id)
             enc = self._enc()
             fw = {"h": self._buf("h", nb * self.H), "loc": self._buf("loc", nb), "raw": self._buf("raw", nb)}
+            n_pk = be.norm_enc_pack_floats(icfg) if hasattr(be, "norm_enc_pack_floats") else 0
+            if n_pk > 0:
+                fw["packws"] = self._buf("nenc_packws", n_pk)
             gloc, graw = self._buf("gloc", nb), self._buf("graw", nb)
             nb_ws = self._buf("nencb_ws", be.norm_enc_bwd_workspace(icfg, nb))
             with self._phase("guide_forward"):
