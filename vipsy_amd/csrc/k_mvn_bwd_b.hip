@@ -102,7 +102,7 @@ __global__ __launch_bounds__(BWB_THREADS, 1) void k_mvn_enc_bwd_w_b(
     constexpr uint32_t BUF = NBUF == 3 ? BB_BUF3 : BB_BUF;
     const int Rp = pk_rows(D);
     int rb_, blk_pr;
-    bt_decode(rb_, blk_pr);
+    bt_decode(vgrid_launch(), rb_, blk_pr);
     const int64_t rbase = (int64_t)rb_ * BT_ROWS + (int64_t)wave * BWB_RT * 32;
     const int rE = bt_row_E(D), rH = bb_row_H(D), rGD = bb_row_GD(D), rOnes = bb_row_ones(D), rZero = rOnes + 1;
     const bool need_gd = (int64_t)(rb_ + 1) * BT_ROWS > pk_off_total(D);

@@ -61,9 +61,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 // workgroup ids round-robin over the 8 XCDs, and the row blocks of one person range all read the same tiles.  They
 // are placed on consecutive slots of ONE XCD (a group straddles two XCDs at most), so that the re-reads are served by
 // that XCD's L2 instead of crossing the fabric once per XCD.
-__device__ __forceinline__ void bt_decode(int& rb, int& pr) {
-    const int n_rb = gridDim.x, nblk = gridDim.x * gridDim.y;
-    const int id = blockIdx.x + n_rb * blockIdx.y, x = id & 7;
+// (the grid may be a VIRTUAL one: k_bwd_wt_fc1 gives this body the first gx * gy workgroups of a launch it shares; `id` is
+// the workgroup's linear index in it)
+struct VGrid { int id, gx, gy; };
+__device__ __forceinline__ VGrid vgrid_launch() { return VGrid{(int)(blockIdx.x + gridDim.x * blockIdx.y), (int)gridDim.x, (int)gridDim.y}; }
+__device__ __forceinline__ void bt_decode(const VGrid& vg, int& rb, int& pr) {
+    const int n_rb = vg.gx, nblk = vg.gx * vg.gy;
+    const int id = vg.id, x = id & 7;
     int p = id >> 3;                                                   // slot within the XCD
     for (int xx = 0; xx < x; ++xx) p += (nblk - xx + 7) >> 3;          // + the slots of the XCDs before it
     pr = p / n_rb;
@@ -73,7 +77,7 @@ __device__ __forceinline__ void bt_decode(int& rb, int& pr) {
 __device__ __forceinline__ void bwd_w_t_body(
     const EncDims& dm, const float* __restrict__ hT, const float* __restrict__ epsT, const float* __restrict__ gdT,
     const float* __restrict__ gxT, const uint32_t* __restrict__ gtab, float* __restrict__ slabs, int64_t slab_len,
-    char* smem) {
+    char* smem, const VGrid vg) {
     const int D = dm.D;
     const int64_t nb = dm.nb;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,7 +85,7 @@ __device__ __forceinline__ void bwd_w_t_body(
     constexpr uint32_t BUF = BT_BUF;
     const int Rp = pk_rows(D);
     int rb_, pr_;
-    bt_decode(rb_, pr_);
+    bt_decode(vg, rb_, pr_);
     const int64_t rbase = (int64_t)rb_ * BT_ROWS + (int64_t)wave * BT_RT * 32;
     const int rE = bt_row_E(D), rH = bt_row_H(D), rGD = bt_row_GD(D), rOnes = bt_row_ones(D), rZero = bt_row_zero(D);
     // workgroups whose rows reach into the DIAG section also stage the GD region (block-uniform)
@@ -205,14 +209,14 @@ __device__ __forceinline__ void bwd_w_t_body(
     while (tile < n_ptiles) {
         vx_wait_vmem();
         __syncthreads();                                               // tile in buffer 0 landed; buffer 1 free
-        int64_t nx = tile + gridDim.y;
+        int64_t nx = tile + vg.gy;
         if (nx < n_ptiles) stage(nx, 1);
         compute(std::integral_constant<int, 0>{});
         tile = nx;
         if (tile >= n_ptiles) break;
         vx_wait_vmem();
         __syncthreads();                                               // tile in buffer 1 landed; buffer 0 free
-        nx = tile + gridDim.y;
+        nx = tile + vg.gy;
         if (nx < n_ptiles) stage(nx, 0);
         compute(std::integral_constant<int, 1>{});
         tile = nx;
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(BT_THREADS, 1) void k_mvn_enc_bwd_w_t(
     EncDims dm, const float* __restrict__ hT, const float* __restrict__ epsT, const float* __restrict__ gdT,
     const float* __restrict__ gxT, const uint32_t* __restrict__ gtab, float* __restrict__ slabs, int64_t slab_len) {
     extern __shared__ __attribute__((aligned(16))) char smem_bt[];
-    bwd_w_t_body(dm, hT, epsT, gdT, gxT, gtab, slabs, slab_len, smem_bt);
+    bwd_w_t_body(dm, hT, epsT, gdT, gxT, gtab, slabs, slab_len, smem_bt, vgrid_launch());
 }
 
 // gdT[k][i] = gxT[k][i] * epsT[k][i] * exp(M_kk)[i] + scale: the DIAG-row operand (vi.py:686 and the entropy term)

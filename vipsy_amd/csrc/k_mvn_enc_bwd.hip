@@ -240,18 +240,18 @@ __host__ __device__ inline size_t fc1_bwd_lds_floats(int Hp) {
 // 4-byte loads one person tile ahead (issue before the MFMA phase, write to LDS after it).
 // IT: item tiles of 32 a wave -- 128 IT items a workgroup.  IT = 4 is the form for large batches; IT = 1 (round 5) gives a small
 // batch four times the workgroups: at B = 100 the kernel was two workgroups, each with 8 fp32 MFMAs a step and a 128 KB slab.
-template <int HT, int IT = 4>
-__global__ __launch_bounds__(ENC_THREADS) void k_fc1_bwd(
-    EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows,
-    const float* __restrict__ ghpre, float* __restrict__ slabs, int64_t slab_len, int fast) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// (vbx, vby, vgy: the workgroup's place in a grid that may be a virtual one, see k_bwd_wt_fc1)
+template <int HT, int IT>
+__device__ __forceinline__ void fc1_bwd_body(
+    const EncDims& dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows,
+    const float* __restrict__ ghpre, float* __restrict__ slabs, int64_t slab_len, int fast, float* smem, int vbx, int vby, int vgy) {
     const int J = dm.J, H = dm.H, Hp = dm.Hp;
     const int HS = fast ? 64 : Hp + 1;
     float* g_lds = smem;                                   // [P][HS]
     int8_t* Yi = (int8_t*)(g_lds + ENC_P * (Hp + 1));      // [P][YSI] encoder input as int8 (-1,0,1)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     constexpr int JG = 4 * IT * 32, YSI = JG + 4, WPP = JG / 4;          // items, LDS row stride, response words a person
-    const int jg0 = blockIdx.x * JG;
+    const int jg0 = vbx * JG;
     f32x16 acc[IT][HT];
     float bsum[HT];
 #pragma unroll
@@ -283,9 +283,9 @@ __global__ __launch_bounds__(ENC_THREADS) void k_fc1_bwd(
             }
         }
     };
-    int64_t tile = blockIdx.y;
+    int64_t tile = vby;
     if (fast && tile < n_ptiles) prefetch(tile);
-    for (; tile < n_ptiles; tile += gridDim.y) {
+    for (; tile < n_ptiles; tile += vgy) {
         const int64_t i0 = tile * ENC_P;
         __syncthreads();
         if (fast) {
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_fc1_bwd(
             }
         }
         __syncthreads();
-        if (fast && tile + gridDim.y < n_ptiles) prefetch(tile + gridDim.y);
+        if (fast && tile + vgy < n_ptiles) prefetch(tile + vgy);
 #pragma unroll 2
         for (int s = 0; s < ENC_P / 2; ++s) {
             const int p = 2 * s + half;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_fc1_bwd(
             }
         }
     }
-    float* slab = slabs + (int64_t)blockIdx.y * slab_len;
+    float* slab = slabs + (int64_t)vby * slab_len;
 #pragma unroll
     for (int t = 0; t < IT; ++t) {
         const int j = jg0 + 32 * (wave * IT + t) + l31;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_fc1_bwd(
                 if (hh < H && j < J) slab[(int64_t)hh * J + j] = acc[t][ht][r];
             }
     }
-    if (blockIdx.x == 0 && wave == 0) {
+    if (vbx == 0 && wave == 0) {
 #pragma unroll
         for (int ht = 0; ht < HT; ++ht) {
             const float bt = bsum[ht] + __shfl_xor(bsum[ht], 32, 64);
@@ -350,4 +350,11 @@ __global__ __launch_bounds__(ENC_THREADS) void k_fc1_bwd(
             if (half == 0 && hh < H) slab[(int64_t)H * J + hh] = bt;
         }
     }
+}
+template <int HT, int IT = 4>
+__global__ __launch_bounds__(ENC_THREADS) void k_fc1_bwd(
+    EncDims dm, const uint8_t* __restrict__ y, const int64_t* __restrict__ rows,
+    const float* __restrict__ ghpre, float* __restrict__ slabs, int64_t slab_len, int fast) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    fc1_bwd_body<HT, IT>(dm, y, rows, ghpre, slabs, slab_len, fast, smem, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
 }

@@ -121,3 +121,22 @@ __global__ __launch_bounds__(256) void k_enc_bwd_tail(int D, int H, const float*
     if (blk < n_unpack + n_f1) { reduce_slabs_cols(blk - n_unpack, n_f1, part, slabs_f, n_prf, lenf, lenf, alpha, out_f); return; }
     if (ll) sum_block(0, 1, &part[0][0], ll, nb, sum_ws, ent, loss_alpha, loss, tick);
 }
+
+// A small batch's head weight gradient (k_mvn_enc_bwd_w_t: 44 workgroups at B = 100) and its fc1 weight gradient
+// (k_fc1_bwd<2, 1>: 16) need nothing from each other and both run behind the hidden gradient: ONE launch, the first n_wt
+// workgroups the one, the rest the other (15 + 9 us one after the other on a chip they fill to a sixth).  Same bodies, same
+// slabs.  (Registers and LDS are the larger kernel's: one wave a SIMD, as k_mvn_enc_bwd_w_t alone.)
+__global__ __launch_bounds__(BT_THREADS, 1) void k_bwd_wt_fc1(
+    EncDims dm, const float* __restrict__ hT, const float* __restrict__ epsT, const float* __restrict__ gdT,
+    const float* __restrict__ gxT, const uint32_t* __restrict__ gtab, float* __restrict__ slabs_w, int64_t lenw, int wt_gx, int wt_gy,
+    const uint8_t* __restrict__ y, const int64_t* __restrict__ rows, const float* __restrict__ ghpre, float* __restrict__ slabs_f,
+    int64_t lenf, int fast, int f_gx, int f_gy) {
+    extern __shared__ __attribute__((aligned(16))) char smem_wf[];
+    const int L = blockIdx.x, n_wt = wt_gx * wt_gy;
+    if (L < n_wt) {
+        bwd_w_t_body(dm, hT, epsT, gdT, gxT, gtab, slabs_w, lenw, smem_wf, VGrid{L, wt_gx, wt_gy});
+        return;
+    }
+    const int Lf = L - n_wt;
+    fc1_bwd_body<2, 1>(dm, y, rows, ghpre, slabs_f, lenf, fast, (float*)smem_wf, Lf % f_gx, Lf / f_gx, f_gy);
+}

@@ -1168,6 +1168,7 @@ static int mvn_enc_backward_impl(const vx_irt_cfg* cfg, const uint8_t* y, const 
     bool f1t = false;                                      // fc1 gradient on the dimension-major kernel (ghpre holds ghpreT)
     bool maxw_ready = false;                               // k_mvn_enc_bwd_h_b ran: the operand maxima of the step are collected
     bool f1_done = false;                                  // the fc1 gradient (and its slab sum) went out on the side stream
+    bool f1_launched = false;                              // ... rode in the head weight gradient's launch (k_bwd_wt_fc1)
     ForkScope f1_fork;                                     // ... joined below, or by the scope on an error return
     ForkScope bwb_fork;
     bool bwb_done = false;
@@ -1366,14 +1367,30 @@ static int mvn_enc_backward_impl(const vx_irt_cfg* cfg, const uint8_t* y, const 
             rc = launch_bwb_on(st, gdT, hs3);
             if (rc) return rc;
         } else if (use_t) {
-            const size_t lds = bt_lds_bytes(dm.D);
-            rc = set_lds(k_mvn_enc_bwd_w_t, lds);
-            if (rc) return rc;
+            size_t lds = bt_lds_bytes(dm.D);
             float* gdT = slabs_f + (int64_t)n_prf * lenf;     // DIAG-row operand, dimension-major (made above)
-            ProfScope ps("k_mvn_enc_bwd_w_t", st);
-            hipLaunchKernelGGL(k_mvn_enc_bwd_w_t, dim3((unsigned)n_rowslabs, (unsigned)n_prw), dim3(BT_THREADS), lds, st,
-                               dm, hT, epsT, gdT, gxT, gtab, slabs_w, Rp * (H + 1));
-            VX_CHECK_LAUNCH();
+            const int n_jg1 = (int)((cfg->J + 127) / 128);
+            if (!f1_done && !f1t && dm.Hp == 64 && (int64_t)n_jg * n_prf * 16 <= num_cu() && BT_THREADS == ENC_THREADS) {
+                // a small batch: the fc1 weight gradient (k_fc1_bwd<2, 1>) rides in the same launch (k_bwd_wt_fc1)
+                const size_t ldsf = fc1_bwd_lds_floats(dm.Hp) * sizeof(float);
+                if (ldsf > lds) lds = ldsf;
+                rc = set_lds(k_bwd_wt_fc1, lds);
+                if (rc) return rc;
+                const int f1fast = (!force_generic() && cfg->H == 64 && cfg->J % 4 == 0 && aligned16(ghpre) && aligned16(y)) ? 1 : 0;
+                ProfScope ps("k_mvn_enc_bwd_w_t + k_fc1_bwd", st);
+                hipLaunchKernelGGL(k_bwd_wt_fc1, dim3((unsigned)(n_rowslabs * n_prw + n_jg1 * n_prf)), dim3(BT_THREADS), lds, st, dm, hT,
+                                   epsT, (const float*)gdT, gxT, gtab, slabs_w, Rp * (H + 1), n_rowslabs, n_prw, y, rows,
+                                   (const float*)ghpre, slabs_f, lenf, f1fast, n_jg1, n_prf);
+                VX_CHECK_LAUNCH();
+                f1_launched = true;
+            } else {
+                rc = set_lds(k_mvn_enc_bwd_w_t, lds);
+                if (rc) return rc;
+                ProfScope ps("k_mvn_enc_bwd_w_t", st);
+                hipLaunchKernelGGL(k_mvn_enc_bwd_w_t, dim3((unsigned)n_rowslabs, (unsigned)n_prw), dim3(BT_THREADS), lds, st,
+                                   dm, hT, epsT, gdT, gxT, gtab, slabs_w, Rp * (H + 1));
+                VX_CHECK_LAUNCH();
+            }
         } else {
             const size_t lds = enc_bwdw_fast_lds_floats(dm.D) * sizeof(float);
             rc = set_lds(k_mvn_enc_bwd_w_fast<true>, lds);
@@ -1430,8 +1447,8 @@ static int mvn_enc_backward_impl(const vx_irt_cfg* cfg, const uint8_t* y, const 
             VX_CHECK_LAUNCH();
         }
     }
-    if (f1_done) {
-        // (joined below)
+    if (f1_done || f1_launched) {
+        // (joined below | launched with the head weight gradient: its slabs are summed below)
     } else if (nb > 0 && f1t && (mfma16_mode() & 8)) {
         rc = launch_fc1_c(st);
         if (rc) return rc;
