@@ -308,6 +308,8 @@ typedef struct vx_hodina_cfg {
     float scale, _pad2;
     uint64_t seed;
     uint32_t step, stream;
+    const uint32_t* step_dev; /* or NULL: the step counter in DEVICE memory (a captured step), read instead of `step`; vx_sum
+                                 advances it behind the gradients, vx_adam_step reads it as t_dev */
 } vx_hodina_cfg;
 int64_t vx_hodina_workspace_floats(const vx_hodina_cfg* cfg, int64_t nb);
 int vx_hodina_grad(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t* rows, int64_t nb, int64_t gid0,
@@ -398,7 +400,8 @@ int vx_reduce_slabs(const float* slabs, int64_t n_slabs, int64_t len, float alph
 /* out[0] = alpha * sum(v) (fixed-order two-stage tree; used for the loss);
  * workspace: vx_sum_workspace_floats() floats */
 int64_t vx_sum_workspace_floats(void);
-int vx_sum(const float* v, int64_t n, float alpha, float* out, float* workspace, void* hip_stream);
+int vx_sum(const float* v, int64_t n, float alpha, float* out, float* workspace, uint32_t* step_dev /*or NULL: advanced by
+           one in the last launch, as vx_sum2 does*/, void* hip_stream);
 /* out[0] = alpha * (sum v1 + sum v2), both of length n, in one pass (the loss of the MVN guides: log-lik + entropy).
  * step_dev (or NULL): the device step counter of a captured step (vx_irt_cfg.step_dev): advanced by one here, the last
  * launch of loss-and-gradients, so that vx_adam_step's t_dev may point at the same word (Adam's count is the step + 1). */

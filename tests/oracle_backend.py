@@ -66,7 +66,7 @@ class OracleBackend(object):
             out[3 * J:4 * J] = -cfg.scale * (g["d"] * d * (1 - d)).reshape(-1)
         _put(gitem, out)
 
-    def sum_into(self, v, n, alpha, out, ws):
+    def sum_into(self, v, n, alpha, out, ws, step_dev=None):
         out[0] = float(alpha) * float(v[:n].double().sum())
 
     def sum2_into(self, v1, v2, n, alpha, out, ws):

@@ -828,6 +828,41 @@ def test_captured_step_equals_eager_step(miss, model):
         assert np.array_equal(u, v)
 
 
+@pytest.mark.parametrize("K,amort", [(8, False), (6, True), (3, False)])
+def test_captured_hodina_step_equals_eager_step(K, amort):
+    """The enumerated HO-DINA step (k_hodina_m for 5 <= K <= 8, k_hodina otherwise; either guide) replayed from its HIP graph
+    -- the Philox step and Adam's t from the device counter that the loss sum advances -- against the same steps launched
+    kernel by kernel: same bits, across a scheduler milestone, also four steps a replay."""
+    from vipsy_amd.engine import HoDinaEngine, LrSpec
+    rng = np.random.RandomState(17)
+    N, J = 3000, 30
+    q = (rng.rand(K, J) < 0.4).astype(np.float32)
+    q[rng.randint(0, K, size=J), np.arange(J)] = 1.0
+    y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+    y[rng.rand(N, J) < 0.1] = 255
+    out = []
+    for mode in ("graph", "eager", "steps"):
+        eng = HoDinaEngine(torch.from_numpy(y).to(_dev()), q, amortized=amort, H=64, seed=11)
+        eng.use_graph = mode != "eager"
+        lrs = LrSpec(lambda m, p: {"lr": 1e-2 if p in ("g", "s") else 1e-3}, milestones=(5,), gamma=0.5)
+        if mode == "steps":
+            losses = eng.steps(lrs, [None] * 11, scheduler=True)
+        else:
+            losses = []
+            for _ in range(11):
+                losses.append(eng.step(lrs))
+                lrs.scheduler_step()
+        torch.cuda.synchronize()
+        assert eng.t == 11
+        assert ((getattr(eng, "_graph", None) or {}).get("graph") is not None) == (mode != "eager")
+        out.append((torch.stack(losses).cpu().numpy(), eng.P.cpu().numpy().copy(),
+                    eng.PP.cpu().numpy().copy() if eng.per_person else None))
+    assert np.isfinite(out[0][0]).all() and len(set(out[0][0].tolist())) == 11
+    for other in out[1:]:
+        for u, v in zip(out[0], other):
+            assert (u is None and v is None) or np.array_equal(u, v)
+
+
 @pytest.mark.parametrize("N,B", [
     (2048, None),        # the headline's model, small-batch kernels (SPLIT forward / hidden gradient), full batch
     (33024, None),       # ... the large-batch kernels of the judged step, second-stream tails included in the capture

@@ -44,7 +44,7 @@ class HoDinaCfg(ctypes.Structure):
     """struct vx_hodina_cfg (include/vipsy_amd.h)."""
     _fields_ = [("K", ctypes.c_int32), ("J", ctypes.c_int32), ("H", ctypes.c_int32), ("_pad", ctypes.c_int32),
                 ("scale", ctypes.c_float), ("_pad2", ctypes.c_float), ("seed", ctypes.c_uint64),
-                ("step", ctypes.c_uint32), ("stream", ctypes.c_uint32)]
+                ("step", ctypes.c_uint32), ("stream", ctypes.c_uint32), ("step_dev", ctypes.c_void_p)]
 
 
 _P = ctypes.c_void_p
@@ -121,7 +121,7 @@ SIGNATURES = {
     "vx_sm_enc_backward": (ctypes.c_int, [ctypes.POINTER(HoDinaCfg), _P, _P, _I64] + [_P] * 5 + [_P, _P, _P, _P]),
     "vx_reduce_slabs": (ctypes.c_int, [_P, _I64, _I64, _F, _P, _P]),
     "vx_sum_workspace_floats": (_I64, []),
-    "vx_sum": (ctypes.c_int, [_P, _I64, _F, _P, _P, _P]),
+    "vx_sum": (ctypes.c_int, [_P, _I64, _F, _P, _P, _P, _P]),
     "vx_sum2": (ctypes.c_int, [_P, _P, _I64, _F, _P, _P, _P, _P]),
     "vx_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, ctypes.POINTER(AdamSeg), _I32, _I32, _P, _F, _F, _F, _P, _P, _P]),
     "vx_adam_step2": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, ctypes.POINTER(AdamSeg), _I32, _P, _P, _P, _P, _I64,

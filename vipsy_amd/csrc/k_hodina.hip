@@ -22,6 +22,7 @@ struct HoDinaDims {
     // (vi.py:86-101) INCLUDING its in-place sequencing: eta = [item needs >= 2 attributes] * [c masters one of them]
     int uniform_prior, dino;       // uniform_prior: 0 HO-DINA prior, 1 uniform (VCCDM), 2 per-person row of pattern scores (VaeCCDM)
     int unmasked;                  // VaeCCDM (vi.py:882-891): a missing response stays in `obs` as -1 (no mask)
+    const uint32_t* step_dev = nullptr;   // or the step counter in device memory (a captured step): read instead of `step`
 };
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
     const float* __restrict__ zoff = nullptr /*[C] column offsets: prior weight = exp(z - off)*/,
     float* __restrict__ gla = nullptr /*[nb][C] out: d ELBO / d log(prior weight), scaled*/) {
     constexpr int CPL = 1 << LOGCPL;
+    if (dm.step_dev) step = *dm.step_dev;                          // replayed from a HIP graph: the counter lives on the device
     extern __shared__ __attribute__((aligned(16))) float smem[];   // per wave: [C] scatter/gather table; then block reduce
     const int K = dm.K, J = dm.J, C = dm.C;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(HM_THREADS, 2) void k_hodina_m(
     const float* __restrict__ lam1_un, const float* __restrict__ g_un, const float* __restrict__ s_un,
     float* __restrict__ gloc, float* __restrict__ graw, float* __restrict__ elbo, float* __restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if (dm.step_dev) step = *dm.step_dev;                                 // replayed from a HIP graph: the counter lives on the device
     const int K = dm.K, J = dm.J;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
     constexpr size_t IMG = (size_t)NT * 2 * 1024;

@@ -386,20 +386,20 @@ static int reduce_step_slabs(const float* slabs, int64_t n_slabs, int J, float* 
 
 int64_t vx_sum_workspace_floats(void) { return 1024; }
 
-int vx_sum(const float* v, int64_t n, float alpha, float* out, float* workspace, void* hs) {
+int vx_sum(const float* v, int64_t n, float alpha, float* out, float* workspace, uint32_t* step_dev, void* hs) {
     if (!v || !out || !workspace || n < 0) return VX_EINVAL;
     int nblk = (int)((n + 4095) / 4096);
     if (nblk < 1) nblk = 1;
     if (nblk > 1024) nblk = 1024;
     if (nblk == 1) {                                       // a small batch: one launch (k_sum_stage1's final form)
         hipLaunchKernelGGL(k_sum_stage1, dim3(1), dim3(256), 0, (hipStream_t)hs, v, n, workspace, (const float*)nullptr, alpha, out,
-                           (uint32_t*)nullptr);
+                           step_dev);
         VX_CHECK_LAUNCH();
         return VX_OK;
     }
     hipLaunchKernelGGL(k_sum_stage1, dim3(nblk), dim3(256), 0, (hipStream_t)hs, v, n, workspace, (const float*)nullptr);
     VX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_sum_stage2, dim3(1), dim3(256), 0, (hipStream_t)hs, workspace, nblk, alpha, out);
+    hipLaunchKernelGGL(k_sum_stage2, dim3(1), dim3(256), 0, (hipStream_t)hs, workspace, nblk, alpha, out, step_dev);
     VX_CHECK_LAUNCH();
     return VX_OK;
 }
@@ -1993,6 +1993,7 @@ int vx_hodina_grad(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t* ro
     HoDinaDims dm;
     dm.K = cfg->K; dm.J = cfg->J; dm.C = 1 << cfg->K; dm.scale = cfg->scale; dm.nb = nb;
     dm.uniform_prior = 0; dm.dino = 0; dm.unmasked = 0;
+    dm.step_dev = cfg->step_dev;
     const int len = 2 * cfg->J + 2 * cfg->K;
     hipStream_t st = (hipStream_t)hs;
     if (cfg->K >= 5 && cfg->K <= 8 && cfg->J <= 32) {

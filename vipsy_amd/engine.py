@@ -223,8 +223,8 @@ class HipBackend(object):
         _hip.check(rc, "vx_norm_enc_backward")
 
     @staticmethod
-    def hodina_cfg(K, J, H, scale, seed, step, stream):
-        return _hip.HoDinaCfg(K, J, H, 0, scale, 0.0, seed, step, stream)
+    def hodina_cfg(K, J, H, scale, seed, step, stream, step_dev=None):
+        return _hip.HoDinaCfg(K, J, H, 0, scale, 0.0, seed, step, stream, None if step_dev is None else step_dev.data_ptr())
 
     def hodina_workspace(self, cfg, nb):
         n = self.L.vx_hodina_workspace_floats(ctypes.byref(cfg), nb)
@@ -340,8 +340,8 @@ class HipBackend(object):
                                        _hip.ptr(ws), _hip.stream_ptr())
         _hip.check(rc, "vx_sm_enc_backward")
 
-    def sum_into(self, v, n, alpha, out, ws):
-        rc = self.L.vx_sum(_hip.ptr(v), n, alpha, _hip.ptr(out), _hip.ptr(ws), _hip.stream_ptr())
+    def sum_into(self, v, n, alpha, out, ws, step_dev=None):
+        rc = self.L.vx_sum(_hip.ptr(v), n, alpha, _hip.ptr(out), _hip.ptr(ws), _hip.ptr(step_dev), _hip.stream_ptr())
         _hip.check(rc, "vx_sum")
 
     def adam2(self, bufA, free, nA, segsA, bufB, nB, segsB, t, betas=(0.9, 0.999), eps=1e-8, t_dev=None, loss=None):
@@ -686,6 +686,8 @@ class _EngineBase(object):
             if rows is not None and not isinstance(rows, (list, tuple)) and self.n_local > 0:
                 nb = int(rows.numel())
                 return ("rows", nb, int(b_global) if b_global is not None else nb)
+        if isinstance(self, HoDinaEngine) and full:
+            return ("full", self.n_local, self.N)            # the enumerated HO-DINA step (either guide): three or six launches
         return None
 
     def _graphable(self):
@@ -1402,7 +1404,9 @@ class HoDinaEngine(_EngineBase):
         nb = self.n_local if rows is None else int(rows.numel())
         Bg = int(b_global) if b_global is not None else (self.N if rows is None else nb)
         scale = float(self.N) / float(Bg)
-        cfg = be.hodina_cfg(self.K, self.J, self.H, scale, self.seed, self.t, stream_id)
+        sd = getattr(self, "_step_dev", None)               # captured step: the step count lives in device memory
+        sdc = {"step_dev": sd} if sd is not None else {}
+        cfg = be.hodina_cfg(self.K, self.J, self.H, scale, self.seed, self.t, stream_id, **sdc)
         elbo = self._buf("elbo", nb)
         ws = self._buf("hd_ws", be.hodina_workspace(cfg, nb))
         lossslot = self.G[self.n_params:self.n_params + 1]
@@ -1431,7 +1435,7 @@ class HoDinaEngine(_EngineBase):
                                      yT=self._item_major_y(rows))
         else:
             self._scatter_pp(rows, nb, gloc, graw)
-        be.sum_into(elbo, nb, -scale, lossslot, self.sum_ws)
+        be.sum_into(elbo, nb, -scale, lossslot, self.sum_ws, **sdc)   # (a captured step's counter advances here)
         self.last = {"elbo": elbo, "nb": nb}
 
 
