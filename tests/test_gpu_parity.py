@@ -828,6 +828,39 @@ def test_captured_step_equals_eager_step(miss, model):
         assert np.array_equal(u, v)
 
 
+@pytest.mark.parametrize("N,J,miss,B", [(5000, 500, 0.9, None), (3000, 64, 0.2, 100), (4500, 260, 0.5, None)])
+def test_captured_amortized_1d_step_equals_eager_step(N, J, miss, B):
+    """VaeIRT with one latent dimension (NormEncoder, vi.py:417-435, 677-684) replayed from its HIP graph -- full batches (the
+    observed-cell lists at 90 % missing; the f16 forward from 4 096 persons on) and the reference's own subsample of 100
+    (Irt2PLMissing.test_ai, test.py:311-327) -- against the same steps launched kernel by kernel: same bits."""
+    from vipsy_amd.engine import IrtEngine, LrSpec
+    rng = np.random.RandomState(N + J)
+    y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+    y[rng.rand(N, J) < miss] = 255
+    n_steps = 9
+    rows_all = [None if B is None else torch.from_numpy(rng.choice(N, size=B, replace=False).astype(np.int64)) for _ in range(n_steps)]
+    out = []
+    for mode in ("graph", "eager", "steps"):
+        eng = IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_2pl", D=1, amortized=True, H=64, seed=11)
+        eng.use_graph = mode != "eager"
+        lrs = LrSpec(lambda m, p: {"lr": 1e-2 if p in ("a", "b") else 1e-3}, milestones=(4,), gamma=0.5)
+        if mode == "steps":
+            losses = eng.steps(lrs, rows_all, b_global=B, scheduler=True)
+        else:
+            losses = []
+            for t in range(n_steps):
+                losses.append(eng.step(lrs, rows=rows_all[t], b_global=B))
+                lrs.scheduler_step()
+        torch.cuda.synchronize()
+        assert eng.t == n_steps
+        assert ((getattr(eng, "_graph", None) or {}).get("graph") is not None) == (mode != "eager")
+        out.append((torch.stack(losses).cpu().numpy(), eng.P.cpu().numpy().copy()))
+    assert np.isfinite(out[0][0]).all() and len(set(out[0][0].tolist())) == n_steps
+    for other in out[1:]:
+        for u, v in zip(out[0], other):
+            assert np.array_equal(u, v)
+
+
 @pytest.mark.parametrize("K,amort", [(8, False), (6, True), (3, False)])
 def test_captured_hodina_step_equals_eager_step(K, amort):
     """The enumerated HO-DINA step (k_hodina_m for 5 <= K <= 8, k_hodina otherwise; either guide) replayed from its HIP graph

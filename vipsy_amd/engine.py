@@ -686,6 +686,14 @@ class _EngineBase(object):
             if rows is not None and not isinstance(rows, (list, tuple)) and self.n_local > 0:
                 nb = int(rows.numel())
                 return ("rows", nb, int(b_global) if b_global is not None else nb)
+        if D == 1 and amort and isinstance(self, IrtEngine):
+            # the amortized 1-D guide (VaeIRT x_feature == 1; the reference's Irt2PLMissing.test_ai draws 100 rows a step): the
+            # step kernel's slab sum advances the counter, nothing behind it reads it but Adam
+            if full:
+                return ("full", self.n_local, self.N)
+            if rows is not None and not isinstance(rows, (list, tuple)) and self.n_local > 0:
+                nb = int(rows.numel())
+                return ("rows", nb, int(b_global) if b_global is not None else nb)
         if isinstance(self, HoDinaEngine) and full:
             return ("full", self.n_local, self.N)            # the enumerated HO-DINA step (either guide): three or six launches
         return None
