@@ -51,7 +51,7 @@ typedef struct vx_irt_cfg {
     uint64_t seed;       /* Philox key */
     uint32_t step;       /* Philox counter word 2: optimisation step */
     uint32_t stream;     /* Philox counter word 3 high half: particle index */
-    const uint32_t* step_dev; /* or NULL: the step counter in DEVICE memory -- vx_mvn_enc_forward reads the Philox step from it
+    const uint32_t* step_dev; /* or NULL: the step counter in DEVICE memory -- vx_mvn_enc_forward / vx_mvn_bbvi_forward read the Philox step from it
                             instead of `step`, so that a whole step can be captured once in a HIP graph and replayed
                             (vx_sum2 advances it, vx_adam_step reads it; the D = 1 entry points take it as an argument) */
     const int64_t* rows_ring; /* or NULL.  A captured subsampled step (test.py:338-343: a new draw of B rows every step) needs its

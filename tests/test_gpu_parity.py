@@ -861,6 +861,62 @@ def test_captured_amortized_1d_step_equals_eager_step(N, J, miss, B):
             assert np.array_equal(u, v)
 
 
+@pytest.mark.parametrize("kind", ["cfa_bbvi_d2_rows", "bbvi_d3_share_full", "irt1d_full", "amortized_d100_rows", "hodina_full",
+                                  "vaechodina_rows"])
+def test_captured_particles_equal_eager_particles(kind):
+    """Trace_ELBO(num_particles = S) (the reference's CFA demo: 20 particles of 100 rows, test.py:420-430): the S passes -- every
+    particle its own subsample and its own Philox stream --, their mean and the one optimiser step replayed as ONE HIP graph,
+    against the host loop over the particles: same bits in every loss and every parameter, across a scheduler milestone."""
+    from vipsy_amd.engine import IrtEngine, HoDinaEngine, LrSpec
+    rng = np.random.RandomState(23)
+    n_steps = 7
+    lr_fn = lambda m, p: {"lr": 1e-2 if p in ("a", "b", "g", "s") else 1e-3}
+    if kind == "cfa_bbvi_d2_rows":
+        N, J, S, B = 900, 6, 5, 100
+        y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+        a_free = np.array([[1, 1, 1, 0, 0, 0], [0, 0, 0, 1, 1, 1]], dtype=np.float32)
+        mk = lambda: IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_2pl", D=2, a_free=torch.from_numpy(a_free), a0=torch.from_numpy(a_free), seed=11)
+    elif kind == "bbvi_d3_share_full":
+        N, J, S, B = 400, 20, 3, None
+        y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+        y[rng.rand(N, J) < 0.1] = 255
+        mk = lambda: IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_2pl", D=3, share_cov=True, seed=11)
+    elif kind == "irt1d_full":
+        N, J, S, B = 3000, 40, 3, None
+        y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+        mk = lambda: IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_3pl", D=1, seed=11)
+    elif kind == "amortized_d100_rows":
+        N, J, D, H, S, B = 3000, 500, 100, 64, 2, 100
+        y, _, _ = _random_problem(N, J, D, H, "irt_2pl", 0.1, seed=N + 5)
+        mk = lambda: IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_2pl", D=D, amortized=True, H=H, seed=11)
+    else:
+        N, J, K, S, B = (2000, 30, 6, 2, None) if kind == "hodina_full" else (1000, 30, 5, 4, 20)   # test.py:598-607: 20 rows, 10 particles
+        q = (rng.rand(K, J) < 0.4).astype(np.float32)
+        q[rng.randint(0, K, size=J), np.arange(J)] = 1.0
+        y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+        mk = lambda: HoDinaEngine(torch.from_numpy(y).to(_dev()), q, amortized=kind != "hodina_full", H=64, seed=11)
+    rows_all = [None if B is None else [torch.from_numpy(rng.choice(N, size=B, replace=False).astype(np.int64)) for _ in range(S)]
+                for _ in range(n_steps)]
+    out = []
+    for graph in (True, False):
+        eng = mk()
+        eng.use_graph = graph
+        lrs = LrSpec(lr_fn, milestones=(4,), gamma=0.5)
+        losses = []
+        for t in range(n_steps):
+            losses.append(eng.step(lrs, rows=rows_all[t], b_global=B, num_particles=S))
+            lrs.scheduler_step()
+        torch.cuda.synchronize()
+        assert eng.t == n_steps
+        st = getattr(eng, "_graph", None) or {}
+        assert (st.get("graph") is not None) == graph
+        out.append((torch.stack(losses).cpu().numpy(), eng.P.cpu().numpy().copy(),
+                    eng.PP.cpu().numpy().copy() if eng.per_person else None))
+    assert np.isfinite(out[0][0]).all() and len(set(out[0][0].tolist())) == n_steps
+    for u, v in zip(out[0], out[1]):
+        assert (u is None and v is None) or np.array_equal(u, v)
+
+
 @pytest.mark.parametrize("K,amort", [(8, False), (6, True), (3, False)])
 def test_captured_hodina_step_equals_eager_step(K, amort):
     """The enumerated HO-DINA step (k_hodina_m for 5 <= K <= 8, k_hodina otherwise; either guide) replayed from its HIP graph

@@ -13,7 +13,9 @@
 __global__ __launch_bounds__(BB_THREADS) void k_mvn_bbvi_fwd(
     int D, int64_t nb, const int64_t* __restrict__ rows, int64_t gid0, const float* __restrict__ loc,
     const float* __restrict__ M, int shared, const float* __restrict__ eps_in, uint64_t seed, uint32_t step,
-    uint32_t stream, float* __restrict__ x, float* __restrict__ eps_out, float* __restrict__ ent) {
+    uint32_t stream, float* __restrict__ x, float* __restrict__ eps_out, float* __restrict__ ent,
+    const uint32_t* __restrict__ step_dev = nullptr /*or the step counter in device memory (a captured step)*/) {
+    if (step_dev) step = *step_dev;
     const int lane = threadIdx.x & 63;
     const int64_t nw = (int64_t)gridDim.x * (BB_THREADS / 64);
     for (int64_t i = (int64_t)blockIdx.x * (BB_THREADS / 64) + (threadIdx.x >> 6); i < nb; i += nw) {

@@ -1750,7 +1750,7 @@ int vx_mvn_bbvi_forward(const vx_irt_cfg* cfg, int64_t nb, const int64_t* rows, 
     int64_t blocks = (nb + 3) / 4;
     if (blocks > (int64_t)num_cu() * 8) blocks = (int64_t)num_cu() * 8;
     hipLaunchKernelGGL(k_mvn_bbvi_fwd, dim3((unsigned)blocks), dim3(BB_THREADS), 0, (hipStream_t)hs, (int)cfg->D, nb, rows,
-                       gid0, loc, M, (int)shared, eps_in, cfg->seed, cfg->step, cfg->stream, x, eps, ent);
+                       gid0, loc, M, (int)shared, eps_in, cfg->seed, cfg->step, cfg->stream, x, eps, ent, cfg->step_dev);
     VX_CHECK_LAUNCH();
     return VX_OK;
 }

@@ -667,10 +667,24 @@ class _EngineBase(object):
     graph_max_persons = int(os.environ.get("VX_GRAPH_MAX_PERSONS", "300000"))
 
     def _graph_mode(self, rows, b_global, eps, S):
-        """The captured form this call can replay -- ('full' | 'rows', nb, b_global) -- or None for an eager step."""
-        if not (self.use_graph and S == 1 and eps is None and self.events is None and isinstance(self.be, HipBackend)
+        """The captured form this call can replay -- ('full' | 'rows', nb, b_global) and, with S > 1 particles, S as a fourth
+        entry -- or None for an eager step."""
+        if not (self.use_graph and eps is None and self.events is None and isinstance(self.be, HipBackend)
                 and getattr(self, "estimator", "pathwise") == "pathwise"):
             return None
+        if S > 1:
+            # Trace_ELBO(num_particles = S) (test.py:430: 20, test.py:607: 10): the S passes, their accumulation and the one
+            # optimiser step as ONE graph.  Every particle draws its own subsample (SURVEY.md App. A.2): S host index
+            # tensors of one length, staged with one copy
+            if rows is None:
+                r0 = None
+            elif (isinstance(rows, (list, tuple)) and len(rows) == S and all(torch.is_tensor(r) and not r.is_cuda for r in rows)
+                  and len({int(r.numel()) for r in rows}) == 1):
+                r0 = rows[0]
+            else:
+                return None
+            base = self._graph_mode(r0, b_global, None, 1)
+            return None if base is None else base + (S,)
         D, amort = getattr(self, "D", 0), getattr(self, "amortized", True)
         full = rows is None and (b_global is None or int(b_global) == self.N)
         if D == 1 and not amort and isinstance(self, IrtEngine):
@@ -694,8 +708,20 @@ class _EngineBase(object):
             if rows is not None and not isinstance(rows, (list, tuple)) and self.n_local > 0:
                 nb = int(rows.numel())
                 return ("rows", nb, int(b_global) if b_global is not None else nb)
-        if isinstance(self, HoDinaEngine) and full:
-            return ("full", self.n_local, self.N)            # the enumerated HO-DINA step (either guide): three or six launches
+        if D > 1 and not amort and isinstance(self, IrtEngine):
+            # VIRT with x_feature > 1 (vi.py:706-723; the CFA demo of test.py:420-430 draws 100 rows a particle): the backward
+            # kernel scatters the batch's rows into the zeroed per-person gradients itself
+            if full:
+                return ("full", self.n_local, self.N)
+            if rows is not None and not isinstance(rows, (list, tuple)) and self.n_local > 0:
+                nb = int(rows.numel())
+                return ("rows", nb, int(b_global) if b_global is not None else nb)
+        if isinstance(self, HoDinaEngine):
+            if full:
+                return ("full", self.n_local, self.N)        # the enumerated HO-DINA step (either guide): three or six launches
+            if amort and rows is not None and not isinstance(rows, (list, tuple)) and self.n_local > 0:
+                nb = int(rows.numel())                       # VaeCHoDina on a subsample (test.py:598-607: 20 rows, 10 particles)
+                return ("rows", nb, int(b_global) if b_global is not None else nb)
         return None
 
     def _graphable(self):
@@ -727,6 +753,8 @@ class _EngineBase(object):
         draws) go through a small ring of pinned buffers: one asynchronous copy, no staging allocation, no sync unless the
         GPU is a whole ring behind.  A form whose capture reads the ring itself (st["ring"]: vx_irt_cfg.rows_ring) only has
         the draw written into slot t % slots -- the replay fetches it."""
+        if isinstance(rows, (list, tuple)):                  # S particles, S draws: [S][nb] in one buffer, one copy
+            rows = torch.cat([r.reshape(-1) for r in rows])
         nb = buf.numel()
         if st is not None and st.get("ring") is not None:
             if rows.is_cuda:
@@ -772,13 +800,14 @@ class _EngineBase(object):
                 self._ctr, self._ctr_t = torch.zeros(1, dtype=torch.int32, device=self.dev), None
             rows_buf = None
             ring = None
+            S = mode[3] if len(mode) > 3 else 1
             if mode[0] == "rows":
                 rows_buf = st.get("rows")
                 if rows_buf is None:
-                    rows_buf = torch.zeros(mode[1], dtype=torch.int64, device=self.dev)
+                    rows_buf = torch.zeros(mode[1] * S, dtype=torch.int64, device=self.dev)
                 self._stage_rows(rows, rows_buf)             # valid indices while the capture records
                 ring = st.get("ring")
-                if ring is None and not rows.is_cuda:
+                if ring is None and S == 1 and not rows.is_cuda:
                     ring = torch.zeros(self.rows_ring_slots, max(int(mode[1]), 1), dtype=torch.int64).pin_memory()
             one = self._one_graph()
             torch.cuda.synchronize()
@@ -790,7 +819,13 @@ class _EngineBase(object):
                 # (thread-local capture mode: a process group's watchdog thread may query its events while this thread records)
                 with torch.cuda.graph(gA, capture_error_mode="thread_local"):
                     # reads the counter as the Philox step, then advances it
-                    if one:
+                    if S > 1:
+                        self._particles(S, lambda sidx: None if rows_buf is None else rows_buf[sidx * mode[1]:(sidx + 1) * mode[1]],
+                                        mode[2] if mode[0] == "rows" else None, lambda sidx: None)
+                        if one:
+                            self.allreduce()
+                            self.apply_optim(lrs)
+                    elif one:
                         self._grads_and_optim(lrs, rows_buf, mode[2] if mode[0] == "rows" else None)   # (Adam's t: the counter)
                     else:
                         self.loss_and_grads(rows_buf, mode[2] if mode[0] == "rows" else None, None, 0)
@@ -947,6 +982,24 @@ class _EngineBase(object):
                 self._graph = None
             st.clear()                                       # releases the CUDAGraph objects (and their pool) and the rows buffer
 
+    def _particles(self, S, rows_of, b_global, eps_of):
+        """S passes of loss_and_grads (particle sidx = Philox stream sidx) and their mean in G / GP: surrogate / num_particles
+        (SURVEY.md App. B.2).  While a capture records, every pass's last launch advances the device step counter: it is set
+        back behind all but the last, so that the S particles share the step and the optimiser sees step + 1."""
+        accG = torch.zeros_like(self.G)
+        accP = torch.zeros_like(self.GP) if self.per_person else None
+        sd = getattr(self, "_step_dev", None)
+        for sidx in range(S):
+            self.loss_and_grads(rows_of(sidx), b_global, eps_of(sidx), sidx)
+            if sd is not None and sidx < S - 1:
+                sd.sub_(1)
+            accG.add_(self.G, alpha=1.0 / S)
+            if accP is not None:
+                accP.add_(self.GP, alpha=1.0 / S)
+        self.G.copy_(accG)
+        if accP is not None:
+            self.GP.copy_(accP)
+
     def _rows_on_device(self, rows):
         """Host row indices (the fit loop's draw) for an eager step."""
         if rows is None or isinstance(rows, (list, tuple)):
@@ -986,18 +1039,8 @@ class _EngineBase(object):
                                   eps[0] if isinstance(eps, (list, tuple)) else eps)
             return self.step_loss()
         else:
-            accG = torch.zeros_like(self.G)
-            accP = torch.zeros_like(self.GP) if self.per_person else None
-            for sidx in range(S):
-                r = rows[sidx] if isinstance(rows, (list, tuple)) else rows
-                e = eps[sidx] if isinstance(eps, (list, tuple)) else eps
-                self.loss_and_grads(r, b_global, e, sidx)
-                accG.add_(self.G, alpha=1.0 / S)                 # surrogate / num_particles (App. B.2)
-                if accP is not None:
-                    accP.add_(self.GP, alpha=1.0 / S)
-            self.G.copy_(accG)
-            if accP is not None:
-                self.GP.copy_(accP)
+            self._particles(S, lambda sidx: rows[sidx] if isinstance(rows, (list, tuple)) else rows, b_global,
+                            lambda sidx: eps[sidx] if isinstance(eps, (list, tuple)) else eps)
         with self._phase("allreduce"):
             self.allreduce()
         with self._phase("optimizer"):
@@ -1181,7 +1224,7 @@ class IrtEngine(_EngineBase):
                                      self._buf("bbvi_ws", be.mvn_bbvi_bwd_workspace(cfg, nb, self.share_cov)))
                 if self.estimator == "score":
                     be.mvn_score_diag(cfg, nb, rows, w_sf, self.share_cov, gM)
-            be.sum2_into(ll, fw["ent"], nb, -scale, lossslot, self.sum_ws)        # loss = -scale * sum_i (ll_i + ent_i)
+            be.sum2_into(ll, fw["ent"], nb, -scale, lossslot, self.sum_ws, **sdc)   # loss = -scale * sum_i (ll_i + ent_i)
             self.last = {"fw": fw, "gx": gx, "ll": ll, "nb": nb}
         elif self.D > 1:
             D, H = self.D, self.H
