@@ -862,7 +862,7 @@ def test_captured_amortized_1d_step_equals_eager_step(N, J, miss, B):
 
 
 @pytest.mark.parametrize("kind", ["cfa_bbvi_d2_rows", "bbvi_d3_share_full", "irt1d_full", "amortized_d100_rows", "hodina_full",
-                                  "vaechodina_rows"])
+                                  "vaechodina_rows", "irt1d_rows"])
 def test_captured_particles_equal_eager_particles(kind):
     """Trace_ELBO(num_particles = S) (the reference's CFA demo: 20 particles of 100 rows, test.py:420-430): the S passes -- every
     particle its own subsample and its own Philox stream --, their mean and the one optimiser step replayed as ONE HIP graph,
@@ -881,8 +881,8 @@ def test_captured_particles_equal_eager_particles(kind):
         y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
         y[rng.rand(N, J) < 0.1] = 255
         mk = lambda: IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_2pl", D=3, share_cov=True, seed=11)
-    elif kind == "irt1d_full":
-        N, J, S, B = 3000, 40, 3, None
+    elif kind in ("irt1d_full", "irt1d_rows"):
+        N, J, S, B = (3000, 40, 3, None) if kind == "irt1d_full" else (3000, 40, 2, 100)
         y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
         mk = lambda: IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_3pl", D=1, seed=11)
     elif kind == "amortized_d100_rows":

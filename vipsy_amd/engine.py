@@ -688,7 +688,12 @@ class _EngineBase(object):
         D, amort = getattr(self, "D", 0), getattr(self, "amortized", True)
         full = rows is None and (b_global is None or int(b_global) == self.N)
         if D == 1 and not amort and isinstance(self, IrtEngine):
-            return ("full", self.n_local, self.N) if full else None       # per-person rows: a subsample scatters dense gradients
+            if full:
+                return ("full", self.n_local, self.N)
+            if rows is not None and not isinstance(rows, (list, tuple)) and self.n_local > 0:
+                nb = int(rows.numel())                       # a subsample: the rows' gradients are scattered into zeroed dense ones
+                return ("rows", nb, int(b_global) if b_global is not None else nb)
+            return None
         if D > 1 and amort and isinstance(self, IrtEngine):
             if full:
                 # a large shard runs short kernels BESIDE long ones on a second stream (the last chip round of the forward and
