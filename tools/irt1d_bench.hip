@@ -37,7 +37,7 @@ static float run(int J, int64_t nb, int64_t n_rows_src, bool use_rows, bool chec
     CK(hipMalloc(&y, hy.size())); CK(hipMalloc(&l, nb * 4)); CK(hipMalloc(&r, nb * 4)); CK(hipMalloc(&e, nb * 4));
     CK(hipMalloc(&a, J * 4)); CK(hipMalloc(&b, J * 4)); CK(hipMalloc(&c, J * 4)); CK(hipMalloc(&d, J * 4));
     CK(hipMalloc(&gl, nb * 4)); CK(hipMalloc(&gr, nb * 4)); CK(hipMalloc(&el, nb * 4)); CK(hipMalloc(&rows, nb * 8));
-    CK(hipMalloc(&slabs, (size_t)blocks * (4 * J + 1) * 4));
+    CK(hipMalloc(&slabs, ((size_t)blocks * (4 * J + 1) + 4) * 4));     // (+ the word the kernels leave behind the slabs)
     CK(hipMemcpy(y, hy.data(), hy.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(l, hl.data(), nb * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(r, hr.data(), nb * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(e, he.data(), nb * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(a, ha.data(), J * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(b, hb.data(), J * 4, hipMemcpyHostToDevice));
