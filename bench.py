@@ -82,6 +82,9 @@ def kernel_model(name, J, D, H):
         # three bf16 terms = three products per f32 product
         bf16x3 = "response bytes exact in bf16 x three bf16 terms of the f32 operand: three products on the bf16 MFMA, fp32 accumulate"
         table = {"k_norm_enc_fwd_b": (2.0 * J * H, PEAK_BF16_MFMA_TFLOPS / 3.0, bf16x3),
+                 # round 5 (batches from 4 096 persons on): W1 as two fp16 terms against the exact response bytes
+                 "k_norm_enc_fwd_h": (2.0 * J * H, PEAK_BF16_MFMA_TFLOPS / 2.0,
+                                      "response bytes exact in fp16 x two fp16 terms of W1: two products on the fp16 MFMA, fp32 accumulate"),
                  "k_fc1_bwd_c": (2.0 * J * H, PEAK_BF16_MFMA_TFLOPS / 3.0, bf16x3)}
     return table.get(name)
 
