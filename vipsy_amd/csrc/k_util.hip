@@ -267,6 +267,30 @@ __device__ __forceinline__ void adam_one(const AdamBuf& buf, const AdamSegs& seg
     buf.p[i] = buf.p[i] - (lr / bc1) * (mi / denom);
 }
 
+// the same update in two halves, so that a launch that still has to SUM the gradient has Adam's operands in flight meanwhile
+// (one memory round trip instead of two behind each other)
+struct AdamOperands { float p, m, v, fm, lr; bool found; };
+__device__ __forceinline__ AdamOperands adam_fetch(bool on, const AdamBuf& buf, const AdamSegs& segs, int64_t i) {
+    AdamOperands o{0.f, 0.f, 0.f, 1.f, 0.f, false};
+    if (!on) return o;
+    for (int s = 0; s < segs.n; ++s)
+        if (i >= segs.begin[s] && i < segs.end[s]) { o.lr = segs.lr[s]; o.found = true; }
+    if (!o.found) return o;
+    o.p = buf.p[i]; o.m = buf.m[i]; o.v = buf.v[i];
+    if (buf.free_mask) o.fm = buf.free_mask[i];
+    return o;
+}
+__device__ __forceinline__ void adam_finish(const AdamBuf& buf, int64_t i, float gi, const AdamOperands& o, float beta1, float beta2,
+                                            float eps, float bc1, float bc2_sqrt) {
+    if (!o.found) return;
+    if (buf.free_mask) gi *= o.fm;
+    const float mi = beta1 * o.m + (1.f - beta1) * gi;
+    const float vi = beta2 * o.v + (1.f - beta2) * gi * gi;
+    buf.m[i] = mi; buf.v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    buf.p[i] = o.p - (o.lr / bc1) * (mi / denom);
+}
+
 // The tail of a D = 1 step on ONE rank in ONE launch (k_reduce_wide + k_adam2, 5 us each at BASELINE config 2, a quarter of
 // its step): blocks [0, n_red) sum the slabs column by column exactly as k_reduce_wide<COLS> does -- and hand every finished
 // column straight to Adam (buffer A = the item leaves, gA = out) or, the last column, to the loss slot and the loss ring;
@@ -300,6 +324,7 @@ __global__ __launch_bounds__(1024) void k_reduce_adam(const float* __restrict__ 
         return;
     }
     const int col = threadIdx.x % COLS, grp = threadIdx.x / COLS;
+    AdamOperands ops;
     auto finish = [&](int64_t i, float t) __attribute__((always_inline)) {
         const float g = alpha * t;
         if (last_out && i == len - 1) {
@@ -307,11 +332,13 @@ __global__ __launch_bounds__(1024) void k_reduce_adam(const float* __restrict__ 
             if (loss_ring) loss_ring[tt & (VX_LOSS_RING - 1)] = g;
         } else {
             out[i] = g;
-            adam_one(A, sA, i, g, beta1, beta2, eps, bc1, bc2_sqrt);
+            adam_finish(A, i, g, ops, beta1, beta2, eps, bc1, bc2_sqrt);
         }
     };
     for (int64_t c0 = (int64_t)blockIdx.x * COLS; c0 < len; c0 += (int64_t)n_red * COLS) {
         const int64_t i = c0 + col;
+        // (Adam's operands of this column in flight under the slab sum)
+        ops = adam_fetch(grp == 0 && i < len && !(last_out && i == len - 1), A, sA, i);
         float acc = 0.f;
         if (i < len) {
 #pragma unroll 8
