@@ -78,38 +78,6 @@ __global__ __launch_bounds__(LR_THREADS) void k_irt_lik_r(
     const bool jv = jw < J;
     const int64_t n_ptiles = (dm.nb + LR_P - 1) / LR_P;
 
-    // ---- register-resident item operands
-    float aZ[NQ][4], aG[16][4];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = 8 * q + 4 * half + i;
-            float v = 0.f;
-            if (jv) {
-                if (k < D) v = a[(int64_t)k * J + jw];
-                else if (k == D) v = b[jw];
-            }
-            aZ[q][i] = dm.Dc * v;                         // z = Dc * (x.a + b)
-        }
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int kg = 32 * wave + l31, j = j0 + 8 * q + 4 * half + i;
-            aG[q][i] = (kg < D && j < J) ? a[(int64_t)kg * J + j] : 0.f;
-        }
-    float cj = 0.f, dj = 1.0f, omdj = 0.f, gc = 0.f, gd = 0.f;
-    if (GEN) {
-        cj = jv ? fminf(sigmoidf_(c_un[jw]), 1.0f - VX_EPS32) : 0.f;
-        const bool has_d = (dm.model == 4 && jv);
-        dj = has_d ? fminf(sigmoidf_(d_un[jw]), 1.0f - VX_EPS32) : 1.0f;
-        omdj = has_d ? fmaxf(sigmoidf_(-d_un[jw]), VX_EPS32) : 0.f;
-    }
-    f32x16 ga[4];
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) ga[kt] = zero16();
-
     // ---- staging of one person tile: global -> registers (stage_load), registers -> LDS (stage_store)
     // Staging of one person tile.  FAST (D % 4 == 0, J % 4 == 0, aligned bases): global -> LDS DMA, no registers,
     // issued from phase D of the previous tile and waited for (vmcnt) just before the barrier that opens the tile.
@@ -244,6 +212,41 @@ __global__ __launch_bounds__(LR_THREADS) void k_irt_lik_r(
     f32x16 gx1 = zero16();                                 // gx of persons 32..63: stored one tile late (see S1)
     int64_t i0_prev = -1;
     if (tile < n_ptiles) stage(tile, 0);
+    // (the item operands are fetched BEHIND the first tile's transfers: in front of them the barrier that orders the pad fills
+    // against the transfers also waited for these 116 loads, and a workgroup with one tile -- the reference's B = 100 step --
+    // had the two latencies one after the other)
+    // ---- register-resident item operands
+    float aZ[NQ][4], aG[16][4];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = 8 * q + 4 * half + i;
+            float v = 0.f;
+            if (jv) {
+                if (k < D) v = a[(int64_t)k * J + jw];
+                else if (k == D) v = b[jw];
+            }
+            aZ[q][i] = dm.Dc * v;                         // z = Dc * (x.a + b)
+        }
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kg = 32 * wave + l31, j = j0 + 8 * q + 4 * half + i;
+            aG[q][i] = (kg < D && j < J) ? a[(int64_t)kg * J + j] : 0.f;
+        }
+    float cj = 0.f, dj = 1.0f, omdj = 0.f, gc = 0.f, gd = 0.f;
+    if (GEN) {
+        cj = jv ? fminf(sigmoidf_(c_un[jw]), 1.0f - VX_EPS32) : 0.f;
+        const bool has_d = (dm.model == 4 && jv);
+        dj = has_d ? fminf(sigmoidf_(d_un[jw]), 1.0f - VX_EPS32) : 1.0f;
+        omdj = has_d ? fmaxf(sigmoidf_(-d_un[jw]), VX_EPS32) : 0.f;
+    }
+    f32x16 ga[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) ga[kt] = zero16();
+
     for (; tile < n_ptiles; tile += dm.n_pr, buf ^= 1) {
         // this wave's DMA of the tile has landed.  The wait also covers older stores: the only recent ones would be
         // the gx of persons 32..63, which is why that store is deferred to just after this barrier.
