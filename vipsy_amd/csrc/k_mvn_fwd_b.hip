@@ -353,7 +353,12 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
     const int n_off = pk_off_total(D) / 32;                   // multiple of 6
     const int n_sec = pk_sec(D) / 32;
     const int t_end = n_off + 2 * n_sec;
-    for (int e = tid; e < 4 * n_off; e += FB_THREADS) gt_lds[e] = gt2[e];   // published by the barrier before the OFF loop
+    // the OFF group table: fetched NOW into registers, written to LDS behind the response staging (published by the barrier
+    // before the OFF loop) -- a load + LDS store here made the kernel wait one memory latency before it asked for anything else
+    constexpr int FB_GQ = 5;                                  // 4 n_off <= 1 080 words (D <= 128) over 256 threads
+    uint32_t gtv[FB_GQ];
+#pragma unroll
+    for (int q = 0; q < FB_GQ; ++q) { const int e = tid + q * FB_THREADS; gtv[q] = e < 4 * n_off ? gt2[e] : 0u; }
     const float w1_inv = sc[1], h_scale = sc[3], acc_inv = sc[4];
 
     // ---------------------------------------------------------------- stage this wave's response rows (bytes)
@@ -462,6 +467,8 @@ __global__ __launch_bounds__(FB_THREADS, 1) void k_mvn_enc_fwd_b(
             }
         }
     }
+#pragma unroll
+    for (int q = 0; q < FB_GQ; ++q) { const int e = tid + q * FB_THREADS; if (e < 4 * n_off) gt_lds[e] = gtv[q]; }
     __builtin_amdgcn_wave_barrier();
     FSTAMP();                                                 // 1: responses staged, normals drawn
     // ---------------------------------------------------------------- phase A: fc1 (+ softplus), both hidden tiles
