@@ -103,3 +103,29 @@ def test_bench_self_launch_two_ranks():
     assert len(line) == 1
     d = json.loads(line[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["persons_per_rank"] == 32768
+
+
+def test_rccl_one_rank_group():
+    """RCCL itself on the box this suite runs on: a ONE-rank process group with backend nccl (a GPU box of the builder's pool
+    has one card, and RCCL refuses two ranks on one device).  The all-reduce is then the identity, so the sharded code path --
+    kernel by kernel, two graph replays around the eager all-reduce (a capture beside a live communicator), and the collective
+    captured INTO the step's graph (VX_GRAPH_COLLECTIVE=1) -- must reproduce the group-less run bit for bit.  What it cannot
+    show is the transport between GPUs.  Skips when the communicator cannot be made."""
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_SOCKET_IFNAME="lo")
+    try:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_one_rank.py"), "29761"], env=env, capture_output=True,
+                           text=True, timeout=600)
+    except subprocess.TimeoutExpired:
+        pytest.skip("the one-rank RCCL communicator did not come up within ten minutes on this box")
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if p.returncode != 0 and not lines:
+        pytest.skip("the one-rank RCCL worker ended with code %d: %s" % (p.returncode, p.stderr[-500:]))
+    out = json.loads(lines[-1])
+    if "skip" in out:
+        pytest.skip("no RCCL communicator on this box: " + out["skip"])
+    assert out["backend"] == "nccl"
+    for name in ("eager", "two_replays", "captured_collective"):
+        m = out["modes"][name]
+        assert "error" not in m, (name, m)
+        assert m["same_losses"] and m["same_params"], (name, m)
+    assert out["modes"]["two_replays"]["fallback"] is None     # the capture beside the live communicator did not fall back
