@@ -38,7 +38,9 @@ __host__ __device__ inline size_t f1c_lds_bytes() { return F1C_NBUF * (size_t)F1
 #endif
 #define F1C_WAVES (16 / F1C_NT)
 #define F1C_THREADS (64 * F1C_WAVES)
-template <bool F16>
+// TILED: the responses come from a TILE-MAJOR copy, [chunk of 64 persons][J][64 bytes] (ystride unused): a workgroup's 512 item
+// rows of a chunk are one contiguous 32 KB instead of 64-byte pieces of rows a whole batch apart.
+template <bool F16, bool TILED = false>
 __global__ __launch_bounds__(F1C_THREADS, 1) void k_fc1_bwd_c(
     EncDims dm, const uint8_t* __restrict__ yT, int64_t ystride, const float* __restrict__ ghpreT,
     float* __restrict__ slabs, int64_t slab_len, const uint32_t* __restrict__ maxw = nullptr /*F16: float bits, [3] = max |ghpre|*/) {
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(F1C_THREADS, 1) void k_fc1_bwd_c(
         const int d = wave + NW * u, row = 16 * d + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
         // (rows of the bias column and past it are never read as data: their transfers re-read row 0, so that every wave
         // issues the same number of transfers a chunk)
-        ysrc[u] = (const char*)(yT + (int64_t)(jb0 + row < J ? jb0 + row : 0) * ystride + 16 * c);
+        ysrc[u] = (const char*)(yT + (int64_t)(jb0 + row < J ? jb0 + row : 0) * (TILED ? (int64_t)F1C_PC : ystride) + 16 * c);
     }
     auto stage = [&](int64_t ch, int b) __attribute__((always_inline)) {
         const int64_t p0 = ch * F1C_PC;
@@ -108,7 +110,8 @@ __global__ __launch_bounds__(F1C_THREADS, 1) void k_fc1_bwd_c(
 #pragma unroll
         for (int u = 0; u < NY; ++u) {                                  // (a yT row is ystride bytes long: nothing is read past it)
             const int row = 16 * (wave + NW * u) + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
-            if (whole || p0 + 16 * c + 16 <= ystride) dma16(ysrc[u] + p0, lb + (uint32_t)F1C_GBYTES + (uint32_t)u * (1024u * NW));
+            if constexpr (TILED) dma16(ysrc[u] + ch * (int64_t)J * F1C_PC, lb + (uint32_t)F1C_GBYTES + (uint32_t)u * (1024u * NW));
+            else if (whole || p0 + 16 * c + 16 <= ystride) dma16(ysrc[u] + p0, lb + (uint32_t)F1C_GBYTES + (uint32_t)u * (1024u * NW));
         }
     };
 
