@@ -64,7 +64,7 @@ static float run(int D, int J, int64_t nb, int model, int n_pr_req, bool check, 
     CK(hipEventSynchronize(e2));
     CK(hipGetLastError());
     if (reps > 0) { hipEventElapsedTime(&ms, e1, e2); ms /= reps; }
-    hipLaunchKernelGGL(k_lik_reduce_parts, dim3((unsigned)n_ptiles), dim3(256), 0, 0, gxp, llp, x, dm.groups, D, nb, nbp, dm.scale, gxT, llo);
+    hipLaunchKernelGGL(k_lik_reduce_parts, dim3((unsigned)n_ptiles), dim3(256), (size_t)64 * (D | 1) * sizeof(float), 0, gxp, llp, x, dm.groups, D, nb, nbp, dm.scale, gxT, llo);
     CK(hipDeviceSynchronize());
     (void)ms_img;
     if (check) {

@@ -842,7 +842,7 @@ static int irt_lik_grad_kernels(const vx_irt_cfg* cfg, const uint8_t* y, const i
         }
         VX_CHECK_LAUNCH();
         gd_done = true;
-        hipLaunchKernelGGL(k_lik_reduce_parts, dim3((unsigned)n_ptiles), dim3(256), 0, st, (const float*)gx_part, (const float*)ll_part,
+        hipLaunchKernelGGL(k_lik_reduce_parts, dim3((unsigned)n_ptiles), dim3(256), (size_t)64 * (cfg->D | 1) * sizeof(float), st, (const float*)gx_part, (const float*)ll_part,
                            x, groups, (int)cfg->D, nb, nbp, cfg->scale, gxT, ll, epsT, ldT, gdT, opmax);
         VX_CHECK_LAUNCH();
         if (gx) {                                          // both orders requested: gx[nb][D] = transpose(gxT[D][nb])
