@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     # the ctypes binding covers exactly the declared surface
     assert sorted(_hip.SIGNATURES) == declared
     lib = _hip.lib()
-    assert lib.vx_abi_version() == 4
+    assert lib.vx_abi_version() == _hip.ABI_VERSION
     assert b"gfx950" in lib.vx_build_info()
 
 

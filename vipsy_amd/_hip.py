@@ -9,7 +9,10 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libvipsy_hip.so")
+# VX_LIB names another build of the same sources (tests/test_gpu_schedules.py runs the oracle comparisons against a library
+# compiled with a different instruction schedule: a hazard that only one schedule hides must show in the other)
+LIB_PATH = os.environ.get("VX_LIB") or os.path.join(_HERE, "_lib", "libvipsy_hip.so")
+ABI_VERSION = 4         # include/vipsy_amd.h: VX_ABI_VERSION (struct layouts and argument lists this binding was written for)
 
 
 class VxError(RuntimeError):
@@ -142,8 +145,19 @@ def lib():
             handle = ctypes.CDLL(LIB_PATH)
         except OSError as e:  # pragma: no cover
             raise VxError("cannot load %s: %s" % (LIB_PATH, e))
+        try:
+            handle.vx_abi_version.restype = ctypes.c_int
+            abi = handle.vx_abi_version()
+        except AttributeError:
+            raise VxError("%s does not export vx_abi_version -- not a vipsy_amd library" % LIB_PATH)
+        if abi != ABI_VERSION:
+            raise VxError("%s has ABI %d, this binding expects %d -- rebuild (`make -C vipsy_amd/csrc`)" %
+                          (LIB_PATH, abi, ABI_VERSION))
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(handle, name)
+            try:
+                fn = getattr(handle, name)
+            except AttributeError:
+                raise VxError("%s lacks %s -- stale build, rebuild (`make -C vipsy_amd/csrc`)" % (LIB_PATH, name))
             fn.restype = res
             fn.argtypes = args
         _lib = handle

@@ -34,12 +34,6 @@ __host__ __device__ inline size_t hm_lds_bytes(int NT) {
     return (img > red ? img : red) + 32 * 3 * 16 + (size_t)HM_WAVES * 32 * HM_YS;
 }
 
-__device__ __forceinline__ float hm_swap32(float v) {                     // the partner lane's value (lane ^ 32)
-    unsigned a = __builtin_bit_cast(unsigned, v), b;
-    asm("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "=&v"(b));
-    return __builtin_bit_cast(float, (threadIdx.x & 32) ? a : b) ;
-}
-
 // two bf16 terms of eight fp32 values (round to nearest): v = hi + mid up to 2^-17 relative
 __device__ __forceinline__ void hm_split2(const float (&v)[8], bf16x8& fh, bf16x8& fm) {
 #pragma unroll
@@ -241,11 +235,10 @@ __global__ __launch_bounds__(HM_THREADS, 2) void k_hodina_m(
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, __builtin_amdgcn_fmed3f(a[r], LE, LH) + b[r]);
         }
-        mx = fmaxf(mx, hm_swap32(mx));
-        // keep the two passes apart in the schedule.  With one tile (K = 5) the loops are straight-line code and the
-        // compiler slides pass 2's products between pass 1's reads of its accumulators; that interleaving returned wrong
-        // gradients on gfx950 (measured: tools/dbg_hm.py, fixed by this barrier alone), so it is not left to the scheduler
-        __builtin_amdgcn_sched_barrier(0);
+        mx = fmaxf(mx, half_swap32(mx));
+        // (Rounds 2-5 kept a sched_barrier here: with one tile the passes are straight-line code, the scheduler slides pass 2's
+        // products up between pass 1's reads, and the gradients came out wrong.  What was wrong was not the interleaving but
+        // the swap's scratch register inside an accumulator in flight -- vx_common.h, permlane32_swap; docs/HARDWARE.md rule 40.)
         const float moff = -mx * L2E;                                     // exp(F - mx') = exp2(F log2 e + moff), mx' = -moff / log2 e
         // ---- pass 2: posterior weights and the backward products; the forward accumulators are the B operand as they stand
         f32x16 aE = zero16(), aT = zero16();

@@ -339,12 +339,30 @@ __device__ __forceinline__ void atomic_max_raise(uint32_t* w, float v) {
     const uint32_t b = __builtin_bit_cast(uint32_t, v);
     if (b > *(volatile const uint32_t*)w) atomicMax(w, b);
 }
-// v[lane & 31] + v[(lane & 31) + 32] in every lane: gfx950 v_permlane32_swap (VALU, no LDS round trip).
-// (the clang builtin for it mis-assigns its second result on this toolchain, hence the asm)
+// The partner half's value: after `v_permlane32_swap_b32 a, b` lanes 0..31 of `b` hold what lanes 32..63 of `a` held and lanes
+// 32..63 of `a` what lanes 0..31 of `b` held (gfx950, VALU: no LDS round trip).  The clang builtin mis-assigns its second
+// result on this toolchain, hence the asm -- and the asm must not OWN a register: hipcc checks nothing an asm statement
+// writes against MFMAs in flight (docs/HARDWARE.md rule 40).  A scratch output ("=&v") was free to land in the dead upper
+// registers of an accumulator whose MFMA had just been issued (k_hodina_m reads 5 of the 16 registers of its attribute
+// product); the MFMA then wrote its result over the copy several passes later and the swap returned garbage for those
+// lanes -- in one schedule, not in the next.  Both operands are therefore read-write and initialised by compiler-visible
+// code: the compiler pads ITS write against the MFMA (12 states behind a 32x32x16 product), after which the register is
+// live and nothing in flight can still write it.  The two wait states a vector write needs in front of a permlane swap
+// open the statement.
+__device__ __forceinline__ void permlane32_swap(unsigned& a, unsigned& b) {
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+// v[lane & 31] + v[(lane & 31) + 32] in every lane
 __device__ __forceinline__ float half_sum32(float v) {
-    unsigned a = __builtin_bit_cast(unsigned, v), b;
-    asm("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "=&v"(b));
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    permlane32_swap(a, b);
     return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+// the partner lane's value (lane ^ 32)
+__device__ __forceinline__ float half_swap32(float v) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    permlane32_swap(a, b);
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? a : b);
 }
 __device__ __forceinline__ float lane_bcast(float v, int lane_uniform) {      // lane index must be wave-uniform
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane_uniform));
