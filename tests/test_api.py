@@ -9,7 +9,7 @@ def test_surface_matches_reference_names():
     from vipsy_amd import vi
     for n in ("VIRT", "VaeIRT", "VCHoDina", "VaeCHoDina", "VCDM", "VaeCDM", "VCCDM", "VaeCCDM", "Adam", "MultiStepLR",
               "Trace_ELBO", "TraceEnum_ELBO", "param", "clear_param_store", "rmse_", "Irt2PL", "Irt4PL", "IrtMultiDim",
-              "HoDina", "RandomIrt1PL", "RandomIrt2PL", "RandomIrt3PL", "RandomIrt4PL", "RandomMilIrt2PL", "RandomMilIrt3PL",
+              "HoDina", "Dina", "RandomIrt1PL", "RandomIrt2PL", "RandomIrt3PL", "RandomIrt4PL", "RandomMilIrt2PL", "RandomMilIrt3PL",
               "RandomMilIrt4PL", "RandomDina", "RandomDino", "RandomHoDina"):
         assert hasattr(vi, n), n
     spec2 = vi.Adam(lambda m, n: {"lr": 1e-2, "betas": (0.8, 0.9), "eps": 1e-6} if n == "a" else {"lr": 1e-3}).spec()

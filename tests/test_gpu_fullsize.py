@@ -12,7 +12,19 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import vi_oracle as vo          # the checker (tests only)
+
 pytestmark = pytest.mark.gpu
+
+N_SAMPLE = 4096
+
+
+def _sample_rows(N, seed):
+    """4 096 persons of the 1M: random ones, the first 64, and the LAST 256 (the end of every buffer; 64-bit offsets of the
+    5 050-row x 1M-person arrays only go wrong out there)."""
+    rng = np.random.RandomState(seed)
+    idx = np.concatenate([rng.choice(N - 320, N_SAMPLE - 320, replace=False) + 64, np.arange(64), np.arange(N - 256, N)])
+    return np.sort(idx)
 
 
 def _dev():
@@ -50,6 +62,7 @@ def test_cfg3_headline_sharding_additivity_and_determinism():
     full.loss_and_grads()
     torch.cuda.synchronize()
     assert np.array_equal(_flat(full), g_full)
+    _check_cfg3_sample_against_oracle(full, y, N, J, D, H)
     # two shards of 500k persons
     acc = np.zeros_like(g_full)
     for s in range(2):
@@ -63,6 +76,53 @@ def test_cfg3_headline_sharding_additivity_and_determinism():
     scale = np.abs(g_full).max()
     assert np.abs(acc[:-1] - g_full[:-1]).max() <= 2e-4 * scale
     assert acc[-1] == pytest.approx(g_full[-1], rel=2e-5)
+
+
+def _check_cfg3_sample_against_oracle(eng, y, N, J, D, H):
+    """The judged size against the oracle, on a sample: everything the step computes PER PERSON -- h, x, ent of the guide
+    (vi.py:448-455, 686-693), the person's log-likelihood + prior term and d ELBO / d x (vi.py:32-41, 596-625) -- depends on
+    that person's responses and draws alone, so 4 096 of the 1M persons cost a 4 096-person oracle call (float64, the kernel's
+    own Philox draws, which are themselves compared with the oracle's generator).  Tolerances: those of
+    tests/test_gpu_parity.py::test_headline_large_batch_kernels_vs_oracle (2e-5 of the range; 3e-5 of the tensor's max for
+    the gradient rows)."""
+    idx = _sample_rows(N, 11)
+    it = torch.from_numpy(idx).to(y.device)
+    fw = eng.last["fw"]
+    ys = y[it].cpu().numpy()
+    eps = fw["eps"][:N * D].reshape(N, D)[it].cpu().numpy()
+    np.testing.assert_allclose(eps, vo.philox_normals(1234, 0, 0, idx, D), atol=2e-5)
+    params = {n: eng.unconstrained(n).cpu().numpy().astype(np.float64) for n in eng.names()}
+    W = {k: params["encoder$$$" + k] for k in vo.ENC_KEYS}
+    loc, raw, cache = vo.enc_forward(W, vo.enc_input(ys, np.float64))
+    ec = eps.astype(np.float64)
+    x_o, col0, msum = loc.copy(), 0, np.zeros(len(idx))
+    for k in range(D):                                  # row k of L (vi.py:452-454): raw[(k, 0..k-1)], exp on the diagonal
+        x_o[:, k] += (raw[:, col0:col0 + k] * ec[:, :k]).sum(1) + np.exp(raw[:, col0 + k]) * ec[:, k]
+        msum += raw[:, col0 + k]
+        col0 += k + 1
+    ent_o = 0.5 * (ec ** 2).sum(1) + msum
+    ll_o, g = vo.irt_loglik("irt_2pl", x_o, params["a"], params["b"], None, None, 1.0, ys)
+    ll_o = ll_o - 0.5 * (x_o ** 2).sum(1)               # + the N(0, I) prior on x without its constant (vi.py:607-613)
+    gx_o = g["x"] - x_o                                 # plate scale 1 (full batch)
+    x_h = fw["x"][:N * D].reshape(N, D)[it].cpu().numpy()
+    h_h = fw["h"][:N * H].reshape(N, H)[it].cpu().numpy()
+    np.testing.assert_allclose(h_h, cache[2], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(x_h, x_o, atol=2e-5 * max(1.0, np.abs(x_o).max()), rtol=1e-5)
+    np.testing.assert_allclose(fw["ent"][:N][it].cpu().numpy(), ent_o, atol=2e-5 * max(1.0, np.abs(ent_o).max()), rtol=1e-5)
+    # cells whose float32 logit and float64 logit lie on different sides of the Bernoulli clamp move a person's ll by up to
+    # 1.2e-7 and a gx row by |a|: leave out the persons with such a cell (a dozen of 2 M cells at slopes of 1)
+    z = x_o @ params["a"] + params["b"]
+    zc = float(np.log((1.0 - vo.EPS32) / vo.EPS32))
+    clear = ~((np.abs(np.abs(z) - zc) < 1e-3 * np.abs(z)) & (ys != 255)).any(1)
+    assert clear.mean() > 0.9
+    ll_h = eng.last["ll"][:N][it].cpu().numpy()
+    np.testing.assert_allclose(ll_h[clear], ll_o[clear], rtol=3e-5, atol=3e-5 * np.abs(ll_o).max())
+    gx_h = eng.last["gxT"][:N * D].reshape(D, N)[:, it].t().cpu().numpy()
+    sc = np.abs(gx_o[clear]).max()
+    err = np.abs(gx_h[clear] - gx_o[clear]).max() / sc
+    print("cfg3 at 1M persons, %d sampled persons (%d clear of the clamp): gx rows within %.2e of the tensor's max" %
+          (len(idx), int(clear.sum()), err))
+    assert err < 3e-5, err
 
 
 def test_cfg4_bbvi_missing90_sharding_additivity():
@@ -81,6 +141,20 @@ def test_cfg4_bbvi_missing90_sharding_additivity():
     full.loss_and_grads()                                   # determinism: a repeated step is bit-identical
     torch.cuda.synchronize()
     assert np.array_equal(_flat(full), g_full) and np.array_equal(full.GP.double().cpu().numpy(), gp_full)
+    # the judged size against the oracle, on a sample: the per-person gradient rows (d loss / d x_local, d x_scale;
+    # vi.py:698-705) of 4 096 persons from a 4 096-person oracle call with the same parameters and the same Philox draws
+    idx = _sample_rows(N, 12)
+    it = torch.from_numpy(idx).to(_dev())
+    spec = {"family": "irt", "model": "irt_2pl", "D": 1, "Dc": 1.0, "N": len(idx), "amortized": False, "share_cov": False,
+            "a_free": None}
+    params = {n: full.unconstrained(n).cpu().numpy().astype(np.float64) for n in full.names()}
+    pp = full.PP.double().cpu().numpy()
+    params["x_local"], params["x_scale"] = pp[:N][idx].reshape(-1, 1), pp[N:][idx].reshape(-1, 1)
+    _, g_o = vo.loss_and_grads(spec, params, y[it].cpu().numpy(), [np.arange(len(idx))], [vo.philox_normals(1234, 0, 0, idx, 1)])
+    for name, rows in (("x_local", gp_full[:N][idx]), ("x_scale", gp_full[N:][idx])):
+        go = g_o[name].reshape(-1)
+        err = np.abs(rows - go).max() / max(1e-6, np.abs(go).max())
+        assert err < 3e-5, (name, err)
     acc = np.zeros_like(g_full)
     for s in range(2):
         lo, hi = s * (N // 2), (s + 1) * (N // 2)
@@ -111,6 +185,21 @@ def test_cfg5_hodina_sharding_additivity():
     full.loss_and_grads()                                   # determinism (fixed-point pattern table, per-wave reduce slots)
     torch.cuda.synchronize()
     assert np.array_equal(_flat(full), g_full)
+    # the judged size against the oracle, on a sample: the per-person gradient rows (d loss / d theta_local, d theta_scale;
+    # vi.py:925-934 through the enumerated model, vi.py:897-923) of 4 096 of the 1M persons
+    idx = _sample_rows(N, 13)
+    it = torch.from_numpy(idx).to(_dev())
+    spec = {"family": "hodina", "K": K, "N": len(idx), "amortized": False, "q": prm["q"].cpu().numpy() if hasattr(prm["q"], "cpu")
+            else np.asarray(prm["q"])}
+    params = {n: full.unconstrained(n).cpu().numpy().astype(np.float64) for n in full.all_names() if n not in full.pp_off}
+    pp = full.PP.double().cpu().numpy()
+    gp = full.GP.double().cpu().numpy()
+    params["theta_local"], params["theta_scale"] = pp[:N][idx].reshape(-1, 1), pp[N:][idx].reshape(-1, 1)
+    _, g_o = vo.loss_and_grads(spec, params, y[it].cpu().numpy(), [np.arange(len(idx))], [vo.philox_normals(1234, 0, 0, idx, 1)])
+    for name, rows in (("theta_local", gp[:N][idx]), ("theta_scale", gp[N:][idx])):
+        go = g_o[name].reshape(-1)
+        err = np.abs(rows - go).max() / max(1e-6, np.abs(go).max())
+        assert err < 3e-5, (name, err)
     acc = np.zeros_like(g_full)
     for s in range(2):
         lo, hi = s * (N // 2), (s + 1) * (N // 2)

@@ -24,8 +24,14 @@ python3 $R/tools/rocpd_pmc.py /tmp/pmc_${TAG}_1/r_results.db /tmp/pmc_${TAG}_2/r
 python3 - "$OUT/pmc_counters.json" "$OUT/hbm_traffic.json" <<'PY'
 import json, sys
 c = json.load(open(sys.argv[1]))
+import os
+head = None
+try:        # the box has no .git: the caller leaves `git rev-parse --short HEAD` (+ "-dirty") in .git_head before gpurun
+    head = open(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), ".git_head")).read().strip() or None
+except OSError:
+    pass
 out = {"note": "per launch; hbm_read_bytes_corrected = FETCH_SIZE KB x 1024 x 2 (gfx950), hbm_write_bytes = WRITE_SIZE KB x 1024",
-       "kernels": {}}
+       "git_head": head, "kernels": {}}
 for k, v in c.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         out["kernels"][k] = {"FETCH_SIZE_KB": v["FETCH_SIZE"], "WRITE_SIZE_KB": v["WRITE_SIZE"],

@@ -431,6 +431,14 @@ def IrtMultiDim(x_feature, model="irt_2pl", **kw):
     return VaeIRT(model=model, x_feature=x_feature, **kw)
 
 
+def Dina(amortized=False, enumerate=True, model="dina", **kw):
+    """The DINA / DINO surface: pattern-enumerated (`VCCDM` / `VaeCCDM`, what the reference's PaDina tests run,
+    test.py:558-566) or the Bernoulli-guide score-function classes (`VCDM` / `VaeCDM`, test.py:520-550)."""
+    if enumerate:
+        return (VaeCCDM if amortized else VCCDM)(model=model, **kw)
+    return (VaeCDM if amortized else VCDM)(model=model, **kw)
+
+
 def HoDina(amortized=False, **kw):
     return (VaeCHoDina if amortized else VCHoDina)(**kw)
 
