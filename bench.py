@@ -272,7 +272,8 @@ def main():
                          "large kernels (0); auto = 0 for the judged headline run on one GPU (its roofline must be measured "
                          "inside the timed region), 1 wherever the engine can replay (shards, secondary workloads)")
     ap.add_argument("--dist-backend", default=os.environ.get("VX_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
-                    help="nccl = RCCL over xGMI (the product path); gloo only to rehearse N ranks on fewer GPUs")
+                    help="nccl = RCCL over xGMI (the product path); gloo only to rehearse N ranks on fewer GPUs -- the line "
+                         "such a run prints is marked a rehearsal (metric, config.collective) and is not an N-GPU result")
     args = ap.parse_args()
     # a secondary workload's step is 50 us - 1 ms: 5 + 2 of them end before the GPU has left its idle clock (551 MHz; measured:
     # HO-DINA 2 830 steps/s over 5 steps, 3 310 over 200)
@@ -305,6 +306,13 @@ def main():
         else:
             torch.distributed.init_process_group(backend="gloo", rank=rank, world_size=world)
         group = torch.distributed.group.WORLD              # the ranks SHARE the problem: persons are sharded over them
+        # what the line is allowed to claim: an N-GPU figure needs N ranks on RCCL, one device each
+        got_backend = torch.distributed.get_backend(group)
+        got_world = torch.distributed.get_world_size(group)
+        if got_world != world:
+            raise SystemExit("bench.py: the process group has %d ranks, the launcher announced %d" % (got_world, world))
+        if args.dist_backend == "nccl" and got_backend != "nccl":
+            raise SystemExit("bench.py: asked for RCCL, the process group runs on %r -- no N-GPU line from this run" % got_backend)
 
     from vipsy_amd import synth
     from vipsy_amd.engine import IrtEngine, LrSpec
@@ -438,6 +446,18 @@ def main():
             "person_rows_per_s": N * args.steps / dt,
             "loss_first": loss_first_v, "loss_last": loss_v, "phase_ms": phase_ms,
         }
+        if world > 1:
+            # the ONE exchange of a step: what ran it, over how many ranks, how many bytes, and what it
+            # took on rank 0 between the last gradient kernel and the optimiser (HIP events on the launch stream; for a
+            # replayed step from the eager pass behind the timed region).  Not overlapped with anything: it is this long.
+            n_red = int(eng.n_params + 1)
+            out["collective"] = {"backend": torch.distributed.get_backend(group), "ranks": torch.distributed.get_world_size(group),
+                                 "devices_visible": n_dev, "op": "all_reduce(SUM, f32)", "floats": n_red, "bytes": 4 * n_red,
+                                 "allreduce_ms": phase_ms.get("allreduce"),
+                                 "calls_per_step": 1}
+            if args.dist_backend != "nccl":
+                out["metric"] += " [REHEARSAL over %s on %d visible device(s): not an %d-GPU result]" % (args.dist_backend, n_dev, world)
+                out["rehearsal"] = True
         out["config"]["launch"] = ("whole step replayed from HIP graphs (one; two around the eager all-reduce when sharded); "
                                    "phase_ms / kernel_ms / roofline.avg_launch_ms from an eager pass with HIP events AFTER the "
                                    "timed region") if graphed else "kernel by kernel, HIP events around the large kernels inside the timed region"

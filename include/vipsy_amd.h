@@ -202,7 +202,10 @@ int64_t vx_mvn_enc_bwd_hs_offset(const vx_irt_cfg* cfg, int64_t nb);
  *   outputs: gloc[nb], graw[nb] = d LOSS / d loc, d raw;  elbo[nb] = per-person
  *            log p(y|x) + log p(x) - log q(x) (unscaled);
  *   gitem:   d LOSS / d [a: J | b: J | c_un: J | d_un: J] for this rank's batch (a = 0 for 1PL).
- * J <= 1024.  workspace: vx_irt1d_workspace_floats(cfg, nb) floats.
+ * J <= 1024.  workspace: vx_irt1d_workspace_floats(cfg, nb) floats -- size it with THAT call, not by hand: behind the
+ *   n_slabs x (4 J + 1) slab words the step kernels (vx_irt1d_grad and vx_irt1d_sparse_grad alike, with or without the
+ *   *_adam tail) leave Adam's count in one trailing word, slabs[n_slabs * (4 J + 1)], for k_reduce_adam; the size query
+ *   includes it (+ 4 floats).  A buffer of n_slabs * (4 J + 1) floats is 4 bytes short.
  * loss (or NULL): receives d LOSS itself, -scale * sum(elbo), summed in a fixed order.
  * step_dev (or NULL): the step counter in DEVICE memory -- the kernel reads the Philox step from it instead of cfg->step,
  * and the call ADVANCES it by one when the gradients are done (so vx_adam_step's t_dev may point at the same word: Adam's

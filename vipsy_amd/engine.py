@@ -907,8 +907,7 @@ class _EngineBase(object):
         mode = self._steps_form(lrs, [rows] * self.graph_steps, b_global, False)
         if mode is None:
             return False
-        self._steps_capture(lrs, mode)
-        return True
+        return self._steps_capture(lrs, mode) is not None
 
     def _steps_capture(self, lrs, mode):
         st, K = self._graphs[mode], self.graph_steps
@@ -924,6 +923,20 @@ class _EngineBase(object):
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     for _ in range(K):                        # (with a group: the captured collective inside)
                         self._grads_and_optim(lrs, st.get("rows"), mode[2] if mode[0] == "rows" else None)
+            except Exception as e:
+                # as in _step_graph: with a collective inside the capture the communicator may be unusable -- no way on; a
+                # capture WITHOUT one (a second private pool that does not fit, a driver refusing the K-fold graph) leaves
+                # nothing half-done: the form keeps its single-step graph and the fit loop takes the steps one by one
+                if self.group is not None and self._one_graph():
+                    raise RuntimeError("capturing %d steps with their RCCL all-reduce failed; the communicator may be unusable "
+                                       "after a half-recorded collective -- run again without VX_GRAPH_COLLECTIVE=1" % K) from e
+                if os.environ.get("VX_GRAPH_STRICT", "0") == "1":
+                    raise
+                import warnings
+                warnings.warn("capturing %d steps as one graph failed (%r): this engine replays its steps one at a time from "
+                              "now on (same results)" % (K, e))
+                self.graph_steps = 1
+                return None
             finally:
                 self._step_dev = None
                 self._capture_ring = None
@@ -936,6 +949,8 @@ class _EngineBase(object):
         self._graphs[mode] = self._graphs.pop(mode)          # most recently used last
         self._graph = st
         mk = self._steps_capture(lrs, mode)
+        if mk is None:                                       # the K-step capture failed and was withdrawn: single steps
+            return None
         t0 = self.t
         if mode[0] == "rows":
             for j in range(K):
@@ -965,9 +980,12 @@ class _EngineBase(object):
         while i < n:
             mode = self._steps_form(lrs, rows_seq[i:], b_global, scheduler)
             if mode is not None:
-                out += self._steps_graph(lrs, mode, rows_seq[i:i + self.graph_steps], scheduler)
-                i += self.graph_steps
-                continue
+                K = self.graph_steps
+                got = self._steps_graph(lrs, mode, rows_seq[i:i + K], scheduler)
+                if got is not None:
+                    out += got
+                    i += K
+                    continue
             out.append(self.step(lrs, rows=rows_seq[i], b_global=b_global))
             if scheduler:
                 lrs.scheduler_step()
@@ -985,6 +1003,14 @@ class _EngineBase(object):
             st = self._graphs.pop(m)
             if self._graph is st:
                 self._graph = None
+            # a replay of this form may still be queued: it reads the pinned rows ring through a raw device pointer (no event
+            # of torch's host allocator guards that use) and runs out of the graph's private pool -- wait for the newest event
+            # recorded behind its replays, or for the stream when there is none, before any of it can be handed out again
+            evs = st.get("ring_ev")
+            if evs:
+                evs[max(evs)].synchronize()
+            elif st.get("graph") is not None:
+                torch.cuda.current_stream().synchronize()
             st.clear()                                       # releases the CUDAGraph objects (and their pool) and the rows buffer
 
     def _particles(self, S, rows_of, b_global, eps_of):
