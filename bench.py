@@ -271,6 +271,13 @@ def main():
                     help="timed region replays the step's HIP graph (1) or launches kernel by kernel with HIP events around the "
                          "large kernels (0); auto = 0 for the judged headline run on one GPU (its roofline must be measured "
                          "inside the timed region), 1 wherever the engine can replay (shards, secondary workloads)")
+    ap.add_argument("--estimator", default="pathwise", choices=["pathwise", "score"],
+                    help="pathwise = what the reference's Normal / MultivariateNormal guides get from pyro's Trace_ELBO (the judged "
+                         "line); score = the REINFORCE score-function gradient with a control-variate baseline that BASELINE.json's "
+                         "north_star names (SURVEY.md F5, App. A.5): same forward, likelihood and item gradients, the guide's "
+                         "gradient through d log q.  A line of its own, never the BASELINE metric")
+    ap.add_argument("--baseline", default="avg", choices=["none", "avg"],
+                    help="control variate of --estimator score: per-person decaying average (pyro's use_decaying_avg_baseline) or none")
     ap.add_argument("--dist-backend", default=os.environ.get("VX_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path); gloo only to rehearse N ranks on fewer GPUs -- the line "
                          "such a run prints is marked a rehearsal (metric, config.collective) and is not an N-GPU result")
@@ -343,7 +350,8 @@ def main():
         from vipsy_amd.engine import HoDinaEngine
         eng = HoDinaEngine(y, prm["q"], n_global=N, gid0=gid0, amortized=amortized, H=H, seed=1234, group=group)
     else:
-        eng = IrtEngine(y, model=model, D=D, n_global=N, gid0=gid0, amortized=amortized, H=H, seed=1234, group=group)
+        est_kw = {"estimator": "score", "baseline": args.baseline} if args.estimator == "score" else {}
+        eng = IrtEngine(y, model=model, D=D, n_global=N, gid0=gid0, amortized=amortized, H=H, seed=1234, group=group, **est_kw)
 
     def sync():
         if world > 1:
@@ -358,7 +366,7 @@ def main():
     from vipsy_amd import _hip
     # D = 1 per-person guides replay the whole step from one HIP graph (engine.py::_step_graph): no events inside the
     # timed region there; the per-phase figures come from an eager pass afterwards
-    judged = headline and world == 1 and not args.persons
+    judged = headline and world == 1 and not args.persons and args.estimator == "pathwise"
     graphed = eng._graphable() and (args.graph == "1" or (args.graph == "auto" and not judged))
     if not graphed:
         eng.events = ev
@@ -446,6 +454,9 @@ def main():
             "person_rows_per_s": N * args.steps / dt,
             "loss_first": loss_first_v, "loss_last": loss_v, "phase_ms": phase_ms,
         }
+        if args.estimator == "score":
+            out["metric"] += " [score-function (REINFORCE) estimator with the '%s' control variate: not the BASELINE metric]" % args.baseline
+            out["config"]["estimator"] = "score-function gradient of the guide, baseline %s; item gradients pathwise" % args.baseline
         if world > 1:
             # the ONE exchange of a step: what ran it, over how many ranks, how many bytes, and what it
             # took on rank 0 between the last gradient kernel and the optimiser (HIP events on the launch stream; for a
@@ -478,7 +489,8 @@ def main():
             fl_pp, peak, arith = kernel_model(name, J, D, H)
             fl = fl_pp * kernel_units.get(name, n_local)
             ach = fl / (priced[name] * 1e-3) / 1e12
-            headline = args.workload == "irt2pl_100d_amortized_1Mx500" and world == 1 and not args.persons
+            headline = (args.workload == "irt2pl_100d_amortized_1Mx500" and world == 1 and not args.persons
+                        and args.estimator == "pathwise")
             traffic = measured_traffic(name) if headline else None
             out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                                "frac": ach / peak, "traffic": traffic,
