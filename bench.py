@@ -92,6 +92,9 @@ def kernel_model(name, J, D, H):
         PAIR: (2.0 * heads, PEAK_F16X2_TFLOPS, f16x2),
         "k_fc1_bwd_c": (2.0 * J * H, PEAK_BF16_MFMA_TFLOPS / 2.0,
                         "response bytes exact in fp16 x two fp16 terms of ghpre: two products on the fp16 MFMA, fp32 accumulate"),
+        # --estimator score: u = L^-T eps with the rows of L from the heads (the strictly lower triangle: T - D rows of H
+        # multiply-adds) and the back-substitution itself (T - D multiply-adds)
+        "k_mvn_score_b": (2.0 * (T - D) * (H + 1), PEAK_F16X2_TFLOPS, f16x2),
     }
     if D == 1:
         # the 1-D amortized guide (BASELINE config 4, amortized variant; SURVEY.md section 8d: "MFMA/FMA (encoder)"): fc1 and

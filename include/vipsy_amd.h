@@ -36,7 +36,7 @@ extern "C" {
 #define VX_OK 0
 #define VX_EINVAL (-1)       /* bad argument / unsupported shape */
 #define VX_EUNIMPL (-2)
-#define VX_ABI_VERSION 4
+#define VX_ABI_VERSION 5
 
 enum vx_model { VX_IRT_1PL = 1, VX_IRT_2PL = 2, VX_IRT_3PL = 3, VX_IRT_4PL = 4 }; /* vi.py:538-543 */
 
@@ -249,6 +249,19 @@ int vx_mvn_score_operands(const vx_irt_cfg* cfg, int64_t nb, const int64_t* rows
                           float* gx, float* gxT, float* gdT, void* hip_stream);
 int vx_mvn_score_diag(const vx_irt_cfg* cfg, int64_t nb, const int64_t* rows, const float* w, int32_t shared, float* gM,
                       void* hip_stream);
+/* The kind-0 operands (L from the encoder heads) on the fp16 MFMA, for the shapes the f16x2 guide kernels take (hidden_dim 64,
+ * x_feature % 4 == 0, 8 <= x_feature <= 124): u = L^-T eps as a back-substitution over COLUMN tiles of the head GEMM the
+ * forward runs, 32 persons a wave (k_mvn_score_b.hip).  Same outputs as vx_mvn_score_operands(kind 0) with gx / w = NULL, to
+ * the f16x2 products' 2^-22.  Made AFTER vx_mvn_enc_forward of the same batch and parameters:
+ *   packws: the forward's pack workspace (the powers of two of its operands are read from its scale block);
+ *   h[nb][64], eps[nb][D]: the forward's outputs (L_kk = exp(M_kk) is recomputed with the rows below it);
+ *   workspace: vx_mvn_score_heads_workspace_floats(cfg) floats (the column-ordered weight image, rebuilt every call).
+ * VX_EINVAL for any other shape (the caller then uses vx_mvn_score_operands). */
+int64_t vx_mvn_score_heads_workspace_floats(const vx_irt_cfg* cfg);
+int vx_mvn_score_heads(const vx_irt_cfg* cfg, int64_t nb, const int64_t* rows, const float* h, const float* W22, const float* b22,
+                       const float* packws, const float* eps, const float* ll, const float* ent,
+                       float* baseline, float base_beta, int32_t base_by_row, float* log_r, float* gxT, float* gdT,
+                       float* workspace, void* hip_stream);
 
 /* ---- black-box MVN guide with per-person or shared Cholesky rows (VIRT.guide, x_feature > 1, vi.py:706-723).
  *   loc: [n_local][D];  M: [n_local][D][D] unconstrained (shared == 0) or [D][D] (shared == 1, share_cov=True)

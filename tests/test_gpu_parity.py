@@ -1323,6 +1323,58 @@ def test_mvn_score_function_step_vs_oracle(guide, N, J, D, model, B, baseline):
             assert np.abs(gh.reshape(go.shape) - go).max() / sc < GRAD_TOL, (name, t, np.abs(gh.reshape(go.shape) - go).max() / sc)
 
 
+@pytest.mark.parametrize("N,D,J", [(33024, 100, 500), (4104, 8, 36), (1000, 100, 40), (8200, 32, 40)])
+def test_mvn_score_operands_mfma_kernel_vs_scalar_kernel_and_oracle(N, D, J):
+    """k_mvn_score_b (u = L^-T eps by column tiles of the head GEMM on the fp16 MFMA, k_mvn_score_b.hip) against (1) the scalar
+    kernel it replaces for these shapes (k_mvn_score_operands<0>, same engine state, the seam `score_mfma`) and (2) float64:
+    L rebuilt from the heads (vi.py:448-455), u by a triangular solve, for a sample of the persons -- at the headline's shape
+    with every CU busy (33 024 persons), at the smallest dimension the kernel takes, at a large one with a ragged last wave
+    (1 000 = 31 waves + 8 persons) and at D = 32 (columns of one tile each)."""
+    from vipsy_amd.engine import IrtEngine
+    y, enc, rng = _random_problem(N, J, D, 64, "irt_2pl", 0.1, seed=N + D)
+    eng = IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_2pl", D=D, amortized=True, H=64, seed=7, estimator="score",
+                    baseline="avg", baseline_beta=0.8, encoder_init={k: v.astype(np.float32) for k, v in enc.items()})
+    a0 = eng.unconstrained("a") * torch.from_numpy(1 + 0.3 * rng.randn(D, J)).float().to(_dev())
+    eng.unconstrained("a").copy_((0.05 if D >= 64 else 1.0) * a0 * eng.unconstrained("a", eng.free))
+    out = {}
+    for mfma in (True, False):
+        eng.score_mfma = mfma
+        eng.base.zero_()
+        eng.loss_and_grads()
+        torch.cuda.synchronize()
+        gd_off = eng.be.mvn_enc_bwd_gd_offset(eng.be.cfg(eng.model, D, J, 64, 1.0, 1.0, 7, 0, 0), N)
+        assert gd_off >= 0
+        out[mfma] = (eng.last["gxT"][:N * D].reshape(D, N).cpu().numpy().copy(),
+                     eng._ws["encb_ws"][gd_off:gd_off + N * D].reshape(D, N).cpu().numpy().copy(),
+                     eng.unconstrained("encoder$$$fc22.weight", eng.G).cpu().numpy().copy(), eng.last_log_r.cpu().numpy().copy())
+    for q, name in enumerate(("gxT", "gdT", "G_W22", "log_r")):
+        sc = np.abs(out[False][q]).max()
+        err = np.abs(out[True][q] - out[False][q]).max() / sc
+        print("score operands, N = %d D = %d: %s MFMA against scalar kernel %.2e of the max" % (N, D, name, err))
+        assert err < GRAD_TOL, (name, err)
+    # float64 for a sample of the persons (the first, the last, random ones)
+    idx = np.unique(np.concatenate([np.arange(40), np.arange(N - 40, N), rng.choice(N, 200, replace=False)]))
+    fw = eng.last["fw"]
+    params = {n: eng.unconstrained(n).cpu().numpy().astype(np.float64) for n in eng.names()}
+    W = {k: params["encoder$$$" + k] for k in vo.ENC_KEYS}
+    loc, raw, _ = vo.enc_forward(W, vo.enc_input(y[idx], np.float64))
+    eps = fw["eps"][:N * D].reshape(N, D).cpu().numpy()[idx].astype(np.float64)
+    r_, c_ = vo.tril_rows_cols(D)
+    w = out[True][3][idx].astype(np.float64)                  # log_r - baseline (the baseline starts at zero)
+    gx_o = np.empty((len(idx), D))
+    gd_o = np.empty((len(idx), D))
+    for n in range(len(idx)):
+        M = np.zeros((D, D))
+        M[r_, c_] = raw[n]
+        L = np.tril(M, -1) + np.diag(np.exp(np.diag(M)))
+        u = np.linalg.solve(L.T, eps[n])
+        gx_o[n] = w[n] * u
+        gd_o[n] = w[n] * (u * eps[n] * np.diag(L) - 1.0)
+    for got, want, name in ((out[True][0][:, idx].T, gx_o, "gxT"), (out[True][1][:, idx].T, gd_o, "gdT")):
+        err = np.abs(got - want).max() / np.abs(want).max()
+        assert err < GRAD_TOL, (name, err)
+
+
 def test_mvn_score_function_loo_baseline_through_step():
     """baseline='loo' for a multivariate guide (per-person Cholesky rows, D = 3) through IrtEngine.step: three particles share
     the batch, each with the leave-one-out mean of the others' log_r as its control variate (lr = 0 keeps the parameters)."""

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VX_LIB names another build of the same sources (tests/test_gpu_schedules.py runs the oracle comparisons against a library
 # compiled with a different instruction schedule: a hazard that only one schedule hides must show in the other)
 LIB_PATH = os.environ.get("VX_LIB") or os.path.join(_HERE, "_lib", "libvipsy_hip.so")
-ABI_VERSION = 4         # include/vipsy_amd.h: VX_ABI_VERSION (struct layouts and argument lists this binding was written for)
+ABI_VERSION = 5         # include/vipsy_amd.h: VX_ABI_VERSION (struct layouts and argument lists this binding was written for)
 
 
 class VxError(RuntimeError):
@@ -108,6 +108,8 @@ SIGNATURES = {
     "vx_irt1d_score_grad": (ctypes.c_int, [_I64, ctypes.c_float, _P, _P, _P, _P, _P, ctypes.c_float, _I32, _P, _P, _P, _P]),
     "vx_mvn_score_operands": (ctypes.c_int, [_CFG, _I64, _P, _I32] + [_P] * 8 + [_F, _I32] + [_P] * 6),
     "vx_mvn_score_diag": (ctypes.c_int, [_CFG, _I64, _P, _P, _I32, _P, _P]),
+    "vx_mvn_score_heads_workspace_floats": (_I64, [_CFG]),
+    "vx_mvn_score_heads": (ctypes.c_int, [_CFG, _I64, _P] + [_P] * 7 + [_P, _F, _I32] + [_P] * 5),
     "vx_bin_enc_param_floats": (_I64, [ctypes.POINTER(HoDinaCfg)]),
     "vx_bin_enc_forward": (ctypes.c_int, [ctypes.POINTER(HoDinaCfg), _P, _P, _I64] + [_P] * 4 + [_P, _P, _P]),
     "vx_bin_enc_bwd_workspace_floats": (_I64, [ctypes.POINTER(HoDinaCfg), _I64]),

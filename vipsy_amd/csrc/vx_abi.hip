@@ -22,6 +22,7 @@
 #include "k_mvn_bwd_b.hip"
 #include "k_mvn_fwd_b.hip"
 #include "k_mvn_fwd_b2.hip"
+#include "k_mvn_score_b.hip"
 #include "k_mvn_bwd_hb.hip"
 #include "k_mvn_bwd_hb2.hip"
 #include "k_pack_fused.hip"
@@ -1656,6 +1657,41 @@ int vx_mvn_score_operands(const vx_irt_cfg* cfg, int64_t nb, const int64_t* rows
                        cfg->scale, rows, h, W22, b22, M, eps, ll, ent, baseline, base_beta, (int)base_by_row, log_r, w, gx, gxT, gdT)
     if (kind == 0) { LAUNCH_MS(0); } else if (kind == 1) { LAUNCH_MS(1); } else { LAUNCH_MS(2); }
 #undef LAUNCH_MS
+    VX_CHECK_LAUNCH();
+    return VX_OK;
+}
+
+// the MFMA form of kind 0 (k_mvn_score_b.hip): the shapes whose forward ran on the f16x2 kernels
+static bool score_heads_shape(const vx_irt_cfg* cfg) {
+    return cfg && !force_generic() && fwb_shape(cfg) && cfg->H == 64 && cfg->D % 4 == 0 && cfg->D >= 8 && cfg->D <= 124 &&
+           sb_lds_bytes(cfg->D) <= 160 * 1024;
+}
+int64_t vx_mvn_score_heads_workspace_floats(const vx_irt_cfg* cfg) {
+    if (!score_heads_shape(cfg)) return VX_EINVAL;
+    return sb_img_floats(cfg->D);
+}
+int vx_mvn_score_heads(const vx_irt_cfg* cfg, int64_t nb, const int64_t* rows, const float* h, const float* W22, const float* b22,
+                       const float* packws, const float* eps, const float* ll, const float* ent,
+                       float* baseline, float base_beta, int32_t base_by_row, float* log_r, float* gxT, float* gdT,
+                       float* workspace, void* hs) {
+    if (!score_heads_shape(cfg) || nb < 0 || !h || !W22 || !b22 || !packws || !eps || !ll || !ent || !gxT || !workspace ||
+        !aligned16(h) || !aligned16(eps) || !aligned16(workspace))
+        return VX_EINVAL;
+    if (nb == 0) return VX_OK;
+    const float* sc = packws + vx_mvn_pack_floats(cfg) - FB_NSCALES;
+    hipStream_t st = (hipStream_t)hs;
+    const int D = cfg->D;
+    hipLaunchKernelGGL(k_pack_heads_col, dim3((unsigned)sb_tiles(D)), dim3(256), 0, st, D, W22, b22, sc, (uint8_t*)workspace);
+    VX_CHECK_LAUNCH();
+    const size_t lds = sb_lds_bytes(D);
+    int rc = set_lds(k_mvn_score_b, lds);
+    if (rc) return rc;
+    {
+        ProfScope ps("k_mvn_score_b", st, nb);
+        hipLaunchKernelGGL(k_mvn_score_b, dim3((unsigned)((nb + SB_WAVES * SB_WP - 1) / (SB_WAVES * SB_WP))), dim3(SB_THREADS), lds, st,
+                           D, nb, cfg->scale, rows, h, (const uint8_t*)workspace, sc, eps, ll, ent, baseline, base_beta,
+                           (int)base_by_row, log_r, gxT, gdT);
+    }
     VX_CHECK_LAUNCH();
     return VX_OK;
 }

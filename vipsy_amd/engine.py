@@ -278,6 +278,18 @@ class HipBackend(object):
                                           _hip.ptr(gx), _hip.ptr(gxT), _hip.ptr(gdT), _hip.stream_ptr())
         _hip.check(rc, "vx_mvn_score_operands")
 
+    def mvn_score_heads_workspace(self, cfg):
+        """floats of the column image of the MFMA score kernel, or -1 when the shape is not its own"""
+        return int(self.L.vx_mvn_score_heads_workspace_floats(ctypes.byref(cfg)))
+
+    def mvn_score_heads(self, cfg, nb, rows, h, W22, b22, packws, eps, ll, ent, baseline, base_beta, base_by_row, log_r,
+                        gxT, gdT, ws):
+        rc = self.L.vx_mvn_score_heads(ctypes.byref(cfg), nb, _hip.ptr(rows), _hip.ptr(h), _hip.ptr(W22), _hip.ptr(b22),
+                                       _hip.ptr(packws), _hip.ptr(eps), _hip.ptr(ll), _hip.ptr(ent),
+                                       _hip.ptr(baseline), float(base_beta), int(base_by_row), _hip.ptr(log_r), _hip.ptr(gxT),
+                                       _hip.ptr(gdT), _hip.ptr(ws), _hip.stream_ptr())
+        _hip.check(rc, "vx_mvn_score_heads")
+
     def mvn_score_diag(self, cfg, nb, rows, w, shared, gM):
         _hip.check(self.L.vx_mvn_score_diag(ctypes.byref(cfg), nb, _hip.ptr(rows), _hip.ptr(w), int(bool(shared)), _hip.ptr(gM),
                                             _hip.stream_ptr()), "vx_mvn_score_diag")
@@ -664,6 +676,7 @@ class _EngineBase(object):
     # build could reach, so it is opt-in, and a capture that fails with a collective inside it RAISES: the communicator may be
     # unusable after a half-recorded collective, so the process must not carry on (no eager retry).
     use_graph = True
+    score_mfma = os.environ.get("VX_SCORE_MFMA", "1") != "0"      # test seam: 0 = the scalar score-operand kernel for every shape
     graph_max_persons = int(os.environ.get("VX_GRAPH_MAX_PERSONS", "300000"))
 
     def _graph_mode(self, rows, b_global, eps, S):
@@ -1312,8 +1325,15 @@ class IrtEngine(_EngineBase):
                 with self._phase("mvn_score"):
                     log_r = self._buf("sf_lr%d" % stream_id if not guide_grads else "sf_lr", nb)
                     base, beta, by_row = self._score_baseline(baseline_buf, guide_grads)
-                    be.mvn_score_operands(cfg, nb, rows, 0, fw["h"], enc["fc22.weight"], enc["fc22.bias"], None, fw["eps"], ll,
-                                          fw["ent"], base, beta, by_row, log_r, None, None, gxT, gdT)
+                    n_sh = be.mvn_score_heads_workspace(cfg) if (isinstance(be, HipBackend) and self.score_mfma) else -1
+                    if n_sh > 0:
+                        # u = L^-T eps on the fp16 MFMA, the head rows in column order (k_mvn_score_b.hip)
+                        be.mvn_score_heads(cfg, nb, rows, fw["h"], enc["fc22.weight"], enc["fc22.bias"], fw["packws"], fw["eps"],
+                                           ll, fw["ent"], base, beta, by_row, log_r, gxT, gdT,
+                                           self._buf("score_img", n_sh))
+                    else:
+                        be.mvn_score_operands(cfg, nb, rows, 0, fw["h"], enc["fc22.weight"], enc["fc22.bias"], None, fw["eps"], ll,
+                                              fw["ent"], base, beta, by_row, log_r, None, None, gxT, gdT)
                     self.last_log_r = log_r
             with self._phase("guide_backward"):
                 # loss = -scale * sum_i (ll_i + ent_i), from the backward call's last launch; a captured step's counter
