@@ -273,11 +273,13 @@ __global__ __launch_bounds__(FB2_THREADS, (NS == 1 ? 2 : 1)) void k_mvn_enc_fwd_
                 const int64_t c0 = i0 + 32 * u;
                 if constexpr (SEQ) {
                     __builtin_amdgcn_wave_barrier();
+#ifndef FB2_NO_HT                                                 // (tools/fwd2_bench.hip -DFB2_NO_HT: what the fp32 hT copy costs)
 #pragma unroll
                     for (int it = 0; it < 8; ++it) {              // hT: 64 rows x 8 pieces of 4 persons
                         const int e = lane + 64 * it, hh = e >> 3, g = e & 7;
                         *(f32x4*)(hT_out + (int64_t)hh * dm.nb + c0 + 4 * g) = *(const f32x4*)(stT + hh * ST_T + 4 * g);
                     }
+#endif
                     __builtin_amdgcn_wave_barrier();
                 }
                 // the hs planes (operand of k_mvn_enc_bwd_w_b) take the fragments' two fp16 terms of h 2^sh

@@ -435,7 +435,7 @@ int vx_adam_step(float* p, const float* g, float* m, float* v, const float* free
     }
     const double bc1 = 1.0 - pow((double)beta1, (double)(t_dev ? 1 : t));
     const double bc2 = 1.0 - pow((double)beta2, (double)(t_dev ? 1 : t));
-    hipLaunchKernelGGL(k_adam, dim3(grid_1d(n, 256)), dim3(256), 0, (hipStream_t)hs, p, g, m, v, free_mask, n, s,
+    hipLaunchKernelGGL(k_adam, dim3(grid_1d((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)hs, p, g, m, v, free_mask, n, s,
                        beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), t_dev, (uint32_t)t, loss_src, loss_ring);
     VX_CHECK_LAUNCH();
     return VX_OK;
@@ -461,7 +461,7 @@ int vx_adam_step2(float* pA, const float* gA, float* mA, float* vA, const float*
     const AdamBuf A{pA, gA, mA, vA, freeA, nA}, B{pB, gB, mB, vB, nullptr, nB};
     const double bc1 = 1.0 - pow((double)beta1, (double)(t_dev ? 1 : t));
     const double bc2 = 1.0 - pow((double)beta2, (double)(t_dev ? 1 : t));
-    hipLaunchKernelGGL(k_adam2, dim3(grid_1d(nA + nB, 256)), dim3(256), 0, (hipStream_t)hs, A, sa, B, sb, beta1, beta2, eps,
+    hipLaunchKernelGGL(k_adam2, dim3(grid_1d((nA + 3) / 4 + (nB + 3) / 4, 256)), dim3(256), 0, (hipStream_t)hs, A, sa, B, sb, beta1, beta2, eps,
                        (float)bc1, (float)sqrt(bc2), t_dev, (uint32_t)t, loss_src, loss_ring);
     VX_CHECK_LAUNCH();
     return VX_OK;
