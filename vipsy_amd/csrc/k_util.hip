@@ -215,6 +215,18 @@ struct AdamSegs { int64_t begin[VX_MAX_SEGS]; int64_t end[VX_MAX_SEGS]; float lr
 
 // torch.optim.Adam for element i of one buffer with gradient gi (k_adam / k_adam2 / k_reduce_adam: one arithmetic)
 struct AdamBuf { float* p; const float* g; float* m; float* v; const float* free_mask; int64_t n; };
+// The update of ONE element, written once and compiled without fused-multiply-add contraction: the scalar, the 16-byte and the
+// operands-in-flight forms below inline it in different surroundings, and a contraction chosen differently in one of them would
+// cost the last bit that tests/test_gpu_parity.py::test_optimiser_in_the_steps_last_launch_equals_separate_launches compares.
+__device__ __forceinline__ void adam_math(float gi, float& p, float& m, float& v, float lr, float beta1, float beta2, float eps,
+                                          float bc1, float bc2_sqrt) {
+#pragma clang fp contract(off)
+    const float mi = beta1 * m + (1.f - beta1) * gi;
+    const float vi = beta2 * v + (1.f - beta2) * gi * gi;
+    m = mi; v = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p = p - (lr / bc1) * (mi / denom);
+}
 __device__ __forceinline__ void adam_one(const AdamBuf& buf, const AdamSegs& segs, int64_t i, float gi, float beta1, float beta2,
                                          float eps, float bc1, float bc2_sqrt) {
     float lr = 0.f;
@@ -223,11 +235,9 @@ __device__ __forceinline__ void adam_one(const AdamBuf& buf, const AdamSegs& seg
         if (i >= segs.begin[s] && i < segs.end[s]) { lr = segs.lr[s]; found = true; }
     if (!found) return;
     if (buf.free_mask) gi *= buf.free_mask[i];
-    const float mi = beta1 * buf.m[i] + (1.f - beta1) * gi;
-    const float vi = beta2 * buf.v[i] + (1.f - beta2) * gi * gi;
-    buf.m[i] = mi; buf.v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    buf.p[i] = buf.p[i] - (lr / bc1) * (mi / denom);
+    float pi = buf.p[i], mi = buf.m[i], vi = buf.v[i];
+    adam_math(gi, pi, mi, vi, lr, beta1, beta2, eps, bc1, bc2_sqrt);
+    buf.m[i] = mi; buf.v[i] = vi; buf.p[i] = pi;
 }
 
 // Four consecutive elements i .. i + 3 of one buffer (i % 4 == 0, cnt = how many of them exist) in one thread: 16-byte loads and
@@ -252,12 +262,9 @@ __device__ __forceinline__ void adam_quad(const AdamBuf& buf, const AdamSegs& se
         f32x4 mo, vo, po;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float gi = g4[e];
-            const float mi = beta1 * m4[e] + (1.f - beta1) * gi;
-            const float vi = beta2 * v4[e] + (1.f - beta2) * gi * gi;
-            mo[e] = mi; vo[e] = vi;
-            const float denom = sqrtf(vi) / bc2_sqrt + eps;
-            po[e] = p4[e] - (lr / bc1) * (mi / denom);
+            float pe = p4[e], me = m4[e], ve = v4[e];
+            adam_math(g4[e], pe, me, ve, lr, beta1, beta2, eps, bc1, bc2_sqrt);
+            mo[e] = me; vo[e] = ve; po[e] = pe;
         }
         *(f32x4*)(buf.m + i) = mo; *(f32x4*)(buf.v + i) = vo; *(f32x4*)(buf.p + i) = po;
         return;
@@ -311,11 +318,9 @@ __device__ __forceinline__ void adam_finish(const AdamBuf& buf, int64_t i, float
                                             float eps, float bc1, float bc2_sqrt) {
     if (!o.found) return;
     if (buf.free_mask) gi *= o.fm;
-    const float mi = beta1 * o.m + (1.f - beta1) * gi;
-    const float vi = beta2 * o.v + (1.f - beta2) * gi * gi;
-    buf.m[i] = mi; buf.v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    buf.p[i] = o.p - (o.lr / bc1) * (mi / denom);
+    float pi = o.p, mi = o.m, vi = o.v;
+    adam_math(gi, pi, mi, vi, o.lr, beta1, beta2, eps, bc1, bc2_sqrt);
+    buf.m[i] = mi; buf.v[i] = vi; buf.p[i] = pi;
 }
 
 // The tail of a D = 1 step on ONE rank in ONE launch (k_reduce_wide + k_adam2, 5 us each at BASELINE config 2, a quarter of
@@ -345,9 +350,9 @@ __global__ __launch_bounds__(1024) void k_reduce_adam(const float* __restrict__ 
         bc1 = bc[0]; bc2_sqrt = bc[1];
     }
     if ((int)blockIdx.x >= n_red) {
-        const int64_t nblk = (int64_t)gridDim.x - n_red;
-        for (int64_t i = ((int64_t)blockIdx.x - n_red) * 1024 + threadIdx.x; i < B.n; i += nblk * 1024)
-            adam_one(B, sB, i, B.g[i], beta1, beta2, eps, bc1, bc2_sqrt);
+        const int64_t nblk = (int64_t)gridDim.x - n_red, nq = (B.n + 3) >> 2;
+        for (int64_t q = ((int64_t)blockIdx.x - n_red) * 1024 + threadIdx.x; q < nq; q += nblk * 1024)      // four elements a thread
+            adam_quad(B, sB, 4 * q, (int)((B.n - 4 * q) < 4 ? (B.n - 4 * q) : 4), beta1, beta2, eps, bc1, bc2_sqrt);
         return;
     }
     const int col = threadIdx.x % COLS, grp = threadIdx.x / COLS;
@@ -411,9 +416,13 @@ __global__ void k_adam2(AdamBuf A, AdamSegs sA, AdamBuf B, AdamSegs sB, float be
     // quads of A, then quads of B: each buffer's quads start at ITS element 0 (16-byte aligned whatever A.n is)
     const int64_t qA = (A.n + 3) >> 2, qB = (B.n + 3) >> 2;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < qA + qB; q += (int64_t)gridDim.x * blockDim.x) {
-        const bool inA = q < qA;
-        const AdamBuf& buf = inA ? A : B;
-        const int64_t i = 4 * (inA ? q : q - qA);
-        adam_quad(buf, inA ? sA : sB, i, (int)((buf.n - i) < 4 ? (buf.n - i) : 4), beta1, beta2, eps, bc1, bc2_sqrt);
+        // (two calls, not one call on a buffer chosen at run time: a kernel-argument structure selected by reference is copied to
+        // scratch memory -- the optimiser launch of BASELINE config 5 took 67 us that way, 19 before it)
+        if (q < qA) {
+            adam_quad(A, sA, 4 * q, (int)((A.n - 4 * q) < 4 ? (A.n - 4 * q) : 4), beta1, beta2, eps, bc1, bc2_sqrt);
+        } else {
+            const int64_t i = 4 * (q - qA);
+            adam_quad(B, sB, i, (int)((B.n - i) < 4 ? (B.n - i) : 4), beta1, beta2, eps, bc1, bc2_sqrt);
+        }
     }
 }

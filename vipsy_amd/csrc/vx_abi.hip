@@ -359,7 +359,7 @@ static int reduce_step_slabs(const float* slabs, int64_t n_slabs, int J, float* 
         const double bc2 = 1.0 - pow((double)opt->beta2, (double)(tick ? 1 : opt->t));
         // Adam's count of a captured step: the word the step kernel left behind its slabs (one slab = 4 J + 1 floats)
         const uint32_t* t_copy = tick ? (const uint32_t*)(slabs + n_slabs * (4 * (int64_t)J + 1)) : nullptr;
-        int64_t nb_blk = (opt->nB + 1023) / 1024;
+        int64_t nb_blk = ((opt->nB + 3) / 4 + 1023) / 1024;                      // four elements a thread (adam_quad)
         if (nb_blk > (int64_t)num_cu() * 2) nb_blk = (int64_t)num_cu() * 2;
         if (n_slabs > 512) {
             const int n_red = grid_1d(len, 8);
