@@ -1022,7 +1022,7 @@ class _EngineBase(object):
             evs = st.get("ring_ev")
             if evs:
                 evs[max(evs)].synchronize()
-            elif st.get("graph") is not None:
+            elif st.get("graph") is not None and self.dev.type == "cuda":
                 torch.cuda.current_stream().synchronize()
             st.clear()                                       # releases the CUDAGraph objects (and their pool) and the rows buffer
 
