@@ -194,7 +194,9 @@ __device__ __forceinline__ float softplusf_(float x) {
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 // ln of a NORMAL positive float on the hardware log2 (one transcendental + one multiply; the library's __logf expands to ten
 // instructions of denormal handling and an extended-precision multiply by ln 2 -- the clamped probabilities of the 3PL / 4PL
-// cell lie in [eps32, 1 - eps32])
+// cell lie in [eps32, 1 - eps32]).  Measured against double-precision log (tools/fast_log_check.hip, profiles/r06_fast_log_check.txt):
+// relative error <= 1.44e-7 over (0, 1) and <= 1.36e-7 for 1 - 1e-3 <= x <= 1 - 1.2e-7, where log is small (absolute 1.1e-10) --
+// the hardware log2 is accurate relative to its RESULT near 1, as the library call is (1.58e-7 there))
 __device__ __forceinline__ float fast_log(float x) { return 0.6931471805599453f * __builtin_amdgcn_logf(x); }
 
 template <int MODEL>
