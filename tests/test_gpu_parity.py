@@ -1099,6 +1099,41 @@ def test_failed_capture_of_a_sharded_step_degrades_to_the_eager_step(monkeypatch
     dist.destroy_process_group()
 
 
+def test_failed_capture_of_four_steps_degrades_to_single_steps(monkeypatch):
+    """`steps()` records graph_steps steps as ONE graph once the single-step graph of the form exists.  If that
+    second capture fails (a private pool that does not fit, a driver refusing the K-fold graph) nothing is half-done -- no
+    collective was being recorded -- so the engine warns, keeps its single-step graph and takes the steps one by one with the
+    same results; VX_GRAPH_STRICT=1 keeps it an error.  The failure is injected into the capture of the K-step graph only."""
+    from vipsy_amd.engine import IrtEngine, LrSpec
+    rng = np.random.RandomState(5)
+    y = rng.randint(0, 2, size=(3000, 40)).astype(np.uint8)
+    lrs = LrSpec(1e-2)
+    ref = IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_2pl", D=1, seed=3)
+    want = [float(v) for v in ref.steps(lrs, [None] * 12)]
+    eng = IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_2pl", D=1, seed=3)
+    got = [float(v) for v in eng.steps(lrs, [None] * 2)]              # eager, then the single-step capture
+    real = torch.cuda.CUDAGraph
+
+    class Broken(real):
+        def capture_begin(self, *a, **k):
+            raise RuntimeError("injected: K-step capture refused")
+    monkeypatch.setattr(torch.cuda, "CUDAGraph", Broken)
+    with pytest.warns(UserWarning, match="as one graph failed"):
+        got += [float(v) for v in eng.steps(lrs, [None] * 6)]
+    monkeypatch.undo()
+    got += [float(v) for v in eng.steps(lrs, [None] * 4)]             # and stays on single steps afterwards
+    torch.cuda.synchronize()
+    assert eng.graph_steps == 1 and got == want
+    np.testing.assert_array_equal(eng.P.cpu().numpy(), ref.P.cpu().numpy())
+    eng2 = IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_2pl", D=1, seed=3)
+    eng2.steps(lrs, [None] * 2)
+    monkeypatch.setattr(torch.cuda, "CUDAGraph", Broken)
+    monkeypatch.setenv("VX_GRAPH_STRICT", "1")
+    with pytest.raises(RuntimeError, match="injected"):
+        eng2.steps(lrs, [None] * 4)
+    monkeypatch.undo()
+
+
 @pytest.mark.parametrize("H", [96, 128])
 def test_irt1d_amortized_wide_hidden_layer(H):
     """NormEncoder with hidden_dim > 64 (vi.py:417-435 takes any width)."""
