@@ -72,6 +72,8 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL(k_csum, dim3(2048), dim3(256), 0, 0, (const uint32_t*)p, (int64_t)(bytes / 4), cs);
         unsigned long long v = 0; hipMemcpy(&v, cs, 8, hipMemcpyDeviceToHost); return v;
     };
+    float* eps_given = nullptr;
+    if (getenv("FWD2_EPS_IN")) { CK(hipMalloc(&eps_given, nb * D * 4)); k_fill<<<1024, 256>>>(eps_given, nb * D, 1.0f, 9); }
     auto run = [&](auto nsc, auto w3c) -> int {
         constexpr int NS = decltype(nsc)::value;
         constexpr bool W3 = decltype(w3c)::value;
@@ -86,11 +88,11 @@ int main(int argc, char** argv) {
             hipEventRecord(e0);
             hipLaunchKernelGGL((k_mvn_enc_fwd_b2<NS, W3>), dim3((unsigned)((nb + wg - 1) / wg)), dim3(FB2_THREADS), lds, 0, dm, (const uint8_t*)y,
                                (const int64_t*)nullptr, (int64_t)0, (const uint8_t*)w1img, (const float*)b1, (const uint8_t*)img,
-                               (const uint32_t*)gt2, (const float*)sc, (const float*)nullptr, (uint64_t)1234, 0u, (const uint32_t*)nullptr, 0u, h, x, eps, ldT, ent, hT,
+                               (const uint32_t*)gt2, (const float*)sc, (const float*)eps_given, (uint64_t)1234, 0u, (const uint32_t*)nullptr, 0u, h, x, eps, ldT, ent, hT,
                                epsT, ximg, hs);
             hipEventRecord(e1); CK(hipEventSynchronize(e1));
             float ms; hipEventElapsedTime(&ms, e0, e1);
-            printf("k_mvn_enc_fwd_b2<%d,%d> nb=%lld: %.3f ms (lds %zu)\n", NS, (int)W3, (long long)nb, ms, lds);
+            printf("k_mvn_enc_fwd_b2<%d,%d> nb=%lld%s: %.3f ms (lds %zu)\n", NS, (int)W3, (long long)nb, eps_given ? " eps given" : "", ms, lds);
         }
         std::vector<float> o(4);
         CK(hipMemcpy(o.data(), x + 1000, 16, hipMemcpyDeviceToHost));
