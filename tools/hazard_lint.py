@@ -46,8 +46,8 @@ REG_RE = re.compile(r"\b([vas])\[(\d+):(\d+)\]|\b([vas])(\d+)\b|\b(vcc_lo|vcc_hi
 TRANS = ("v_exp_", "v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_sin_", "v_cos_")
 TWO_DST = ("v_div_scale_", "v_add_co_", "v_sub_co_", "v_subrev_co_", "v_addc_co_", "v_subb_co_", "v_subbrev_co_",
            "v_mad_u64_u32", "v_mad_i64_i32")
-DST_ALSO_READ = ("v_fmac_", "v_mac_", "v_pk_fmac_", "v_dot2c_", "v_dot4c_", "v_dot8c_", "v_writelane_", "v_movreld_",
-                 "v_fmamk_", "v_permlane")          # (fmamk does not read its dst; harmless to over-approximate? no: removed below)
+# instructions whose destination is also a source (accumulating forms, lane writes, the two-way swaps)
+DST_ALSO_READ = ("v_fmac_", "v_mac_", "v_pk_fmac_", "v_dot2c_", "v_dot4c_", "v_dot8c_", "v_writelane_", "v_movreld_")
 DPP_RE = re.compile(r"\b(quad_perm|row_shl|row_shr|row_ror|wave_shl|wave_shr|wave_rol|wave_ror|row_mirror|row_half_mirror|"
                     r"row_bcast|row_newbcast|dpp8)\b")
 
@@ -180,15 +180,12 @@ class Inst:
                 self.defs |= regs_of(o)
             for o in src_ops:
                 self.uses |= regs_of(o)
-            if mn.startswith(("v_fmac_", "v_mac_", "v_pk_fmac_", "v_dot2c_", "v_dot4c_", "v_dot8c_", "v_writelane_",
-                              "v_movreld_")) or (mn.startswith("v_permlane") and "swap" in mn) or mn.startswith("v_swap_"):
+            if mn.startswith(DST_ALSO_READ) or (mn.startswith("v_permlane") and "swap" in mn) or mn.startswith("v_swap_"):
                 for o in dst_ops:
                     self.uses |= regs_of(o)
             if mn.startswith(("v_cndmask_b32_e32", "v_addc_co_u32_e32", "v_subb_co_u32_e32", "v_subbrev_co_u32_e32")) or \
                     mn.startswith("v_div_fmas"):
                 self.uses |= {("vcc", 0), ("vcc", 1)}
-            if self.is_dpp and not re.search(r"bound_ctrl:1|bound_ctrl:0", opstr) or (self.is_dpp and mn.startswith("v_mov_b32")):
-                pass
             if mn.startswith(("v_readlane_", "v_writelane_")) and len(reg_ops) >= 3:
                 self.lane_sel = {r for r in regs_of(reg_ops[2]) if r[0] in ("s", "vcc", "m0")}
             # 16-bit half writes that keep the other half: v_*_mixhi, op_sel with the dst bit, SDWA dst_sel
@@ -377,7 +374,7 @@ def required(p, c):
             if hit and (c.is_valu or c.is_vmem or c.is_ds):
                 out.append(("R1", raw_waw, hit))
         war = p.srcc & cv_def
-        if war and c.is_valu and c.kind != "mfma" and not (p.srcc == p.defs and False):
+        if war and c.is_valu and c.kind != "mfma":
             out.append(("R2", {2: 1, 4: 3, 8: 7, 16: 13}.get(p.passes, 13), war))
         return out
     if p.is_valu:
