@@ -22,10 +22,23 @@
 // register c & 3 of lane half 0, so L_cc needs neither a tile of its own in LDS nor the forward's ldT -- and without that tile a
 // workgroup is 68 KB of LDS: TWO workgroups a CU, two waves a SIMD (rules 12 / 26).  Its product with the tile's u row (still
 // eps_c there) is taken back out of the dot product.
-// Every wave streams the tiles by itself, L2 -> registers, one tile ahead (the forward's plain form).  Measured at 1M x 100
-// (bench.py --estimator score): with an L tile in LDS and one wave a SIMD 3.71 ms; the same with the tiles shared through a
-// three-slot LDS ring and a barrier a tile (the forward's SH protocol) 4.15 -- at one wave a SIMD the kernel waits for latency,
-// not for the L2, and the barrier adds to it; this form: see DESIGN.md section 6.
+// Two forms (template RING).  RING = false, batches under 16 384 persons or when the LDS does not hold the other: four waves of
+// 32 persons a workgroup, every wave streams the tiles by itself, L2 -> registers, one tile ahead (the forward's plain form).
+// RING = true: ONE workgroup a CU of eight consumer waves (two a SIMD) and a ninth LOADER wave that moves tile t + 2 by LDS-DMA
+// into the slot tile t has left (two 9 KB slots behind the eight u tiles: 154 KB) and waits for it before the barrier that ends
+// iteration t -- a tile crosses the L2 -> CU path once a workgroup instead of eight times (60 -> 7.5 GB a launch at 1M persons).
+// The loader issues nothing but transfers, so its `vmcnt(0)` counts them alone; the consumers' column stores stay in flight as
+// long as they like.  Measured at 1M x 100 (bench.py --estimator score, alternating runs on one box):
+//     an L tile in LDS beside the u tile (L_cc from the forward's ldT), one wave a SIMD                       3.71 ms
+//     ... with the tiles through a three-slot ring whose CONSUMERS moved their own fragments (counted vmcnt:
+//         the column stores, a microsecond in flight, stood in front of every tile)                           4.15
+//     the diagonal row in the image, two workgroups a CU, plain form; u reads where they are used             2.74-2.78
+//     ... the u reads at the head of the iteration, exp / rcp of L_cc at the column's START                   2.77-2.80
+//     RING (loader wave), u reads where used                                                                  2.78
+//     RING, u reads at the head, exp / rcp at the column's start  (ships for large batches)                   2.63-2.65
+// The L2 was NOT what the plain form waited for (an eighth of the traffic, the same time): at two waves a SIMD a wave's in-order
+// issue stream is the limit -- thirteen dependent MFMAs (416 cycles), then ~100 instructions of epilogue, column bookkeeping and
+// branches during which it issues no MFMA; the matrix pipe is 50 % busy in both forms (profiles/r06_score_pmc_counters.json).
 #pragma once
 // (included by vx_abi.hip behind k_mvn_fwd_b.hip: the tile format FB_*, split2h_bits and the scale block are its own)
 
@@ -48,6 +61,12 @@ __host__ __device__ inline int sb_ds(int D) {
     return ds;
 }
 __host__ __device__ inline size_t sb_lds_bytes(int D) { return (size_t)SB_WAVES * SB_WP * sb_ds(D) * sizeof(float); }
+// RING form: eight consumer waves (u tiles) + one loader wave, the column tiles through two slots in LDS
+#define SBR_CONSUMERS 8
+#define SBR_THREADS (64 * (SBR_CONSUMERS + 1))
+__host__ __device__ inline size_t sbr_lds_bytes(int D) {
+    return (size_t)SBR_CONSUMERS * SB_WP * sb_ds(D) * sizeof(float) + 2 * (size_t)FB_IMG_BYTES;
+}
 __host__ __device__ inline int64_t sb_img_floats(int D) { return (int64_t)sb_tiles(D) * (FB_IMG_BYTES / 4); }
 
 // tile t of the image: blockIdx.x = t.  (c, tile within the column) by a walk over the columns -- 100 trips of scalar
@@ -93,7 +112,8 @@ __global__ __launch_bounds__(256) void k_pack_heads_col(int D, const float* __re
     }
 }
 
-__global__ __launch_bounds__(SB_THREADS, 2) void k_mvn_score_b(
+template <bool RING>
+__global__ __launch_bounds__(RING ? SBR_THREADS : SB_THREADS, RING ? 1 : 2) void k_mvn_score_b(
     int D, int64_t nb, float scale, const int64_t* __restrict__ rows, const float* __restrict__ h /*[nb][64]*/,
     const uint8_t* __restrict__ img, const float* __restrict__ sc, const float* __restrict__ eps /*[nb][D]*/,
     const float* __restrict__ ll, const float* __restrict__ ent, float* __restrict__ baseline, float base_beta, int base_by_row,
@@ -102,9 +122,48 @@ __global__ __launch_bounds__(SB_THREADS, 2) void k_mvn_score_b(
     const int DS = sb_ds(D);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, p = lane & 31;
+    constexpr int NCW = RING ? SBR_CONSUMERS : SB_WAVES;                    // waves with persons
+    const int n_tiles = sb_tiles(D);
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    lds_u8* const ring = (lds_u8*)(sb_lds + (size_t)NCW * SB_WP * DS);      // RING: two tile slots behind the u tiles
+    // LDS accesses of this wave done, then the workgroup barrier (no release fence: nobody waits for the column stores)
+    auto turn = [&]() __attribute__((always_inline)) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                  // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    if constexpr (RING) {
+        if (wave == NCW) {
+            // ---- the loader wave: tile t + 2 into the slot tile t has left, landed before the barrier that ends iteration t.
+            // It issues nothing but these transfers, so its vmcnt counts them alone (a consumer's column stores, in flight for
+            // a microsecond, never stand in front of a tile: the three-slot ring whose consumers moved their own fragments
+            // measured 4.15 ms for that reason)
+            const uint32_t ring_l = lds_addr_uniform((const void*)(sb_lds + (size_t)NCW * SB_WP * DS));
+            auto stage = [&](int t) __attribute__((always_inline)) {
+                const int tc = t < n_tiles ? t : n_tiles - 1;                // past the end: a harmless duplicate
+                const uint8_t* gb = img + (int64_t)tc * FB_IMG_BYTES + lane * 16;
+                const uint32_t dst = ring_l + (uint32_t)(t & 1) * FB_IMG_BYTES;
+#pragma unroll
+                for (int f = 0; f < 9; ++f) dma16(gb + f * 1024, __builtin_amdgcn_readfirstlane(dst + (uint32_t)f * 1024u));
+            };
+            stage(0); stage(1);
+            vx_wait_vmem();
+            turn();                                                          // B1: tiles 0 and 1 have landed
+            turn();                                                          // B2: every consumer holds tile 0
+            for (int t = 0; t < n_tiles; ++t) {
+                stage(t + 2);
+                vx_wait_vmem();
+                turn();
+            }
+            return;
+        }
+    }
     float* const u_t = sb_lds + (size_t)wave * SB_WP * DS;                   // [32][DS]: eps, then u column by column
-    const int64_t i0 = ((int64_t)blockIdx.x * SB_WAVES + wave) * SB_WP;
-    if (i0 >= nb) return;                                                    // (no workgroup barrier anywhere: a wave may leave)
+    const int64_t i0 = ((int64_t)blockIdx.x * NCW + wave) * SB_WP;
+    if constexpr (!RING)
+        if (i0 >= nb) return;                                                // (no workgroup barrier in this form: a wave may leave)
+    // (RING: a wave past the last person stays for the barriers, on clamped inputs, and stores nothing)
     const int64_t i = i0 + p;
     const bool live = i < nb;
     const int64_t ic = live ? i : nb - 1;                                    // absent persons: the last one, never stored
@@ -155,15 +214,23 @@ __global__ __launch_bounds__(SB_THREADS, 2) void k_mvn_score_b(
     float* const up = u_t + p * DS;
 
     struct TileRegs { f16x8 a[2][4]; f16x8 bias; };
-    const int n_tiles = sb_tiles(D);
     auto pull = [&](TileRegs& R, int t) __attribute__((always_inline)) {
-        const int tc = t < n_tiles ? t : n_tiles - 1;                        // past the end: a harmless duplicate
-        const uint8_t* gb = img + (int64_t)tc * FB_IMG_BYTES + lane * 16;
-        R.bias = *(const f16x8*)(gb + FB_A_BYTES);
+        if constexpr (RING) {
+            lds_u8* lb = ring + (t & 1) * FB_IMG_BYTES + lane * 16;
+            R.bias = *(const __attribute__((address_space(3))) f16x8*)(lb + FB_A_BYTES);
 #pragma unroll
-        for (int sp = 1; sp >= 0; --sp)
+            for (int sp = 1; sp >= 0; --sp)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) R.a[sp][s] = *(const f16x8*)(gb + (sp * 4 + s) * 1024);
+                for (int s = 0; s < 4; ++s) R.a[sp][s] = *(const __attribute__((address_space(3))) f16x8*)(lb + (sp * 4 + s) * 1024);
+        } else {
+            const int tc = t < n_tiles ? t : n_tiles - 1;                    // past the end: a harmless duplicate
+            const uint8_t* gb = img + (int64_t)tc * FB_IMG_BYTES + lane * 16;
+            R.bias = *(const f16x8*)(gb + FB_A_BYTES);
+#pragma unroll
+            for (int sp = 1; sp >= 0; --sp)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) R.a[sp][s] = *(const f16x8*)(gb + (sp * 4 + s) * 1024);
+        }
     };
     f16x8 cfrag;                                                             // the bias product's constant 2^(sw + sh - sb)
     {
@@ -177,15 +244,22 @@ __global__ __launch_bounds__(SB_THREADS, 2) void k_mvn_score_b(
     bool fst = true;
     int cP = 0, jbP = 0;
     bool endP = false, fstP = false;
-    float dot = 0.f, mcc = 0.f, e_c = 0.f;                                   // (mcc: lane half 0)
+    float dot = 0.f, lcc = 1.f, rlc = 1.f, e_c = 0.f;                        // (lcc = exp(M_cc), rlc = 1 / lcc: lane half 0)
     f32x16 accP = zero16();
     const float* up_h = up + 4 * half;
+    // the four 16-byte reads of u for the tile before: issued at the HEAD of an iteration, consumed between its MFMA groups (read
+    // where they are used, every group put an LDS latency into the wave's in-order issue stream in front of the next MFMAs:
+    // ~1 640 cycles a tile and wave for 416 of matrix pipe)
+    f32x4 uq[4];
+    auto epi_read = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) uq[g] = *(const f32x4*)(up_h + jbP + 8 * g);
+    };
     auto epi_group = [&](int g) __attribute__((always_inline)) {
-        const f32x4 u4 = *(const f32x4*)(up_h + jbP + 8 * g);
-        dot = fmaf(accP[4 * g + 0], u4[0], dot);
-        dot = fmaf(accP[4 * g + 1], u4[1], dot);
-        dot = fmaf(accP[4 * g + 2], u4[2], dot);
-        dot = fmaf(accP[4 * g + 3], u4[3], dot);
+        dot = fmaf(accP[4 * g + 0], uq[g][0], dot);
+        dot = fmaf(accP[4 * g + 1], uq[g][1], dot);
+        dot = fmaf(accP[4 * g + 2], uq[g][2], dot);
+        dot = fmaf(accP[4 * g + 3], uq[g][3], dot);
     };
     // the tile before is the FIRST of its column: its row cP - jbP (0..3: accumulator register cP & 3 of lane half 0) is the
     // diagonal row -- keep M_cc, and take its product with the tile's u row (eps_c: the column is not solved yet) out of the sum
@@ -193,14 +267,17 @@ __global__ __launch_bounds__(SB_THREADS, 2) void k_mvn_score_b(
         const int q = cP & 3;                                                // wave-uniform
         const float m = q == 0 ? accP[0] : (q == 1 ? accP[1] : (q == 2 ? accP[2] : accP[3]));
         e_c = up[cP];
-        if (half == 0) { mcc = m; dot = fmaf(-m, e_c, dot); }
+        if (half == 0) {
+            dot = fmaf(-m, e_c, dot);
+            lcc = __expf(m * acc_inv);                                       // (two transcendentals: made HERE, tiles before the column ends)
+            rlc = fast_rcp(lcc);
+        }
     };
     // a column is done: join the lane halves, u_c into the tile, the operands of the backward kernels to global memory
     auto column_end = [&]() __attribute__((always_inline)) {
         const float tot = half_sum32(dot) * acc_inv;
         if (half == 0) {
-            const float lcc = __expf(mcc * acc_inv);
-            const float uc = (e_c - tot) * fast_rcp(lcc);
+            const float uc = (e_c - tot) * rlc;
             up[cP] = uc;
             if (live) {
                 const float g = w * uc;
@@ -212,6 +289,7 @@ __global__ __launch_bounds__(SB_THREADS, 2) void k_mvn_score_b(
     };
     auto tile_iter = [&](TileRegs& Rc, TileRegs& Rn, int t, auto firstc) __attribute__((always_inline)) {
         constexpr bool first = decltype(firstc)::value;
+        if constexpr (!first) epi_read();
         pull(Rn, t + 1);
         f32x16 a = mfma_f16(Rc.bias, cfrag, zero16());
         a = mfma_f16(Rc.a[1][0], hb[0][0], a);
@@ -246,9 +324,16 @@ __global__ __launch_bounds__(SB_THREADS, 2) void k_mvn_score_b(
             --left;
             fst = false;
         }
+        if constexpr (RING) turn();                                          // tile t + 1 is in everybody's registers, t + 2 has landed
     };
     TileRegs RA, RB;
-    pull(RA, 0);
+    if constexpr (RING) {
+        turn();                                                              // B1
+        pull(RA, 0);
+        turn();                                                              // B2
+    } else {
+        pull(RA, 0);
+    }
     tile_iter(RA, RB, 0, std::true_type{});
     int t = 1;
     for (; t + 1 < n_tiles; t += 2) {
@@ -256,6 +341,7 @@ __global__ __launch_bounds__(SB_THREADS, 2) void k_mvn_score_b(
         tile_iter(RA, RB, t + 1, std::false_type{});
     }
     if (t < n_tiles) tile_iter(RB, RA, t, std::false_type{});
+    epi_read();
     epi_group(0); epi_group(1); epi_group(2); epi_group(3);                  // the last tile: column 0 (one tile when D <= 32)
     if (fstP) column_start();
     column_end();

@@ -1683,13 +1683,25 @@ int vx_mvn_score_heads(const vx_irt_cfg* cfg, int64_t nb, const int64_t* rows, c
     const int D = cfg->D;
     hipLaunchKernelGGL(k_pack_heads_col, dim3((unsigned)sb_tiles(D)), dim3(256), 0, st, D, W22, b22, sc, (uint8_t*)workspace);
     VX_CHECK_LAUNCH();
-    const size_t lds = sb_lds_bytes(D);
-    int rc = set_lds(k_mvn_score_b, lds);
-    if (rc) return rc;
-    {
-        ProfScope ps("k_mvn_score_b", st, nb);
-        hipLaunchKernelGGL(k_mvn_score_b, dim3((unsigned)((nb + SB_WAVES * SB_WP - 1) / (SB_WAVES * SB_WP))), dim3(SB_THREADS), lds, st,
-                           D, nb, cfg->scale, rows, h, (const uint8_t*)workspace, sc, eps, ll, ent, baseline, base_beta,
+    // a batch that fills the chip: one workgroup of eight consumer waves and a loader wave a CU, the tiles through LDS once
+    // (the L2 serves the 2 MB image to every wave of the plain form at 22 TB/s: rule 30); a smaller one: the plain form
+    static const bool no_ring = getenv("VX_SCORE_NO_RING") != nullptr;
+    const bool ring = !no_ring && nb >= 16384 && sbr_lds_bytes(D) <= 160 * 1024;
+    int rc;
+    ProfScope ps("k_mvn_score_b", st, nb);
+    if (ring) {
+        const size_t lds = sbr_lds_bytes(D);
+        rc = set_lds(k_mvn_score_b<true>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_mvn_score_b<true>, dim3((unsigned)((nb + SBR_CONSUMERS * SB_WP - 1) / (SBR_CONSUMERS * SB_WP))),
+                           dim3(SBR_THREADS), lds, st, D, nb, cfg->scale, rows, h, (const uint8_t*)workspace, sc, eps, ll, ent, baseline,
+                           base_beta, (int)base_by_row, log_r, gxT, gdT);
+    } else {
+        const size_t lds = sb_lds_bytes(D);
+        rc = set_lds(k_mvn_score_b<false>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_mvn_score_b<false>, dim3((unsigned)((nb + SB_WAVES * SB_WP - 1) / (SB_WAVES * SB_WP))), dim3(SB_THREADS), lds,
+                           st, D, nb, cfg->scale, rows, h, (const uint8_t*)workspace, sc, eps, ll, ent, baseline, base_beta,
                            (int)base_by_row, log_r, gxT, gdT);
     }
     VX_CHECK_LAUNCH();
