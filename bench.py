@@ -281,6 +281,8 @@ def main():
                          "gradient through d log q.  A line of its own, never the BASELINE metric")
     ap.add_argument("--baseline", default="avg", choices=["none", "avg"],
                     help="control variate of --estimator score: per-person decaying average (pyro's use_decaying_avg_baseline) or none")
+    ap.add_argument("--event-every", type=int, default=5,
+                    help="kernel-by-kernel timed region: HIP events on every n-th step of it (1 = on all)")
     ap.add_argument("--dist-backend", default=os.environ.get("VX_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path); gloo only to rehearse N ranks on fewer GPUs -- the line "
                          "such a run prints is marked a rehearsal (metric, config.collective) and is not an N-GPU result")
@@ -390,11 +392,23 @@ def main():
             loss = losses[-1]
             i += n
     else:
+        # HIP events inside the timed region, on a SAMPLE of its steps (every `every`-th, from the first): a pair of events
+        # around each large kernel and each phase is ~25 records a step, and each costs the stream a few microseconds -- 0.11 ms of
+        # a 9.0 ms headline step when every step carries them (tools/step_events_cost.py); the sampled steps are ordinary steps
+        # of the timed region, `roofline.avg_launch_ms` is the mean over their launches (`roofline.launches_sampled`)
+        every = max(1, int(args.event_every))
         for i in range(args.steps):
+            sampled = (i % every) == 0
+            if every > 1:
+                eng.events = ev if sampled else None
+                _hip.lib().vx_prof_enable(2 if sampled else 3)
             loss = eng.step(lrs)
             if i == 0:
                 loss_first = loss if args.steps < 60 else loss.clone()
             lrs.scheduler_step()
+        if every > 1:
+            eng.events = ev
+            _hip.lib().vx_prof_enable(2)
     sync()
     dt = time.perf_counter() - t0
     loss_v = float(loss.item())
@@ -408,12 +422,13 @@ def main():
             lrs.scheduler_step()
         sync()
     eng.events = None
-    kernel_ms, kernel_units = {}, {}
+    kernel_ms, kernel_units, kernel_launches = {}, {}, {}
     import ctypes
     for slot in range(_hip.lib().vx_prof_count()):
         nm, ms, cnt = ctypes.create_string_buffer(64), ctypes.c_float(0), ctypes.c_int(0)
         if _hip.lib().vx_prof_read(slot, nm, 64, ctypes.byref(ms), ctypes.byref(cnt)) == 0 and cnt.value:
             kernel_ms[nm.value.decode()] = float(ms.value)
+            kernel_launches[nm.value.decode()] = int(cnt.value)
             un = ctypes.c_int64(0)                             # persons of a launch that takes only part of the batch
             if _hip.lib().vx_prof_units(slot, ctypes.byref(un)) == 0 and un.value:
                 kernel_units[nm.value.decode()] = int(un.value)
@@ -511,7 +526,8 @@ def main():
                                              "dense fp16 MFMA peak 2500 / 2 products per f32 x {-1,0,1} product"
                                              if peak == PEAK_BF16_MFMA_TFLOPS / 2.0 else "dense f32 MFMA peak",
                                "algorithmic_flops_per_launch": fl, "avg_launch_ms": priced[name],
-                               "persons_per_launch": kernel_units.get(name, n_local)}
+                               "persons_per_launch": kernel_units.get(name, n_local),
+                               "launches_sampled": kernel_launches.get(name)}
             if graphed:
                 out["roofline"]["avg_launch_ms_source"] = ("HIP events around the kernel in an eager pass after the "
                                                            "timed region (the timed region replays a graph)")

@@ -78,6 +78,36 @@ def test_cfg3_headline_sharding_additivity_and_determinism():
     assert acc[-1] == pytest.approx(g_full[-1], rel=2e-5)
 
 
+def test_cfg3_half_shard_replayed_steps_equal_eager_steps():
+    """A 500 000-person shard of the headline (what each of two GPUs holds): seven steps replayed from the HIP graph against
+    the same steps launched kernel by kernel -- same bits in every loss and every parameter, across a scheduler milestone.
+    (The second-stream branches of the large-batch forward and backward are inside the capture; shards of this size replay
+    since round 6, tools/step_events_cost.py.)"""
+    from vipsy_amd import synth
+    from vipsy_amd.engine import IrtEngine, LrSpec
+    N, J, D, H = 500000, 500, 100, 64
+    a, b = synth.mirt_item_params(J, D, seed=20243)
+    y = synth.simulate_responses(N, 0, {"a": a, "b": b}, "irt_2pl", _dev(), seed=20241)
+    out = []
+    for graph in (True, False):
+        eng = IrtEngine(y, model="irt_2pl", D=D, amortized=True, H=H, seed=11)
+        eng.use_graph = graph
+        assert eng._graphable() == graph
+        lrs = LrSpec(lambda m, p: {"lr": 1e-2 if p in ("a", "b") else 1e-3}, milestones=(4,), gamma=0.5)
+        losses = []
+        for t in range(7):
+            losses.append(eng.step(lrs))
+            lrs.scheduler_step()
+        torch.cuda.synchronize()
+        st = getattr(eng, "_graph", None) or {}
+        assert (st.get("graph") is not None) == graph
+        out.append((torch.stack(losses).cpu().numpy(), eng.P.cpu().numpy().copy()))
+        del eng
+    assert np.isfinite(out[0][0]).all() and len(set(out[0][0].tolist())) == 7
+    for u, v in zip(out[0], out[1]):
+        assert np.array_equal(u, v)
+
+
 def _check_cfg3_sample_against_oracle(eng, y, N, J, D, H):
     """The judged size against the oracle, on a sample: everything the step computes PER PERSON -- h, x, ent of the guide
     (vi.py:448-455, 686-693), the person's log-likelihood + prior term and d ELBO / d x (vi.py:32-41, 596-625) -- depends on

@@ -263,6 +263,7 @@ int vx_abi_version(void) { return VX_ABI_VERSION; }
 const char* vx_build_info(void) { return "vipsy_amd gfx950 fp32-mfma " __DATE__ " " __TIME__; }
 
 int vx_prof_enable(int on) {
+    if (on == 2 || on == 3) { g_prof = on == 2; return VX_OK; }       // resume / pause: the records stay
     for (int i = 0; i < g_prof_n; ++i) {
         for (auto& e : g_prof_slots[i].ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         g_prof_slots[i].ev.clear();

@@ -677,7 +677,7 @@ class _EngineBase(object):
     # unusable after a half-recorded collective, so the process must not carry on (no eager retry).
     use_graph = True
     score_mfma = os.environ.get("VX_SCORE_MFMA", "1") != "0"      # test seam: 0 = the scalar score-operand kernel for every shape
-    graph_max_persons = int(os.environ.get("VX_GRAPH_MAX_PERSONS", "300000"))
+    graph_max_persons = int(os.environ.get("VX_GRAPH_MAX_PERSONS", str(1 << 40)))
 
     def _graph_mode(self, rows, b_global, eps, S):
         """The captured form this call can replay -- ('full' | 'rows', nb, b_global) and, with S > 1 particles, S as a fourth
@@ -710,10 +710,11 @@ class _EngineBase(object):
         if D > 1 and amort and isinstance(self, IrtEngine):
             if full:
                 # a large shard runs short kernels BESIDE long ones on a second stream (the last chip round of the forward and
-                # the hidden gradient, the fc1 gradient); replayed from a graph the branches keep their dependencies but not
-                # their launch order, and the short kernel ends up behind the long one: measured 10.7 against 10.1 ms at 1M
-                # persons, 1.46 against 1.63 at 125 k (where the ~25 launch gaps dominate) -- so only shards up to
-                # GRAPH_MAX_PERSONS persons replay
+                # the hidden gradient, the fc1 gradient); the capture keeps those branches as graph edges.  Until round 5 the
+                # replayed 1M step was the slower one (10.7 against 10.1 ms) and shards above 300 k ran eagerly; with the
+                # round-6 kernels it is the faster one at every size measured (tools/step_events_cost.py: 8.97 against
+                # 9.00 ms at 1M, 4.53 against 4.65 at 500 k, 1.46 against 1.63 at 125 k), so every shard replays.
+                # VX_GRAPH_MAX_PERSONS remains as the switch back
                 return ("full", self.n_local, self.N) if self.n_local <= self.graph_max_persons else None
             if rows is not None and not isinstance(rows, (list, tuple)) and self.n_local > 0:
                 nb = int(rows.numel())
