@@ -31,6 +31,12 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: dense bf16 / fp16 matrix peak (t
 # an fp32 product computed from two fp16 terms per operand costs three fp16 MFMA products:
 PEAK_F16X2_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBS = 8000.0
+# What the 16-bit matrix pipe SUSTAINS on this board: a loop of nothing but dense v_mfma_f32_32x32x16_f16 on random operands, every
+# CU busy, runs at the 1 400 W package power cap with the graphics clock at 1.52 GHz instead of 2.4 -- 1 590 TFLOP/s, 0.633 of
+# the guide's dense peak (tools/power_ubench.hip, profiles/r06_power_ubench.txt; the judged step itself draws 1 375-1 399 W at
+# 1.85-1.87 GHz: profiles/r06_power_headline.txt; docs/HARDWARE.md rule 41).  `roofline.peak` stays the guide's figure;
+# `roofline.power_capped` prices the same kernel against this one.
+SUSTAINED_MFMA16_FRACTION = 1590.0 / 2517.0
 
 
 def _newest_profile_tag():
@@ -528,6 +534,15 @@ def main():
                                "algorithmic_flops_per_launch": fl, "avg_launch_ms": priced[name],
                                "persons_per_launch": kernel_units.get(name, n_local),
                                "launches_sampled": kernel_launches.get(name)}
+            if peak != PEAK_F32_MFMA_TFLOPS:
+                cap = peak * SUSTAINED_MFMA16_FRACTION
+                out["roofline"]["power_capped"] = {
+                    "peak": cap, "frac": ach / cap,
+                    "basis": "the 16-bit matrix pipe's SUSTAINED rate on this board: a loop of dense 32x32x16 fp16 MFMAs on random "
+                             "operands and nothing else holds 1 590 TFLOP/s (0.633 of the guide's 2 517: the 1 400 W package cap "
+                             "brings the clock to 1.52 GHz; tools/power_ubench.hip, profiles/r06_power_ubench.txt), and this step "
+                             "runs at that cap too (1 375-1 399 W, 1.85-1.87 GHz: profiles/r06_power_headline.txt); not measured "
+                             "in this run"}
             if graphed:
                 out["roofline"]["avg_launch_ms_source"] = ("HIP events around the kernel in an eager pass after the "
                                                            "timed region (the timed region replays a graph)")

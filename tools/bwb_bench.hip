@@ -51,7 +51,7 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(k_split2_f16, dim3(2048), dim3(256), 0, 0, hT, nb * 64, sc + 3, hs);
     EncDims dm; dm.D = D; dm.J = 500; dm.H = 64; dm.Hp = 64; dm.DS = enc_ds(D); dm.T = T; dm.nb = nb;
     const int n_rowslabs = (Rp + BT_ROWS - 1) / BT_ROWS;
-    int n_prw = 256 / n_rowslabs;
+    int n_prw = argc > 2 ? atoi(argv[2]) : 256 / n_rowslabs;            // (fewer person slabs: the kernel on part of the chip)
     CK(hipMalloc(&slabs, (size_t)n_prw * Rp * 65 * 4));
 #ifdef BWB_KERNEL_FILE
     const size_t lds = bb_lds_bytes(D);

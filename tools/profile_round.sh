@@ -40,3 +40,5 @@ for k, v in c.items():
 json.dump(out, open(sys.argv[2], "w"), indent=1, sort_keys=True)
 PY
 rm -rf /tmp/prof_$TAG /tmp/pmc_${TAG}_*
+# the graphics clock each large kernel ran at (docs/HARDWARE.md rule 41: the step runs at the board's power cap)
+CLK_JSON=$OUT/clock.json bash $R/tools/clk_probe.sh k_ python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 2 "$@" > $OUT/clock.txt 2>&1

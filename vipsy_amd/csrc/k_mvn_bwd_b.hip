@@ -215,14 +215,22 @@ __global__ __launch_bounds__(BWB_THREADS, 1) void k_mvn_enc_bwd_w_b(
             const int dd = d - dH0, s3 = dd >> 2;
             const int hh = 16 * (dd & 3) + 4 * (lane >> 4) + ((lane & 15) >> 2);
             const int s = (lane & 3) ^ ((hh >> 2) & 3);
+#ifdef BWB_TILE_MAJOR                                                  // (harness experiment: every operand in 32-person blocks)
+            voff[u] = (uint32_t)((((int64_t)s3 * 64 + hh) * 32 + 8 * s) * 2);
+#else
             voff[u] = (uint32_t)((((int64_t)s3 * 64 + hh) * nb + 8 * s) * 2);
+#endif
         } else {
             const int i = 4 * (d & 1) + (lane >> 4), beta = (lane >> 3) & 1;
             const int R = 16 * (d >> 1) + 8 * beta + i;
             const int c = (lane & 7) ^ i;
             int rl = R >= rGD ? R - rGD : R >= rE ? R - rE : R;
             if (rl >= D) rl = D - 1;                                   // padding rows of a region: a harmless duplicate
+#ifdef BWB_TILE_MAJOR
+            voff[u] = (uint32_t)(((int64_t)rl * 32 + 4 * c) * 4);
+#else
             voff[u] = (uint32_t)(((int64_t)rl * nb + 4 * c) * 4);
+#endif
         }
         const bool isH = d >= dH0 && d < dGD0;
         sbase[u] = d >= dGD0 ? (const char*)gdT : isH ? (const char*)hs : d >= rE / 8 ? (const char*)epsT : (const char*)gxT;
@@ -244,8 +252,14 @@ __global__ __launch_bounds__(BWB_THREADS, 1) void k_mvn_enc_bwd_w_b(
         const uint32_t lb0 = lds_addr_uniform(smem_bb);
 #pragma unroll
         for (int u = 0; u < BB_MAXD; ++u) {
+#ifdef BWB_TILE_MAJOR
+            const uint32_t tstride = vsh[u] == 1u ? 2u * 64u * 32u * 2u : (uint32_t)D * 128u;
+            sptr[u] = (uint64_t)sbase[u] + (uint64_t)blk_pr * tstride;
+            sdel[u] = (uint32_t)GS * tstride;
+#else
             sptr[u] = (uint64_t)sbase[u] + ((uint64_t)((int64_t)blk_pr * BT_P) << vsh[u]);
             sdel[u] = (uint32_t)(GS * BT_P) << vsh[u];
+#endif
 #pragma unroll
             for (int b2 = 0; b2 < NBUF; ++b2) lm0[b2][u] = lb0 + (uint32_t)b2 * BUF + ldst[u];
         }
