@@ -13,7 +13,9 @@ for w in "cfg2 irt4pl_1d_bbvi_100kx100" "cfg4 irt2pl_1d_bbvi_missing90_1Mx500" "
     set -- $w
     timeout -k 10 300 python3 bench.py --workload $2 --steps 200 --warmup 5 > $OUT/$1_bench.json 2> $OUT/$1.err || exit 1
 done
-timeout -k 10 300 python3 bench.py --persons 125000 --steps 200 --warmup 5 --no-cpu-baseline > $OUT/shard_125k_bench.json 2> $OUT/shard.err || exit 1
+for n in 125 250 500; do
+    timeout -k 10 300 python3 bench.py --persons ${n}000 --steps 200 --warmup 5 --no-cpu-baseline > $OUT/shard_${n}k_bench.json 2> $OUT/shard.err || exit 1
+done
 timeout -k 10 120 python3 tools/minibatch_probe.py --steps 1000 > $OUT/minibatch_probe.txt 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/mb_$TAG -o r -- python3 $R/tools/minibatch_probe.py --modes graph4 --steps 1000 > $OUT/mb_trace.log 2>&1 || exit 1
