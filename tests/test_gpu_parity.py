@@ -299,6 +299,8 @@ def _oracle_latents_chunked(params, y, eps, D, chunk=4096):
     (70016, "small"),   # one full chip round (65 536) on fwd_b2 + a 4 480-person tail on k_mvn_enc_fwd_b<false>
     (33024, "ones"),    # the same kernels in the BENCH's regime: a as vi.py:567-572 initialises it (ones + the zero pattern),
     (70016, "ones"),    # |z| up to 40, every ninth cell beyond the clamp; the few cells ON the clamp are marked missing
+    (33021, "small"),   # a shard whose size is no multiple of 8 (nor of 4): three phantom persons (engine.py::_pad_persons) keep
+    (70010, "small"),   # it on these kernels -- six of them, a chip round + tail; every gradient and the loss as if they were not there
 ])
 def test_headline_large_batch_kernels_vs_oracle(N, slopes):
     """The kernels that run the judged 1M x 500 x 100 step -- the large-batch forms of the forward (k_mvn_fwd_b2.hip,
@@ -372,8 +374,10 @@ def test_headline_large_batch_kernels_vs_oracle(N, slopes):
     np.testing.assert_allclose(h_h, h_o, atol=2e-5, rtol=1e-5)
     np.testing.assert_allclose(ent_h, ent_o, atol=2e-5 * max(1.0, np.abs(ent_o).max()), rtol=1e-5)
     # the dimension-major copies the backward kernels read
-    hT = fw["hT"][:H * N].reshape(H, N).cpu().numpy()
-    epsT = fw["epsT"][:D * N].reshape(D, N).cpu().numpy()
+    nbk = eng.last["nb"]                                 # persons the kernels were launched over (N, or N + phantoms)
+    assert nbk == (N + 7) // 8 * 8 and eng.last["n_valid"] == N
+    hT = fw["hT"][:H * nbk].reshape(H, nbk)[:, :N].cpu().numpy()
+    epsT = fw["epsT"][:D * nbk].reshape(D, nbk)[:, :N].cpu().numpy()
     assert np.array_equal(hT, h_h.T) and np.array_equal(epsT, eps.T)
     loss_h = float(eng.G[eng.n_params].item())
     assert loss_h == pytest.approx(loss_o, rel=3e-5)
@@ -387,6 +391,35 @@ def test_headline_large_batch_kernels_vs_oracle(N, slopes):
 
 
 GRAD_TOL_LARGE = 3e-5       # the tolerance of the golden replays
+
+
+@pytest.mark.parametrize("N", [4099, 33021])
+def test_phantom_persons_add_nothing(N):
+    """A full batch whose size is no multiple of 8, launched over the next multiple with phantom persons (all responses missing;
+    taken out behind the likelihood: engine.py::_pad_persons) against the same batch launched over its own size (the fp32-MFMA
+    generation of the backward kernels): loss and every gradient agree to the parity tolerance, three steps of Adam keep the
+    parameters together, and the padded step replayed from its HIP graph equals the padded eager one bit for bit."""
+    from vipsy_amd.engine import IrtEngine, LrSpec
+    J, D, H = 500, 100, 64
+    y, _, _ = _random_problem(N, J, D, H, "irt_2pl", 0.1, seed=N)
+    out = []
+    for pad, graph in ((True, False), (False, False), (True, True)):      # (the third: the padded step replayed from its graph)
+        eng = IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_2pl", D=D, amortized=True, H=H, seed=11)
+        eng.pad_persons = pad
+        eng.use_graph = graph
+        eng.loss_and_grads()
+        torch.cuda.synchronize()
+        assert eng.last["nb"] == ((N + 7) // 8 * 8 if pad else N) and eng.last["n_valid"] == N
+        g = eng.G[:eng.n_params + 1].double().cpu().numpy().copy()
+        lrs = LrSpec(lambda m, p: {"lr": 1e-3})
+        losses = [float(eng.step(lrs)) for _ in range(3)]
+        out.append((g, np.array(losses), eng.P.double().cpu().numpy().copy()))
+    assert np.array_equal(out[0][0], out[2][0]) and np.array_equal(out[0][2], out[2][2])
+    g_pad, g_own = out[0][0], out[1][0]
+    assert g_pad[-1] == pytest.approx(g_own[-1], rel=3e-5)
+    assert np.abs(g_pad[:-1] - g_own[:-1]).max() <= GRAD_TOL_LARGE * np.abs(g_own[:-1]).max()
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=3e-5)
+    assert np.abs(out[0][2] - out[1][2]).max() <= 1e-4 * max(1.0, np.abs(out[1][2]).max())
 
 
 @pytest.mark.parametrize("N,J,model,miss,B", [

@@ -491,11 +491,39 @@ class _EngineBase(object):
         if rows is not None or self.n_local == 0:
             return None
         if getattr(self, "_yT", None) is None:
-            stride = (self.n_local + 63) // 64 * 64
+            y = self._padded_y()                             # (the shard's own responses unless its size is padded, below)
+            stride = (y.shape[0] + 63) // 64 * 64
             yT = torch.full((self.J + 1, stride), 254, dtype=torch.uint8, device=self.dev)
-            yT[:self.J, :self.n_local] = self.y.t()
+            yT[:self.J, :y.shape[0]] = y.t()
             self._yT = yT
         return self._yT
+
+    def _pad_persons(self, be, cfg, rows):
+        """Persons the full-batch kernels of the amortized multivariate guide are launched over: the shard's own count, or --
+        when that is not a multiple of 8 -- the next one.  The dimension-major operands of the large-batch kernels are rows of
+        `nb` floats (fp16 planes: `nb` halves) read in 16-byte pieces, so a count that is not a multiple of 8 sends the head
+        weight gradient (and, below a multiple of 4, everything) to the fp32-MFMA generation: 13.9 ms a step at 1 000 004
+        persons, 26.3 at 999 999, against 9.1 at 1 000 000.  The 1-7 PHANTOM persons appended instead have every response
+        missing (byte 255: a finite guide sample, no likelihood term) and are taken out of the step behind the likelihood:
+        their columns of gxT / gdT (everything the backward kernels see of a person) and their entries of ll / ent are zeroed,
+        so they add nothing to any gradient or to the loss.  Pathwise estimator, HIP backend, full batch only."""
+        n = self.n_local
+        if (rows is not None or n % 8 == 0 or n < 8 or not isinstance(be, HipBackend)
+                or getattr(self, "estimator", "pathwise") != "pathwise" or not self.pad_persons):
+            return n
+        n_pad = (n + 7) // 8 * 8
+        return n_pad if (be.mvn_enc_bwd_layout(cfg, n_pad) == 1 and be.mvn_enc_bwd_gd_offset(cfg, n_pad) >= 0) else n
+
+    pad_persons = os.environ.get("VX_PAD_PERSONS", "1") != "0"      # test seam: 0 = launch over the shard's own count
+
+    def _padded_y(self):
+        """The responses with the phantom persons of _pad_persons appended (made once; self.y itself when none are)."""
+        n_pad = getattr(self, "_n_pad", self.n_local)
+        if n_pad == self.n_local:
+            return self.y
+        if getattr(self, "_y_pad", None) is None:
+            self._y_pad = torch.cat([self.y, torch.full((n_pad - self.n_local, self.J), 255, dtype=torch.uint8, device=self.dev)])
+        return self._y_pad
 
     def _sparse_lists(self, rows):
         """Observed-cell lists for the D = 1 kernel (include/vipsy_amd.h, vx_irt1d_sparse_grad): built once -- the
@@ -1273,6 +1301,11 @@ class IrtEngine(_EngineBase):
             self.last = {"fw": fw, "gx": gx, "ll": ll, "nb": nb}
         elif self.D > 1:
             D, H = self.D, self.H
+            n_valid, y_k = nb, self.y
+            if rows is None and eps is None:
+                self._n_pad = self._pad_persons(be, cfg, rows)
+                if self._n_pad != nb:                      # phantom persons up to a multiple of 8 (_pad_persons)
+                    nb, y_k = self._n_pad, self._padded_y()
             fw = {"h": self._buf("h", nb * H), "x": self._buf("x", nb * D), "eps": self._buf("eps", nb * D),
                   "ldT": self._buf("ldT", nb * D), "ent": self._buf("ent", nb)}
             fw["packws"] = self._buf("packws", be.mvn_pack_floats(cfg))
@@ -1303,7 +1336,7 @@ class IrtEngine(_EngineBase):
                     cfg_f = be.cfg(self.model, self.D, self.J, self.H, self.Dc, scale, self.seed, self.t, stream_id,
                                    step_dev=sd, rows_ring=ring)
                     self._capture_ring_used = True
-                be.mvn_enc_forward(cfg_f, self.y, rows, nb, self.gid0, enc, eps, fw)
+                be.mvn_enc_forward(cfg_f, y_k, rows, nb, self.gid0, enc, eps, fw)
             gd_off = be.mvn_enc_bwd_gd_offset(cfg, nb)     # the backward's DIAG-row operand, made in the likelihood's last pass
             gdT = encb_ws[gd_off:gd_off + nb * D] if gd_off >= 0 else None
             # the step's largest |gx|, |gd|, |eps| (the head weight gradient's power of two), collected by the likelihood's last
@@ -1314,9 +1347,15 @@ class IrtEngine(_EngineBase):
                 if om >= 0:
                     opmax = fw["packws"][om:om + 3]
             with self._phase("likelihood"):
-                be.lik_grad(cfg, self.y, rows, nb, fw["x"], a, self.view("b"), c_un, d_un, gx, ll, gitem, lik_ws,
+                be.lik_grad(cfg, y_k, rows, nb, fw["x"], a, self.view("b"), c_un, d_un, gx, ll, gitem, lik_ws,
                             gxT=gxT, yT=yT, ximg=fw.get("ximg"), epsT=fw["epsT"] if gdT is not None else None,
                             ldT=fw["ldT"] if gdT is not None else None, gdT=gdT, **({"opmax": opmax} if opmax is not None else {}))
+                if nb != n_valid:
+                    # the phantom persons leave the step here: nothing behind this line sees them but as zeros
+                    gxT[:nb * D].view(D, nb)[:, n_valid:].zero_()
+                    gdT[:nb * D].view(D, nb)[:, n_valid:].zero_()
+                    ll[n_valid:nb].zero_()
+                    fw["ent"][n_valid:nb].zero_()
             if self.estimator == "score":
                 # gxT, gdT <- the score-function operands (k_mvn_score.hip); item gradients and loss stand
                 if gx is not None or gdT is None:
@@ -1340,13 +1379,13 @@ class IrtEngine(_EngineBase):
                 # loss = -scale * sum_i (ll_i + ent_i), from the backward call's last launch; a captured step's counter
                 # advances there, behind every kernel that read it
                 fused_loss = isinstance(be, HipBackend)
-                be.mvn_enc_backward(cfg, self.y, rows, nb, enc, fw, gx,
+                be.mvn_enc_backward(cfg, y_k, rows, nb, enc, fw, gx,
                                     self.G[self.enc_off0:self.enc_off0 + self.n_enc], encb_ws, gxT=gxT,
                                     gd_ready=gdT is not None, **({"opmax_ready": True} if opmax is not None else {}),
                                     **({"loss": (ll, fw["ent"], -scale, lossslot, self.sum_ws)} if fused_loss else {}))
             if not fused_loss:
                 be.sum2_into(ll, fw["ent"], nb, -scale, lossslot, self.sum_ws, **sdc)
-            self.last = {"fw": fw, "gx": gx, "gxT": gxT, "ll": ll, "nb": nb}
+            self.last = {"fw": fw, "gx": gx, "gxT": gxT, "ll": ll, "nb": nb, "n_valid": n_valid}
         else:
             # D = 1: the flat item layout [a: J | b: J | c: J | d: J] IS the kernels' gradient layout -> written in place
             g1d, i1d_ws = gitem, self._buf("i1d_ws", be.irt1d_workspace(cfg, nb))
