@@ -181,6 +181,62 @@ def _usable_cpus():
     return max(1, min(n, 32))
 
 
+def board_probe(run_steps, ms_per_step, seconds=1.6, settle=0.5):
+    """Board power, graphics clock and energy WHILE further steps of the same workload run (after the timed region, never
+    inside it): amdsmi's socket power and gfx clock every 20 ms from a second thread, and the board's energy accumulator
+    around the part behind the first `settle` seconds.  None where amdsmi is not there or refuses (docs/HARDWARE.md rule 41:
+    the judged step runs at the package power cap; this puts the evidence into the line itself)."""
+    try:
+        import threading
+        import amdsmi
+        amdsmi.amdsmi_init()
+        handles = amdsmi.amdsmi_get_processor_handles()
+        if len(handles) != 1:                                # one visible GPU: no guessing which handle this process runs on
+            amdsmi.amdsmi_shut_down()
+            return None
+        h = handles[0]
+        cap_w = float(amdsmi.amdsmi_get_power_cap_info(h)["power_cap"]) / 1e6
+        samples, stop = [], threading.Event()
+
+        def poll():
+            while not stop.is_set():
+                try:
+                    pw = amdsmi.amdsmi_get_power_info(h)["current_socket_power"]
+                    ck = amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)["clk"]
+                    samples.append((time.perf_counter(), float(pw), float(ck)))
+                except Exception:
+                    pass
+                time.sleep(0.02)
+
+        def energy_j():
+            e = amdsmi.amdsmi_get_energy_count(h)
+            return float(e["energy_accumulator"]) * float(e["counter_resolution"]) * 1e-6
+
+        th = threading.Thread(target=poll, daemon=True)
+        n_settle = max(1, int(settle * 1e3 / ms_per_step))
+        n_run = max(4, int((seconds - settle) * 1e3 / ms_per_step))
+        th.start()
+        run_steps(n_settle)
+        t0, e0 = time.perf_counter(), energy_j()
+        run_steps(n_run)
+        t1, e1 = time.perf_counter(), energy_j()
+        stop.set()
+        th.join(timeout=1.0)
+        amdsmi.amdsmi_shut_down()
+        inside = [(pw, ck) for (t, pw, ck) in samples if t0 <= t <= t1]
+        if not inside:
+            return None
+        pws, cks = sorted(v[0] for v in inside), sorted(v[1] for v in inside)
+        return {"power_w": pws[len(pws) // 2], "power_w_min": pws[0], "power_w_max": pws[-1], "power_cap_w": cap_w,
+                "gfx_clock_mhz": cks[len(cks) // 2], "gfx_clock_peak_mhz": 2400.0, "samples": len(inside),
+                "steps": n_run, "ms_per_step": 1e3 * (t1 - t0) / n_run,
+                "joule_per_step": (e1 - e0) / n_run if e1 > e0 else None,
+                "source": "amdsmi (socket power, gfx clock every 20 ms; energy accumulator) beside %d further steps of this "
+                          "workload AFTER the timed region, the first %.1f s of them left out" % (n_run, settle)}
+    except Exception:
+        return None
+
+
 def cpu_baseline(J, D, H, n_sample, min_seconds=6.0):
     """The CPU restatement of the reference step (oracle/vi_oracle.py, numpy float32) on a bounded sample of the same
     workload: full step (loss, all gradients, Adam).  Three figures: all host threads numpy's
@@ -287,6 +343,8 @@ def main():
                          "gradient through d log q.  A line of its own, never the BASELINE metric")
     ap.add_argument("--baseline", default="avg", choices=["none", "avg"],
                     help="control variate of --estimator score: per-person decaying average (pyro's use_decaying_avg_baseline) or none")
+    ap.add_argument("--no-board-probe", action="store_true",
+                    help="skip the ~1.6 s of further steps behind the timed region during which board power / clock are sampled")
     ap.add_argument("--event-every", type=int, default=5,
                     help="kernel-by-kernel timed region: HIP events on every n-th step of it (1 = on all)")
     ap.add_argument("--dist-backend", default=os.environ.get("VX_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
@@ -450,6 +508,14 @@ def main():
         eng.steps(lrs, [None] * ng)
         sync()
         graph_ms = 1e3 * (time.perf_counter() - tg) / ng
+    board = None
+    if world == 1 and not args.no_board_probe:
+        def run_more(n):
+            for _ in range(n):
+                eng.step(lrs)
+                lrs.scheduler_step()
+            sync()
+        board = board_probe(run_more, 1e3 * dt / args.steps)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -501,6 +567,8 @@ def main():
                                        "kernels, launched one by one" % eng.graph_fallback[:160])
         if graph_ms is not None:
             out["graph_replay_ms_per_step"] = graph_ms         # same step, same engine, replayed from its HIP graph afterwards
+        if board is not None:
+            out["board"] = board                               # power / clock / energy beside further steps (board_probe)
         if os.environ.get("VX_MFMA16"):                     # non-default kernel selection: say so in the line itself
             out["config"]["kernel_switch"] = "VX_MFMA16=" + os.environ["VX_MFMA16"]
         if kernel_ms:
