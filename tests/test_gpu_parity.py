@@ -622,6 +622,8 @@ HODINA_TOL = 3e-5        # (measured: <= 5.2e-6, theta_local of the K = 8 case)
     (4500, 500, "irt_2pl", 0.9, None),               # >= 4 096 persons: fc1 from the fp16-pair images (k_norm_enc_fwd_h), rows by DMA
     (4300, 260, "irt_4pl", 0.2, 4200),               # ... gathered rows, a ragged last tile
     (4128, 504, "irt_1pl", 0.5, None),               # ... rows staged word by word (J / 4 even)
+    (4501, 500, "irt_2pl", 0.9, None),               # no multiple of 4: the encoder over 4 504 persons, three of them phantoms
+    (4503, 500, "irt_2pl", 0.2, None),               # (engine.py, D = 1 branch); observed-cell lists / the dense step kernel
 ])
 def test_irt1d_amortized_step_vs_oracle(N, J, model, miss, B, H=64):
     from vipsy_amd.engine import IrtEngine

@@ -1390,17 +1390,26 @@ class IrtEngine(_EngineBase):
             # D = 1: the flat item layout [a: J | b: J | c: J | d: J] IS the kernels' gradient layout -> written in place
             g1d, i1d_ws = gitem, self._buf("i1d_ws", be.irt1d_workspace(cfg, nb))
             elbo = self._buf("elbo", nb)
+            nb_e, y_e = nb, self.y                                 # persons the ENCODER kernels are launched over
             if self.amortized:
                 H = self.H
                 enc = self._enc()
-                fw = {"h": self._buf("h", nb * H), "loc": self._buf("loc", nb), "raw": self._buf("raw", nb)}
+                if (rows is None and eps is None and nb % 8 != 0 and nb >= 8 and isinstance(be, HipBackend)
+                        and self.estimator == "pathwise" and self.pad_persons):
+                    # phantom persons up to a multiple of 8 for the encoder's kernels only (their dimension-major operands want
+                    # 16-byte row starts: 2.0 against 0.87 ms a step at 999 999 x 500 persons); the step kernel below runs over
+                    # the shard's own persons, so the phantoms never reach the likelihood, the loss or the item gradients, and
+                    # their entries of gloc / graw -- all the encoder's backward sees of a person -- are zeroed
+                    self._n_pad = (nb + 7) // 8 * 8
+                    nb_e, y_e = self._n_pad, self._padded_y()
+                fw = {"h": self._buf("h", nb_e * H), "loc": self._buf("loc", nb_e), "raw": self._buf("raw", nb_e)}
                 n_pk = be.norm_enc_pack_floats(cfg) if hasattr(be, "norm_enc_pack_floats") else 0
                 if n_pk > 0:
                     fw["packws"] = self._buf("nenc_packws", n_pk)      # the forward's fp16-pair images of W1 (large batches)
-                gloc, graw = self._buf("gloc", nb), self._buf("graw", nb)
-                nb_ws = self._buf("nencb_ws", be.norm_enc_bwd_workspace(cfg, nb))
+                gloc, graw = self._buf("gloc", nb_e), self._buf("graw", nb_e)
+                nb_ws = self._buf("nencb_ws", be.norm_enc_bwd_workspace(cfg, nb_e))
                 with self._phase("guide_forward"):
-                    be.norm_enc_forward(cfg, self.y, rows, nb, enc, fw)
+                    be.norm_enc_forward(cfg, y_e, rows, nb_e, enc, fw)
                 loc, raw = fw["loc"], fw["raw"]
             else:
                 loc, raw, gloc, graw = self._gather_pp(rows, nb)
@@ -1430,7 +1439,10 @@ class IrtEngine(_EngineBase):
                     self.last_log_r = log_r
             if self.amortized:
                 with self._phase("guide_backward"):
-                    be.norm_enc_backward(cfg, self.y, rows, nb, enc, fw["h"], gloc, graw,
+                    if nb_e != nb:
+                        gloc[nb:nb_e].zero_()
+                        graw[nb:nb_e].zero_()
+                    be.norm_enc_backward(cfg, y_e, rows, nb_e, enc, fw["h"], gloc, graw,
                                          self.G[self.enc_off0:self.enc_off0 + self.n_enc], nb_ws,
                                          yT=self._item_major_y(rows))
             else:
