@@ -191,10 +191,16 @@ def board_probe(run_steps, ms_per_step, seconds=1.6, settle=0.5):
         import amdsmi
         amdsmi.amdsmi_init()
         handles = amdsmi.amdsmi_get_processor_handles()
-        if len(handles) != 1:                                # one visible GPU: no guessing which handle this process runs on
+        h = handles[0] if len(handles) == 1 else None
+        if h is None:                                        # several boards in sight: the one whose PCI address is this device's
+            pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+            want = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            for cand in handles:
+                if str(amdsmi.amdsmi_get_gpu_device_bdf(cand)).lower().startswith(want):
+                    h = cand
+        if h is None:                                        # no guessing which handle this process runs on
             amdsmi.amdsmi_shut_down()
             return None
-        h = handles[0]
         cap_w = float(amdsmi.amdsmi_get_power_cap_info(h)["power_cap"]) / 1e6
         samples, stop = [], threading.Event()
 
