@@ -207,6 +207,18 @@ def _random_problem(N, J, D, H, model, miss, seed):
     (464, 132, 108, 64, "irt_2pl", 0.2, None),
     (320, 500, 100, 64, "irt_4pl", 0.1, None),
     (208, 260, 104, 64, "irt_3pl", 0.2, None),
+    # item counts that are no multiple of 4: phantom items (IrtEngine.__init__) keep the MFMA kernels -- absent for the
+    # likelihood, zero for the encoder; loss and every gradient over the problem's own items as if they were not there
+    (300, 499, 100, 64, "irt_2pl", 0.1, None),      # ... k_irt_lik_h through the item-major copy
+    (320, 501, 100, 64, "irt_4pl", 0.1, None),      # ... k_irt_lik_b
+    (2000, 498, 100, 64, "irt_2pl", 0.0, 1000),     # ... a subsample: the likelihood reads the person-major copy with byte 254
+    (9000, 37, 8, 64, "irt_2pl", 0.1, None),        # ... a small shape, whole workgroups of the forward
+    # latent dimensions that are no multiple of 4: phantom dimensions (a_k = 0 for ever, zero head rows kept at zero)
+    (1000, 45, 3, 64, "irt_3pl", 0.2, None),        # ... with phantom items
+    (320, 500, 99, 64, "irt_2pl", 0.1, None),       # ... 99 + 1 dimensions on k_irt_lik_h and the dimension-major backward
+    (2000, 500, 98, 64, "irt_2pl", 0.0, 1000),      # ... a subsample
+    (9001, 40, 6, 64, "irt_2pl", 0.1, None),        # ... with phantom persons
+    (333, 131, 10, 64, "irt_4pl", 0.2, 77),         # ... everything ragged, a batch that is no multiple of 4 (person-major backward)
 ])
 def test_mvn_amortized_step_vs_oracle(N, J, D, H, model, miss, B):
     from vipsy_amd.engine import IrtEngine, ENC_KEYS
@@ -227,7 +239,7 @@ def test_mvn_amortized_step_vs_oracle(N, J, D, H, model, miss, B):
     torch.cuda.synchronize()
     nb = len(idx)
     fw = eng.last["fw"]
-    eps = fw["eps"][:nb * D].reshape(nb, D).cpu().numpy()
+    eps = fw["eps"][:nb * eng.D].reshape(nb, eng.D)[:, :D].cpu().numpy()      # (eng.D: D + phantom dimensions, if any)
     # RNG inside the fused kernel == vx_philox_normals == oracle spec, keyed by global person id
     np.testing.assert_allclose(eps, vo.philox_normals(11, 0, 0, idx, D), atol=2e-5)
     spec = {"family": "irt", "model": model, "D": D, "Dc": 1.0, "N": N, "amortized": True, "share_cov": False,
@@ -294,6 +306,14 @@ def _oracle_latents_chunked(params, y, eps, D, chunk=4096):
     return x
 
 
+@pytest.mark.parametrize("N,slopes,J", [
+    (33024, "small", 499),  # the same kernels on 499 items + one phantom item (IrtEngine.__init__: absent / zero)
+    (33021, "small", 498),  # ... and three phantom persons
+])
+def test_headline_large_batch_kernels_with_phantom_items_vs_oracle(N, slopes, J):
+    test_headline_large_batch_kernels_vs_oracle(N, slopes, J)
+
+
 @pytest.mark.parametrize("N,slopes", [
     (33024, "small"),   # 129 workgroups of 256 persons: every person on k_mvn_enc_fwd_b2 (64 per wave) and bwd_h_b2
     (70016, "small"),   # one full chip round (65 536) on fwd_b2 + a 4 480-person tail on k_mvn_enc_fwd_b<false>
@@ -302,7 +322,7 @@ def _oracle_latents_chunked(params, y, eps, D, chunk=4096):
     (33021, "small"),   # a shard whose size is no multiple of 8 (nor of 4): three phantom persons (engine.py::_pad_persons) keep
     (70010, "small"),   # it on these kernels -- six of them, a chip round + tail; every gradient and the loss as if they were not there
 ])
-def test_headline_large_batch_kernels_vs_oracle(N, slopes):
+def test_headline_large_batch_kernels_vs_oracle(N, slopes, J=500):
     """The kernels that run the judged 1M x 500 x 100 step -- the large-batch forms of the forward (k_mvn_fwd_b2.hip,
     k_mvn_enc_fwd_b<false>), the hidden gradient (k_mvn_enc_bwd_h_b2 / _b<false>), bwd_w_b, lik_h, fc1_bwd_b -- at the
     headline's own J = 500, D = 100, H = 64 (all eight k-blocks of 16, 176 head tiles, multi-block DIAG / LOC sections),
@@ -316,7 +336,7 @@ def test_headline_large_batch_kernels_vs_oracle(N, slopes):
     1e-3 |z| of the clamp point -- are set to 255 (missing) in y BEFORE either side runs; since the responses are also the
     encoder's input, the marking is iterated until no unmarked cell is left in the band.  Same tolerance as the rest."""
     from vipsy_amd.engine import IrtEngine
-    J, D, H = 500, 100, 64
+    D, H = 100, 64
     y, _, rng = _random_problem(N, J, D, H, "irt_2pl", 0.1, seed=N)
     a_mult = 0.05 * (1 + 0.3 * rng.randn(D, J))
     b_new = 0.5 * rng.randn(1, J)

@@ -491,7 +491,7 @@ class _EngineBase(object):
         if rows is not None or self.n_local == 0:
             return None
         if getattr(self, "_yT", None) is None:
-            y = self._padded_y()                             # (the shard's own responses unless its size is padded, below)
+            y = self._padded_y(lik=True)                     # (the shard's own responses unless persons / items are padded)
             stride = (y.shape[0] + 63) // 64 * 64
             yT = torch.full((self.J + 1, stride), 254, dtype=torch.uint8, device=self.dev)
             yT[:self.J, :y.shape[0]] = y.t()
@@ -516,14 +516,17 @@ class _EngineBase(object):
 
     pad_persons = os.environ.get("VX_PAD_PERSONS", "1") != "0"      # test seam: 0 = launch over the shard's own count
 
-    def _padded_y(self):
-        """The responses with the phantom persons of _pad_persons appended (made once; self.y itself when none are)."""
+    def _padded_y(self, lik=False):
+        """The responses with the phantom persons of _pad_persons appended (made once; the responses themselves when none
+        are).  lik: the copy the likelihood reads (phantom ITEMS absent instead of zero, IrtEngine.__init__)."""
+        y = self.y_lik if (lik and getattr(self, "y_lik", None) is not None) else self.y
         n_pad = getattr(self, "_n_pad", self.n_local)
         if n_pad == self.n_local:
-            return self.y
-        if getattr(self, "_y_pad", None) is None:
-            self._y_pad = torch.cat([self.y, torch.full((n_pad - self.n_local, self.J), 255, dtype=torch.uint8, device=self.dev)])
-        return self._y_pad
+            return y
+        key = "_y_pad_lik" if y is not self.y else "_y_pad"
+        if getattr(self, key, None) is None:
+            setattr(self, key, torch.cat([y, torch.full((n_pad - self.n_local, self.J), 255, dtype=torch.uint8, device=self.dev)]))
+        return getattr(self, key)
 
     def _sparse_lists(self, rows):
         """Observed-cell lists for the D = 1 kernel (include/vipsy_amd.h, vx_irt1d_sparse_grad): built once -- the
@@ -1151,10 +1154,36 @@ class IrtEngine(_EngineBase):
         self.y = y_u8.contiguous()
         assert self.y.dtype == torch.uint8 and self.y.dim() == 2
         self.dev = self.y.device
-        self.n_local, self.J = self.y.shape
+        self.n_local, self.J_items = self.y.shape
+        self.y_lik = None
+        if (amortized and int(D) > 1 and int(H) == 64 and self.J_items % 4 != 0 and self.J_items > 0
+                and isinstance(self.be, HipBackend) and self.pad_items):
+            # PHANTOM ITEMS up to a multiple of 4: the MFMA kernels of the amortized multivariate guide read response rows in
+            # 16-byte pieces and refuse other item counts (J = 499: 18.0 ms a step where J = 500 takes 2.1, tools/shape_cliffs.py).
+            # A phantom item is ABSENT for the likelihood (byte 254, "outside the problem": no log-probability, no gradient)
+            # and ZERO for the encoder (its input and the fc1 gradient's activation), so there are two copies of the responses:
+            # self.y (phantom byte 0) for the guide's forward / backward calls, self.y_lik (254) for the likelihood call and
+            # the item-major copy.  Its parameters -- a column of a, entries of b / c / d, a column of fc1.weight -- take
+            # zero gradients for ever (Adam leaves them where they start) and are not visible through unconstrained() / param().
+            pad = (-self.J_items) % 4
+            self.y_lik = torch.cat([self.y, torch.full((self.n_local, pad), 254, dtype=torch.uint8, device=self.dev)], 1).contiguous()
+            self.y = torch.cat([self.y, torch.zeros((self.n_local, pad), dtype=torch.uint8, device=self.dev)], 1).contiguous()
+        self.J = int(self.y.shape[1])                              # items the kernels see (J_items + phantoms)
         self.N = int(n_global) if n_global is not None else self.n_local
         self.gid0 = int(gid0)
         self.model, self.D, self.Dc = model, int(D), float(Dc)
+        self.D_model = self.D                                      # the model's latent dimensions; self.D: what the kernels see
+        if (amortized and self.D > 1 and self.D % 4 != 0 and self.D + 3 <= 124 and int(H) == 64 and isinstance(self.be, HipBackend)
+                and self.pad_dims):
+            # PHANTOM DIMENSIONS up to a multiple of 4 (the MFMA kernels' other shape condition: D = 99: 31 ms a step where
+            # D = 100 takes 2.1).  A phantom dimension k has a_k = 0 for ever (free mask 0: it never reaches a logit) and head
+            # rows (fc21 row k, the fc22 rows (k, .), their biases) that start at ZERO and are kept there by zeroing their
+            # gradients behind the backward call: mu_k = 0, L_kk = e^0 = 1, L_kl = 0, so x_k = eps_k and the phantom's
+            # terms of the ELBO cancel (-x_k^2 / 2 from the prior, +eps_k^2 / 2 + M_kk from the entropy), and the shared
+            # hidden layer gets nothing from it (its rows of the head weights are what the hidden gradient multiplies by).
+            # The draws of the real dimensions are the same (Philox blocks of four dimensions), tril order puts the real
+            # fc22 rows first.  Not visible through unconstrained() / param().
+            self.D = (self.D + 3) // 4 * 4
         self.amortized, self.H, self.share_cov = bool(amortized), int(H) if amortized else 0, bool(share_cov)
         self.seed, self.group = int(seed), group
         J, Dd = self.J, self.D
@@ -1184,31 +1213,70 @@ class IrtEngine(_EngineBase):
                 else:
                     self.pp_shape = {"x_local": (self.n_local, Dd), "x_scale": (self.n_local, Dd, Dd)}
         self._alloc(o, self.n_local, per_person=not self.amortized)
-        # reference initial values (vi.py:567-587)
-        a_init = torch.ones(Dd, J) if a0 is None else torch.as_tensor(a0, dtype=torch.float32).reshape(Dd, J).clone()
-        if a_free is None and Dd > 1:
-            af = torch.ones(Dd, J)
-            for i in range(Dd):
-                af[i, J - i:] = 0                                  # vi.py:570-572
+        # reference initial values (vi.py:567-587), over the problem's own items; phantom items (above) start at zero
+        Ji, Dm = self.J_items, self.D_model
+
+        def pad_j(t):                                              # [..., J_items] -> [..., J]
+            return t if J == Ji else torch.nn.functional.pad(t, (0, J - Ji))
+
+        def pad_rows(t, n):                                        # [r, ...] -> [n, ...], zero rows behind
+            return t if t.shape[0] == n else torch.cat([t, torch.zeros((n - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)])
+        a_init = torch.ones(Dm, Ji) if a0 is None else torch.as_tensor(a0, dtype=torch.float32).reshape(Dm, Ji).clone()
+        if a_free is None and Dm > 1:
+            af = torch.ones(Dm, Ji)
+            for i in range(Dm):
+                af[i, Ji - i:] = 0                                 # vi.py:570-572
             a_init = a_init * af                                   # also a user-supplied a0 is zeroed there (vi.py:571)
             a_free = af
+        if Dd != Dm and a_free is None:
+            a_free = torch.ones(Dm, Ji)
         if model != "irt_1pl":
-            self.view("a").copy_(a_init.reshape(-1))
+            self.view("a").copy_(pad_rows(pad_j(a_init), Dd).reshape(-1))
             if a_free is not None:
-                self.free[self.off["a"]:self.off["a"] + Dd * J] = torch.as_tensor(a_free, dtype=torch.float32).reshape(-1)
+                self.free[self.off["a"]:self.off["a"] + Dd * J] = pad_rows(pad_j(
+                    torch.as_tensor(a_free, dtype=torch.float32).reshape(Dm, Ji)), Dd).reshape(-1)
         if b0 is not None:
-            self.view("b").copy_(torch.as_tensor(b0, dtype=torch.float32).reshape(-1))
+            self.view("b").copy_(pad_j(torch.as_tensor(b0, dtype=torch.float32).reshape(1, Ji)).reshape(-1))
         if model in ("irt_3pl", "irt_4pl"):
             self.view("c").fill_(float(np.float32(_logit(np.float32(0.1)))))
         if model == "irt_4pl":
             self.view("d").fill_(float(np.float32(_logit(np.float32(1.0) - np.float32(0.1)))))
         if self.amortized:
             if encoder_init is None:
-                encoder_init = default_encoder_init(J, Dd, self.H, seed)
+                encoder_init = default_encoder_init(Ji, Dm, self.H, seed)
             for k in ENC_KEYS:
-                self.view("encoder$$$" + k).copy_(torch.as_tensor(encoder_init[k], dtype=torch.float32).reshape(-1))
+                w = torch.as_tensor(encoder_init[k], dtype=torch.float32)
+                if k == "fc1.weight":
+                    w = pad_j(w.reshape(self.H, Ji))
+                elif Dd != Dm and k != "fc1.bias":                 # the heads: zero rows for the phantom dimensions
+                    w = pad_rows(w.reshape((-1, self.H) if k.endswith("weight") else (-1,)), self.enc_shapes[k][0])
+                self.view("encoder$$$" + k).copy_(w.reshape(-1))
         self.base = (torch.zeros(max(self.n_local, 1), dtype=torch.float32, device=self.dev)
                      if (estimator == "score" and baseline == "avg") else None)
+
+    pad_items = os.environ.get("VX_PAD_ITEMS", "1") != "0"          # test seam: 0 = the kernels see the problem's own item count
+
+    pad_dims = os.environ.get("VX_PAD_DIMS", "1") != "0"            # test seam: 0 = the kernels see the model's own dimensions
+
+    def unconstrained(self, name, buf=None):
+        u = super().unconstrained(name, buf)
+        if self.J != self.J_items and name in ("a", "b", "c", "d", "encoder$$$fc1.weight"):
+            u = u[..., :self.J_items]                              # (phantom items are nobody's business)
+        if self.D != self.D_model:                                 # (nor are phantom dimensions)
+            if name == "a" or name.startswith("encoder$$$fc21"):
+                u = u[:self.D_model]
+            elif name.startswith("encoder$$$fc22"):
+                u = u[:self.D_model * (self.D_model + 1) // 2]
+        return u
+
+    def _zero_phantom_head_grads(self):
+        """Phantom dimensions: the gradients of their head rows go back to zero (IrtEngine.__init__)."""
+        Dm, Dp, H = self.D_model, self.D, self.H
+        if Dp == Dm:
+            return
+        Tm = Dm * (Dm + 1) // 2
+        for k, lo in (("fc21.weight", Dm * H), ("fc21.bias", Dm), ("fc22.weight", Tm * H), ("fc22.bias", Tm)):
+            self.view("encoder$$$" + k, self.G)[lo:].zero_()
 
     # -- parameter access (constrained values as pyro.param(name) returns them) -----------------
     def names(self):
@@ -1301,11 +1369,15 @@ class IrtEngine(_EngineBase):
             self.last = {"fw": fw, "gx": gx, "ll": ll, "nb": nb}
         elif self.D > 1:
             D, H = self.D, self.H
-            n_valid, y_k = nb, self.y
+            if eps is not None and D != self.D_model:      # a caller's draws are the model's: the phantom dimensions draw zero
+                e_p = torch.zeros(nb, D, dtype=torch.float32, device=self.dev)
+                e_p[:, :self.D_model] = eps.reshape(nb, self.D_model)
+                eps = e_p
+            n_valid, y_k, y_l = nb, self.y, (self.y_lik if self.y_lik is not None else self.y)
             if rows is None and eps is None:
                 self._n_pad = self._pad_persons(be, cfg, rows)
                 if self._n_pad != nb:                      # phantom persons up to a multiple of 8 (_pad_persons)
-                    nb, y_k = self._n_pad, self._padded_y()
+                    nb, y_k, y_l = self._n_pad, self._padded_y(), self._padded_y(lik=True)
             fw = {"h": self._buf("h", nb * H), "x": self._buf("x", nb * D), "eps": self._buf("eps", nb * D),
                   "ldT": self._buf("ldT", nb * D), "ent": self._buf("ent", nb)}
             fw["packws"] = self._buf("packws", be.mvn_pack_floats(cfg))
@@ -1347,7 +1419,7 @@ class IrtEngine(_EngineBase):
                 if om >= 0:
                     opmax = fw["packws"][om:om + 3]
             with self._phase("likelihood"):
-                be.lik_grad(cfg, y_k, rows, nb, fw["x"], a, self.view("b"), c_un, d_un, gx, ll, gitem, lik_ws,
+                be.lik_grad(cfg, y_l, rows, nb, fw["x"], a, self.view("b"), c_un, d_un, gx, ll, gitem, lik_ws,
                             gxT=gxT, yT=yT, ximg=fw.get("ximg"), epsT=fw["epsT"] if gdT is not None else None,
                             ldT=fw["ldT"] if gdT is not None else None, gdT=gdT, **({"opmax": opmax} if opmax is not None else {}))
                 if nb != n_valid:
@@ -1385,6 +1457,7 @@ class IrtEngine(_EngineBase):
                                     **({"loss": (ll, fw["ent"], -scale, lossslot, self.sum_ws)} if fused_loss else {}))
             if not fused_loss:
                 be.sum2_into(ll, fw["ent"], nb, -scale, lossslot, self.sum_ws, **sdc)
+            self._zero_phantom_head_grads()
             self.last = {"fw": fw, "gx": gx, "gxT": gxT, "ll": ll, "nb": nb, "n_valid": n_valid}
         else:
             # D = 1: the flat item layout [a: J | b: J | c: J | d: J] IS the kernels' gradient layout -> written in place
