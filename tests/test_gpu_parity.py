@@ -644,6 +644,9 @@ HODINA_TOL = 3e-5        # (measured: <= 5.2e-6, theta_local of the K = 8 case)
     (4128, 504, "irt_1pl", 0.5, None),               # ... rows staged word by word (J / 4 even)
     (4501, 500, "irt_2pl", 0.9, None),               # no multiple of 4: the encoder over 4 504 persons, three of them phantoms
     (4503, 500, "irt_2pl", 0.2, None),               # (engine.py, D = 1 branch); observed-cell lists / the dense step kernel
+    (4500, 499, "irt_2pl", 0.9, None),               # an item count that is no multiple of 4: one phantom item (absent / zero);
+    (4301, 257, "irt_4pl", 0.2, 4200),               # ... observed-cell lists, gathered rows, a small shape
+    (320, 37, "irt_2pl", 0.3, None),
 ])
 def test_irt1d_amortized_step_vs_oracle(N, J, model, miss, B, H=64):
     from vipsy_amd.engine import IrtEngine

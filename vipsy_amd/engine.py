@@ -535,14 +535,14 @@ class _EngineBase(object):
         if rows is not None or self.n_local == 0 or self.J > 1024 or not self.observed_lists:
             return None
         if getattr(self, "_sp", None) is None:
-            y, n, J = self.y, self.n_local, self.J
+            y, n, J = (self.y_lik if getattr(self, "y_lik", None) is not None else self.y), self.n_local, self.J
             frac = float((y == 255).sum().item()) / float(n * J)
             if frac < 0.5:
                 self._sp = False
             else:
                 ng = (n + 63) // 64
                 cnt = torch.full((ng * 64,), -1, dtype=torch.int64, device=self.dev)             # -1: empty slot, sorts last
-                cnt[:n] = (y != 255).sum(1)
+                cnt[:n] = (y < 254).sum(1)                                                     # (254: a phantom item, absent)
                 slot = torch.arange(ng * 64, device=self.dev)
                 perm = torch.argsort((slot // 4096) * (J + 2) + (J - cnt), stable=True)           # slot -> person
                 cnt_s = cnt[perm].clamp_(min=0)
@@ -554,7 +554,7 @@ class _EngineBase(object):
                 for lo in range(0, ng * 64, 65536):                                               # bounded temporaries
                     hi = min(ng * 64, lo + 65536)
                     yc = y[perm[lo:hi].clamp(max=n - 1)]
-                    order = torch.argsort((yc == 255).to(torch.uint8), dim=1, stable=True)[:, :W]  # observed items first
+                    order = torch.argsort((yc >= 254).to(torch.uint8), dim=1, stable=True)[:, :W]  # observed items first
                     code = order.to(torch.int32) | ((torch.gather(yc, 1, order) == 1).to(torch.int32) << 15)
                     code = torch.where(ar < cnt_s[lo:hi, None], code, torch.full_like(code, 0xFFFF))
                     pent[lo:hi, :W] = code.to(torch.int16)                                        # wraps: bit pattern kept
@@ -1156,15 +1156,17 @@ class IrtEngine(_EngineBase):
         self.dev = self.y.device
         self.n_local, self.J_items = self.y.shape
         self.y_lik = None
-        if (amortized and int(D) > 1 and int(H) == 64 and self.J_items % 4 != 0 and self.J_items > 0
+        if (amortized and int(H) == 64 and self.J_items % 4 != 0 and self.J_items > 0
                 and isinstance(self.be, HipBackend) and self.pad_items):
-            # PHANTOM ITEMS up to a multiple of 4: the MFMA kernels of the amortized multivariate guide read response rows in
+            # PHANTOM ITEMS up to a multiple of 4: the MFMA kernels of the amortized guides read response rows in
             # 16-byte pieces and refuse other item counts (J = 499: 18.0 ms a step where J = 500 takes 2.1, tools/shape_cliffs.py).
             # A phantom item is ABSENT for the likelihood (byte 254, "outside the problem": no log-probability, no gradient)
             # and ZERO for the encoder (its input and the fc1 gradient's activation), so there are two copies of the responses:
             # self.y (phantom byte 0) for the guide's forward / backward calls, self.y_lik (254) for the likelihood call and
             # the item-major copy.  Its parameters -- a column of a, entries of b / c / d, a column of fc1.weight -- take
             # zero gradients for ever (Adam leaves them where they start) and are not visible through unconstrained() / param().
+            # (The observed-cell lists of the 1-D step count a phantom among a person's J - n_observed unobserved items, each
+            # of which carries the reference's constant log Bern(0 | clamp(0)) = -1.19e-7: 1e-9 of a person's ELBO.)
             pad = (-self.J_items) % 4
             self.y_lik = torch.cat([self.y, torch.full((self.n_local, pad), 254, dtype=torch.uint8, device=self.dev)], 1).contiguous()
             self.y = torch.cat([self.y, torch.zeros((self.n_local, pad), dtype=torch.uint8, device=self.dev)], 1).contiguous()
@@ -1494,7 +1496,8 @@ class IrtEngine(_EngineBase):
                     be.irt1d_sparse_grad(cfg, lists, self.gid0, loc, raw, eps, a, self.view("b"), c_un, d_un,
                                          gloc, graw, elbo, g1d, sp_ws, loss=lossslot, **sdk, **self._take_fused_tail())
                 else:
-                    be.irt1d_grad(cfg, self.y, rows, nb, self.gid0, loc, raw, eps, a, self.view("b"), c_un, d_un,
+                    be.irt1d_grad(cfg, self.y_lik if self.y_lik is not None else self.y, rows, nb, self.gid0, loc, raw, eps, a,
+                                  self.view("b"), c_un, d_un,
                                   gloc, graw, elbo, g1d, i1d_ws, loss=lossslot, **sdk, **self._take_fused_tail())
             if self.estimator == "score":
                 # score-function gradient of the guide in place of the pathwise one (the step kernel's item gradients and
