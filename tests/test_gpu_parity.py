@@ -413,6 +413,37 @@ def test_headline_large_batch_kernels_vs_oracle(N, slopes, J=500):
 GRAD_TOL_LARGE = 3e-5       # the tolerance of the golden replays
 
 
+@pytest.mark.parametrize("N,J,D,H,B", [(2000, 37, 6, 32, None), (1203, 130, 3, 24, 100), (4500, 499, 1, 40, None)])
+def test_phantom_items_dimensions_and_hidden_units_train_like_the_problem_itself(N, J, D, H, B, monkeypatch):
+    """Item, dimension and hidden-unit counts the MFMA kernels do not take, padded with phantoms on the host
+    (IrtEngine.__init__), against the same problem handed to the kernels as it is (the generic tier): five Adam steps, the same
+    losses and the same parameters -- the phantoms never move and never reach the problem's own parameters."""
+    from vipsy_amd.engine import IrtEngine, LrSpec
+    rng = np.random.RandomState(N + J)
+    y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+    y[rng.rand(N, J) < 0.2] = 255
+    draws = np.random.RandomState(3)
+    rows_all = [None if B is None else torch.from_numpy(np.sort(draws.choice(N, size=B, replace=False)).astype(np.int64)).to(_dev())
+                for _ in range(5)]
+    out = []
+    for pad in (True, False):
+        for name in ("pad_items", "pad_dims", "pad_hidden"):
+            monkeypatch.setattr(IrtEngine, name, pad)
+        eng = IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_2pl", D=D, amortized=True, H=H, seed=11)
+        assert (eng.J, eng.D, eng.H) == (((J + 3) // 4 * 4, (D + 3) // 4 * 4 if D > 1 else 1, 64) if pad else (J, D, H))
+        assert tuple(eng.unconstrained("a").shape) == (D, J) and tuple(eng.unconstrained("encoder$$$fc1.weight").shape) == (H, J)
+        lrs = LrSpec(lambda m, p: {"lr": 1e-2})
+        losses = [float(eng.step(lrs, rows=rows_all[t], b_global=B)) for t in range(5)]
+        torch.cuda.synchronize()
+        out.append((np.array(losses), {n: eng.unconstrained(n).double().cpu().numpy().copy() for n in eng.names()}))
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=3e-5)
+    for n in out[0][1]:
+        # (Adam's first steps move every entry by ~lr whatever its gradient's size, so entries whose gradient is rounding
+        # noise may differ by a step: compare where it matters, on the scale of the tensor)
+        sc = max(1e-3, float(np.abs(out[1][1][n]).max()))
+        assert np.abs(out[0][1][n] - out[1][1][n]).max() <= 2e-3 * sc, n
+
+
 @pytest.mark.parametrize("N", [4099, 33021])
 def test_phantom_persons_add_nothing(N):
     """A full batch whose size is no multiple of 8, launched over the next multiple with phantom persons (all responses missing;

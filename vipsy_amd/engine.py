@@ -1156,6 +1156,14 @@ class IrtEngine(_EngineBase):
         self.dev = self.y.device
         self.n_local, self.J_items = self.y.shape
         self.y_lik = None
+        self.H_model = int(H) if amortized else 0                  # the encoder's hidden units; self.H: what the kernels see
+        if amortized and 0 < int(H) < 64 and isinstance(self.be, HipBackend) and self.pad_hidden:
+            # PHANTOM HIDDEN UNITS up to 64, the width the MFMA kernels are built for (hidden_dim 32: 23.6 ms a step where 64
+            # takes 2.4, tools/hidden_cliffs.py).  A phantom unit has a zero row of fc1 (weight and bias) and zero columns in
+            # both heads.  Its activation is softplus(0) = log 2, not zero (vi.py:430,447), so the heads' columns WOULD take
+            # gradients: they are zeroed behind the backward call (_zero_phantom_head_grads) and the columns stay zero; d ELBO /
+            # d h_u is a sum over head rows times those zero columns, so fc1's row takes no gradient at all.
+            H = 64
         if (amortized and int(H) == 64 and self.J_items % 4 != 0 and self.J_items > 0
                 and isinstance(self.be, HipBackend) and self.pad_items):
             # PHANTOM ITEMS up to a multiple of 4: the MFMA kernels of the amortized guides read response rows in
@@ -1244,13 +1252,18 @@ class IrtEngine(_EngineBase):
         if model == "irt_4pl":
             self.view("d").fill_(float(np.float32(_logit(np.float32(1.0) - np.float32(0.1)))))
         if self.amortized:
+            Hm = self.H_model
             if encoder_init is None:
-                encoder_init = default_encoder_init(Ji, Dm, self.H, seed)
+                encoder_init = default_encoder_init(Ji, Dm, Hm, seed)
             for k in ENC_KEYS:
                 w = torch.as_tensor(encoder_init[k], dtype=torch.float32)
                 if k == "fc1.weight":
-                    w = pad_j(w.reshape(self.H, Ji))
-                elif Dd != Dm and k != "fc1.bias":                 # the heads: zero rows for the phantom dimensions
+                    w = pad_rows(pad_j(w.reshape(Hm, Ji)), self.H)       # phantom items: zero columns; phantom units: zero rows
+                elif k == "fc1.bias":
+                    w = pad_rows(w.reshape(-1), self.H)
+                else:                                              # the heads: zero columns for the phantom units, zero rows
+                    if k.endswith("weight"):                       # for the phantom dimensions
+                        w = torch.nn.functional.pad(w.reshape(-1, Hm), (0, self.H - Hm))
                     w = pad_rows(w.reshape((-1, self.H) if k.endswith("weight") else (-1,)), self.enc_shapes[k][0])
                 self.view("encoder$$$" + k).copy_(w.reshape(-1))
         self.base = (torch.zeros(max(self.n_local, 1), dtype=torch.float32, device=self.dev)
@@ -1258,6 +1271,7 @@ class IrtEngine(_EngineBase):
 
     pad_items = os.environ.get("VX_PAD_ITEMS", "1") != "0"          # test seam: 0 = the kernels see the problem's own item count
 
+    pad_hidden = os.environ.get("VX_PAD_HIDDEN", "1") != "0"        # test seam: 0 = the kernels see the encoder's own width
     pad_dims = os.environ.get("VX_PAD_DIMS", "1") != "0"            # test seam: 0 = the kernels see the model's own dimensions
 
     def unconstrained(self, name, buf=None):
@@ -1269,16 +1283,24 @@ class IrtEngine(_EngineBase):
                 u = u[:self.D_model]
             elif name.startswith("encoder$$$fc22"):
                 u = u[:self.D_model * (self.D_model + 1) // 2]
+        if self.amortized and self.H != self.H_model:              # (nor phantom hidden units)
+            if name.startswith("encoder$$$fc1."):
+                u = u[:self.H_model]
+            elif name in ("encoder$$$fc21.weight", "encoder$$$fc22.weight"):
+                u = u[:, :self.H_model]
         return u
 
     def _zero_phantom_head_grads(self):
-        """Phantom dimensions: the gradients of their head rows go back to zero (IrtEngine.__init__)."""
-        Dm, Dp, H = self.D_model, self.D, self.H
-        if Dp == Dm:
-            return
-        Tm = Dm * (Dm + 1) // 2
-        for k, lo in (("fc21.weight", Dm * H), ("fc21.bias", Dm), ("fc22.weight", Tm * H), ("fc22.bias", Tm)):
-            self.view("encoder$$$" + k, self.G)[lo:].zero_()
+        """Phantom dimensions: the gradients of their head rows go back to zero; phantom hidden units: the gradients of their
+        head columns (IrtEngine.__init__)."""
+        Dm, Dp, H, Hm = self.D_model, self.D, self.H, self.H_model
+        if Dp != Dm:
+            Tm = Dm * (Dm + 1) // 2
+            for k, lo in (("fc21.weight", Dm * H), ("fc21.bias", Dm), ("fc22.weight", Tm * H), ("fc22.bias", Tm)):
+                self.view("encoder$$$" + k, self.G)[lo:].zero_()
+        if self.amortized and H != Hm:
+            for k in ("fc21.weight", "fc22.weight"):
+                self.view("encoder$$$" + k, self.G).view(-1, H)[:, Hm:].zero_()
 
     # -- parameter access (constrained values as pyro.param(name) returns them) -----------------
     def names(self):
@@ -1521,6 +1543,7 @@ class IrtEngine(_EngineBase):
                     be.norm_enc_backward(cfg, y_e, rows, nb_e, enc, fw["h"], gloc, graw,
                                          self.G[self.enc_off0:self.enc_off0 + self.n_enc], nb_ws,
                                          yT=self._item_major_y(rows))
+                    self._zero_phantom_head_grads()
             else:
                 self._scatter_pp(rows, nb, gloc, graw)
             self.last = {"elbo": elbo, "nb": nb}                # the loss itself came out of the kernel's reduction
