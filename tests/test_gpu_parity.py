@@ -413,7 +413,9 @@ def test_headline_large_batch_kernels_vs_oracle(N, slopes, J=500):
 GRAD_TOL_LARGE = 3e-5       # the tolerance of the golden replays
 
 
-@pytest.mark.parametrize("N,J,D,H,B", [(2000, 37, 6, 32, None), (1203, 130, 3, 24, 100), (4500, 499, 1, 40, None)])
+@pytest.mark.parametrize("N,J,D,H,B", [(2000, 37, 6, 32, None), (1203, 130, 3, 24, 100), (4500, 499, 1, 40, None),
+                                       (3000, 500, 100, 64, 50),      # a subsample that is no multiple of 4: two phantom rows
+                                       (1500, 45, 7, 64, 10)])        # ... with everything else
 def test_phantom_items_dimensions_and_hidden_units_train_like_the_problem_itself(N, J, D, H, B, monkeypatch):
     """Item, dimension and hidden-unit counts the MFMA kernels do not take, padded with phantoms on the host
     (IrtEngine.__init__), against the same problem handed to the kernels as it is (the generic tier): five Adam steps, the same
@@ -427,7 +429,7 @@ def test_phantom_items_dimensions_and_hidden_units_train_like_the_problem_itself
                 for _ in range(5)]
     out = []
     for pad in (True, False):
-        for name in ("pad_items", "pad_dims", "pad_hidden"):
+        for name in ("pad_items", "pad_dims", "pad_hidden", "pad_batch"):
             monkeypatch.setattr(IrtEngine, name, pad)
         eng = IrtEngine(torch.from_numpy(y).to(_dev()), model="irt_2pl", D=D, amortized=True, H=H, seed=11)
         assert (eng.J, eng.D, eng.H) == (((J + 3) // 4 * 4, (D + 3) // 4 * 4 if D > 1 else 1, 64) if pad else (J, D, H))
@@ -1045,6 +1047,7 @@ def test_captured_hodina_step_equals_eager_step(K, amort):
     (2048, None),        # the headline's model, small-batch kernels (SPLIT forward / hidden gradient), full batch
     (33024, None),       # ... the large-batch kernels of the judged step, second-stream tails included in the capture
     (5000, 100),         # the reference's own usage: subsample_size = 100 (test.py:338), host-drawn rows staged per replay
+    (5000, 50),          # ... a subsample that is no multiple of 4: drawn two phantom rows longer (IrtEngine._pad_batch)
 ])
 def test_captured_amortized_step_equals_eager_step(N, B):
     """The amortized D = 100 step (VaeIRT, vi.py:673-693) replayed from its HIP graph -- Philox step and Adam's t read from

@@ -1271,6 +1271,46 @@ class IrtEngine(_EngineBase):
 
     pad_items = os.environ.get("VX_PAD_ITEMS", "1") != "0"          # test seam: 0 = the kernels see the problem's own item count
 
+    pad_batch = os.environ.get("VX_PAD_BATCH", "1") != "0"          # test seam: 0 = a subsample is launched over its own size
+
+    def _pad_batch(self, rows, b_global, eps):
+        """A SUBSAMPLE whose size is no multiple of 4 (B = 50: 315 us a step where B = 100 takes 144 -- the person-major
+        generation of the backward kernels) is drawn 1-3 rows longer: the extra rows point at ONE phantom person behind the
+        shard's own (index n_local of an extended copy of the responses, every response missing), and loss_and_grads takes
+        them out behind the likelihood by their index (columns of gxT / gdT, entries of ll / ent times 0), as _pad_persons
+        does for a full batch.  The plate scale stays the caller's: b_global is made explicit.  Amortized multivariate guide,
+        pathwise estimator, HIP backend; rows: one tensor or one per particle."""
+        if (rows is None or eps is not None or not self.pad_batch or not (self.amortized and self.D > 1 and self.H == 64)
+                or not isinstance(self.be, HipBackend) or self.estimator != "pathwise"):
+            return rows, b_global
+        many = isinstance(rows, (list, tuple))
+        rs = list(rows) if many else [rows]
+        if not rs or not all(torch.is_tensor(r) for r in rs) or len({int(r.numel()) for r in rs}) != 1:
+            return rows, b_global
+        n = int(rs[0].numel())
+        pad = (-n) % 4
+        if pad == 0 or n == 0:
+            return rows, b_global
+        cfg = self.be.cfg(self.model, self.D, self.J, self.H, self.Dc, 1.0, self.seed, 0, 0)
+        if self.be.mvn_enc_bwd_layout(cfg, n + pad) != 1 or self.be.mvn_enc_bwd_gd_offset(cfg, n + pad) < 0:
+            return rows, b_global
+        if getattr(self, "_y_ext", None) is None:
+            miss = torch.full((1, self.J), 255, dtype=torch.uint8, device=self.dev)
+            self._y_ext = torch.cat([self.y, miss]).contiguous()
+            self._y_ext_lik = self._y_ext if self.y_lik is None else torch.cat([self.y_lik, miss]).contiguous()
+        rs = [torch.cat([r.reshape(-1), torch.full((pad,), self.n_local, dtype=r.dtype, device=r.device)]) for r in rs]
+        return (rs if many else rs[0]), (n if b_global is None else b_global)
+
+    def step(self, lrs, rows=None, b_global=None, eps=None, num_particles=1):
+        rows, b_global = self._pad_batch(rows, b_global, eps)
+        return super().step(lrs, rows=rows, b_global=b_global, eps=eps, num_particles=num_particles)
+
+    def steps(self, lrs, rows_seq, b_global=None, scheduler=False):
+        if rows_seq and all(torch.is_tensor(r) for r in rows_seq) and len({int(r.numel()) for r in rows_seq}) == 1:
+            padded, b_global = self._pad_batch(list(rows_seq), b_global, None)   # (a list: the same rule as for particles)
+            rows_seq = padded
+        return super().steps(lrs, rows_seq, b_global=b_global, scheduler=scheduler)
+
     pad_hidden = os.environ.get("VX_PAD_HIDDEN", "1") != "0"        # test seam: 0 = the kernels see the encoder's own width
     pad_dims = os.environ.get("VX_PAD_DIMS", "1") != "0"            # test seam: 0 = the kernels see the model's own dimensions
 
@@ -1398,6 +1438,11 @@ class IrtEngine(_EngineBase):
                 e_p[:, :self.D_model] = eps.reshape(nb, self.D_model)
                 eps = e_p
             n_valid, y_k, y_l = nb, self.y, (self.y_lik if self.y_lik is not None else self.y)
+            keep = None
+            if rows is not None and getattr(self, "_y_ext", None) is not None:
+                # rows of a padded subsample may point at the phantom person behind the shard's own (_pad_batch)
+                y_k, y_l = self._y_ext, self._y_ext_lik
+                keep = (rows != self.n_local).to(torch.float32)
             if rows is None and eps is None:
                 self._n_pad = self._pad_persons(be, cfg, rows)
                 if self._n_pad != nb:                      # phantom persons up to a multiple of 8 (_pad_persons)
@@ -1452,6 +1497,11 @@ class IrtEngine(_EngineBase):
                     gdT[:nb * D].view(D, nb)[:, n_valid:].zero_()
                     ll[n_valid:nb].zero_()
                     fw["ent"][n_valid:nb].zero_()
+                if keep is not None and gdT is not None and gx is None:
+                    gxT[:nb * D].view(D, nb).mul_(keep)    # (a padded subsample's phantom rows, wherever they stand)
+                    gdT[:nb * D].view(D, nb).mul_(keep)
+                    ll[:nb].mul_(keep)
+                    fw["ent"][:nb].mul_(keep)
             if self.estimator == "score":
                 # gxT, gdT <- the score-function operands (k_mvn_score.hip); item gradients and loss stand
                 if gx is not None or gdT is None:
