@@ -75,6 +75,40 @@ def test_vaeirt_multidim_runs_reference_call_pattern():
 
 
 @pytest.mark.gpu
+def test_vaeirt_with_sizes_the_mfma_kernels_do_not_take():
+    """The same call pattern with 37 items, 3 latent dimensions, 32 hidden units and 50 rows a step: the engine pads every one
+    of them with phantoms for the MFMA kernels (engine.py: IrtEngine.__init__, _pad_batch); the caller sees its own shapes."""
+    from vipsy_amd import vi, synth
+    vi.clear_param_store()
+    dev = torch.device("cuda:0")
+    a, b = synth.mirt_item_params(37, 3, seed=5)
+    y = synth.simulate_responses(3001, 0, {"a": a, "b": b}, "irt_2pl", dev, seed=6)
+
+    def optim(_, param_name):
+        return {"lr": 1e-2} if param_name in ("a", "b") else {"lr": 1e-3}
+    sched = vi.MultiStepLR({"optimizer": torch.optim.Adam, "optim_args": optim, "milestones": [250], "gamma": 0.1})
+    m = vi.VaeIRT(data=y, model="irt_2pl", subsample_size=50, x_feature=3, hidden_dim=32)
+    eng = m.engine
+    assert (eng.J, eng.D, eng.H) == (40, 4, 64) and (eng.J_items, eng.D_model, eng.H_model) == (37, 3, 32)
+    first = m.fit(optim=sched, max_iter=1, loss=vi.Trace_ELBO(num_particles=1), progress=False)
+    last = m.fit(optim=sched, max_iter=300, loss=vi.Trace_ELBO(num_particles=1), progress=False)
+    assert np.isfinite(last) and last < first
+    ahat = vi.param("a")
+    assert ahat.shape == (3, 37) and vi.param("b").shape[-1] == 37
+    assert float(ahat[1, -1]) == 0.0 and float(ahat[2, -2:].abs().sum()) == 0.0     # identification zeros stay frozen
+    assert tuple(vi.param("encoder$$$fc1.weight").shape) == (32, 37) and tuple(vi.param("encoder$$$fc22.weight").shape) == (6, 32)
+    # the phantoms have not moved: zero head rows / columns, zero a row, zero fc1 rows and columns
+    from vipsy_amd.engine import _EngineBase
+    w22 = _EngineBase.unconstrained(eng, "encoder$$$fc22.weight")
+    assert float(w22[6:].abs().max()) == 0.0 and float(w22[:, 32:].abs().max()) == 0.0
+    w1 = _EngineBase.unconstrained(eng, "encoder$$$fc1.weight")
+    assert float(w1[32:].abs().max()) == 0.0 and float(w1[:, 37:].abs().max()) == 0.0
+    assert float(_EngineBase.unconstrained(eng, "a")[3:].abs().max()) == 0.0
+    err = float((vi.param("b").cpu() - b).abs().mean())
+    assert err < 0.8
+
+
+@pytest.mark.gpu
 def test_vchodina_recovers_guess_and_slip():
     """PaHoDinaTestCase.test_bbvi (test.py:638-641) at N=3000, J=30, K=3."""
     from vipsy_amd import vi, synth
