@@ -446,6 +446,36 @@ def test_phantom_items_dimensions_and_hidden_units_train_like_the_problem_itself
         assert np.abs(out[0][1][n] - out[1][1][n]).max() <= 2e-3 * sc, n
 
 
+@pytest.mark.parametrize("N,J,K,H,B", [(3000, 30, 5, 32, None), (2500, 30, 8, 64, 20), (1000, 13, 3, 24, 100)])
+def test_amortized_hodina_encoder_with_phantoms_trains_like_the_encoder_itself(N, J, K, H, B, monkeypatch):
+    """VaeCHoDina's NormEncoder over item counts / widths the MFMA encoder kernels do not take (the reference's HO-DINA has 30
+    items): only the ENCODER sees phantom items and hidden units (HoDinaEngine.__init__), the HO-DINA kernel the problem as it is.
+    Five Adam steps against the encoder handed over in its own shape: same losses, same parameters."""
+    from vipsy_amd.engine import HoDinaEngine, LrSpec
+    rng = np.random.RandomState(N + J)
+    q = (rng.rand(K, J) < 0.4).astype(np.float32)
+    q[0, q.sum(0) == 0] = 1
+    y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+    y[rng.rand(N, J) < 0.1] = 255
+    draws = np.random.RandomState(3)
+    rows_all = [None if B is None else torch.from_numpy(np.sort(draws.choice(N, size=B, replace=False)).astype(np.int64)).to(_dev())
+                for _ in range(5)]
+    out = []
+    for pad in (True, False):
+        monkeypatch.setattr(HoDinaEngine, "pad_encoder", pad)
+        eng = HoDinaEngine(torch.from_numpy(y).to(_dev()), torch.from_numpy(q), amortized=True, H=H, seed=11)
+        assert (eng.J_enc, eng.H) == (((J + 3) // 4 * 4, 64) if pad else (J, H)) and eng.J == J
+        assert tuple(eng.unconstrained("encoder$$$fc1.weight").shape) == (H, J)
+        lrs = LrSpec(lambda m, p: {"lr": 1e-2})
+        losses = [float(eng.step(lrs, rows=rows_all[t], b_global=B)) for t in range(5)]
+        torch.cuda.synchronize()
+        out.append((np.array(losses), {n: eng.unconstrained(n).double().cpu().numpy().copy() for n in eng.names()}))
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=3e-5)
+    for n in out[0][1]:
+        sc = max(1e-3, float(np.abs(out[1][1][n]).max()))
+        assert np.abs(out[0][1][n] - out[1][1][n]).max() <= 2e-3 * sc, n
+
+
 @pytest.mark.parametrize("N", [4099, 33021])
 def test_phantom_persons_add_nothing(N):
     """A full batch whose size is no multiple of 8, launched over the next multiple with phantom persons (all responses missing;

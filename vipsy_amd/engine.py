@@ -1659,6 +1659,20 @@ class HoDinaEngine(_EngineBase):
         self.K = int(q.shape[0])
         self.q = q.to(self.dev).contiguous()
         self.amortized, self.H = bool(amortized), int(H) if amortized else 0
+        # The amortized guide's ENCODER on the MFMA kernels whatever the item count and width (the reference's HO-DINA has 30
+        # items: its full-batch step took 0.81 ms at 200 k persons where 32 items take 0.24, tools/hodina_cliffs.py): the
+        # encoder and the HO-DINA kernel are separate calls with separate configurations, so only the ENCODER sees phantom
+        # items (J_enc, a copy of the responses with zero columns behind) and phantom hidden units (zero fc1 rows, zero head
+        # columns whose gradients are zeroed behind the backward call: softplus(0) = log 2) -- IrtEngine.__init__ has the
+        # argument; the HO-DINA kernel keeps the problem's own items and responses.
+        self.H_model, self.J_enc, self.y_enc = self.H, self.J, self.y
+        if self.amortized and isinstance(self.be, HipBackend) and self.pad_encoder:
+            if 0 < self.H < 64:
+                self.H = 64
+            if self.H == 64 and self.J % 4 != 0:
+                self.J_enc = (self.J + 3) // 4 * 4
+                self.y_enc = torch.cat([self.y, torch.zeros((self.n_local, self.J_enc - self.J), dtype=torch.uint8,
+                                                            device=self.dev)], 1).contiguous()
         self.seed, self.group = int(seed), group
         J, K = self.J, self.K
         self.off = {"g": 0, "s": J, "lam0": 2 * J, "lam1": 2 * J + K}
@@ -1667,7 +1681,7 @@ class HoDinaEngine(_EngineBase):
         o = self.n_item
         if self.amortized:
             o = (self.n_item + 63) // 64 * 64
-            self.enc_shapes = {"fc1.weight": (self.H, J), "fc1.bias": (self.H,), "fc21.weight": (1, self.H),
+            self.enc_shapes = {"fc1.weight": (self.H, self.J_enc), "fc1.bias": (self.H,), "fc21.weight": (1, self.H),
                                "fc21.bias": (1,), "fc22.weight": (1, self.H), "fc22.bias": (1,)}
             self.enc_off0 = o
             for k in ENC_KEYS:
@@ -1680,10 +1694,44 @@ class HoDinaEngine(_EngineBase):
         self.view("g").fill_(float(np.float32(_logit(np.float32(0.1)))))
         self.view("s").fill_(float(np.float32(_logit(np.float32(0.1)))))
         if self.amortized:
+            Hm = self.H_model
             if encoder_init is None:
-                encoder_init = default_encoder_init(J, 1, self.H, seed)
+                encoder_init = default_encoder_init(J, 1, Hm, seed)
             for k in ENC_KEYS:
-                self.view("encoder$$$" + k).copy_(torch.as_tensor(encoder_init[k], dtype=torch.float32).reshape(-1))
+                w = torch.as_tensor(encoder_init[k], dtype=torch.float32)
+                if k == "fc1.weight":
+                    w = torch.nn.functional.pad(w.reshape(Hm, J), (0, self.J_enc - J, 0, self.H - Hm))
+                elif k == "fc1.bias":
+                    w = torch.nn.functional.pad(w.reshape(-1), (0, self.H - Hm))
+                elif k.endswith("weight"):
+                    w = torch.nn.functional.pad(w.reshape(1, Hm), (0, self.H - Hm))
+                self.view("encoder$$$" + k).copy_(w.reshape(-1))
+
+    pad_encoder = os.environ.get("VX_PAD_ENCODER", "1") != "0"      # test seam: 0 = the encoder in the problem's own shape
+
+    def unconstrained(self, name, buf=None):
+        u = super().unconstrained(name, buf)
+        if self.amortized and name.startswith("encoder$$$"):       # (phantom items / hidden units are nobody's business)
+            if name == "encoder$$$fc1.weight":
+                u = u[:self.H_model, :self.J]
+            elif name == "encoder$$$fc1.bias":
+                u = u[:self.H_model]
+            elif name.endswith("weight"):
+                u = u[:, :self.H_model]
+        return u
+
+    def _item_major_y_enc(self, rows):
+        """The encoder's item-major responses (_item_major_y over the encoder's copy: phantom item rows hold byte 0)."""
+        if self.J_enc == self.J:
+            return self._item_major_y(rows)
+        if rows is not None or self.n_local == 0:
+            return None
+        if getattr(self, "_yT_enc", None) is None:
+            stride = (self.n_local + 63) // 64 * 64
+            yT = torch.full((self.J_enc + 1, stride), 254, dtype=torch.uint8, device=self.dev)
+            yT[:self.J_enc, :self.n_local] = self.y_enc.t()
+            self._yT_enc = yT
+        return self._yT_enc
 
     def names(self):
         out = ["g", "s", "lam0", "lam1"]
@@ -1714,7 +1762,7 @@ class HoDinaEngine(_EngineBase):
         ws = self._buf("hd_ws", be.hodina_workspace(cfg, nb))
         lossslot = self.G[self.n_params:self.n_params + 1]
         if self.amortized:
-            icfg = be.cfg("irt_2pl", 1, self.J, self.H, 1.0, scale, self.seed, self.t, stream_id)
+            icfg = be.cfg("irt_2pl", 1, self.J_enc, self.H, 1.0, scale, self.seed, self.t, stream_id)
             enc = self._enc()
             fw = {"h": self._buf("h", nb * self.H), "loc": self._buf("loc", nb), "raw": self._buf("raw", nb)}
             n_pk = be.norm_enc_pack_floats(icfg) if hasattr(be, "norm_enc_pack_floats") else 0
@@ -1723,7 +1771,7 @@ class HoDinaEngine(_EngineBase):
             gloc, graw = self._buf("gloc", nb), self._buf("graw", nb)
             nb_ws = self._buf("nencb_ws", be.norm_enc_bwd_workspace(icfg, nb))
             with self._phase("guide_forward"):
-                be.norm_enc_forward(icfg, self.y, rows, nb, enc, fw)
+                be.norm_enc_forward(icfg, self.y_enc, rows, nb, enc, fw)
             loc, raw = fw["loc"], fw["raw"]
         else:
             loc, raw, gloc, graw = self._gather_pp(rows, nb)
@@ -1733,9 +1781,12 @@ class HoDinaEngine(_EngineBase):
                            self.G[:self.n_item], ws)
         if self.amortized:
             with self._phase("guide_backward"):
-                be.norm_enc_backward(icfg, self.y, rows, nb, enc, fw["h"], gloc, graw,
+                be.norm_enc_backward(icfg, self.y_enc, rows, nb, enc, fw["h"], gloc, graw,
                                      self.G[self.enc_off0:self.enc_off0 + self.n_enc], nb_ws,
-                                     yT=self._item_major_y(rows))
+                                     yT=self._item_major_y_enc(rows))
+                if self.H != self.H_model:                         # phantom hidden units: their head columns take no gradient
+                    for k in ("fc21.weight", "fc22.weight"):
+                        self.view("encoder$$$" + k, self.G)[self.H_model:].zero_()
         else:
             self._scatter_pp(rows, nb, gloc, graw)
         be.sum_into(elbo, nb, -scale, lossslot, self.sum_ws, **sdc)   # (a captured step's counter advances here)
