@@ -20,12 +20,12 @@ for name, mk in (("VCCDM (enumerated)", lambda: CcdmEngine(y, qt)), ("VaeCCDM (S
         draws = np.random.RandomState(2)
         def rows():
             return None if B is None else torch.from_numpy(np.unique(draws.randint(0, N, 3 * B))[:B].astype(np.int64))
-        for _ in range(8):
-            eng.step(lrs, rows=rows(), b_global=B)
+        n = 48
+        pre = [rows() for _ in range(n)]                       # (drawn ahead: the fit loop's draw is not what is timed)
+        eng.steps(lrs, pre[:12], b_global=B)
         torch.cuda.synchronize()
-        t0 = time.perf_counter(); n = 50
-        for _ in range(n):
-            eng.step(lrs, rows=rows(), b_global=B)
+        t0 = time.perf_counter()
+        eng.steps(lrs, pre, b_global=B)
         torch.cuda.synchronize()
         print("%-38s N = %d  J = %d  K = %d  batch %-6s: %8.3f ms/step" % (name, N, J, K, "full" if B is None else B, 1e3 * (time.perf_counter() - t0) / n), flush=True)
     del eng

@@ -23,7 +23,16 @@ struct HoDinaDims {
     int uniform_prior, dino;       // uniform_prior: 0 HO-DINA prior, 1 uniform (VCCDM), 2 per-person row of pattern scores (VaeCCDM)
     int unmasked;                  // VaeCCDM (vi.py:882-891): a missing response stays in `obs` as -1 (no mask)
     const uint32_t* step_dev = nullptr;   // or the step counter in device memory (a captured step): read instead of `step`
+    // persons a wave takes at a time (1..64; hd_group_size): a wave walks its group ONE PERSON AFTER THE OTHER (~2 us each), so a
+    // small batch in groups of 64 is two waves busy for 200 us (VCCDM with the reference's 100 rows a step: 204 us of a 215 us
+    // step); groups shrink until the batch fills 4 096 waves
+    int gsz = 64;
 };
+
+__host__ __device__ inline int hd_group_size(int64_t nb, int64_t max_waves) {
+    int64_t g = (nb + max_waves - 1) / max_waves;
+    return (int)(g < 1 ? 1 : g > 64 ? 64 : g);
+}
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -93,7 +102,8 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
     float* tab = (float*)tabx;
     const int64_t n_waves = (int64_t)gridDim.x * HD_WAVES;
     const int64_t wg = (int64_t)blockIdx.x * HD_WAVES + wave;
-    const int64_t n_groups = (dm.nb + 63) / 64;
+    const int G = dm.gsz;
+    const int64_t n_groups = (dm.nb + G - 1) / G;
     // ---- per-item constants in lane j (+64, ...)
     float gj[JPL], sj[JPL], og[JPL], os[JPL], gg[JPL], gs[JPL];
     int qpat[JPL];
@@ -116,8 +126,8 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
     float gl0 = 0.f, gl1 = 0.f;
 
     for (int64_t grp = wg; grp < n_groups; grp += n_waves) {
-        const int64_t i = grp * 64 + lane;
-        const bool valid = i < dm.nb;
+        const int64_t i = grp * G + lane;
+        const bool valid = lane < G && i < dm.nb;
         int64_t row = 0;
         float lc = 0.f, rw = 0.f, e = 0.f;
         if (valid) {
@@ -130,7 +140,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
         const float sig = __expf(rw);
         const float thv = lc + sig * e;
         float my_elbo = 0.f, my_gth = 0.f;
-        const int cnt = (int)((dm.nb - grp * 64) < 64 ? (dm.nb - grp * 64) : 64);
+        const int cnt = (int)((dm.nb - grp * G) < G ? (dm.nb - grp * G) : G);
         for (int pp = 0; pp < cnt; ++pp) {
             const float th = lane_bcast(thv, pp);
             const int64_t prow = __shfl(row, pp, 64);
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
 #pragma unroll
             for (int ii = 0; ii < CPL; ++ii) {
                 const int c = CPL * lane + ii;
-                const int64_t ip = grp * 64 + pp;
+                const int64_t ip = grp * G + pp;
                 pr[ii] = (c < C) ? (dm.uniform_prior == 2 ? __expf(zrow[ip * C + c] - zoff[c])
                                     : dm.uniform_prior ? 1.0f : __expf(Ac[ii])) : 0.f;       // Categorical(1 / C): vi.py:849
                 psum += pr[ii];
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_hodina(
 #pragma unroll
                 for (int ii = 0; ii < CPL; ++ii) {
                     const int c = CPL * lane + ii;
-                    if (c < C) gla[(grp * 64 + pp) * C + c] = dm.scale * rho[ii];
+                    if (c < C) gla[(grp * G + pp) * C + c] = dm.scale * rho[ii];
                 }
             }
             // -- E_j = sum_c r_c eta_cj.  DINA: superset sums gathered at q_j.  DINO: 1 - (subset sum at ~q_j), and 0

@@ -2018,8 +2018,9 @@ static size_t hodina_lds_bytes(int C, int len) {
     const size_t tab = (size_t)HD_WAVES * C * sizeof(long long), red = (size_t)HD_WAVES * len * sizeof(float);
     return tab > red ? tab : red;
 }
+static int hodina_gsz(int64_t nb) { return hd_group_size(nb, (int64_t)num_cu() * 4 * HD_WAVES); }
 static int hodina_blocks(int64_t nb) {
-    const int64_t n_groups = (nb + 63) / 64;
+    const int64_t g = hodina_gsz(nb), n_groups = (nb + g - 1) / g;
     int64_t blocks = (n_groups + HD_WAVES - 1) / HD_WAVES;
     const int64_t cap = (int64_t)num_cu() * 4;
     if (blocks > cap) blocks = cap;
@@ -2043,6 +2044,7 @@ int vx_hodina_grad(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t* ro
     dm.K = cfg->K; dm.J = cfg->J; dm.C = 1 << cfg->K; dm.scale = cfg->scale; dm.nb = nb;
     dm.uniform_prior = 0; dm.dino = 0; dm.unmasked = 0;
     dm.step_dev = cfg->step_dev;
+    dm.gsz = hodina_gsz(nb);
     const int len = 2 * cfg->J + 2 * cfg->K;
     hipStream_t st = (hipStream_t)hs;
     if (cfg->K >= 5 && cfg->K <= 8 && cfg->J <= 32) {
@@ -2093,6 +2095,7 @@ int vx_ccdm_grad(const vx_hodina_cfg* cfg, int32_t dino, const uint8_t* y, const
     HoDinaDims dm;
     dm.K = cfg->K; dm.J = cfg->J; dm.C = 1 << cfg->K; dm.scale = cfg->scale; dm.nb = nb;
     dm.uniform_prior = 1; dm.dino = dino ? 1 : 0; dm.unmasked = 0;
+    dm.gsz = hodina_gsz(nb);
     const int len = 2 * cfg->J + 2 * cfg->K;                  // slab layout of k_hodina; the lambda tail stays zero
     const size_t lds = hodina_lds_bytes(dm.C, len);
     hipStream_t st = (hipStream_t)hs;
@@ -2350,6 +2353,7 @@ int vx_vaeccdm_grad(const vx_hodina_cfg* cfg, int32_t dino, const uint8_t* y, co
     HoDinaDims dm;
     dm.K = cfg->K; dm.J = cfg->J; dm.C = 1 << cfg->K; dm.scale = cfg->scale; dm.nb = nb;
     dm.uniform_prior = 2; dm.dino = dino ? 1 : 0; dm.unmasked = 1;
+    dm.gsz = hodina_gsz(nb);
     const int len = 2 * cfg->J + 2 * cfg->K;
     const size_t lds = hodina_lds_bytes(dm.C, len);
     hipStream_t st = (hipStream_t)hs;

@@ -766,6 +766,14 @@ class _EngineBase(object):
             if rows is not None and not isinstance(rows, (list, tuple)) and self.n_local > 0:
                 nb = int(rows.numel())
                 return ("rows", nb, int(b_global) if b_global is not None else nb)
+        if isinstance(self, CcdmEngine):
+            # VCCDM (vi.py:819-865; test.py:560,585,624: 100-1500 rows a step): no guide, no random numbers -- the pattern
+            # kernel, the loss sum (which advances the counter Adam reads) and the optimiser
+            if full:
+                return ("full", self.n_local, self.N)
+            if rows is not None and not isinstance(rows, (list, tuple)) and self.n_local > 0:
+                nb = int(rows.numel())
+                return ("rows", nb, int(b_global) if b_global is not None else nb)
         if isinstance(self, HoDinaEngine):
             if full:
                 return ("full", self.n_local, self.N)        # the enumerated HO-DINA step (either guide): three or six launches
@@ -1839,13 +1847,15 @@ class CcdmEngine(_EngineBase):
         nb = self.n_local if rows is None else int(rows.numel())
         Bg = int(b_global) if b_global is not None else (self.N if rows is None else nb)
         scale = float(self.N) / float(Bg)
+        sd = getattr(self, "_step_dev", None)               # captured step: the loss sum advances the device counter
+        sdc = {"step_dev": sd} if sd is not None else {}
         cfg = be.hodina_cfg(self.K, self.J, 0, scale, self.seed, self.t, stream_id)
         elbo = self._buf("elbo", nb)
         ws = self._buf("cd_ws", be.ccdm_workspace(cfg, nb))
         with self._phase("ccdm"):
             be.ccdm_grad(cfg, self.cdm == "dino", self.y, rows, nb, self.q, self.view("g"), self.view("s"), elbo,
                          self.G[:self.n_item], ws)
-        be.sum_into(elbo, nb, -scale, self.G[self.n_params:self.n_params + 1], self.sum_ws)
+        be.sum_into(elbo, nb, -scale, self.G[self.n_params:self.n_params + 1], self.sum_ws, **sdc)
         self.last = {"elbo": elbo, "nb": nb}
 
 
