@@ -1073,13 +1073,54 @@ def test_captured_hodina_step_equals_eager_step(K, amort):
             assert (u is None and v is None) or np.array_equal(u, v)
 
 
-@pytest.mark.parametrize("cdm,B", [("dina", None), ("dino", 100)])
-def test_captured_ccdm_step_equals_eager_step(cdm, B):
+@pytest.mark.parametrize("amort,baseline,B", [(False, "avg", 100), (True, "avg", 100), (False, "none", None), (True, "none", None)])
+def test_captured_cdm_sf_step_equals_eager_step(amort, baseline, B):
+    """VCDM / VaeCDM (the score-function CDMs, vi.py:733-816; test.py:522-549 draws 100 or 1000 rows a step) replayed from HIP
+    graphs -- the Bernoulli draws' Philox step and Adam's t from the device counter, the per-person guide's gather / scatter
+    inside the capture, the decaying-average baseline updated by the kernel -- against the same steps launched kernel by
+    kernel: same bits, across a scheduler milestone, also four steps a replay."""
+    from vipsy_amd.engine import CdmSfEngine, LrSpec
+    rng = np.random.RandomState(29)
+    N, J, K = 3000, 30, 5
+    q = (rng.rand(K, J) < 0.4).astype(np.float32)
+    q[rng.randint(0, K, size=J), np.arange(J)] = 1.0
+    y = rng.randint(0, 2, size=(N, J)).astype(np.uint8)
+    draws = np.random.RandomState(5)
+    n_steps = 19
+    rows_all = [None if B is None else torch.from_numpy(np.sort(draws.choice(N, size=B, replace=False)).astype(np.int64))
+                for _ in range(n_steps)]
+    out = []
+    for mode in ("graph", "eager", "steps"):
+        eng = CdmSfEngine(torch.from_numpy(y).to(_dev()), q, amortized=amort, H=64, seed=11, baseline=baseline)
+        eng.use_graph = mode != "eager"
+        lrs = LrSpec(lambda m, p: {"lr": 1e-2}, milestones=(5,), gamma=0.5)
+        if mode == "steps":
+            losses = eng.steps(lrs, rows_all, b_global=B, scheduler=True)[-8:]
+        else:
+            losses = []
+            for t in range(n_steps):
+                losses.append(eng.step(lrs, rows=rows_all[t], b_global=B).clone())
+                lrs.scheduler_step()
+            losses = losses[-8:]
+        torch.cuda.synchronize()
+        assert eng.t == n_steps
+        assert ((getattr(eng, "_graph", None) or {}).get("graph") is not None) == (mode != "eager")
+        out.append((torch.stack(losses).cpu().numpy(), eng.P.cpu().numpy().copy(),
+                    eng.PP.cpu().numpy().copy() if eng.per_person else None,
+                    eng.base.cpu().numpy().copy() if eng.base is not None else None))
+    assert np.isfinite(out[0][0]).all()
+    for other in out[1:]:
+        for u, v in zip(out[0], other):
+            assert (u is None and v is None) or np.array_equal(u, v)
+
+
+@pytest.mark.parametrize("cdm,B,vae", [("dina", None, False), ("dino", 100, False), ("dina", 100, True), ("dino", None, True)])
+def test_captured_ccdm_step_equals_eager_step(cdm, B, vae):
     """VCCDM's step (the pattern-enumerated DINA / DINO with an empty guide, vi.py:819-865; test.py:560,585,624 draws 100-1500
     rows a step) replayed from its HIP graph -- Adam's t from the device counter the loss sum advances, host-drawn rows staged
     per replay -- against the same steps launched kernel by kernel: same bits, across a scheduler milestone, also four steps a
     replay."""
-    from vipsy_amd.engine import CcdmEngine, LrSpec
+    from vipsy_amd.engine import CcdmEngine, VaeCcdmEngine, LrSpec
     rng = np.random.RandomState(23)
     N, J, K = 3000, 30, 5
     q = (rng.rand(K, J) < 0.4).astype(np.float32)
@@ -1091,7 +1132,8 @@ def test_captured_ccdm_step_equals_eager_step(cdm, B):
     rows_all = [None if B is None else torch.from_numpy(draws.choice(N, size=B, replace=False).astype(np.int64)) for _ in range(n_steps)]
     out = []
     for mode in ("graph", "eager", "steps"):
-        eng = CcdmEngine(torch.from_numpy(y).to(_dev()), q, cdm=cdm, seed=11)
+        eng = (VaeCcdmEngine(torch.from_numpy(y).to(_dev()), q, cdm=cdm, H=64, seed=11) if vae     # (VaeCCDM: the same, with its
+               else CcdmEngine(torch.from_numpy(y).to(_dev()), q, cdm=cdm, seed=11))                 # SoftmaxEncoder prior)
         eng.use_graph = mode != "eager"
         lrs = LrSpec(lambda m, p: {"lr": 1e-2}, milestones=(5,), gamma=0.5)
         if mode == "steps":

@@ -5,7 +5,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vipsy_amd.engine import CcdmEngine, VaeCcdmEngine, CdmSfEngine, LrSpec
 dev = torch.device("cuda:0"); N = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
-J, K = 30, 5
+J, K = int(os.environ.get("CDM_J", "30")), 5
 rng = np.random.RandomState(1)
 q = (rng.rand(K, J) < 0.4).astype(np.float32); q[0, q.sum(0) == 0] = 1
 g = torch.Generator(device=dev); g.manual_seed(1)
@@ -22,7 +22,7 @@ for name, mk in (("VCCDM (enumerated)", lambda: CcdmEngine(y, qt)), ("VaeCCDM (S
             return None if B is None else torch.from_numpy(np.unique(draws.randint(0, N, 3 * B))[:B].astype(np.int64))
         n = 48
         pre = [rows() for _ in range(n)]                       # (drawn ahead: the fit loop's draw is not what is timed)
-        eng.steps(lrs, pre[:12], b_global=B)
+        eng.steps(lrs, pre[:24], b_global=B)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         eng.steps(lrs, pre, b_global=B)

@@ -25,6 +25,7 @@ struct CdmSfDims {
     float base_beta;                  // >= 0: baseline[.] <- beta * baseline + (1 - beta) * log_r after use (decaying average)
     int base_by_row;                  // the baseline is indexed by the local person row (else by the batch position)
     int64_t nb;
+    const uint32_t* step_dev = nullptr;   // or the step counter in device memory (a captured step): read instead of `step`
 };
 
 // u01 draws for the attribute bits of person gid: word (k & 3) of Philox block k >> 2 (same rule in oracle/vi_oracle.py)
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cdm_sf(
     float* __restrict__ gu /*[nb][K]*/, float* __restrict__ log_r /*[nb]*/, uint8_t* __restrict__ attr_out /*[nb][K] or null*/,
     int* __restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) char smem_cs[];
+    if (dm.step_dev) step = *dm.step_dev;                  // replayed from a HIP graph: the counter lives on the device
     const int K = dm.K, J = dm.J;
     float* L = (float*)smem_cs;                            // [J][4]: log-lik term of (eta, y) = c >> 1, c & 1
     int* cnt = (int*)(L + 4 * J);                          // [4][J]

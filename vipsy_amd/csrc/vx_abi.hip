@@ -1999,7 +1999,13 @@ int vx_norm_enc_backward(const vx_irt_cfg* cfg, const uint8_t* y, const int64_t*
     rc = set_lds(k_fc1_bwd<HT>, lds);                                                                        \
     if (rc) return rc;                                                                                       \
     hipLaunchKernelGGL(k_fc1_bwd<HT>, grid, dim3(ENC_THREADS), lds, st, dm, y, rows, ghpre, slabs_f, lenf, f1fast)
-        if (dm.Hp == 32) { LAUNCH_F1(1); } else if (dm.Hp == 64) { LAUNCH_F1(2); } else if (dm.Hp == 96) { LAUNCH_F1(3); } else { LAUNCH_F1(4); }
+        if (dm.Hp == 64 && (int64_t)n_jg * n_prf * 16 <= num_cu()) {
+            // a small batch: 128 items a workgroup instead of 512 (the form the multivariate guide's small batches take above)
+            rc = set_lds((k_fc1_bwd<2, 1>), lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_fc1_bwd<2, 1>), dim3((unsigned)((cfg->J + 127) / 128), (unsigned)n_prf), dim3(ENC_THREADS), lds, st, dm, y,
+                               rows, ghpre, slabs_f, lenf, f1fast);
+        } else if (dm.Hp == 32) { LAUNCH_F1(1); } else if (dm.Hp == 64) { LAUNCH_F1(2); } else if (dm.Hp == 96) { LAUNCH_F1(3); } else { LAUNCH_F1(4); }
 #undef LAUNCH_F1
         VX_CHECK_LAUNCH();
     }
@@ -2152,6 +2158,7 @@ int vx_cdm_sf_grad(const vx_hodina_cfg* cfg, int32_t dino, int32_t clamp_t, floa
     const float pc = fminf(fmaxf(prior_p, VX_EPS32), 1.0f - VX_EPS32);        // Bernoulli(probs).log_prob clamps (vi.py:753: 1.5)
     dm.lp1 = logf(pc); dm.lp0 = log1pf(-pc);
     dm.base_beta = base_beta; dm.base_by_row = base_by_row ? 1 : 0;
+    dm.step_dev = cfg->step_dev;
     hipStream_t st = (hipStream_t)hs;
     const size_t lds = (size_t)cfg->J * (4 * sizeof(float) + 4 * sizeof(int) + sizeof(uint32_t));
     int rc = set_lds(k_cdm_sf, lds);
@@ -2242,7 +2249,13 @@ int vx_bin_enc_backward(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_
     rc = set_lds(k_fc1_bwd<HT>, lds);                                                                        \
     if (rc) return rc;                                                                                       \
     hipLaunchKernelGGL(k_fc1_bwd<HT>, grid, dim3(ENC_THREADS), lds, st, dm, y, rows, ghpre, slabs_f, lenf, 0)
-        if (dm.Hp == 32) { LAUNCH_F1(1); } else if (dm.Hp == 64) { LAUNCH_F1(2); } else if (dm.Hp == 96) { LAUNCH_F1(3); } else { LAUNCH_F1(4); }
+        if (dm.Hp == 64 && (int64_t)n_jg * n_prf * 16 <= num_cu()) {
+            // a small batch: 128 items a workgroup instead of 512 (the form the multivariate guide's small batches take above)
+            rc = set_lds((k_fc1_bwd<2, 1>), lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_fc1_bwd<2, 1>), dim3((unsigned)((cfg->J + 127) / 128), (unsigned)n_prf), dim3(ENC_THREADS), lds, st, dm, y,
+                               rows, ghpre, slabs_f, lenf, 0);
+        } else if (dm.Hp == 32) { LAUNCH_F1(1); } else if (dm.Hp == 64) { LAUNCH_F1(2); } else if (dm.Hp == 96) { LAUNCH_F1(3); } else { LAUNCH_F1(4); }
 #undef LAUNCH_F1
         VX_CHECK_LAUNCH();
     }
@@ -2437,7 +2450,13 @@ int vx_sm_enc_backward(const vx_hodina_cfg* cfg, const uint8_t* y, const int64_t
     rc = set_lds(k_fc1_bwd<HT>, lds);                                                                        \
     if (rc) return rc;                                                                                       \
     hipLaunchKernelGGL(k_fc1_bwd<HT>, grid, dim3(ENC_THREADS), lds, st, dm, y, rows, ghpre, slabs_f, lenf, 0)
-        if (dm.Hp == 32) { LAUNCH_F1(1); } else if (dm.Hp == 64) { LAUNCH_F1(2); } else if (dm.Hp == 96) { LAUNCH_F1(3); } else { LAUNCH_F1(4); }
+        if (dm.Hp == 64 && (int64_t)n_jg * n_prf * 16 <= num_cu()) {
+            // a small batch: 128 items a workgroup instead of 512 (the form the multivariate guide's small batches take above)
+            rc = set_lds((k_fc1_bwd<2, 1>), lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_fc1_bwd<2, 1>), dim3((unsigned)((cfg->J + 127) / 128), (unsigned)n_prf), dim3(ENC_THREADS), lds, st, dm, y,
+                               rows, ghpre, slabs_f, lenf, 0);
+        } else if (dm.Hp == 32) { LAUNCH_F1(1); } else if (dm.Hp == 64) { LAUNCH_F1(2); } else if (dm.Hp == 96) { LAUNCH_F1(3); } else { LAUNCH_F1(4); }
 #undef LAUNCH_F1
         VX_CHECK_LAUNCH();
     }

@@ -766,6 +766,23 @@ class _EngineBase(object):
             if rows is not None and not isinstance(rows, (list, tuple)) and self.n_local > 0:
                 nb = int(rows.numel())
                 return ("rows", nb, int(b_global) if b_global is not None else nb)
+        if isinstance(self, CdmSfEngine) and getattr(self, "baseline", "none") != "loo":
+            # VCDM / VaeCDM (vi.py:733-816; test.py:522-549: 100 or 1000 rows a step): the Bernoulli draws' Philox step and Adam's
+            # t from the device counter that the loss sum advances (k_cdm_sf reads vx_hodina_cfg.step_dev); the per-person
+            # guide's gather / scatter of the batch rows are torch index kernels inside the capture
+            if full:
+                return ("full", self.n_local, self.N)
+            if rows is not None and not isinstance(rows, (list, tuple)) and self.n_local > 0:
+                nb = int(rows.numel())
+                return ("rows", nb, int(b_global) if b_global is not None else nb)
+        if isinstance(self, VaeCcdmEngine) and self.group is None:
+            # VaeCCDM (vi.py:868-891; test.py:565,629: 100 or 50 rows a step) on one rank: no random numbers; the softmax over
+            # the batch is three column reductions on the device (sharded, they are small all-reduces between kernels: eager)
+            if full:
+                return ("full", self.n_local, self.N)
+            if rows is not None and not isinstance(rows, (list, tuple)) and self.n_local > 0:
+                nb = int(rows.numel())
+                return ("rows", nb, int(b_global) if b_global is not None else nb)
         if isinstance(self, CcdmEngine):
             # VCCDM (vi.py:819-865; test.py:560,585,624: 100-1500 rows a step): no guide, no random numbers -- the pattern
             # kernel, the loss sum (which advances the counter Adam reads) and the optimiser
@@ -1932,6 +1949,8 @@ class VaeCcdmEngine(_EngineBase):
         Bg = int(b_global) if b_global is not None else (self.N if rows is None else nb)
         scale = float(self.N) / float(Bg)
         C, H = self.C, self.H
+        sd = getattr(self, "_step_dev", None)               # captured step: the loss sum advances the device counter
+        sdc = {"step_dev": sd} if sd is not None else {}
         cfg = be.hodina_cfg(self.K, self.J, H, scale, self.seed, self.t, stream_id)
         enc = {k: self.view("encoder$$$" + k) for k in BIN_ENC_KEYS}
         h, z, gla = self._buf("vc_h", nb * H), self._buf("vc_z", nb * C), self._buf("vc_gla", nb * C)
@@ -1956,7 +1975,7 @@ class VaeCcdmEngine(_EngineBase):
             bws = self._buf("vc_bws", be.sm_enc_bwd_workspace(cfg, nb))
             be.sm_enc_backward(cfg, self.y, rows, nb, enc, h, z, off, T, gla,
                                self.G[self.enc_off0:self.enc_off0 + self.n_enc], bws)
-        be.sum_into(elbo, nb, -scale, self.G[self.n_params:self.n_params + 1], self.sum_ws)
+        be.sum_into(elbo, nb, -scale, self.G[self.n_params:self.n_params + 1], self.sum_ws, **sdc)
         self.last = {"elbo": elbo, "nb": nb}
 
 
@@ -2048,7 +2067,9 @@ class CdmSfEngine(_EngineBase):
         Bg = int(b_global) if b_global is not None else (self.N if rows is None else nb)
         scale = float(self.N) / float(Bg)
         K = self.K
-        cfg = be.hodina_cfg(K, self.J, self.H, scale, self.seed, self.t, stream_id)
+        sd = getattr(self, "_step_dev", None)               # captured step: the step count lives in device memory
+        sdc = {"step_dev": sd} if sd is not None else {}
+        cfg = be.hodina_cfg(K, self.J, self.H, scale, self.seed, self.t, stream_id, **sdc)
         ws = self._buf("cs_ws", be.cdm_sf_workspace(cfg, nb))
         gu, log_r = self._buf("cs_gu", nb * K), self._buf("cs_lr%d" % stream_id if not grads else "cs_lr", nb)
         if self.amortized:
@@ -2079,7 +2100,7 @@ class CdmSfEngine(_EngineBase):
             else:                                              # dense per-person gradient: zero off the batch (vi.py:811)
                 self.GP.zero_()
                 self.GP.reshape(self.n_local, K).index_add_(0, rows, gu[:nb * K].reshape(nb, K))
-        be.sum_into(log_r, nb, -1.0, self.G[self.n_params:self.n_params + 1], self.sum_ws)
+        be.sum_into(log_r, nb, -1.0, self.G[self.n_params:self.n_params + 1], self.sum_ws, **(sdc if grads else {}))
         self.last = {"log_r": log_r, "gu": gu, "nb": nb}
 
     def step(self, lrs, rows=None, b_global=None, eps=None, num_particles=1):
