@@ -27,7 +27,16 @@ struct Irt1dDims {
     int J, model;
     float Dc, scale;
     int64_t nb;
+    // k_irt1d_items: persons a wave takes at a time (1..64).  It walks its group ONE PERSON AFTER THE OTHER (the items on the
+    // lanes, ~1 us a person), so the reference's 100 rows a step in groups of 64 were two waves busy for 69 us: the group shrinks
+    // with the batch until it fills the chip's waves (i1_group_size)
+    int gsz = 64;
 };
+
+__host__ __device__ inline int i1_group_size(int64_t nb, int64_t max_waves) {
+    int64_t g = (nb + max_waves - 1) / max_waves;
+    return (int)(g < 1 ? 1 : g > 64 ? 64 : g);
+}
 
 // LDS of a workgroup (floats): item table [J][NPF] | item sums [J][NQ] | per wave: parked terms [16 / NQ][64 NQ + pad] (the
 // wave's (ll, gx)[64] hand-over at the end of a chunk lies in the same region) | per-chunk hand-over: x[64], row[64] (two words)
@@ -233,7 +242,8 @@ __global__ __launch_bounds__(I1_THREADS) void k_irt1d_items(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t n_waves = (int64_t)gridDim.x * (I1_THREADS / 64);
     const int64_t wg = (int64_t)blockIdx.x * (I1_THREADS / 64) + wave;
-    const int64_t n_groups = (dm.nb + 63) / 64;
+    const int G = dm.gsz;
+    const int64_t n_groups = (dm.nb + G - 1) / G;
     float aq[IPL], bq[IPL], cq[IPL], dq[IPL], oq[IPL], ga[IPL], gb[IPL], gc[IPL], gd[IPL];
 #pragma unroll
     for (int q = 0; q < IPL; ++q) {
@@ -265,8 +275,8 @@ __global__ __launch_bounds__(I1_THREADS) void k_irt1d_items(
         }
     };
     for (int64_t grp = wg; grp < n_groups; grp += n_waves) {
-        const int64_t i = grp * 64 + lane;
-        const bool valid = i < dm.nb;
+        const int64_t i = grp * G + lane;
+        const bool valid = lane < G && i < dm.nb;
         int64_t row = 0;
         float l = 0.f, r = 0.f, e = 0.f;
         if (valid) {
@@ -278,7 +288,7 @@ __global__ __launch_bounds__(I1_THREADS) void k_irt1d_items(
         const float xv = l + sig * e;
         const int row_lo = (int)(uint32_t)row, row_hi = (int)(uint32_t)((uint64_t)row >> 32);
         float my_ll = 0.f, my_gx = 0.f;
-        const int cnt = (int)((dm.nb - grp * 64) < 64 ? (dm.nb - grp * 64) : 64);
+        const int cnt = (int)((dm.nb - grp * G) < G ? (dm.nb - grp * G) : G);
         uint32_t wcur[WPL], wnext[WPL];
         auto person_row = [&](int pp) -> int64_t {                  // the response row of person pp of the group
             return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(row_hi, pp) << 32) |

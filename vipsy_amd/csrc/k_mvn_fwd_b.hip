@@ -914,17 +914,35 @@ __global__ __launch_bounds__(NB_THREADS, 2) void k_norm_enc_fwd_b(
         const uint32_t lb = lds_addr_uniform(R1);
         for (int d = 0; d < n_ydma; ++d) dma16(src + d * 1024, lb + (uint32_t)d * 1024u);
     } else {
+        // gathered (or ragged) rows, word by word: the person's row index is read ONCE (lane p of the wave) and handed round,
+        // so the word loads of a person depend on nothing and many are in flight -- with the index looked up per word
+        // (rows[ii], then y[row]: two latencies in a row, 125 rounds a wave at 1000 items) this staging was 90 of the
+        // kernel's 97 us at the reference's 100 rows a step (Irt2PL.test_ai's shape; tools/ref_usage_times.py)
         const int YW = YS / 4, JW = J / 4;
         uint32_t* Yw = (uint32_t*)R1;
-        for (int e = lane; e < EP_WP * YW; e += 64) {
-            const int pp = e / YW, wq = e - pp * YW;
-            const int64_t ii = i0 + pp;
-            uint32_t v = 0u;
-            if (wq < JW && ii < dm.nb) {
-                const int64_t row = rows ? rows[ii] : ii;
-                v = *(const uint32_t*)(y + row * J + 4 * wq);              // bytes 0/1/255 == int8 0/1/-1 (vi.py:680-682)
+        const int64_t ip = i0 + l31;
+        const int64_t myrow = ip < dm.nb ? (rows ? rows[ip] : ip) : (int64_t)-1;
+        const int row_lo = (int)(uint32_t)myrow, row_hi = (int)(uint32_t)((uint64_t)myrow >> 32);
+        if (YW >= 64) {                                                   // a row fills the wave: person by person (118.7 us a step
+#pragma unroll 4                                                          // at 1000 items against 127.8 the other way round)
+            for (int pp = 0; pp < EP_WP; ++pp) {
+                const int64_t row = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(row_hi, pp) << 32) |
+                                              (uint32_t)__builtin_amdgcn_readlane(row_lo, pp));
+                for (int wq = lane; wq < YW; wq += 64) {
+                    uint32_t v = 0u;
+                    if (wq < JW && row >= 0) v = *(const uint32_t*)(y + row * J + 4 * wq);   // bytes 0/1/255 == int8 0/1/-1 (vi.py:680-682)
+                    Yw[pp * YW + wq] = v;
+                }
             }
-            Yw[e] = v;
+        } else {                                                          // short rows: the lanes cover several persons at once
+#pragma unroll 4
+            for (int e = lane; e < EP_WP * YW; e += 64) {
+                const int pp = e / YW, wq = e - pp * YW;
+                const int64_t row = (int64_t)(((uint64_t)(uint32_t)__shfl(row_hi, pp, 64) << 32) | (uint32_t)__shfl(row_lo, pp, 64));
+                uint32_t v = 0u;
+                if (wq < JW && row >= 0) v = *(const uint32_t*)(y + row * J + 4 * wq);
+                Yw[e] = v;
+            }
         }
     }
     // ---- W1 slices: thread = (hidden unit hh, quarter q of the 16 items of a k-step)
@@ -956,14 +974,24 @@ __global__ __launch_bounds__(NB_THREADS, 2) void k_norm_enc_fwd_b(
         }
     };
     put_w(fetch_w(0), 0);
-    float4 wn = fetch_w(1);
+    // W1 slices NB_PF k-steps ahead, in registers: a minibatch is ONE workgroup on one CU, and with the slice of k-step ks + 1
+    // requested only an iteration before it is laid down every iteration waited for that load (the reference's Irt2PL.test_ai
+    // shape, 1000 items x 100 rows: 63 k-steps of 1.6 us = 100 us of a 146 us step; four ahead: tools/ref_usage_times.py)
+    constexpr int NB_PF = 4;
+    float4 wq[NB_PF];
+#pragma unroll
+    for (int u = 0; u < NB_PF; ++u) wq[u] = fetch_w(1 + u);
     vx_wait_vmem();                                                       // the response rows (DMA) have landed
     __syncthreads();
     f32x16 acc0 = zero16(), acc1 = zero16();
-    for (int ks = 0; ks < n_ks; ++ks) {
+    for (int ks0 = 0; ks0 < n_ks; ks0 += NB_PF) {
+#pragma unroll
+      for (int u = 0; u < NB_PF; ++u) {
+        const int ks = ks0 + u;
+        if (ks >= n_ks) break;                                            // (uniform)
         const int buf = ks & 1;
-        const float4 wcur = wn;                                           // slice ks + 1, fetched an iteration ago
-        wn = fetch_w(ks + 2);
+        const float4 wcur = wq[u];                                        // slice ks + 1, requested NB_PF iterations ago
+        wq[u] = fetch_w(ks + 1 + NB_PF);
         const char* fb = frag + buf * 6144 + lane * 16;
         bf16x8 A[6];
 #pragma unroll
@@ -984,6 +1012,7 @@ __global__ __launch_bounds__(NB_THREADS, 2) void k_norm_enc_fwd_b(
         acc0 = mfma_bf16(A[0], yb, acc0); acc1 = mfma_bf16(A[3], yb, acc1);
         if (ks + 1 < n_ks) put_w(wcur, buf ^ 1);                          // the other buffer: read last in iteration ks - 1
         __syncthreads();
+      }
     }
     if (i0 >= dm.nb) return;
     // ---- softplus, the two 1-row heads as per-lane dot products over the 32 hidden units a lane holds

@@ -1546,7 +1546,8 @@ static int irt1d_blocks(int64_t nb, int J) {
         blocks = (nb + 63) / 64;
         cap = (int64_t)num_cu() * 8;
     } else {
-        const int64_t n_groups = (nb + 63) / 64;                       // a wave walks groups of 64 persons
+        const int64_t g = i1_group_size(nb, (int64_t)num_cu() * 4 * (I1_THREADS / 64));
+        const int64_t n_groups = (nb + g - 1) / g;                     // a wave walks groups of up to 64 persons
         blocks = (n_groups + 3) / 4;
         cap = (int64_t)num_cu() * 4;
     }
@@ -1576,6 +1577,7 @@ static int irt1d_grad_impl(const vx_irt_cfg* cfg, const uint8_t* y, const int64_
     const int blocks = irt1d_blocks(nb, cfg->J);
     Irt1dDims dm;
     dm.J = cfg->J; dm.model = cfg->model; dm.Dc = cfg->Dc; dm.scale = cfg->scale; dm.nb = nb;
+    dm.gsz = i1_group_size(nb, (int64_t)num_cu() * 4 * (I1_THREADS / 64));
     const bool by_person = cfg->J <= I1_PERSON_LANES_MAX_J;
     // person-per-lane: item table, item sums, parked terms; item-per-lane: one partial slot per wave
     const size_t lds = by_person ? i1_lds_bytes(cfg->J, cfg->model) : sizeof(float) * 4 * (size_t)cfg->J * (I1_THREADS / 64);
